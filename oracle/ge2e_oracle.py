@@ -1,0 +1,83 @@
+"""CPU oracle for the GE2E speaker-embedder forward and loss.  TEST INFRASTRUCTURE ONLY.
+
+Restates ``GE2E/speech_embedder_net.py`` and ``GE2E/utils.py:16-55`` of the reference
+(cited as speech_embedder_net.py:line / utils.py:line).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+
+The LSTM is written out gate by gate (torch.nn.LSTM is the third-party arithmetic the
+reference calls at speech_embedder_net.py:19,28; gate order i, f, g, o and the update
+equations are torch's documented ones); it is pinned against the reference's own
+``nn.LSTM`` output through ``tests/golden/ge2e_embedder.npz``.  The loss is a vectorised
+restatement of the reference's triple Python loop, pinned by ``tests/golden/ge2e_loss.npz``
+and by the known-answer case the reference carries at utils.py:89-96 (loss = 5.2501).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def lstm_stack(x, sd, num_layers, prefix="LSTM_stack"):
+    """nn.LSTM(batch_first=True), speech_embedder_net.py:19,28.  x: (B, T, F) -> (B, T, H).
+
+    Per layer l and step t:  gates = W_ih x_t + b_ih + W_hh h_{t-1} + b_hh, split as
+    (i, f, g, o); c_t = sigmoid(f) c_{t-1} + sigmoid(i) tanh(g); h_t = sigmoid(o) tanh(c_t).
+    """
+    B, T, _ = x.shape
+    inp = x.float()
+    for l in range(num_layers):
+        w_ih = sd["%s.weight_ih_l%d" % (prefix, l)]
+        w_hh = sd["%s.weight_hh_l%d" % (prefix, l)]
+        b = sd["%s.bias_ih_l%d" % (prefix, l)] + sd["%s.bias_hh_l%d" % (prefix, l)]
+        H = w_hh.shape[1]
+        h = torch.zeros(B, H)
+        c = torch.zeros(B, H)
+        xp = F.linear(inp, w_ih)  # (B, T, 4H): input projection for all steps at once
+        outs = []
+        for t in range(T):
+            gates = xp[:, t] + F.linear(h, w_hh) + b
+            i, f, g, o = gates.chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        inp = torch.stack(outs, dim=1)
+    return inp
+
+
+def speech_embedder(x, sd, num_layers=3):
+    """SpeechEmbedder.forward, speech_embedder_net.py:27-33: last frame -> Linear -> x/||x||."""
+    h = lstm_stack(x, sd, num_layers)[:, -1]
+    e = F.linear(h, sd["projection.weight"], sd["projection.bias"])
+    return e / torch.norm(e, dim=1).unsqueeze(1)
+
+
+def ge2e_cossim(emb):
+    """get_centroids + get_cossim, utils.py:16-46.  emb: (N, M, D) -> (N, M, N).
+
+    cos[j,i,k] = cosine(e_ji, c_k) + 1e-6 with c_k the speaker mean (utils.py:16-25),
+    except k == j where the centroid leaves e_ji out (utils.py:27-34, :42-43).
+    F.cosine_similarity clamps the *product* of norms at eps=1e-8 in torch>=1.12 (each
+    norm separately in older versions); the embeddings are unit vectors so it is inert.
+    """
+    N, M, _ = emb.shape
+    cent = emb.mean(dim=1)                                   # (N, D)
+    loo = (emb.sum(dim=1, keepdim=True) - emb) / (M - 1)     # (N, M, D)
+    cos = F.cosine_similarity(emb.unsqueeze(2), cent.view(1, 1, N, -1), dim=3)
+    own = F.cosine_similarity(emb, loo, dim=2)               # (N, M)
+    idx = torch.arange(N)
+    cos = cos.clone()
+    cos[idx, :, idx] = own
+    return cos + 1e-6
+
+
+def ge2e_loss(emb, w, b):
+    """GE2ELoss.forward + calc_loss, speech_embedder_net.py:43-49, utils.py:48-55.
+
+    S = w*cos + b;  L = sum_ji -(S_jij - log(sum_k exp(S_jik) + 1e-6)).
+    (The torch.clamp(self.w, 1e-6) at :44 discards its result: a no-op.)
+    Returns (loss, per_embedding_loss (N, M)).
+    """
+    S = w * ge2e_cossim(emb) + b
+    N = S.shape[0]
+    idx = torch.arange(N)
+    pos = S[idx, :, idx]                                      # (N, M)
+    per = -(pos - torch.log(torch.exp(S).sum(dim=2) + 1e-6))
+    return per.sum(), per

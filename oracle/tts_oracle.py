@@ -1,0 +1,270 @@
+"""CPU oracle for the Text2Mel / SSRN hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a functional restatement, on stock torch CPU ops, of the algorithm in the
+reference's ``models/TTSModel.py`` (cited per function below as TTSModel.py:line) and of
+the loss expressions in ``train/ordinary.py``.  It is the checker for the HIP path:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it.  The product package (``spoofsv_amd``) never imports anything under
+``oracle/``.
+
+Pinning: every function here is checked against golden vectors produced by importing the
+real reference in the build container (``oracle/gen_golden.py`` -> ``tests/golden/``),
+see ``tests/test_oracle_golden.py``.
+
+All functions take a flat ``sd`` (state-dict style ``name -> tensor``) whose keys are the
+reference's own ``state_dict()`` keys, plus a ``prefix`` selecting the sub-module.
+Backward passes come from torch autograd over these functions.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- helpers
+def _ln_channels(x, w, b, eps=1e-5):
+    """LayerNorm over the channel axis of a (B, C, T) tensor.
+
+    The reference permutes to (B, T, C), applies nn.LayerNorm(C) and permutes back
+    (TTSModel.py:81-82, :129, :175 ...).  Biased variance, eps=1e-5, affine.
+    """
+    return F.layer_norm(x.permute(0, 2, 1), (x.shape[1],), w, b, eps).permute(0, 2, 1)
+
+
+def _pw(x, sd, name):
+    """kernel_size=1 Conv1d (TTSModel.py:115 etc.)."""
+    return F.conv1d(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+# --------------------------------------------------------------------------- a1
+def highway_conv(x, sd, prefix, kernel_size, dilation, causal=False):
+    """highwayConv.forward, TTSModel.py:63-84.
+
+    pad = dilation*(k-1)//2 (:57).  Non-causal: symmetric zero padding ``pad`` (:59).
+    Causal: 2*pad zeros are concatenated on the left, conv is unpadded (:72-74, :59).
+    H1, H2 = the two halves of the 2C output channels (:79-80), each LayerNorm'ed over
+    channels (:81-82); out = sigmoid(H1)*H2 + (1-sigmoid(H1))*x (:83).
+    """
+    w = sd[prefix + ".conv.weight"]
+    b = sd[prefix + ".conv.bias"]
+    C = x.shape[1]
+    pad = dilation * (kernel_size - 1) // 2
+    if causal and pad > 0:
+        xin = F.pad(x, (2 * pad, 0))
+        h = F.conv1d(xin, w, b, dilation=dilation)
+    else:
+        h = F.conv1d(x, w, b, padding=0 if causal else pad, dilation=dilation)
+    h1 = _ln_channels(h[:, :C], sd[prefix + ".ln1.weight"], sd[prefix + ".ln1.bias"])
+    h2 = _ln_channels(h[:, C:], sd[prefix + ".ln2.weight"], sd[prefix + ".ln2.bias"])
+    g = torch.sigmoid(h1)
+    return g * h2 + (1 - g) * x
+
+
+def _hci(x, sd, prefix, causal):
+    """highwayDilationIncrement, TTSModel.py:94-104: dilations 1, 3, 9, 27."""
+    for i, d in enumerate((1, 3, 9, 27)):
+        x = highway_conv(x, sd, "%s.hc%d" % (prefix, i + 1), 3, d, causal)
+    return x
+
+
+# --------------------------------------------------------------------------- a3
+def text_embedding(textid, sd, prefix, vocab_len):
+    """textEmbedding.forward, TTSModel.py:25-35: one-hot scatter then Linear, (B,E,N)."""
+    ids = textid.long()
+    one_hot = torch.zeros(ids.shape[0], vocab_len, ids.shape[2]).scatter_(
+        1, ids, torch.ones(ids.shape))
+    out = F.linear(one_hot.permute(0, 2, 1), sd[prefix + ".W.weight"], sd[prefix + ".W.bias"])
+    return out.permute(0, 2, 1)
+
+
+# --------------------------------------------------------------------------- a4
+def text_encoder(textid, sd, prefix="text_encoder"):
+    """textEncoder.forward, TTSModel.py:126-140.  Returns K, V (each (B, hidden, N))."""
+    vocab_len = sd[prefix + ".textemb_layer.W.weight"].shape[1]
+    x = text_embedding(textid, sd, prefix + ".textemb_layer", vocab_len)
+    x = _ln_channels(_pw(x, sd, prefix + ".conv1"), sd[prefix + ".ln1.weight"], sd[prefix + ".ln1.bias"])
+    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv2"), sd[prefix + ".ln2.weight"], sd[prefix + ".ln2.bias"])
+    x = _hci(x, sd, prefix + ".hci1", False)
+    x = _hci(x, sd, prefix + ".hci2", False)
+    x = highway_conv(x, sd, prefix + ".hc1", 3, 1)
+    x = highway_conv(x, sd, prefix + ".hc2", 3, 1)
+    x = highway_conv(x, sd, prefix + ".hc3", 1, 1)
+    x = highway_conv(x, sd, prefix + ".hc4", 1, 1)
+    hidden = x.shape[1] // 2
+    return x[:, :hidden], x[:, hidden:]
+
+
+# --------------------------------------------------------------------------- a5
+def audio_encoder(mel, spk, sd, prefix="audio_encoder"):
+    """audioEncoder.forward, TTSModel.py:166-196.  ``spk`` is (B, spk_dim, 1) or None.
+
+    With conditioning, fc1(spk) is broadcast-added before ln1 (:174-175) and fc2(spk)
+    before ln3 (:179-180).
+    """
+    cond = (prefix + ".fc1.weight") in sd and spk is not None
+    x = _pw(mel, sd, prefix + ".conv1")
+    if cond:
+        x = x + F.linear(spk.permute(0, 2, 1), sd[prefix + ".fc1.weight"], sd[prefix + ".fc1.bias"]).permute(0, 2, 1)
+    x = _ln_channels(x, sd[prefix + ".ln1.weight"], sd[prefix + ".ln1.bias"])
+    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv2"), sd[prefix + ".ln2.weight"], sd[prefix + ".ln2.bias"])
+    x = _pw(F.relu(x), sd, prefix + ".conv3")
+    if cond:
+        x = x + F.linear(spk.permute(0, 2, 1), sd[prefix + ".fc2.weight"], sd[prefix + ".fc2.bias"]).permute(0, 2, 1)
+    x = _ln_channels(x, sd[prefix + ".ln3.weight"], sd[prefix + ".ln3.bias"])
+    x = _hci(x, sd, prefix + ".hci1", True)
+    x = _hci(x, sd, prefix + ".hci2", True)
+    x = highway_conv(x, sd, prefix + ".hc1", 3, 3, True)
+    x = highway_conv(x, sd, prefix + ".hc2", 3, 3, True)
+    return x
+
+
+# --------------------------------------------------------------------------- a7
+def audio_decoder(rq, sd, prefix="audio_decoder"):
+    """audioDecoder.forward, TTSModel.py:217-232 (no ReLU before conv2, :223)."""
+    x = _ln_channels(_pw(rq, sd, prefix + ".conv1"), sd[prefix + ".ln1.weight"], sd[prefix + ".ln1.bias"])
+    x = _hci(x, sd, prefix + ".hci", True)
+    x = highway_conv(x, sd, prefix + ".hc1", 3, 1, True)
+    x = highway_conv(x, sd, prefix + ".hc2", 3, 1, True)
+    x = _ln_channels(_pw(x, sd, prefix + ".conv2"), sd[prefix + ".ln2.weight"], sd[prefix + ".ln2.bias"])
+    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv3"), sd[prefix + ".ln3.weight"], sd[prefix + ".ln3.bias"])
+    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv4"), sd[prefix + ".ln4.weight"], sd[prefix + ".ln4.bias"])
+    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv5"), sd[prefix + ".ln5.weight"], sd[prefix + ".ln5.bias"])
+    return torch.sigmoid(x)
+
+
+# --------------------------------------------------------------------------- a6
+def melsyn_train(mel_in, textid, spk, sd):
+    """melSyn.forward, training branch, TTSModel.py:263-273.  Returns (Y, A)."""
+    K, V = text_encoder(textid, sd)
+    Q = audio_encoder(mel_in, spk, sd)
+    hidden = Q.shape[1]
+    A = torch.matmul(K.permute(0, 2, 1), Q) / math.sqrt(hidden)
+    A = F.softmax(A, dim=1)
+    R = torch.cat((torch.matmul(V, A), Q), dim=1)
+    return audio_decoder(R, sd), A
+
+
+# --------------------------------------------------------------------------- a8
+def melsyn_step(mel_prefix, textid, spk, sd, K=None, V=None, A_last=None, pma=None):
+    """melSyn.forward, eval branch, TTSModel.py:275-300.
+
+    The last attention column is masked outside the text window [pma, pma+2] with -2**32
+    (:282-286) before the softmax; older columns are taken from ``A_last`` (:289-290);
+    argmax over text positions gives the next ``pma`` (:291).
+    Returns (Y, A, pma_next[, K, V]) exactly as the reference does.
+    """
+    T = mel_prefix.shape[-1]
+    B = mel_prefix.shape[0]
+    first = T == 1
+    if first:
+        K, V = text_encoder(textid, sd)
+    N = K.shape[-1]
+    Q = audio_encoder(mel_prefix, spk, sd)
+    A = torch.matmul(K.permute(0, 2, 1), Q) / math.sqrt(Q.shape[1])
+    for k in range(B):
+        p = int(pma[k])
+        if p > 0:
+            A[k, :p, -1] = -2 ** 32
+        if p + 2 < N - 1:
+            A[k, p + 3:, -1] = -2 ** 32
+    A = F.softmax(A, dim=1)
+    if T > 1:
+        A = torch.cat((A_last, A[:, :, -1:]), dim=-1)
+    amax = torch.argmax(A, dim=1)
+    R = torch.cat((torch.matmul(V, A), Q), dim=1)
+    Y = audio_decoder(R, sd)
+    if first:
+        return Y, A, amax[:, -1], K, V
+    return Y, A, amax[:, -1]
+
+
+def synthesize_loop(textid, spk, sd, steps, freq_bins=80):
+    """The reference's free-running loop, synthesize.py:103-109 / ordinary.py:59-65.
+
+    Returns Y (B,F,steps+1), A (B,N,steps+1) and the int64 pma sequence (steps+1, B).
+    """
+    B = textid.shape[0]
+    init = torch.zeros(B, freq_bins, 1)
+    Y, A, pma, K, V = melsyn_step(init, textid, spk, sd, pma=torch.zeros(B, dtype=torch.long))
+    inputs = torch.cat((init, Y), dim=-1)
+    seq = [pma.clone()]
+    for _ in range(steps):
+        Y, A, pma = melsyn_step(inputs, None, spk, sd, K=K, V=V, A_last=A, pma=pma)
+        inputs = torch.cat((inputs, Y[:, :, -1:]), dim=-1)
+        seq.append(pma.clone())
+    return Y, A, torch.stack(seq)
+
+
+# --------------------------------------------------------------------------- a9/a10
+def _upsampling(x, sd, prefix):
+    """upsampling.forward, TTSModel.py:313-317: ConvTranspose1d(k=2,s=2) + 2 highway."""
+    x = F.conv_transpose1d(x, sd[prefix + ".deconv.weight"], sd[prefix + ".deconv.bias"], stride=2)
+    x = highway_conv(x, sd, prefix + ".hc1", 3, 1)
+    return highway_conv(x, sd, prefix + ".hc2", 3, 3)
+
+
+def ssrn(mel, sd):
+    """SSRN.forward, TTSModel.py:342-362 (note: no ReLU between ln3 and conv4, :355)."""
+    x = _ln_channels(_pw(mel, sd, "conv1"), sd["ln1.weight"], sd["ln1.bias"])
+    x = highway_conv(x, sd, "hc1", 3, 1)
+    x = highway_conv(x, sd, "hc2", 3, 3)
+    x = _upsampling(x, sd, "ups1")
+    x = _upsampling(x, sd, "ups2")
+    x = _ln_channels(_pw(x, sd, "conv2"), sd["ln2.weight"], sd["ln2.bias"])
+    x = highway_conv(x, sd, "hc3", 3, 1)
+    x = highway_conv(x, sd, "hc4", 3, 1)
+    x = _ln_channels(_pw(x, sd, "conv3"), sd["ln3.weight"], sd["ln3.bias"])
+    x = _ln_channels(_pw(x, sd, "conv4"), sd["ln4.weight"], sd["ln4.bias"])
+    x = _ln_channels(_pw(F.relu(x), sd, "conv5"), sd["ln5.weight"], sd["ln5.bias"])
+    x = _ln_channels(_pw(F.relu(x), sd, "conv6"), sd["ln6.weight"], sd["ln6.bias"])
+    return torch.sigmoid(x)
+
+
+# --------------------------------------------------------------------------- a12
+def guided_attention_mat(max_text_len, max_frame_num, g=0.2):
+    """train/ordinary.py:21-28.  W[n,t] = 1-exp(-(t/T - n/N)^2 / (2 g^2)).
+
+    The reference evaluates each entry in Python double precision and stores it into a
+    float32 tensor; doing the same arithmetic in float64 and rounding once is identical.
+    """
+    n = torch.arange(max_text_len, dtype=torch.float64).unsqueeze(1) / max_text_len
+    t = torch.arange(max_frame_num, dtype=torch.float64).unsqueeze(0) / max_frame_num
+    return (1 - torch.exp(-(t - n) ** 2 / (2 * g * g))).float()
+
+
+def text2mel_losses(Y, A, mel_gt, gaw):
+    """train/ordinary.py:230-236.  Returns (l1, bin_div, att).
+
+    The attention matrix is padded with -1 up to (MAX_TEXT_LEN, MAX_FRAME_NUM) and the
+    -1 entries are masked out again (:232-234); softmax outputs are never -1, so this is
+    sum(A * gaw[:N,:T]) / (B*N*T).
+    """
+    l1 = torch.mean(torch.abs(mel_gt - Y))
+    bd = torch.mean(-mel_gt * torch.log(Y + 1e-8) - (1 - mel_gt) * torch.log(1 - Y + 1e-8))
+    aug = F.pad(A, (0, gaw.shape[1] - A.shape[-1], 0, gaw.shape[0] - A.shape[-2]), value=-1)
+    mask = torch.ne(aug, -1).float()
+    att = torch.sum(mask * aug * gaw) / torch.sum(mask)
+    return l1, bd, att
+
+
+def ssrn_losses(P, lin_gt):
+    """train/ordinary.py:249-252.  Returns (l1, bin_div)."""
+    l1 = torch.mean(torch.abs(lin_gt - P))
+    bd = torch.mean(-lin_gt * torch.log(P + 1e-8) - (1 - lin_gt) * torch.log(1 - P + 1e-8))
+    return l1, bd
+
+
+# --------------------------------------------------------------------------- a13
+def adam_step(p, g, m, v, step, lr=2e-4, b1=0.5, b2=0.9, eps=1e-6):
+    """torch.optim.Adam as configured at train/ordinary.py:182 (config.json:41-46).
+
+    In-place on p, m, v; ``step`` is the 1-based step count.  Mirrors torch's
+    single-tensor Adam: denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= lr/(1-b1^t) * m/denom.
+    """
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+    return p

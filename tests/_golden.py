@@ -1,0 +1,31 @@
+"""Helpers shared by the tests: load tests/golden fixtures as torch tensors."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def sub(d, prefix, to_torch=True, device=None):
+    """Entries of ``d`` under ``prefix`` with the prefix stripped."""
+    out = {}
+    for k, v in d.items():
+        if k.startswith(prefix):
+            out[k[len(prefix):]] = torch.from_numpy(np.array(v)).to(device) if to_torch else v
+    return out
+
+
+def t(a, device=None):
+    return torch.from_numpy(np.array(a)).to(device)
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))

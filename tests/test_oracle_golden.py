@@ -1,0 +1,112 @@
+"""Pins the CPU oracle (oracle/*.py) against golden vectors produced by the real reference
+(oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from _golden import load, sub, t, rel_err
+from oracle import ge2e_oracle as GO
+from oracle import tts_oracle as TO
+
+TOL = 2e-6
+
+
+def test_highway_fwd_bwd():
+    g = load("highway.npz")
+    for i, (k, d, causal) in enumerate(g["configs"]):
+        pre = "c%d/" % i
+        sd = {("hc." + n): v.clone().requires_grad_(True) for n, v in sub(g, pre + "sd/").items()}
+        x = t(g[pre + "x"]).requires_grad_(True)
+        y = TO.highway_conv(x, sd, "hc", int(k), int(d), bool(causal))
+        assert rel_err(y, t(g[pre + "y"])) < TOL
+        y.backward(t(g[pre + "dy"]))
+        assert rel_err(x.grad, t(g[pre + "dx"])) < 1e-5
+        for n, gr in sub(g, pre + "grad/").items():
+            assert rel_err(sd["hc." + n].grad, gr) < 1e-5, n
+
+
+def test_melsyn_train_and_losses():
+    g = load("melsyn_train.npz")
+    sd = {n: v.clone().requires_grad_(True) for n, v in sub(g, "sd/").items()}
+    Y, A = TO.melsyn_train(t(g["mel_in"]), t(g["text"]), t(g["spk"]), sd)
+    assert rel_err(Y, t(g["Y"])) < TOL
+    assert rel_err(A, t(g["A"])) < TOL
+    gaw = TO.guided_attention_mat(24, 32)
+    assert torch.equal(gaw, t(g["gaw"]))
+    l1, bd, att = TO.text2mel_losses(Y, A, t(g["mel_gt"]), gaw)
+    for mine, ref in ((l1, "l1"), (bd, "bd"), (att, "att")):
+        assert abs(float(mine) - float(g[ref])) < 1e-6 * max(1.0, abs(float(g[ref])))
+    (l1 + bd + att).backward()
+    worst = max(rel_err(sd[n].grad, gr) for n, gr in sub(g, "grad/").items())
+    assert worst < 2e-4, worst
+
+
+def test_melsyn_eval_loop_indices_exact():
+    g = load("melsyn_eval.npz")
+    sd = sub(g, "sd/")
+    with torch.no_grad():
+        Y, A, pma = TO.synthesize_loop(t(g["text"]), t(g["spk"]), sd, int(g["steps"]))
+    assert torch.equal(pma, t(g["pma"]))          # attention indices: bit-exact
+    assert rel_err(Y, t(g["Y"])) < 1e-5
+    assert rel_err(A, t(g["A"])) < 1e-5
+    assert float(g["margins"].min()) > 1e-2        # recorded top-2 margin >> rounding
+
+
+def test_ssrn_small_and_full():
+    g = load("ssrn_small.npz")
+    sd = {n: v.clone().requires_grad_(True) for n, v in sub(g, "sd/").items()}
+    mel = t(g["mel"]).requires_grad_(True)
+    P = TO.ssrn(mel, sd)
+    assert rel_err(P, t(g["P"])) < TOL
+    l1, bd = TO.ssrn_losses(P, t(g["lin"]))
+    assert abs(float(l1) - float(g["l1"])) < 1e-6 and abs(float(bd) - float(g["bd"])) < 1e-6
+    (l1 + bd).backward()
+    assert rel_err(mel.grad, t(g["dmel"])) < 2e-4
+    worst = max(rel_err(sd[n].grad, gr) for n, gr in sub(g, "grad/").items())
+    assert worst < 2e-4, worst
+
+
+def test_gaw_probes():
+    g = load("gaw.npz")
+    W = TO.guided_attention_mat(186, 325)
+    assert np.array_equal(W.numpy()[g["n"], g["t"]], g["w"])
+    assert np.array_equal(W.numpy()[93], g["row93"])
+    assert abs(float(W.double().sum()) - float(g["total"])) < 1e-6
+
+
+def test_adam_matches_torch():
+    g = load("adam.npz")
+    p = t(g["p0"]).clone()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for s in (1, 2, 3):
+        TO.adam_step(p, t(g["g%d" % s]), m, v, s)
+        assert rel_err(p, t(g["p%d" % s])) < 1e-6
+
+
+def test_ge2e_embedder():
+    g = load("ge2e_embedder.npz")
+    sd = sub(g, "sd/")
+    x = t(g["x"])
+    hs = GO.lstm_stack(x, sd, 3)
+    assert rel_err(hs, t(g["h_last_layer"])) < 1e-5
+    e = GO.speech_embedder(x, sd)
+    assert rel_err(e, t(g["e"])) < 1e-5
+
+
+def test_ge2e_loss_and_known_answer():
+    g = load("ge2e_loss.npz")
+    emb = t(g["emb"]).requires_grad_(True)
+    w = torch.tensor(10.0, requires_grad=True)
+    b = torch.tensor(-5.0, requires_grad=True)
+    assert rel_err(GO.ge2e_cossim(emb), t(g["cossim"])) < 1e-5
+    loss, _ = GO.ge2e_loss(emb, w, b)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    assert rel_err(emb.grad, t(g["demb"])) < 1e-4
+    assert abs(float(w.grad) - float(g["dw"])) < 1e-4 * max(1, abs(float(g["dw"])))
+    assert abs(float(b.grad) - float(g["db"])) < 1e-4 * max(1, abs(float(g["db"])))
+    # the reference's own known-answer case (GE2E/utils.py:89-96): loss = 5.2501
+    kl, kper = GO.ge2e_loss(t(g["kat_emb"]), 1.0, 0.0)
+    assert rel_err(GO.ge2e_cossim(t(g["kat_emb"])), t(g["kat_cossim"])) < 1e-6
+    assert abs(float(kl) - 5.2501) < 1e-4 and abs(float(kl) - float(g["kat_loss"])) < 1e-5
+    assert rel_err(kper, t(g["kat_per"])) < 1e-5
