@@ -1,0 +1,183 @@
+/* libssv_hip.so -- C ABI of the MI355X (gfx950) hot path of SpoofSV.
+ *
+ * The reference (MingruiYuan/SpoofSV) is pure Python on torch and has NO plugin / operator / FFI
+ * interface: its hot path is the nn.Module surface of models/TTSModel.py and
+ * GE2E/speech_embedder_net.py.  Each entry point below therefore replaces a *module forward (or its
+ * autograd backward)* of the reference, cited as file:line; a binding is a ctypes stub
+ * (INTEGRATION.md shows the one a maintainer of the reference would add).
+ *
+ * Conventions (all entries):
+ *   - every pointer is a DEVICE pointer to caller-owned memory; fp32 unless stated; text ids and
+ *     attention indices are int64.  Activations are (B, C, T) with T fastest and rows contiguous
+ *     (channel stride = T); `*_bs` arguments are the batch stride in floats (C*T when dense), which
+ *     lets a caller pass channel slices of a wider tensor (K|V halves, the R|Q concatenation).
+ *   - no allocation, no ownership transfer, no host synchronisation: work is enqueued on `stream`
+ *     (a hipStream_t; NULL = default stream) and the call returns.  Safe under hipGraph capture.
+ *   - scratch memory is passed as (ws, ws_bytes); the matching *_workspace() query gives the size.
+ *   - return value: 0 on success, -1 bad shape/argument, -2 unsupported configuration, otherwise
+ *     -(int)hipError_t.  ssv_last_error() returns a thread-local message for the last failure.
+ *   - re-entrant; callable from any host thread (torch's autograd thread calls the *_bwd entries).
+ *   - outputs listed as "saved" are the tensors the matching backward needs; the caller owns them.
+ */
+#ifndef SSV_HIP_H
+#define SSV_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ssv_stream_t; /* hipStream_t */
+
+int ssv_version(void);            /* ABI version, currently 1 */
+const char* ssv_arch(void);       /* "gfx950" */
+const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
+
+/* ---- Conv1d (stride 1, kernel 1 or 3, dilated, "same" or causal zero padding) -------------------
+ * Replaces nn.Conv1d as used at models/TTSModel.py:59,78 (highway), :115-117, :154-158, :203-214,
+ * :323-339 (kernel 1) and nn.Linear on (B, D, 1) speaker codes (:150-151, :174, :179).
+ * y(b,o,t) = bias[o] + bias_b[b*Cout+o] + sum_{c,j} w[o,c,j] * x(b,c,t + (j-j0)*dilation),
+ * j0 = (k-1)/2 ("same", :57-59) or k-1 (causal: 2*pad zeros on the left, :72-74).
+ * bias and bias_b (the broadcast speaker term of :175,:180) may be NULL. */
+int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b,
+                   float* y, long y_bs, int B, int Cin, int Cout, int L, int k, int dilation, int causal,
+                   ssv_stream_t stream);
+/* dx = conv1d_transpose(dy, w) [+ dx_add if non-NULL, same layout as dx]; ws holds w transposed. */
+size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k);
+int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const float* dx_add, float* dx, long dx_bs,
+                        int B, int Cin, int Cout, int L, int k, int dilation, int causal,
+                        void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* dw(o,c,j) = sum_{b,t} dy(b,o,t) x(b,c,t+(j-j0)*dilation); split over the batch into slabs, summed
+ * in a fixed order (bitwise reproducible). */
+size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int k);
+int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* x, long x_bs, float* dw,
+                          int B, int Cin, int Cout, int L, int k, int dilation, int causal,
+                          void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* out(b,c) = sum_t x(b,c,t): gradient of a (B,C,1) broadcast term / of a bias per batch item. */
+int ssv_rowsum(const float* x, long x_bs, float* out, int B, int C, int L, ssv_stream_t stream);
+/* out[i] = sum_{z<Z} slabs[z*stride + i], i < n, summed in index order (bitwise reproducible). */
+int ssv_sum_slabs(const float* slabs, float* out, long n, int Z, long stride, ssv_stream_t stream);
+/* dst(b, 0:n) = src(b, 0:n) for B rows with independent row strides (the Q half of torch.cat((R, Q), 1),
+ * models/TTSModel.py:270). */
+int ssv_copy_rows(const float* src, long src_bs, float* dst, long dst_bs, int B, long n, ssv_stream_t stream);
+
+/* ---- LayerNorm over channels (+ activation) ----------------------------------------------------
+ * Replaces `ln(x.permute(0,2,1)).permute(0,2,1)` followed by F.relu / F.sigmoid,
+ * models/TTSModel.py:129-131, :175-180, :219-231, :344-361.  act: 0 none, 1 relu, 2 sigmoid.
+ * stats (B,2,L) = mean, rstd: saved for backward (may be NULL for inference). */
+int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const float* beta,
+                           float* y, long y_bs, float* stats, int B, int C, int L, int act, ssv_stream_t stream);
+size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L);
+/* dx: gradient w.r.t. the pre-LN input; pgrads (3,C) = dgamma, dbeta, sum_{b,t} dx (bias gradient of
+ * the producing conv). */
+int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* stats,
+                           const float* gamma, const float* beta, float* dx, long dx_bs, float* pgrads,
+                           int B, int C, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
+
+/* ---- highwayConv ---------------------------------------------------------------------------------
+ * Replaces highwayConv.forward, models/TTSModel.py:63-84:
+ *   h = conv(x) (2C channels); y = sigmoid(LN1(h[:C])) * LN2(h[C:]) + (1 - sigmoid(LN1(h[:C]))) * x.
+ * h (B,2C,L) dense and stats (B,4,L) = mean1, rstd1, mean2, rstd2 are saved for backward. */
+int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias,
+                           const float* g1, const float* b1, const float* g2, const float* b2,
+                           float* h, float* stats, float* y, long y_bs,
+                           int B, int C, int L, int k, int dilation, int causal, ssv_stream_t stream);
+size_t ssv_highway_conv1d_bwd_workspace(int B, int C, int L, int k);
+/* Outputs: dx (B,C,L), dw (2C,C,k), pgrads (6,C) = dgamma1, dbeta1, dgamma2, dbeta2, dbias[:C], dbias[C:]. */
+int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w,
+                           const float* g1, const float* b1, const float* g2, const float* b2,
+                           const float* h, const float* stats, float* dx, long dx_bs, float* dw, float* pgrads,
+                           int B, int C, int L, int k, int dilation, int causal,
+                           void* ws, size_t ws_bytes, ssv_stream_t stream);
+
+/* ---- textEmbedding -------------------------------------------------------------------------------
+ * Replaces textEmbedding.forward, models/TTSModel.py:25-35 (one-hot scatter + Linear):
+ * y(b,e,n) = w[e, ids(b,0,n)] + bias[e]; w is the nn.Linear weight (E, vocab).  ids int64 (B,1,N);
+ * an id outside [0, vocab) contributes the bias only (the reference would raise in scatter_). */
+int ssv_text_embed_fwd(const int64_t* ids, const float* w, const float* bias, float* y,
+                       int B, int N, int E, int vocab, ssv_stream_t stream);
+int ssv_text_embed_bwd(const int64_t* ids, const float* dy, float* dw, float* dbias,
+                       int B, int N, int E, int vocab, ssv_stream_t stream);
+
+/* ---- attention (training) ------------------------------------------------------------------------
+ * Replaces models/TTSModel.py:266-270: A = softmax_N(K^T Q / sqrt(d)); R = V A; cat(R, Q).
+ * k, v: (B,d,N) with batch stride kv_bs; q: (B,d,T); a: (B,N,T) dense (returned attention, saved);
+ * r: (B,d,T) with batch stride r_bs (pass the first half of the (B,2d,T) decoder input). */
+int ssv_attention_train_fwd(const float* k, const float* v, long kv_bs, const float* q, long q_bs,
+                            float* a, float* r, long r_bs, int B, int d, int N, int T, ssv_stream_t stream);
+size_t ssv_attention_train_bwd_workspace(int B, int d, int N, int T);
+/* dr: grad of R; da_ext: extra dL/dA (guided-attention loss), may be NULL; dq_add: gradient reaching
+ * Q through the concatenation, added into dq (may be NULL).  dk, dv have batch stride dkv_bs. */
+int ssv_attention_train_bwd(const float* dr, long dr_bs, const float* da_ext, const float* dq_add, long dq_add_bs,
+                            const float* k, const float* v, long kv_bs, const float* q, long q_bs, const float* a,
+                            float* dk, float* dv, long dkv_bs, float* dq, long dq_bs,
+                            int B, int d, int N, int T, void* ws, size_t ws_bytes, ssv_stream_t stream);
+
+/* ---- attention (one synthesis step) ---------------------------------------------------------------
+ * Replaces models/TTSModel.py:281-291 for the newest frame: logits of the last query column, masked
+ * outside the text window [pma, pma+2] with -2^32 (:282-286), softmax over N, argmax -> pma_out.
+ * q_last: (B,d) column t of Q (element stride q_cs between channels, batch stride q_bs);
+ * a: (B,N,a_T) attention buffer, column `col` is written.  pma_in/pma_out int64 (B). */
+int ssv_attention_step(const float* k, long kv_bs, const float* q_last, long q_bs, long q_cs,
+                       const int64_t* pma_in, float* a, int a_T, int col, int64_t* pma_out,
+                       int B, int d, int N, ssv_stream_t stream);
+/* r(b,c,t) = sum_n v(b,c,n) a(b,n,t) for t < T (a has row stride a_T). */
+int ssv_attention_apply(const float* v, long kv_bs, const float* a, int a_T, float* r, long r_bs,
+                        int B, int d, int N, int T, ssv_stream_t stream);
+
+/* ---- ConvTranspose1d(kernel 2, stride 2) ----------------------------------------------------------
+ * Replaces upsampling.deconv, models/TTSModel.py:309,314.  w: (Cin, Cout, 2) as nn.ConvTranspose1d.
+ * y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t). */
+int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
+                          int B, int Cin, int Cout, int L, ssv_stream_t stream);
+size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout);
+int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w,
+                          float* dx, long dx_bs, float* dw, float* dbias,
+                          int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
+
+/* ---- losses ----------------------------------------------------------------------------------------
+ * Replaces train/ordinary.py:230-231 / :249-250: out[0] = mean|gt - y|,
+ * out[1] = mean(-gt*log(y+1e-8) - (1-gt)*log(1-y+1e-8)) over n elements (dense tensors). */
+size_t ssv_spec_losses_workspace(long n);
+int ssv_spec_losses_fwd(const float* y, const float* gt, long n, float* out, void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* dy = gscale[0] * dl1/dy + gscale[1] * dbd/dy; gscale is a DEVICE pointer to 2 floats. */
+int ssv_spec_losses_bwd(const float* y, const float* gt, long n, const float* gscale, float* dy, ssv_stream_t stream);
+/* Replaces train/ordinary.py:232-234: out[0] = sum(a * gaw[:N,:T]) / (B*N*T); gaw row stride gaw_T. */
+size_t ssv_guided_att_loss_workspace(int B, int N, int T);
+int ssv_guided_att_loss_fwd(const float* a, const float* gaw, int gaw_T, float* out, int B, int N, int T,
+                            void* ws, size_t ws_bytes, ssv_stream_t stream);
+int ssv_guided_att_loss_bwd(const float* gaw, int gaw_T, const float* gscale, float* da, int B, int N, int T,
+                            ssv_stream_t stream);
+
+/* ---- Adam -------------------------------------------------------------------------------------------
+ * Replaces optim.Adam(...).step(), train/ordinary.py:182,238 (config.json:41-46), for many tensors in
+ * one launch.  `chunks` is a DEVICE array describing contiguous pieces of parameters. */
+typedef struct { float* p; const float* g; float* m; float* v; long n; } ssv_adam_chunk;
+/* step: 1-based step count.  If step_dev (DEVICE int*) is non-NULL the count is *step_dev + 1 and the
+ * counter is incremented on the stream after the update, so a captured hipGraph advances on replay. */
+int ssv_adam_multi(const ssv_adam_chunk* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
+                   int step, int* step_dev, ssv_stream_t stream);
+
+/* ---- GE2E speaker embedder --------------------------------------------------------------------------
+ * Replaces SpeechEmbedder.forward, GE2E/speech_embedder_net.py:27-33: 3-layer nn.LSTM(batch_first) ->
+ * last frame -> Linear -> x / ||x||.  x: (Bn, T, F) row-major as the reference feeds it.
+ * Weights in torch layout: w_ih[l] (4H, F or H), w_hh[l] (4H, H), b_ih[l], b_hh[l] (4H), gate order
+ * i, f, g, o.  h_last: (Bn, H) output of the top layer at the last frame. */
+size_t ssv_lstm_fwd_workspace(int Bn, int T, int F, int H, int layers);
+int ssv_lstm_fwd(const float* x, const float* const* w_ih, const float* const* w_hh,
+                 const float* const* b_ih, const float* const* b_hh, float* h_last,
+                 int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* e = normalize(h W^T + b): h (Bn,H), w (P,H), e (Bn,P). */
+size_t ssv_proj_l2norm_fwd_workspace(int Bn, int P);
+int ssv_proj_l2norm_fwd(const float* h, const float* w, const float* bias, float* e, int Bn, int H, int P,
+                        void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* Replaces GE2ELoss.forward, GE2E/speech_embedder_net.py:43-49 with GE2E/utils.py:16-55.
+ * emb (N,M,D); w, b device scalars; loss[0] = total; per (N,M) per-embedding losses (may be NULL). */
+size_t ssv_ge2e_loss_fwd_workspace(int N, int M, int D);
+int ssv_ge2e_loss_fwd(const float* emb, const float* w, const float* b, float* loss, float* per,
+                      int N, int M, int D, void* ws, size_t ws_bytes, ssv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSV_HIP_H */

@@ -1,0 +1,387 @@
+// extern "C" entry points of libssv_hip.so (see include/ssv_hip.h): argument checking and the
+// composition of kernel launches for each replaced module of the reference.  No allocation, no
+// synchronisation: everything is enqueued on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <math.h>
+#include "ssv_common.h"
+#include "../../include/ssv_hip.h"
+
+// ---- error state ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+int ssv_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int ssv_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  ssv_fail(0, "%s: launch failed: %s", what, hipGetErrorString(e));
+  return -(int)e;
+}
+extern "C" int ssv_version(void) { return 1; }
+extern "C" const char* ssv_arch(void) { return "gfx950"; }
+extern "C" const char* ssv_last_error(void) { return g_err; }
+
+// launchers defined in the other translation units
+int ssv_launch_ln_gate_fwd(const float*, long, const float*, long, const float*, const float*, const float*, const float*, float*, long, float*, int, int, int, hipStream_t);
+int ssv_launch_ln_gate_bwd(const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*, const float*, float*, float*, long, float*, float*, int, int, int, hipStream_t);
+int ssv_ln_gate_bwd_nblk(int B, int L);
+int ssv_launch_ln_act_fwd(const float*, long, const float*, const float*, float*, long, float*, int, int, int, int, hipStream_t);
+int ssv_launch_ln_act_bwd(const float*, long, const float*, long, const float*, const float*, const float*, float*, long, float*, float*, int, int, int, int, hipStream_t);
+int ssv_launch_softmax_cols(float*, int, int, int, hipStream_t);
+int ssv_launch_softmax_cols_bwd(const float*, float*, const float*, float, int, int, int, hipStream_t);
+int ssv_launch_lstm_in_transpose(const float*, float*, int, int, int, hipStream_t);
+int ssv_launch_lstm_cell(const float*, float*, float*, int, int, int, hipStream_t);
+int ssv_launch_transpose_out(const float*, float*, int, int, hipStream_t);
+int ssv_launch_l2norm_rows(const float*, float*, int, int, hipStream_t);
+
+static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+static int conv_shifts(int k, int dilation, int causal, int* shift) {
+  SSV_CHECK(k == 1 || k == 3, SSV_UNSUPPORTED, "conv1d: kernel_size %d not supported (1 or 3)", k);
+  SSV_CHECK(dilation >= 1 && dilation * (k - 1) <= 54, SSV_UNSUPPORTED, "conv1d: dilation %d not supported (k=%d)", dilation, k);
+  const int j0 = causal ? k - 1 : (k - 1) / 2;
+  for (int j = 0; j < 3; ++j) shift[j] = j < k ? (j - j0) * dilation : 0;
+  return 0;
+}
+
+static GemmNN nn_zero() {
+  GemmNN g;
+  g.A = nullptr; g.sab = g.sam = g.sac = g.saj = 0;
+  g.X = nullptr; g.sxb = g.sxc = 0; g.sxn = 1; g.Lx = 0;
+  g.C = nullptr; g.scb = g.scm = 0; g.scn = 1;
+  g.bias = nullptr; g.bias_b = nullptr; g.sbb = 0;
+  g.R = nullptr; g.srb = g.srm = 0; g.srn = 1;
+  g.M = g.N = g.Kc = 0; g.KT = 1; g.B = 1;
+  g.shift[0] = g.shift[1] = g.shift[2] = 0;
+  g.alpha = 1.f;
+  return g;
+}
+static GemmNT nt_zero() {
+  GemmNT g;
+  g.A = nullptr; g.sab = g.sam = 0; g.sat = 1; g.La = 0;
+  g.X = nullptr; g.sxb = g.sxc = 0; g.sxn = 1; g.Lx = 0;
+  g.C = nullptr; g.scz = g.scm = 0; g.scc = 1; g.scj = 0;
+  g.M = g.Nc = 0; g.KT = 1; g.B = 1; g.Z = 1; g.bstep = 1;
+  g.shift[0] = g.shift[1] = g.shift[2] = 0;
+  return g;
+}
+
+// ---- Conv1d ----------------------------------------------------------------------------------------
+extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b, float* y, long y_bs,
+                              int B, int Cin, int Cout, int L, int k, int dilation, int causal, ssv_stream_t stream) {
+  SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_fwd: bad argument B=%d Cin=%d Cout=%d L=%d", B, Cin, Cout, L);
+  SSV_CHECK(x_bs >= (long)Cin * L && y_bs >= (long)Cout * L, SSV_BAD_SHAPE, "conv1d_fwd: batch stride smaller than C*L");
+  GemmNN g = nn_zero();
+  SSV_TRY(conv_shifts(k, dilation, causal, g.shift));
+  g.A = w; g.sam = (long)Cin * k; g.sac = k; g.saj = 1;
+  g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
+  g.C = y; g.scb = y_bs; g.scm = L;
+  g.bias = bias; g.bias_b = bias_b; g.sbb = Cout;
+  g.M = Cout; g.N = L; g.Kc = Cin; g.KT = k; g.B = B;
+  return ssv_launch_gemm_nn(g, (hipStream_t)stream);
+}
+
+extern "C" size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k) { return align256((size_t)Cin * Cout * k * sizeof(float)); }
+extern "C" int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const float* dx_add, float* dx, long dx_bs,
+                                   int B, int Cin, int Cout, int L, int k, int dilation, int causal,
+                                   void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dy && w && dx && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_data: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_data_workspace(Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_bwd_data: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  GemmNN g = nn_zero();
+  SSV_TRY(conv_shifts(k, dilation, causal, g.shift));
+  for (int j = 0; j < 3; ++j) g.shift[j] = -g.shift[j];
+  float* wt = (float*)ws;                                 // wt[c][o][j] = w[o][c][j]
+  SSV_TRY(ssv_launch_pack_wt(w, wt, Cout, Cin, k, st));
+  g.A = wt; g.sam = (long)Cout * k; g.sac = k; g.saj = 1;
+  g.X = dy; g.sxb = dy_bs; g.sxc = L; g.Lx = L;
+  g.C = dx; g.scb = dx_bs; g.scm = L;
+  if (dx_add) { g.R = dx_add; g.srb = dx_bs; g.srm = L; }
+  g.M = Cin; g.N = L; g.Kc = Cout; g.KT = k; g.B = B;
+  return ssv_launch_gemm_nn(g, st);
+}
+
+static int dw_splits(int B, int M, int Nc, int k) {
+  const int nch = (k == 3) ? 32 : (Nc > 48 ? 96 : 32);
+  const int tiles = ssv_cdiv(M, 128) * ssv_cdiv(Nc, nch);
+  int z = ssv_cdiv(512, tiles);
+  if (z > B) z = B;
+  if (z < 1) z = 1;
+  return z;
+}
+extern "C" size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int k) {
+  return align256((size_t)dw_splits(B, Cout, Cin, k) * Cout * Cin * k * sizeof(float));
+}
+extern "C" int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* x, long x_bs, float* dw,
+                                     int B, int Cin, int Cout, int L, int k, int dilation, int causal,
+                                     void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dy && x && dw && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_weight: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_bwd_weight: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  GemmNT g = nt_zero();
+  SSV_TRY(conv_shifts(k, dilation, causal, g.shift));
+  const int Z = dw_splits(B, Cout, Cin, k);
+  const long n = (long)Cout * Cin * k;
+  g.A = dy; g.sab = dy_bs; g.sam = L; g.La = L;
+  g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
+  g.C = (Z == 1) ? dw : (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = k; g.scj = 1;
+  g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
+  SSV_TRY(ssv_launch_gemm_nt(g, st));
+  if (Z > 1) SSV_TRY(ssv_launch_reduce_slabs((const float*)ws, dw, n, Z, n, st));
+  return 0;
+}
+
+// ---- LayerNorm over channels ------------------------------------------------------------------------
+extern "C" int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const float* beta, float* y, long y_bs, float* stats,
+                                      int B, int C, int L, int act, ssv_stream_t stream) {
+  SSV_CHECK(x && gamma && beta && y && B > 0 && C > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "channel_ln_act_fwd: bad argument");
+  SSV_CHECK(B <= 65535, SSV_UNSUPPORTED, "channel_ln_act_fwd: batch %d exceeds grid.y", B);
+  return ssv_launch_ln_act_fwd(x, x_bs, gamma, beta, y, y_bs, stats, B, C, L, act, (hipStream_t)stream);
+}
+extern "C" size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L) { return align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * C * sizeof(float)); }
+extern "C" int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* stats, const float* gamma, const float* beta,
+                                      float* dx, long dx_bs, float* pgrads, int B, int C, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dy && x && stats && gamma && beta && dx && pgrads && B > 0 && C > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "channel_ln_act_bwd: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_channel_ln_act_bwd_workspace(B, C, L), SSV_BAD_SHAPE, "channel_ln_act_bwd: workspace too small");
+  return ssv_launch_ln_act_bwd(dy, dy_bs, x, x_bs, stats, gamma, beta, dx, dx_bs, (float*)ws, pgrads, B, C, L, act, (hipStream_t)stream);
+}
+
+// ---- highwayConv ---------------------------------------------------------------------------------------
+extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* g1, const float* b1,
+                                      const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
+                                      int B, int C, int L, int k, int dilation, int causal, ssv_stream_t stream) {
+  SSV_CHECK(x && w && g1 && b1 && g2 && b2 && h && y, SSV_BAD_SHAPE, "highway_conv1d_fwd: null argument");
+  SSV_TRY(ssv_conv1d_fwd(x, x_bs, w, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, stream));
+  return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
+}
+
+struct HwWs { size_t dh, part, wt, slabs, total; };
+static HwWs hw_ws(int B, int C, int L, int k) {
+  HwWs s;
+  s.dh = 0;
+  s.part = s.dh + align256((size_t)B * 2 * C * L * sizeof(float));
+  s.wt = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float));
+  s.slabs = s.wt + ssv_conv1d_bwd_data_workspace(C, 2 * C, k);
+  s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, C, 2 * C, k);
+  return s;
+}
+extern "C" size_t ssv_highway_conv1d_bwd_workspace(int B, int C, int L, int k) { return hw_ws(B, C, L, k).total; }
+extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const float* g1, const float* b1,
+                                      const float* g2, const float* b2, const float* h, const float* stats, float* dx, long dx_bs, float* dw,
+                                      float* pgrads, int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes,
+                                      ssv_stream_t stream) {
+  SSV_CHECK(dy && x && w && g1 && b1 && g2 && b2 && h && stats && dx && dw && pgrads, SSV_BAD_SHAPE, "highway_conv1d_bwd: null argument");
+  SSV_CHECK(B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_conv1d_bwd: bad shape B=%d C=%d L=%d", B, C, L);
+  const HwWs s = hw_ws(B, C, L, k);
+  SSV_CHECK(ws && ws_bytes >= s.total, SSV_BAD_SHAPE, "highway_conv1d_bwd: workspace too small (%zu < %zu)", ws_bytes, s.total);
+  char* base = (char*)ws;
+  float* dH = (float*)(base + s.dh);
+  // gate + both LayerNorms backward: dH (B,2C,L), the residual-path gradient dy*(1-g) into dx, parameter partials
+  SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, (float*)(base + s.part), pgrads, B, C, L, (hipStream_t)stream));
+  // dx += conv^T(dH)
+  SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, w, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
+  return ssv_conv1d_bwd_weight(dH, (long)2 * C * L, x, x_bs, dw, B, C, 2 * C, L, k, dilation, causal, base + s.slabs, s.total - s.slabs, stream);
+}
+
+// ---- attention -------------------------------------------------------------------------------------------
+extern "C" int ssv_attention_apply(const float* v, long kv_bs, const float* a, int a_T, float* r, long r_bs, int B, int d, int N, int T, ssv_stream_t stream) {
+  SSV_CHECK(v && a && r && B > 0 && d > 0 && N > 0 && T > 0 && a_T >= T, SSV_BAD_SHAPE, "attention_apply: bad argument");
+  GemmNN g = nn_zero();
+  g.A = v; g.sab = kv_bs; g.sam = N; g.sac = 1; g.saj = 0;
+  g.X = a; g.sxb = (long)N * a_T; g.sxc = a_T; g.Lx = T;
+  g.C = r; g.scb = r_bs; g.scm = T;
+  g.M = d; g.N = T; g.Kc = N; g.B = B;
+  return ssv_launch_gemm_nn(g, (hipStream_t)stream);
+}
+extern "C" int ssv_attention_train_fwd(const float* k, const float* v, long kv_bs, const float* q, long q_bs, float* a, float* r, long r_bs,
+                                       int B, int d, int N, int T, ssv_stream_t stream) {
+  SSV_CHECK(k && v && q && a && r && B > 0 && d > 0 && N > 0 && T > 0, SSV_BAD_SHAPE, "attention_train_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  GemmNN g = nn_zero();                       // scores(b,n,t) = sum_c k(b,c,n) q(b,c,t) / sqrt(d)
+  g.A = k; g.sab = kv_bs; g.sam = 1; g.sac = N; g.saj = 0;
+  g.X = q; g.sxb = q_bs; g.sxc = T; g.Lx = T;
+  g.C = a; g.scb = (long)N * T; g.scm = T;
+  g.M = N; g.N = T; g.Kc = d; g.B = B; g.alpha = 1.f / sqrtf((float)d);
+  SSV_TRY(ssv_launch_gemm_nn(g, st));
+  SSV_TRY(ssv_launch_softmax_cols(a, B, N, T, st));
+  return ssv_attention_apply(v, kv_bs, a, T, r, r_bs, B, d, N, T, stream);
+}
+extern "C" size_t ssv_attention_train_bwd_workspace(int B, int d, int N, int T) { (void)d; return align256((size_t)B * N * T * sizeof(float)); }
+extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float* da_ext, const float* dq_add, long dq_add_bs,
+                                       const float* k, const float* v, long kv_bs, const float* q, long q_bs, const float* a,
+                                       float* dk, float* dv, long dkv_bs, float* dq, long dq_bs, int B, int d, int N, int T,
+                                       void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dr && k && v && q && a && dk && dv && dq && B > 0 && d > 0 && N > 0 && T > 0, SSV_BAD_SHAPE, "attention_train_bwd: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_attention_train_bwd_workspace(B, d, N, T), SSV_BAD_SHAPE, "attention_train_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* dA = (float*)ws;
+  {  // dA(b,n,t) = sum_c v(b,c,n) dr(b,c,t)
+    GemmNN g = nn_zero();
+    g.A = v; g.sab = kv_bs; g.sam = 1; g.sac = N;
+    g.X = dr; g.sxb = dr_bs; g.sxc = T; g.Lx = T;
+    g.C = dA; g.scb = (long)N * T; g.scm = T;
+    g.M = N; g.N = T; g.Kc = d; g.B = B;
+    SSV_TRY(ssv_launch_gemm_nn(g, st));
+  }
+  {  // dv(b,c,n) = sum_t dr(b,c,t) a(b,n,t)
+    GemmNT g = nt_zero();
+    g.A = dr; g.sab = dr_bs; g.sam = T; g.La = T;
+    g.X = a; g.sxb = (long)N * T; g.sxc = T; g.Lx = T;
+    g.C = dv; g.scz = dkv_bs; g.scm = N; g.scc = 1;
+    g.M = d; g.Nc = N; g.B = B; g.Z = B; g.bstep = B;
+    SSV_TRY(ssv_launch_gemm_nt(g, st));
+  }
+  SSV_TRY(ssv_launch_softmax_cols_bwd(a, dA, da_ext, 1.f / sqrtf((float)d), B, N, T, st));   // dA now holds dScores
+  {  // dk(b,c,n) = sum_t q(b,c,t) ds(b,n,t)
+    GemmNT g = nt_zero();
+    g.A = q; g.sab = q_bs; g.sam = T; g.La = T;
+    g.X = dA; g.sxb = (long)N * T; g.sxc = T; g.Lx = T;
+    g.C = dk; g.scz = dkv_bs; g.scm = N; g.scc = 1;
+    g.M = d; g.Nc = N; g.B = B; g.Z = B; g.bstep = B;
+    SSV_TRY(ssv_launch_gemm_nt(g, st));
+  }
+  {  // dq(b,c,t) = sum_n k(b,c,n) ds(b,n,t) + dq_add
+    GemmNN g = nn_zero();
+    g.A = k; g.sab = kv_bs; g.sam = N; g.sac = 1;
+    g.X = dA; g.sxb = (long)N * T; g.sxc = T; g.Lx = T;
+    g.C = dq; g.scb = dq_bs; g.scm = T;
+    if (dq_add) { g.R = dq_add; g.srb = dq_add_bs; g.srm = T; }
+    g.M = d; g.N = T; g.Kc = N; g.B = B;
+    SSV_TRY(ssv_launch_gemm_nn(g, st));
+  }
+  return 0;
+}
+
+// ---- ConvTranspose1d(k=2, s=2) -----------------------------------------------------------------------------
+extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
+                                     int B, int Cin, int Cout, int L, ssv_stream_t stream) {
+  SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "deconv1d_k2s2_fwd: bad argument");
+  for (int j = 0; j < 2; ++j) {               // y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t)
+    GemmNN g = nn_zero();
+    g.A = w + j; g.sam = 2; g.sac = (long)2 * Cout;
+    g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
+    g.C = y + j; g.scb = y_bs; g.scm = (long)2 * L; g.scn = 2;
+    g.bias = bias;
+    g.M = Cout; g.N = L; g.Kc = Cin; g.B = B;
+    SSV_TRY(ssv_launch_gemm_nn(g, (hipStream_t)stream));
+  }
+  return 0;
+}
+static int deconv_splits(int B, int Cin, int Cout) { return dw_splits(B, Cin, Cout, 1); }
+extern "C" size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout) {
+  return align256((size_t)deconv_splits(B, Cin, Cout) * Cin * Cout * 2 * sizeof(float)) + align256((size_t)B * Cout * sizeof(float));
+}
+extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, float* dx, long dx_bs,
+                                     float* dw, float* dbias, int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dy && x && w && dx && dw && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "deconv1d_k2s2_bwd: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_deconv1d_k2s2_bwd_workspace(B, Cin, Cout), SSV_BAD_SHAPE, "deconv1d_k2s2_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int Z = deconv_splits(B, Cin, Cout);
+  const long n = (long)Cin * Cout * 2;
+  float* slabs = (float*)ws;
+  float* rs = (float*)((char*)ws + align256((size_t)Z * n * sizeof(float)));
+  for (int j = 0; j < 2; ++j) {
+    GemmNN g = nn_zero();                      // dx(b,c,t) (+)= sum_o w[c,o,j] dy(b,o,2t+j)
+    g.A = w + j; g.sam = (long)2 * Cout; g.sac = 2;
+    g.X = dy + j; g.sxb = dy_bs; g.sxc = (long)2 * L; g.sxn = 2; g.Lx = L;
+    g.C = dx; g.scb = dx_bs; g.scm = L;
+    if (j == 1) { g.R = dx; g.srb = dx_bs; g.srm = L; }
+    g.M = Cin; g.N = L; g.Kc = Cout; g.B = B;
+    SSV_TRY(ssv_launch_gemm_nn(g, st));
+    GemmNT t = nt_zero();                      // dw[c,o,j] = sum_{b,t} x(b,c,t) dy(b,o,2t+j)
+    t.A = x; t.sab = x_bs; t.sam = L; t.La = L;
+    t.X = dy + j; t.sxb = dy_bs; t.sxc = (long)2 * L; t.sxn = 2; t.Lx = L;
+    t.C = ((Z == 1) ? dw : slabs) + j; t.scz = n; t.scm = (long)2 * Cout; t.scc = 2;
+    t.M = Cin; t.Nc = Cout; t.B = B; t.Z = Z; t.bstep = Z;
+    SSV_TRY(ssv_launch_gemm_nt(t, st));
+  }
+  if (Z > 1) SSV_TRY(ssv_launch_reduce_slabs(slabs, dw, n, Z, n, st));
+  if (dbias) {
+    SSV_TRY(ssv_rowsum(dy, dy_bs, rs, B, Cout, 2 * L, stream));
+    SSV_TRY(ssv_launch_reduce_slabs(rs, dbias, Cout, B, Cout, st));
+  }
+  return 0;
+}
+
+// ---- GE2E speaker embedder ---------------------------------------------------------------------------------
+struct LstmWs { size_t xt, xp, seq0, seq1, g, c, total; };
+static LstmWs lstm_ws(int Bn, int T, int F, int H) {
+  LstmWs s;
+  s.xt = 0;
+  s.xp = s.xt + align256((size_t)T * F * Bn * sizeof(float));
+  s.seq0 = s.xp + align256((size_t)T * 4 * H * Bn * sizeof(float));
+  s.seq1 = s.seq0 + align256((size_t)T * H * Bn * sizeof(float));
+  s.g = s.seq1 + align256((size_t)T * H * Bn * sizeof(float));
+  s.c = s.g + align256((size_t)4 * H * Bn * sizeof(float));
+  s.total = s.c + align256((size_t)H * Bn * sizeof(float));
+  return s;
+}
+extern "C" size_t ssv_lstm_fwd_workspace(int Bn, int T, int F, int H, int layers) { (void)layers; return lstm_ws(Bn, T, F, H).total; }
+extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                            const float* const* b_hh, float* h_last, int Bn, int T, int F, int H, int layers,
+                            void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(x && w_ih && w_hh && b_ih && b_hh && h_last && Bn > 0 && T > 0 && F > 0 && H > 0 && layers > 0, SSV_BAD_SHAPE, "lstm_fwd: bad argument");
+  SSV_CHECK(T <= 65535, SSV_UNSUPPORTED, "lstm_fwd: T=%d exceeds grid.y", T);
+  const LstmWs s = lstm_ws(Bn, T, F, H);
+  SSV_CHECK(ws && ws_bytes >= s.total, SSV_BAD_SHAPE, "lstm_fwd: workspace too small (%zu < %zu)", ws_bytes, s.total);
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)ws;
+  float* xt = (float*)(base + s.xt);
+  float* xp = (float*)(base + s.xp);
+  float* seq[2] = {(float*)(base + s.seq0), (float*)(base + s.seq1)};
+  float* gbuf = (float*)(base + s.g);
+  float* cbuf = (float*)(base + s.c);
+  SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));    // [T][F][Bn]
+  const float* in = xt;
+  int Fin = F;
+  float* out = nullptr;
+  for (int l = 0; l < layers; ++l) {
+    out = seq[l & 1];
+    {  // input projection for every frame at once: xp[t] = W_ih in[t] + b_ih + b_hh    ("batch" = frame)
+      GemmNN g = nn_zero();
+      g.A = w_ih[l]; g.sam = Fin; g.sac = 1; g.saj = 1;
+      g.X = in; g.sxb = (long)Fin * Bn; g.sxc = Bn; g.Lx = Bn;
+      g.C = xp; g.scb = (long)4 * H * Bn; g.scm = Bn;
+      g.bias = b_ih[l]; g.bias_b = b_hh[l]; g.sbb = 0;
+      g.M = 4 * H; g.N = Bn; g.Kc = Fin; g.B = T;
+      SSV_TRY(ssv_launch_gemm_nn(g, st));
+    }
+    for (int t = 0; t < T; ++t) {
+      const float* gates = xp + (long)t * 4 * H * Bn;
+      if (t > 0) {  // gates = W_hh h_{t-1} + xp[t]
+        GemmNN g = nn_zero();
+        g.A = w_hh[l]; g.sam = H; g.sac = 1; g.saj = 1;
+        g.X = out + (long)(t - 1) * H * Bn; g.sxc = Bn; g.Lx = Bn;
+        g.C = gbuf; g.scm = Bn;
+        g.R = gates; g.srm = Bn;
+        g.M = 4 * H; g.N = Bn; g.Kc = H; g.B = 1;
+        SSV_TRY(ssv_launch_gemm_nn(g, st));
+        gates = gbuf;
+      }
+      SSV_TRY(ssv_launch_lstm_cell(gates, cbuf, out + (long)t * H * Bn, H, Bn, t == 0, st));
+    }
+    in = out;
+    Fin = H;
+  }
+  return ssv_launch_transpose_out(out + (long)(T - 1) * H * Bn, h_last, H, Bn, st);
+}
+
+extern "C" size_t ssv_proj_l2norm_fwd_workspace(int Bn, int P) { return align256((size_t)Bn * P * sizeof(float)); }
+extern "C" int ssv_proj_l2norm_fwd(const float* h, const float* w, const float* bias, float* e, int Bn, int H, int P,
+                                   void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(h && w && e && Bn > 0 && H > 0 && P > 0, SSV_BAD_SHAPE, "proj_l2norm_fwd: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_proj_l2norm_fwd_workspace(Bn, P), SSV_BAD_SHAPE, "proj_l2norm_fwd: workspace too small");
+  GemmNN g = nn_zero();                        // y[p][b] = sum_c w[p][c] h[b][c] + bias[p]
+  g.A = w; g.sam = H; g.sac = 1; g.saj = 1;
+  g.X = h; g.sxc = 1; g.sxn = H; g.Lx = Bn;
+  g.C = (float*)ws; g.scm = Bn;
+  g.bias = bias;
+  g.M = P; g.N = Bn; g.Kc = H; g.B = 1;
+  SSV_TRY(ssv_launch_gemm_nn(g, (hipStream_t)stream));
+  return ssv_launch_l2norm_rows((const float*)ws, e, P, Bn, (hipStream_t)stream);
+}

@@ -1,0 +1,120 @@
+// Attention softmax kernels (column softmax over the text axis N of a (B, N, T) score tensor) and the
+// fused single-step kernel used during synthesis (gfx950).  The two GEMMs around the softmax run on
+// the shared implicit-GEMM kernels (gemm_nn / gemm_nt); these kernels are HBM/L2-bound glue.
+#include "ssv_common.h"
+#include "../../include/ssv_hip.h"
+
+// One thread per (b, t) column; consecutive threads walk consecutive t, so every row read is coalesced.
+__global__ __launch_bounds__(256) void softmax_cols_kernel(float* __restrict__ s, int B, int N, int T) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * T) return;
+  const int b = (int)(i / T), t = (int)(i % T);
+  float* p = s + (long)b * N * T + t;
+  float mx = -INFINITY;
+  for (int n = 0; n < N; ++n) mx = fmaxf(mx, p[(long)n * T]);
+  float sum = 0.f;
+  for (int n = 0; n < N; ++n) { const float e = expf(p[(long)n * T] - mx); p[(long)n * T] = e; sum += e; }
+  const float inv = 1.f / sum;
+  for (int n = 0; n < N; ++n) p[(long)n * T] *= inv;
+}
+
+// ds = a * (da + da_ext - sum_n a*(da + da_ext)) * scale, in place on da.
+__global__ __launch_bounds__(256) void softmax_cols_bwd_kernel(const float* __restrict__ a, float* __restrict__ da,
+                                                               const float* __restrict__ da_ext, float scale, int B, int N, int T) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * T) return;
+  const int b = (int)(i / T), t = (int)(i % T);
+  const long base = (long)b * N * T + t;
+  float dot = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const long k = base + (long)n * T;
+    float g = da[k];
+    if (da_ext) g += da_ext[k];
+    dot += a[k] * g;
+  }
+  for (int n = 0; n < N; ++n) {
+    const long k = base + (long)n * T;
+    float g = da[k];
+    if (da_ext) g += da_ext[k];
+    da[k] = a[k] * (g - dot) * scale;
+  }
+}
+
+int ssv_launch_softmax_cols(float* s, int B, int N, int T, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_cols_kernel, dim3(ssv_cdiv((long)B * T, 256)), dim3(256), 0, st, s, B, N, T);
+  return ssv_check_launch("softmax_cols");
+}
+int ssv_launch_softmax_cols_bwd(const float* a, float* da, const float* da_ext, float scale, int B, int N, int T, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_cols_bwd_kernel, dim3(ssv_cdiv((long)B * T, 256)), dim3(256), 0, st, a, da, da_ext, scale, B, N, T);
+  return ssv_check_launch("softmax_cols_bwd");
+}
+
+// ---- synthesis step: one workgroup per batch item --------------------------------------------------
+// logits[n] = (sum_c k[c][n] q[c]) / sqrt(d); positions outside [pma, pma+2] are set to -2^32 exactly
+// as the reference does before its softmax (their exp underflows to 0); the new attention column and
+// the first arg-max index are written.
+#define STEP_MAXN 1024
+__global__ __launch_bounds__(256) void attention_step_kernel(const float* __restrict__ k, long kv_bs, const float* __restrict__ q, long q_bs, long q_cs,
+                                                             const int64_t* __restrict__ pma_in, float* __restrict__ a, int a_T, int col,
+                                                             int64_t* __restrict__ pma_out, int d, int N, float scale) {
+  __shared__ float logit[STEP_MAXN];
+  __shared__ float red[4];
+  __shared__ int redi[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* kb = k + (long)b * kv_bs;
+  const float* qb = q + (long)b * q_bs;
+  const int64_t pma = pma_in[b];
+  for (int n = tid; n < N; n += 256) {
+    float s = 0.f;
+    for (int c = 0; c < d; ++c) s = fmaf(kb[(long)c * N + n], qb[(long)c * q_cs], s);
+    s *= scale;
+    if (n < pma || n >= pma + 3) s = -4294967296.f;
+    logit[n] = s;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int n = tid; n < N; n += 256) mx = fmaxf(mx, logit[n]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int n = tid; n < N; n += 256) { const float e = expf(logit[n] - mx); logit[n] = e; sum += e; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  sum = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = 1.f / sum;
+  // arg-max over the normalised column (first index wins ties, as torch.argmax on CPU does)
+  float best = -1.f; int bi = N;
+  for (int n = tid; n < N; n += 256) {
+    const float p = logit[n] * inv;
+    a[((long)b * N + n) * a_T + col] = p;
+    if (p > best) { best = p; bi = n; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (red[w] > best || (red[w] == best && redi[w] < bi)) { best = red[w]; bi = redi[w]; }
+    pma_out[b] = bi;
+  }
+}
+
+extern "C" int ssv_attention_step(const float* k, long kv_bs, const float* q_last, long q_bs, long q_cs, const int64_t* pma_in,
+                                  float* a, int a_T, int col, int64_t* pma_out, int B, int d, int N, ssv_stream_t stream) {
+  SSV_CHECK(B > 0 && d > 0 && N > 0 && col >= 0 && col < a_T, SSV_BAD_SHAPE, "attention_step: bad shape B=%d d=%d N=%d col=%d a_T=%d", B, d, N, col, a_T);
+  SSV_CHECK(N <= STEP_MAXN, SSV_UNSUPPORTED, "attention_step: N=%d > %d", N, STEP_MAXN);
+  hipLaunchKernelGGL(attention_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, k, kv_bs, q_last, q_bs, q_cs, pma_in, a, a_T, col,
+                     pma_out, d, N, 1.f / sqrtf((float)d));
+  return ssv_check_launch("attention_step");
+}

@@ -1,0 +1,135 @@
+// GE2E speaker-embedder kernels (gfx950): layout change for the LSTM input, the fused LSTM cell
+// update, projection normalisation and the GE2E loss.  The LSTM's matrix products (input projection
+// for all frames at once, and the per-frame recurrent product) run on the shared implicit-GEMM kernel
+// with activations kept as [hidden][batch] so that the batch is the contiguous, coalesced axis.
+#include "ssv_common.h"
+#include "../../include/ssv_hip.h"
+
+// x (Bn, T, F) row-major  ->  xt [T][F][Bn]
+__global__ __launch_bounds__(256) void lstm_in_transpose_kernel(const float* __restrict__ x, float* __restrict__ xt, int Bn, int T, int F) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index into xt
+  if (i >= (long)Bn * T * F) return;
+  const int b = (int)(i % Bn);
+  const int f = (int)((i / Bn) % F), t = (int)(i / ((long)Bn * F));
+  xt[i] = x[((long)b * T + t) * F + f];
+}
+
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
+
+// g: [4H][Bn] gate pre-activations in torch order i, f, g, o; c: [H][Bn] updated in place; h: [H][Bn].
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ g, float* __restrict__ c, float* __restrict__ h, int H, int Bn, int first) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)H * Bn;
+  if (i >= n) return;
+  const float gi = sigm(g[i]), gf = sigm(g[n + i]), gg = tanhf(g[2 * n + i]), go = sigm(g[3 * n + i]);
+  const float cn = (first ? 0.f : gf * c[i]) + gi * gg;
+  c[i] = cn;
+  h[i] = go * tanhf(cn);
+}
+
+// h_last [H][Bn] -> (Bn, H)
+__global__ __launch_bounds__(256) void transpose_out_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Bn) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index into dst (Bn, R)
+  if (i >= (long)R * Bn) return;
+  const int r = (int)(i % R), b = (int)(i / R);
+  dst[i] = src[(long)r * Bn + b];
+}
+
+int ssv_launch_lstm_in_transpose(const float* x, float* xt, int Bn, int T, int F, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_in_transpose_kernel, dim3(ssv_cdiv((long)Bn * T * F, 256)), dim3(256), 0, st, x, xt, Bn, T, F);
+  return ssv_check_launch("lstm_in_transpose");
+}
+int ssv_launch_lstm_cell(const float* g, float* c, float* h, int H, int Bn, int first, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3(ssv_cdiv((long)H * Bn, 256)), dim3(256), 0, st, g, c, h, H, Bn, first);
+  return ssv_check_launch("lstm_cell");
+}
+int ssv_launch_transpose_out(const float* src, float* dst, int R, int Bn, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_out_kernel, dim3(ssv_cdiv((long)R * Bn, 256)), dim3(256), 0, st, src, dst, R, Bn);
+  return ssv_check_launch("transpose_out");
+}
+
+// y [P][Bn] -> e (Bn, P), each row divided by its L2 norm.  One wave per batch item.
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ y, float* __restrict__ e, int P, int Bn) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= Bn) return;
+  float s = 0.f;
+  for (int p = lane; p < P; p += 64) { const float v = y[(long)p * Bn + b]; s += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float nrm = sqrtf(s);
+  for (int p = lane; p < P; p += 64) e[(long)b * P + p] = y[(long)p * Bn + b] / nrm;
+}
+int ssv_launch_l2norm_rows(const float* y, float* e, int P, int Bn, hipStream_t st) {
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(ssv_cdiv(Bn, 4)), dim3(256), 0, st, y, e, P, Bn);
+  return ssv_check_launch("l2norm_rows");
+}
+
+// ---- GE2E loss -------------------------------------------------------------------------------------
+// csum[k][d] = sum_m emb[k][m][d]
+__global__ __launch_bounds__(256) void ge2e_centroid_kernel(const float* __restrict__ emb, float* __restrict__ csum, int N, int M, int D) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)N * D) return;
+  const int k = (int)(i / D), d = (int)(i % D);
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) s += emb[((long)k * M + m) * D + d];
+  csum[i] = s;
+}
+// One workgroup (one wave) per embedding (j, i): lane k handles centroids k, k+64, ...
+//   cos_k = <e, c_k> / max(|e||c_k|, 1e-8) + 1e-6, c_k = csum_k / M, or (csum_j - e) / (M-1) for k == j
+//   per = -(S_j - log(sum_k exp(S_k) + 1e-6)), S = w cos + b
+__global__ __launch_bounds__(64) void ge2e_rows_kernel(const float* __restrict__ emb, const float* __restrict__ csum, const float* __restrict__ w,
+                                                        const float* __restrict__ bb, float* __restrict__ per, int N, int M, int D) {
+  const int ji = blockIdx.x, j = ji / M, lane = threadIdx.x;
+  const float* e = emb + (long)ji * D;
+  float en = 0.f;
+  for (int d = lane; d < D; d += 64) en += e[d] * e[d];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) en += __shfl_xor(en, o);
+  en = sqrtf(en);
+  const float ww = w[0], b0 = bb[0];
+  float sexp = 0.f, spos = 0.f;
+  for (int k = lane; k < N; k += 64) {
+    const float* c = csum + (long)k * D;
+    float dot = 0.f, cn = 0.f;
+    if (k == j) {
+      const float inv = 1.f / (float)(M - 1);
+      for (int d = 0; d < D; ++d) { const float cv = (c[d] - e[d]) * inv; dot += e[d] * cv; cn += cv * cv; }
+    } else {
+      const float inv = 1.f / (float)M;
+      for (int d = 0; d < D; ++d) { const float cv = c[d] * inv; dot += e[d] * cv; cn += cv * cv; }
+    }
+    const float cosv = dot / fmaxf(en * sqrtf(cn), 1e-8f) + 1e-6f;
+    const float S = ww * cosv + b0;
+    sexp += expf(S);
+    if (k == j) spos = S;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sexp += __shfl_xor(sexp, o); spos += __shfl_xor(spos, o); }
+  if (lane == 0) per[ji] = -(spos - logf(sexp + 1e-6f));
+}
+__global__ __launch_bounds__(256) void ge2e_total_kernel(const float* __restrict__ per, float* __restrict__ loss, int n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += per[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" size_t ssv_ge2e_loss_fwd_workspace(int N, int M, int D) { return ((size_t)N * D + (size_t)N * M) * sizeof(float); }
+extern "C" int ssv_ge2e_loss_fwd(const float* emb, const float* w, const float* b, float* loss, float* per, int N, int M, int D,
+                                 void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(N > 0 && M > 1 && D > 0, SSV_BAD_SHAPE, "ge2e_loss_fwd: need N>0, M>1, D>0 (N=%d M=%d D=%d)", N, M, D);
+  SSV_CHECK(ws && ws_bytes >= ssv_ge2e_loss_fwd_workspace(N, M, D), SSV_BAD_SHAPE, "ge2e_loss_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* csum = (float*)ws;
+  float* perbuf = per ? per : csum + (size_t)N * D;
+  hipLaunchKernelGGL(ge2e_centroid_kernel, dim3(ssv_cdiv((long)N * D, 256)), dim3(256), 0, st, emb, csum, N, M, D);
+  SSV_TRY(ssv_check_launch("ge2e_centroid"));
+  hipLaunchKernelGGL(ge2e_rows_kernel, dim3(N * M), dim3(64), 0, st, emb, csum, w, b, perbuf, N, M, D);
+  SSV_TRY(ssv_check_launch("ge2e_rows"));
+  hipLaunchKernelGGL(ge2e_total_kernel, dim3(1), dim3(256), 0, st, perbuf, loss, N * M);
+  return ssv_check_launch("ge2e_total");
+}

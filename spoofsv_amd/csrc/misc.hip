@@ -1,0 +1,251 @@
+// Small HBM-bound kernels around the GEMMs: weight transposition, slab reduction, row sums, the
+// text embedding, the spectrogram / guided-attention losses and multi-tensor Adam (gfx950).
+#include "ssv_common.h"
+#include "../../include/ssv_hip.h"
+
+// ---- out[i] = sum_z slabs[z*stride + i] (fixed order) ---------------------------------------------
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ s, float* __restrict__ out, long n, int Z, long stride) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int z = 0; z < Z; ++z) acc += s[(long)z * stride + i];
+  out[i] = acc;
+}
+int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long stride, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, slabs, out, n, Z, stride);
+  return ssv_check_launch("reduce_slabs");
+}
+
+// ---- wt[c][o][j] = w[o][c][j]: weights for the data gradient ---------------------------------------
+__global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int KT) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index into wt
+  const long n = (long)Cout * Cin * KT;
+  if (i >= n) return;
+  const int j = (int)(i % KT);
+  const long r = i / KT;
+  const int o = (int)(r % Cout), c = (int)(r / Cout);
+  wt[i] = w[((long)o * Cin + c) * KT + j];
+}
+int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hipStream_t st) {
+  const long n = (long)Cout * Cin * KT;
+  hipLaunchKernelGGL(pack_wt_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, wt, Cout, Cin, KT);
+  return ssv_check_launch("pack_wt");
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float v, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int ssv_launch_fill(float* p, float v, long n, hipStream_t st) {
+  hipLaunchKernelGGL(fill_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, p, v, n);
+  return ssv_check_launch("fill");
+}
+
+// ---- out(b,c) = sum_t x(b,c,t): one wave per row ---------------------------------------------------
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ out, int B, int C, int L) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * C) return;
+  const int b = row / C, c = row % C;
+  const float* p = x + (long)b * x_bs + (long)c * L;
+  float s = 0.f;
+  for (int t = lane; t < L; t += 64) s += p[t];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[row] = s;
+}
+extern "C" int ssv_rowsum(const float* x, long x_bs, float* out, int B, int C, int L, ssv_stream_t stream) {
+  SSV_CHECK(B > 0 && C > 0 && L > 0, SSV_BAD_SHAPE, "rowsum: bad shape B=%d C=%d L=%d", B, C, L);
+  hipLaunchKernelGGL(rowsum_kernel, dim3(ssv_cdiv((long)B * C, 4)), dim3(256), 0, (hipStream_t)stream, x, x_bs, out, B, C, L);
+  return ssv_check_launch("rowsum");
+}
+
+extern "C" int ssv_sum_slabs(const float* slabs, float* out, long n, int Z, long stride, ssv_stream_t stream) {
+  SSV_CHECK(slabs && out && n > 0 && Z > 0, SSV_BAD_SHAPE, "sum_slabs: bad argument n=%ld Z=%d", n, Z);
+  return ssv_launch_reduce_slabs(slabs, out, n, Z, stride, (hipStream_t)stream);
+}
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, long src_bs, float* __restrict__ dst, long dst_bs, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[(long)blockIdx.y * dst_bs + i] = src[(long)blockIdx.y * src_bs + i];
+}
+extern "C" int ssv_copy_rows(const float* src, long src_bs, float* dst, long dst_bs, int B, long n, ssv_stream_t stream) {
+  SSV_CHECK(src && dst && B > 0 && B <= 65535 && n > 0, SSV_BAD_SHAPE, "copy_rows: bad argument B=%d n=%ld", B, n);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(ssv_cdiv(n, 256), B), dim3(256), 0, (hipStream_t)stream, src, src_bs, dst, dst_bs, n);
+  return ssv_check_launch("copy_rows");
+}
+
+// ---- text embedding ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int N, int E, int V) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * E * N) return;
+  const int n = (int)(i % N);
+  const int e = (int)((i / N) % E), b = (int)(i / ((long)N * E));
+  const int64_t id = ids[(long)b * N + n];
+  float v = bias ? bias[e] : 0.f;
+  if (id >= 0 && id < V) v += w[(long)e * V + id];
+  y[i] = v;
+}
+// One workgroup per embedding channel e.  Each of the 128 threads owns a private row of vocabulary
+// bins in LDS and a strided share of the (b, n) positions; the rows are then summed in thread order,
+// so the result does not depend on timing (no atomics).
+#define EMB_MAXV 64
+__global__ __launch_bounds__(128) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dy,
+                                                        float* __restrict__ dw, float* __restrict__ dbias, int B, int N, int E, int V) {
+  __shared__ float bins[128 * (EMB_MAXV + 1)];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  float* mine = bins + tid * (EMB_MAXV + 1);
+  for (int v = 0; v <= V; ++v) mine[v] = 0.f;     // bin V collects every position (bias gradient)
+  const long tot = (long)B * N;
+  for (long i = tid; i < tot; i += 128) {
+    const int b = (int)(i / N), n = (int)(i % N);
+    const float g = dy[((long)b * E + e) * N + n];
+    const int64_t id = ids[i];
+    if (id >= 0 && id < V) mine[id] += g;
+    mine[V] += g;
+  }
+  __syncthreads();
+  if (tid <= V) {
+    float s = 0.f;
+    for (int k = 0; k < 128; ++k) s += bins[k * (EMB_MAXV + 1) + tid];
+    if (tid < V) dw[(long)e * V + tid] = s; else if (dbias) dbias[e] = s;
+  }
+}
+extern "C" int ssv_text_embed_fwd(const int64_t* ids, const float* w, const float* bias, float* y, int B, int N, int E, int vocab, ssv_stream_t stream) {
+  SSV_CHECK(B > 0 && N > 0 && E > 0 && vocab > 0, SSV_BAD_SHAPE, "text_embed_fwd: bad shape");
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(ssv_cdiv((long)B * E * N, 256)), dim3(256), 0, (hipStream_t)stream, ids, w, bias, y, B, N, E, vocab);
+  return ssv_check_launch("text_embed_fwd");
+}
+extern "C" int ssv_text_embed_bwd(const int64_t* ids, const float* dy, float* dw, float* dbias, int B, int N, int E, int vocab, ssv_stream_t stream) {
+  SSV_CHECK(B > 0 && N > 0 && E > 0 && vocab > 0, SSV_BAD_SHAPE, "text_embed_bwd: bad shape");
+  SSV_CHECK(vocab <= EMB_MAXV, SSV_UNSUPPORTED, "text_embed_bwd: vocabulary %d > %d", vocab, EMB_MAXV);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(E), dim3(128), 0, (hipStream_t)stream, ids, dy, dw, dbias, B, N, E, vocab);
+  return ssv_check_launch("text_embed_bwd");
+}
+
+// ---- spectrogram losses --------------------------------------------------------------------------------
+#define LOSS_BLOCKS 1024
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void spec_loss_part_kernel(const float* __restrict__ y, const float* __restrict__ gt, long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s1 = 0.f, s2 = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float a = y[i], g = gt[i];
+    s1 += fabsf(g - a);
+    s2 += -g * logf(a + 1e-8f) - (1.f - g) * logf(1.f - a + 1e-8f);
+  }
+  s1 = block_sum256(s1, red);
+  s2 = block_sum256(s2, red);
+  if (threadIdx.x == 0) { part[blockIdx.x] = s1; part[gridDim.x + blockIdx.x] = s2; }
+}
+// out[k] = scale * sum_i part[k*nblk + i], k < nout; one workgroup, fixed order
+__global__ __launch_bounds__(256) void finish_sums_kernel(const float* __restrict__ part, int nblk, int nout, float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  for (int k = 0; k < nout; ++k) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += part[(long)k * nblk + i];
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) out[k] = s * scale;
+  }
+}
+__global__ __launch_bounds__(256) void spec_loss_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gt, long n,
+                                                            const float* __restrict__ gscale, float* __restrict__ dy) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float inv = 1.f / (float)n, w1 = gscale[0] * inv, w2 = gscale[1] * inv;
+  const float a = y[i], g = gt[i];
+  const float d = a - g;
+  const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  dy[i] = w1 * sgn + w2 * (-g / (a + 1e-8f) + (1.f - g) / (1.f - a + 1e-8f));
+}
+extern "C" size_t ssv_spec_losses_workspace(long n) { (void)n; return 2 * LOSS_BLOCKS * sizeof(float); }
+extern "C" int ssv_spec_losses_fwd(const float* y, const float* gt, long n, float* out, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(n > 0, SSV_BAD_SHAPE, "spec_losses_fwd: n=%ld", n);
+  SSV_CHECK(ws && ws_bytes >= ssv_spec_losses_workspace(n), SSV_BAD_SHAPE, "spec_losses_fwd: workspace too small");
+  const int nblk = (int)((n + 255) / 256 < LOSS_BLOCKS ? (n + 255) / 256 : LOSS_BLOCKS);
+  hipLaunchKernelGGL(spec_loss_part_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, gt, n, (float*)ws);
+  SSV_TRY(ssv_check_launch("spec_loss_part"));
+  hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, 2, 1.f / (float)n, out);
+  return ssv_check_launch("finish_sums");
+}
+extern "C" int ssv_spec_losses_bwd(const float* y, const float* gt, long n, const float* gscale, float* dy, ssv_stream_t stream) {
+  SSV_CHECK(n > 0, SSV_BAD_SHAPE, "spec_losses_bwd: n=%ld", n);
+  hipLaunchKernelGGL(spec_loss_bwd_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, y, gt, n, gscale, dy);
+  return ssv_check_launch("spec_loss_bwd");
+}
+
+// ---- guided attention loss ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gatt_part_kernel(const float* __restrict__ a, const float* __restrict__ gaw, int gaw_T,
+                                                        long tot, int N, int T, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int t = (int)(i % T), n = (int)((i / T) % N);
+    s += a[i] * gaw[(long)n * gaw_T + t];
+  }
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void gatt_bwd_kernel(const float* __restrict__ gaw, int gaw_T, const float* __restrict__ gscale,
+                                                       float* __restrict__ da, long tot, int N, int T) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= tot) return;
+  const int t = (int)(i % T), n = (int)((i / T) % N);
+  da[i] = gscale[0] * gaw[(long)n * gaw_T + t] / (float)tot;
+}
+extern "C" size_t ssv_guided_att_loss_workspace(int B, int N, int T) { (void)B; (void)N; (void)T; return LOSS_BLOCKS * sizeof(float); }
+extern "C" int ssv_guided_att_loss_fwd(const float* a, const float* gaw, int gaw_T, float* out, int B, int N, int T,
+                                       void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(B > 0 && N > 0 && T > 0 && gaw_T >= T, SSV_BAD_SHAPE, "guided_att_loss_fwd: bad shape B=%d N=%d T=%d gaw_T=%d", B, N, T, gaw_T);
+  SSV_CHECK(ws && ws_bytes >= LOSS_BLOCKS * sizeof(float), SSV_BAD_SHAPE, "guided_att_loss_fwd: workspace too small");
+  const long tot = (long)B * N * T;
+  const int nblk = (int)((tot + 255) / 256 < LOSS_BLOCKS ? (tot + 255) / 256 : LOSS_BLOCKS);
+  hipLaunchKernelGGL(gatt_part_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, gaw, gaw_T, tot, N, T, (float*)ws);
+  SSV_TRY(ssv_check_launch("gatt_part"));
+  hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, 1, 1.f / (float)tot, out);
+  return ssv_check_launch("finish_sums");
+}
+extern "C" int ssv_guided_att_loss_bwd(const float* gaw, int gaw_T, const float* gscale, float* da, int B, int N, int T, ssv_stream_t stream) {
+  SSV_CHECK(B > 0 && N > 0 && T > 0 && gaw_T >= T, SSV_BAD_SHAPE, "guided_att_loss_bwd: bad shape");
+  const long tot = (long)B * N * T;
+  hipLaunchKernelGGL(gatt_bwd_kernel, dim3(ssv_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, gaw, gaw_T, gscale, da, tot, N, T);
+  return ssv_check_launch("gatt_bwd");
+}
+
+// ---- multi-tensor Adam -----------------------------------------------------------------------------------
+// Same arithmetic as torch.optim.Adam's single-tensor path: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m / denom.
+__global__ __launch_bounds__(256) void adam_multi_kernel(const ssv_adam_chunk* __restrict__ chunks, float lr, float b1, float b2, float eps,
+                                                         int step_host, const int* __restrict__ step_dev) {
+  // step count: host value, or (device counter + 1) so that a captured hipGraph advances on replay
+  const int step = step_dev ? step_dev[0] + 1 : step_host;
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  const float step_size = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const ssv_adam_chunk ch = chunks[blockIdx.x];
+  for (long i = threadIdx.x; i < ch.n; i += 256) {
+    const float g = ch.g[i];
+    const float m = b1 * ch.m[i] + (1.f - b1) * g;
+    const float v = b2 * ch.v[i] + (1.f - b2) * g * g;
+    ch.m[i] = m; ch.v[i] = v;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+    ch.p[i] -= step_size * (m / denom);
+  }
+}
+__global__ void step_inc_kernel(int* step_dev) { step_dev[0] += 1; }
+extern "C" int ssv_adam_multi(const ssv_adam_chunk* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
+                              int step, int* step_dev, ssv_stream_t stream) {
+  SSV_CHECK(nchunks > 0 && (step_dev || step > 0), SSV_BAD_SHAPE, "adam_multi: nchunks=%d step=%d", nchunks, step);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, chunks, lr, beta1, beta2, eps, step, (const int*)step_dev);
+  SSV_TRY(ssv_check_launch("adam_multi"));
+  if (step_dev) {
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    return ssv_check_launch("step_inc");
+  }
+  return 0;
+}

@@ -1,0 +1,313 @@
+// Channel-axis LayerNorm kernels on (B, C, T) tensors (T fastest), gfx950.  HBM-bound.
+//
+// The reference permutes to (B, T, C) to run nn.LayerNorm(C); here the tensor stays (B, C, T):
+// a 256-thread workgroup owns 16 consecutive time columns of one batch item, laid out as
+// 16 columns (tid & 15) x 16 channel groups (tid >> 4).  Thread (col, g) keeps channels g, g+16, ...
+// of its column in registers (one global read per element), so mean and variance are a true
+// two-pass computation (mean first, then sum of squared deviations) without a second trip to memory.
+// Cross-group sums go through a 16x16 LDS array; per-channel parameter-gradient partials are reduced
+// over the 16 columns with lane shuffles and written per workgroup, then summed in a fixed order by
+// reduce_partials (bitwise reproducible; no float atomics).
+//
+//   ln_gate_*: highwayConv epilogue  y = sigmoid(LN1(H1))*LN2(H2) + (1-sigmoid(LN1(H1)))*x
+//   ln_act_* : y = act(LN(x)), act in {none, relu, sigmoid}
+#include "ssv_common.h"
+
+#define LN_EPS 1e-5f
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// Sum `v` over the 16 channel groups of this thread's column. `red` is a [16][16] LDS array.
+__device__ __forceinline__ float group_sum(float v, float* red, int col, int g) {
+  __syncthreads();
+  red[g * 16 + col] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += red[i * 16 + col];
+  return s;
+}
+
+// Sum over the 16 columns (16 consecutive lanes share one channel group).
+__device__ __forceinline__ float col_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int CPT>
+__global__ __launch_bounds__(256) void ln_gate_fwd_kernel(
+    const float* __restrict__ H, long h_bs, const float* __restrict__ X, long x_bs,
+    const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
+    float* __restrict__ Y, long y_bs, float* __restrict__ stats, int C, int L) {
+  __shared__ float red[256];
+  const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + col, b = blockIdx.y;
+  const bool tv = t < L;
+  const float* Hb = H + (long)b * h_bs + t;
+  float h1[CPT], h2[CPT];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + 16 * i;
+    const bool v = tv && c < C;
+    h1[i] = v ? Hb[(long)c * L] : 0.f;
+    h2[i] = v ? Hb[(long)(C + c) * L] : 0.f;
+    s1 += h1[i]; s2 += h2[i];
+  }
+  const float inv = 1.f / (float)C;
+  const float mu1 = group_sum(s1, red, col, g) * inv;
+  const float mu2 = group_sum(s2, red, col, g) * inv;
+  float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const bool v = (g + 16 * i) < C;
+    const float d1 = v ? h1[i] - mu1 : 0.f, d2 = v ? h2[i] - mu2 : 0.f;
+    q1 += d1 * d1; q2 += d2 * d2;
+  }
+  const float r1 = rsqrtf(group_sum(q1, red, col, g) * inv + LN_EPS);
+  const float r2 = rsqrtf(group_sum(q2, red, col, g) * inv + LN_EPS);
+  if (!tv) return;
+  if (g == 0 && stats) {
+    float* sb = stats + (long)b * 4 * L + t;
+    sb[0] = mu1; sb[L] = r1; sb[2L * L] = mu2; sb[3L * L] = r2;
+  }
+  const float* Xb = X + (long)b * x_bs + t;
+  float* Yb = Y + (long)b * y_bs + t;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + 16 * i;
+    if (c < C) {
+      const float n1 = (h1[i] - mu1) * r1 * g1[c] + b1[c];
+      const float n2 = (h2[i] - mu2) * r2 * g2[c] + b2[c];
+      const float s = sigmoidf_(n1);
+      Yb[(long)c * L] = s * n2 + (1.f - s) * Xb[(long)c * L];
+    }
+  }
+}
+
+// part layout: [block][6][C] = dgamma1, dbeta1, dgamma2, dbeta2, dbiasH1, dbiasH2
+template <int CPT>
+__global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
+    const float* __restrict__ dY, long dy_bs, const float* __restrict__ H, const float* __restrict__ X, long x_bs,
+    const float* __restrict__ stats,
+    const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
+    float* __restrict__ dH, float* __restrict__ dXres, long dx_bs, float* __restrict__ part, int C, int L) {
+  __shared__ float red[256];
+  const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + col, b = blockIdx.y;
+  const bool tv = t < L;
+  const long hb = (long)b * 2 * C * L + t;
+  float mu1 = 0.f, r1 = 0.f, mu2 = 0.f, r2 = 0.f;
+  if (tv) {
+    const float* sb = stats + (long)b * 4 * L + t;
+    mu1 = sb[0]; r1 = sb[L]; mu2 = sb[2L * L]; r2 = sb[3L * L];
+  }
+  float xh1[CPT], xh2[CPT], a1[CPT], a2[CPT];
+  float* pblk = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 6 * C;
+  float sa1 = 0.f, sah1 = 0.f, sa2 = 0.f, sah2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + 16 * i;
+    const bool v = tv && c < C;
+    float dn1 = 0.f, dn2 = 0.f, gg1 = 0.f, gg2 = 0.f;
+    xh1[i] = 0.f; xh2[i] = 0.f;
+    if (v) {
+      const float dy = dY[(long)b * dy_bs + (long)c * L + t];
+      const float x = X[(long)b * x_bs + (long)c * L + t];
+      gg1 = g1[c]; gg2 = g2[c];
+      xh1[i] = (H[hb + (long)c * L] - mu1) * r1;
+      xh2[i] = (H[hb + (long)(C + c) * L] - mu2) * r2;
+      const float n1 = xh1[i] * gg1 + b1[c];
+      const float n2 = xh2[i] * gg2 + b2[c];
+      const float s = sigmoidf_(n1);
+      dn2 = dy * s;
+      dn1 = dy * (n2 - x) * s * (1.f - s);
+      dXres[(long)b * dx_bs + (long)c * L + t] = dy * (1.f - s);
+    }
+    // per-channel parameter-gradient partials over this block's 16 columns
+    const float p0 = col_sum(dn1 * xh1[i]), p1 = col_sum(dn1), p2 = col_sum(dn2 * xh2[i]), p3 = col_sum(dn2);
+    if (col == 0 && c < C) { pblk[c] = p0; pblk[C + c] = p1; pblk[2 * C + c] = p2; pblk[3 * C + c] = p3; }
+    a1[i] = dn1 * gg1; a2[i] = dn2 * gg2;
+    sa1 += a1[i]; sah1 += a1[i] * xh1[i]; sa2 += a2[i]; sah2 += a2[i] * xh2[i];
+  }
+  const float inv = 1.f / (float)C;
+  const float m1 = group_sum(sa1, red, col, g) * inv, mh1 = group_sum(sah1, red, col, g) * inv;
+  const float m2 = group_sum(sa2, red, col, g) * inv, mh2 = group_sum(sah2, red, col, g) * inv;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + 16 * i;
+    const bool v = tv && c < C;
+    const float d1 = v ? r1 * (a1[i] - m1 - xh1[i] * mh1) : 0.f;
+    const float d2 = v ? r2 * (a2[i] - m2 - xh2[i] * mh2) : 0.f;
+    if (v) { dH[hb + (long)c * L] = d1; dH[hb + (long)(C + c) * L] = d2; }
+    const float q0 = col_sum(d1), q1 = col_sum(d2);
+    if (col == 0 && c < C) { pblk[4 * C + c] = q0; pblk[5 * C + c] = q1; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int CPT>
+__global__ __launch_bounds__(256) void ln_act_fwd_kernel(
+    const float* __restrict__ X, long x_bs, const float* __restrict__ gam, const float* __restrict__ bet,
+    float* __restrict__ Y, long y_bs, float* __restrict__ stats, int C, int L, int act) {
+  __shared__ float red[256];
+  const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + col, b = blockIdx.y;
+  const bool tv = t < L;
+  const float* Xb = X + (long)b * x_bs + t;
+  float x[CPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + 16 * i;
+    x[i] = (tv && c < C) ? Xb[(long)c * L] : 0.f;
+    s += x[i];
+  }
+  const float inv = 1.f / (float)C;
+  const float mu = group_sum(s, red, col, g) * inv;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const float d = ((g + 16 * i) < C) ? x[i] - mu : 0.f;
+    q += d * d;
+  }
+  const float r = rsqrtf(group_sum(q, red, col, g) * inv + LN_EPS);
+  if (!tv) return;
+  if (g == 0 && stats) { stats[(long)b * 2 * L + t] = mu; stats[(long)b * 2 * L + L + t] = r; }
+  float* Yb = Y + (long)b * y_bs + t;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + 16 * i;
+    if (c < C) {
+      float n = (x[i] - mu) * r * gam[c] + bet[c];
+      if (act == 1) n = fmaxf(n, 0.f);
+      else if (act == 2) n = sigmoidf_(n);
+      Yb[(long)c * L] = n;
+    }
+  }
+}
+
+// part layout: [block][3][C] = dgamma, dbeta, dbias (= column sums of dX)
+template <int CPT>
+__global__ __launch_bounds__(256) void ln_act_bwd_kernel(
+    const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs, const float* __restrict__ stats,
+    const float* __restrict__ gam, const float* __restrict__ bet,
+    float* __restrict__ dX, long dx_bs, float* __restrict__ part, int C, int L, int act) {
+  __shared__ float red[256];
+  const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + col, b = blockIdx.y;
+  const bool tv = t < L;
+  float mu = 0.f, r = 0.f;
+  if (tv) { mu = stats[(long)b * 2 * L + t]; r = stats[(long)b * 2 * L + L + t]; }
+  float xh[CPT], a[CPT];
+  float* pblk = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 3 * C;
+  float sa = 0.f, sah = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + 16 * i;
+    const bool v = tv && c < C;
+    float dn = 0.f, gg = 0.f;
+    xh[i] = 0.f;
+    if (v) {
+      const float dy = dY[(long)b * dy_bs + (long)c * L + t];
+      gg = gam[c];
+      xh[i] = (X[(long)b * x_bs + (long)c * L + t] - mu) * r;
+      const float n = xh[i] * gg + bet[c];
+      if (act == 1) dn = n > 0.f ? dy : 0.f;
+      else if (act == 2) { const float s = sigmoidf_(n); dn = dy * s * (1.f - s); }
+      else dn = dy;
+    }
+    const float p0 = col_sum(dn * xh[i]), p1 = col_sum(dn);
+    if (col == 0 && c < C) { pblk[c] = p0; pblk[C + c] = p1; }
+    a[i] = dn * gg;
+    sa += a[i]; sah += a[i] * xh[i];
+  }
+  const float inv = 1.f / (float)C;
+  const float m = group_sum(sa, red, col, g) * inv, mh = group_sum(sah, red, col, g) * inv;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + 16 * i;
+    const bool v = tv && c < C;
+    const float d = v ? r * (a[i] - m - xh[i] * mh) : 0.f;
+    if (v) dX[(long)b * dx_bs + (long)c * L + t] = d;
+    const float q0 = col_sum(d);
+    if (col == 0 && c < C) pblk[2 * C + c] = q0;
+  }
+}
+
+// out[i] = sum over blocks of part[blk][i], i < n (n = rows*C), fixed order.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int nblk) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nblk; k += 4) {
+    s0 += part[(long)k * n + i]; s1 += part[(long)(k + 1) * n + i];
+    s2 += part[(long)(k + 2) * n + i]; s3 += part[(long)(k + 3) * n + i];
+  }
+  for (; k < nblk; ++k) s0 += part[(long)k * n + i];
+  out[i] = (s0 + s1) + (s2 + s3);
+}
+
+// ------------------------------------------------------------------------------------------------
+#define LN_DISPATCH(C, CALL)                                            \
+  do {                                                                  \
+    const int _cpt = ((C) + 15) / 16;                                   \
+    if (_cpt <= 2) { CALL(2); } else if (_cpt <= 4) { CALL(4); }        \
+    else if (_cpt <= 8) { CALL(8); } else if (_cpt <= 16) { CALL(16); } \
+    else if (_cpt <= 33) { CALL(33); } else if (_cpt <= 64) { CALL(64); } \
+    else return ssv_fail(SSV_UNSUPPORTED, "LayerNorm over %d channels not supported (max 1024)", (C)); \
+  } while (0)
+
+int ssv_launch_ln_gate_fwd(const float* H, long h_bs, const float* X, long x_bs, const float* g1, const float* b1,
+                           const float* g2, const float* b2, float* Y, long y_bs, float* stats, int B, int C, int L,
+                           hipStream_t st) {
+  dim3 grid(ssv_cdiv(L, 16), B);
+#define CALL(N) hipLaunchKernelGGL(ln_gate_fwd_kernel<N>, grid, dim3(256), 0, st, H, h_bs, X, x_bs, g1, b1, g2, b2, Y, y_bs, stats, C, L)
+  if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
+  LN_DISPATCH(C, CALL);
+#undef CALL
+  return ssv_check_launch("ln_gate_fwd");
+}
+
+int ssv_ln_gate_bwd_nblk(int B, int L) { return B * ssv_cdiv(L, 16); }
+
+int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const float* X, long x_bs, const float* stats,
+                           const float* g1, const float* b1, const float* g2, const float* b2, float* dH, float* dXres,
+                           long dx_bs, float* part, float* pgrads /* [6][C] */, int B, int C, int L, hipStream_t st) {
+  dim3 grid(ssv_cdiv(L, 16), B);
+#define CALL(N) hipLaunchKernelGGL(ln_gate_bwd_kernel<N>, grid, dim3(256), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, C, L)
+  if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
+  LN_DISPATCH(C, CALL);
+#undef CALL
+  SSV_TRY(ssv_check_launch("ln_gate_bwd"));
+  const int n = 6 * C;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, part, pgrads, n, (int)(grid.x * grid.y));
+  return ssv_check_launch("reduce_partials");
+}
+
+int ssv_launch_ln_act_fwd(const float* X, long x_bs, const float* gam, const float* bet, float* Y, long y_bs, float* stats,
+                          int B, int C, int L, int act, hipStream_t st) {
+  dim3 grid(ssv_cdiv(L, 16), B);
+#define CALL(N) hipLaunchKernelGGL(ln_act_fwd_kernel<N>, grid, dim3(256), 0, st, X, x_bs, gam, bet, Y, y_bs, stats, C, L, act)
+  LN_DISPATCH(C, CALL);
+#undef CALL
+  return ssv_check_launch("ln_act_fwd");
+}
+
+int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs, const float* stats, const float* gam,
+                          const float* bet, float* dX, long dx_bs, float* part, float* pgrads /* [3][C] */, int B, int C,
+                          int L, int act, hipStream_t st) {
+  dim3 grid(ssv_cdiv(L, 16), B);
+#define CALL(N) hipLaunchKernelGGL(ln_act_bwd_kernel<N>, grid, dim3(256), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, C, L, act)
+  LN_DISPATCH(C, CALL);
+#undef CALL
+  SSV_TRY(ssv_check_launch("ln_act_bwd"));
+  const int n = 3 * C;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, part, pgrads, n, (int)(grid.x * grid.y));
+  return ssv_check_launch("reduce_partials");
+}

@@ -1,0 +1,53 @@
+// Shared declarations for the libssv_hip kernels (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// ---- error reporting (thread-local, see ssv_last_error in api.hip) -------------------
+int ssv_fail(int code, const char* fmt, ...);
+#define SSV_BAD_SHAPE (-1)
+#define SSV_UNSUPPORTED (-2)
+#define SSV_CHECK(cond, code, ...) do { if (!(cond)) return ssv_fail((code), __VA_ARGS__); } while (0)
+#define SSV_TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+int ssv_check_launch(const char* what);   // hipGetLastError() -> 0 or -(int)hipError_t
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- implicit GEMM, "NN" form --------------------------------------------------------
+//   C(b,m,n) = bias[m] + bias_b[b][m] + R(b,m,n) + sum_{c<Kc} sum_{j<KT} A(b,m,c,j) * X(b,c,n+shift[j])
+// with X(b,c,col) = 0 outside 0 <= col < Lx.  Used for: dilated/causal Conv1d forward,
+// its data gradient (transposed weights, negated shifts), 1x1 convs, the two halves of
+// ConvTranspose1d(k=2,s=2), attention V*A / K*dS / K^T*Q and the LSTM projections.
+struct GemmNN {
+  const float* A; long sab, sam, sac, saj;
+  const float* X; long sxb, sxc, sxn; int Lx;
+  float* C; long scb, scm, scn;
+  const float* bias;
+  const float* bias_b; long sbb;
+  const float* R; long srb, srm, srn;
+  int M, N, Kc, KT, B;
+  int shift[3];
+  float alpha;               // scales the accumulated product only (attention 1/sqrt(d))
+};
+int ssv_launch_gemm_nn(const GemmNN& g, hipStream_t st);
+
+// ---- implicit GEMM, "NT" form (reduction over time) ----------------------------------
+//   C(z,m,c,j) = sum_{b = z, z+bstep, ... < B} sum_{t<La} A(b,m,t) * X(b,c,t+shift[j])
+// Used for: Conv1d weight gradient (split over batches into slabs), ConvTranspose1d
+// weight gradient, attention dV = dR*A^T and dK = Q*dS^T (one output per batch).
+struct GemmNT {
+  const float* A; long sab, sam, sat; int La;
+  const float* X; long sxb, sxc, sxn; int Lx;
+  float* C; long scz, scm, scc, scj;
+  int M, Nc, KT, B, Z, bstep;
+  int shift[3];
+};
+int ssv_launch_gemm_nt(const GemmNT& g, hipStream_t st);
+
+// ---- small helpers (misc.hip) ---------------------------------------------------------
+int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long slab_stride, hipStream_t st);
+int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hipStream_t st);
+int ssv_launch_fill(float* p, float v, long n, hipStream_t st);
+
+static inline int ssv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,456 @@
+"""Host-side operators: thin ``torch.autograd.Function`` wrappers over the C ABI of libssv_hip.so.
+
+PyTorch is plumbing here (device memory, the current HIP stream, the autograd tape); every FLOP of
+the hot path runs in the hand-written gfx950 kernels.  Tensors must live on a ROCm device -- there
+is deliberately no CPU or stock-op fallback (``RuntimeError`` otherwise).
+
+Layout convention: activations are (B, C, T) float32 with contiguous rows (stride(2) == 1,
+stride(1) == T); the batch stride is free, so channel slices of a wider tensor are passed without
+copies.  Each Function cites the reference code its forward replaces.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_F32 = torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _dev(t, what="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError("spoofsv_amd: %s is on %s; the HIP hot path needs a ROCm device tensor "
+                           "(no CPU fallback exists)" % (what, t.device))
+    return t
+
+
+def _act3(t, what="activation"):
+    """Return (tensor, batch_stride) with contiguous rows; copies only when the rows are not."""
+    _dev(t, what)
+    if t.dtype != _F32:
+        t = t.float()
+    if t.dim() != 3:
+        raise RuntimeError("spoofsv_amd: %s must be (B, C, T), got %s" % (what, tuple(t.shape)))
+    B, C, L = t.shape
+    if L == 1:          # strides of a length-1 axis are arbitrary
+        if t.stride(1) != 1 and C > 1:
+            t = t.contiguous()
+        return t, (t.stride(0) if B > 1 else C)
+    if t.stride(2) != 1 or t.stride(1) != L or (B > 1 and t.stride(0) < C * L):
+        t = t.contiguous()
+    return t, (t.stride(0) if B > 1 else C * L)
+
+
+def _c(t):
+    """Dense float32 parameter/tensor."""
+    _dev(t, "parameter")
+    return t if (t.dtype == _F32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _needs_grad(ctx):
+    """True when autograd will call backward for this node (inside Function.forward grad mode is always
+    off, so the tape's own bookkeeping is the reliable signal)."""
+    return any(ctx.needs_input_grad)
+
+
+# ------------------------------------------------------------------------------------------- highway
+class HighwayConvFn(torch.autograd.Function):
+    """highwayConv.forward, models/TTSModel.py:63-84 (conv -> 2x LayerNorm over channels -> gate)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g1, b1, g2, b2, k, dilation, causal):
+        x, xbs = _act3(x, "highwayConv input")
+        B, C, L = x.shape
+        w, bias, g1, b1, g2, b2 = map(_c, (w, bias, g1, b1, g2, b2))
+        if tuple(w.shape) != (2 * C, C, k):
+            raise RuntimeError("highwayConv: weight %s does not match input channels %d" % (tuple(w.shape), C))
+        train = _needs_grad(ctx)
+        y = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        h = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
+        stats = torch.empty((B, 4, L), dtype=_F32, device=x.device) if train else None
+        _lib.call("ssv_highway_conv1d_fwd", _p(x), xbs, _p(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
+                  _p(h), _p(stats), _p(y), C * L, B, C, L, k, dilation, int(causal), _stream())
+        if train:
+            ctx.save_for_backward(x, w, g1, b1, g2, b2, h, stats)
+            ctx.cfg = (k, dilation, int(causal))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, g1, b1, g2, b2, h, stats = ctx.saved_tensors
+        k, dilation, causal = ctx.cfg
+        x, xbs = _act3(x)
+        dy, dybs = _act3(dy, "highwayConv grad")
+        B, C, L = x.shape
+        dx = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        dw = torch.empty_like(w)
+        pg = torch.empty((6, C), dtype=_F32, device=x.device)
+        nb = _lib.query("ssv_highway_conv1d_bwd_workspace", B, C, L, k)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_highway_conv1d_bwd", _p(dy), dybs, _p(x), xbs, _p(w), _p(g1), _p(b1), _p(g2), _p(b2),
+                  _p(h), _p(stats), _p(dx), C * L, _p(dw), _p(pg), B, C, L, k, dilation, causal,
+                  _p(ws), nb, _stream())
+        return dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3], None, None, None
+
+
+# ------------------------------------------------------------------------------------------- conv
+def _conv_fwd(x, xbs, w, bias, bias_b, y, ybs, k, dilation, causal):
+    B, Cin, L = x.shape
+    _lib.call("ssv_conv1d_fwd", _p(x), xbs, _p(w), _p(bias), _p(bias_b), _p(y), ybs, B, Cin, w.shape[0], L,
+              k, dilation, int(causal), _stream())
+
+
+def _conv_bwd_data(dy, dybs, w, Cin, L, k=1, dilation=1, causal=0):
+    B, Cout = dy.shape[0], w.shape[0]
+    dx = torch.empty((B, Cin, L), dtype=_F32, device=dy.device)
+    nb = _lib.query("ssv_conv1d_bwd_data_workspace", Cin, Cout, k)
+    ws = _ws(nb, dy.device)
+    _lib.call("ssv_conv1d_bwd_data", _p(dy), dybs, _p(w), None, _p(dx), Cin * L, B, Cin, Cout, L, k, dilation,
+              int(causal), _p(ws), nb, _stream())
+    return dx
+
+
+def _conv_bwd_weight(dy, dybs, x, xbs, wshape, k=1, dilation=1, causal=0):
+    B, Cin, L = x.shape
+    Cout = wshape[0]
+    dw = torch.empty(wshape, dtype=_F32, device=x.device)
+    nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, Cin, Cout, k)
+    ws = _ws(nb, x.device)
+    _lib.call("ssv_conv1d_bwd_weight", _p(dy), dybs, _p(x), xbs, _p(dw), B, Cin, Cout, L, k, dilation, int(causal),
+              _p(ws), nb, _stream())
+    return dw
+
+
+def _sum_over_batch(rows, B, n):
+    """rows: (B, n) dense -> (n,) summed in batch order."""
+    out = torch.empty((n,), dtype=_F32, device=rows.device)
+    _lib.call("ssv_sum_slabs", _p(rows), _p(out), n, B, n, _stream())
+    return out
+
+
+class PointwiseConvLnActFn(torch.autograd.Function):
+    """`ln(conv1x1(x) [+ s])` followed by relu / sigmoid / nothing.
+
+    Replaces e.g. models/TTSModel.py:128-131 (text encoder), :173-180 (audio encoder, with the
+    broadcast speaker term ``s`` = fc(spk), a (B, C, 1) tensor), :218-231, :343-361.  ``act``: 0 none,
+    1 relu (the reference applies F.relu to this output when feeding the next conv), 2 sigmoid.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, s, act):
+        x, xbs = _act3(x, "conv input")
+        B, Cin, L = x.shape
+        w, bias, gamma, beta = map(_c, (w, bias, gamma, beta))
+        Cout = w.shape[0]
+        if w.shape[1] != Cin or w.shape[2] != 1:
+            raise RuntimeError("pointwise conv: weight %s does not match input channels %d" % (tuple(w.shape), Cin))
+        sb = None
+        if s is not None:
+            sb = _c(s.reshape(B, Cout))
+        train = _needs_grad(ctx)
+        pre = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
+        y = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
+        stats = torch.empty((B, 2, L), dtype=_F32, device=x.device) if train else None
+        _conv_fwd(x, xbs, w, bias, sb, pre, Cout * L, 1, 1, 0)
+        _lib.call("ssv_channel_ln_act_fwd", _p(pre), Cout * L, _p(gamma), _p(beta), _p(y), Cout * L, _p(stats),
+                  B, Cout, L, act, _stream())
+        if train:
+            ctx.save_for_backward(x, w, gamma, beta, pre, stats)
+            ctx.act = act
+            ctx.has_s = s is not None
+            ctx.need_dx = ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, gamma, beta, pre, stats = ctx.saved_tensors
+        x, xbs = _act3(x)
+        dy, dybs = _act3(dy, "grad")
+        B, Cin, L = x.shape
+        Cout = w.shape[0]
+        dpre = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
+        pg = torch.empty((3, Cout), dtype=_F32, device=x.device)
+        nb = _lib.query("ssv_channel_ln_act_bwd_workspace", B, Cout, L)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_channel_ln_act_bwd", _p(dy), dybs, _p(pre), Cout * L, _p(stats), _p(gamma), _p(beta),
+                  _p(dpre), Cout * L, _p(pg), B, Cout, L, ctx.act, _p(ws), nb, _stream())
+        dx = _conv_bwd_data(dpre, Cout * L, w, Cin, L) if ctx.need_dx else None
+        dw = _conv_bwd_weight(dpre, Cout * L, x, xbs, tuple(w.shape))
+        ds = None
+        if ctx.has_s:
+            ds = torch.empty((B, Cout, 1), dtype=_F32, device=x.device)
+            _lib.call("ssv_rowsum", _p(dpre), Cout * L, _p(ds), B, Cout, L, _stream())
+        return dx, dw, pg[2], pg[0], pg[1], ds, None
+
+
+class Conv1dFn(torch.autograd.Function):
+    """Plain Conv1d with bias (kernel 1 or 3).  With L == 1 it is nn.Linear on (B, D, 1) speaker codes,
+    models/TTSModel.py:174,179 (`fc(spk.permute(0,2,1)).permute(0,2,1)`)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, k, dilation, causal):
+        x, xbs = _act3(x, "conv input")
+        B, Cin, L = x.shape
+        w = _c(w)
+        bias = _c(bias) if bias is not None else None
+        Cout = w.shape[0]
+        y = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
+        _conv_fwd(x, xbs, w, bias, None, y, Cout * L, k, dilation, causal)
+        if _needs_grad(ctx):
+            ctx.save_for_backward(x, w)
+            ctx.cfg = (k, dilation, int(causal), ctx.needs_input_grad[0], bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k, dilation, causal, need_dx, has_bias = ctx.cfg
+        x, xbs = _act3(x)
+        dy, dybs = _act3(dy, "grad")
+        B, Cin, L = x.shape
+        Cout = w.shape[0]
+        dx = _conv_bwd_data(dy, dybs, w, Cin, L, k, dilation, causal) if need_dx else None
+        dw = _conv_bwd_weight(dy, dybs, x, xbs, tuple(w.shape), k, dilation, causal)
+        db = None
+        if has_bias:
+            rows = torch.empty((B, Cout), dtype=_F32, device=x.device)
+            _lib.call("ssv_rowsum", _p(dy), dybs, _p(rows), B, Cout, L, _stream())
+            db = _sum_over_batch(rows, B, Cout)
+        return dx, dw, db, None, None, None
+
+
+# ------------------------------------------------------------------------------------------- embedding
+class TextEmbedFn(torch.autograd.Function):
+    """textEmbedding.forward, models/TTSModel.py:25-35: one-hot + Linear == column gather + bias."""
+
+    @staticmethod
+    def forward(ctx, ids, w, bias):
+        _dev(ids, "text ids")
+        ids = ids.long().contiguous()
+        B, one, N = ids.shape
+        w, bias = _c(w), _c(bias)
+        E, V = w.shape
+        y = torch.empty((B, E, N), dtype=_F32, device=w.device)
+        _lib.call("ssv_text_embed_fwd", _p(ids), _p(w), _p(bias), _p(y), B, N, E, V, _stream())
+        if _needs_grad(ctx):
+            ctx.save_for_backward(ids)
+            ctx.dims = (B, N, E, V)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        B, N, E, V = ctx.dims
+        dy = _c(dy)
+        dw = torch.empty((E, V), dtype=_F32, device=dy.device)
+        db = torch.empty((E,), dtype=_F32, device=dy.device)
+        _lib.call("ssv_text_embed_bwd", _p(ids), _p(dy), _p(dw), _p(db), B, N, E, V, _stream())
+        return None, dw, db
+
+
+# ------------------------------------------------------------------------------------------- attention
+class AttentionTrainFn(torch.autograd.Function):
+    """models/TTSModel.py:266-270.  kv: (B, 2d, N) text-encoder output (K = first half, V = second,
+    :138-139); q: (B, d, T).  Returns (cat(R, Q) (B, 2d, T), A (B, N, T))."""
+
+    @staticmethod
+    def forward(ctx, kv, q):
+        kv, kvbs = _act3(kv, "K|V")
+        q, qbs = _act3(q, "Q")
+        B, d2, N = kv.shape
+        d, T = q.shape[1], q.shape[2]
+        if d2 != 2 * d:
+            raise RuntimeError("attention: K|V has %d channels, Q has %d" % (d2, d))
+        a = torch.empty((B, N, T), dtype=_F32, device=q.device)
+        rq = torch.empty((B, 2 * d, T), dtype=_F32, device=q.device)
+        k_ptr = ctypes.c_void_p(kv.data_ptr())
+        v_ptr = ctypes.c_void_p(kv.data_ptr() + 4 * d * N)
+        _lib.call("ssv_attention_train_fwd", k_ptr, v_ptr, kvbs, _p(q), qbs, _p(a), _p(rq), 2 * d * T, B, d, N, T, _stream())
+        _lib.call("ssv_copy_rows", _p(q), qbs, ctypes.c_void_p(rq.data_ptr() + 4 * d * T), 2 * d * T, B, d * T, _stream())
+        if _needs_grad(ctx):
+            ctx.save_for_backward(kv, q, a)
+        return rq, a
+
+    @staticmethod
+    def backward(ctx, drq, da_ext):
+        kv, q, a = ctx.saved_tensors
+        kv, kvbs = _act3(kv)
+        q, qbs = _act3(q)
+        B, d2, N = kv.shape
+        d, T = q.shape[1], q.shape[2]
+        if drq is None:
+            drq = torch.zeros((B, 2 * d, T), dtype=_F32, device=q.device)
+        drq = _c(drq)
+        da_ext = _c(da_ext) if da_ext is not None else None
+        dkv = torch.empty((B, 2 * d, N), dtype=_F32, device=q.device)
+        dq = torch.empty((B, d, T), dtype=_F32, device=q.device)
+        nb = _lib.query("ssv_attention_train_bwd_workspace", B, d, N, T)
+        ws = _ws(nb, q.device)
+        off_q = 4 * d * T
+        _lib.call("ssv_attention_train_bwd", _p(drq), 2 * d * T, _p(da_ext), ctypes.c_void_p(drq.data_ptr() + off_q), 2 * d * T,
+                  ctypes.c_void_p(kv.data_ptr()), ctypes.c_void_p(kv.data_ptr() + 4 * d * N), kvbs, _p(q), qbs, _p(a),
+                  ctypes.c_void_p(dkv.data_ptr()), ctypes.c_void_p(dkv.data_ptr() + 4 * d * N), 2 * d * N, _p(dq), d * T,
+                  B, d, N, T, _p(ws), nb, _stream())
+        return dkv, dq
+
+
+def attention_step(kv, q, pma, a_buf, col):
+    """One synthesis step of models/TTSModel.py:281-291: writes attention column ``col`` of ``a_buf``
+    (B, N, Tcap) from the last query frame and returns the int64 arg-max positions (B,)."""
+    kv, kvbs = _act3(kv, "K|V")
+    q, qbs = _act3(q, "Q")
+    B, d2, N = kv.shape
+    d, T = q.shape[1], q.shape[2]
+    pma = pma.long().contiguous()
+    out = torch.empty((B,), dtype=torch.int64, device=q.device)
+    q_last = ctypes.c_void_p(q.data_ptr() + 4 * (T - 1))
+    _lib.call("ssv_attention_step", ctypes.c_void_p(kv.data_ptr()), kvbs, q_last, qbs, T, _p(pma), _p(a_buf),
+              a_buf.shape[2], col, _p(out), B, d, N, _stream())
+    return out
+
+
+def attention_apply(kv, a_buf, q, T):
+    """cat(V @ A[:, :, :T], Q), models/TTSModel.py:293-294, for inference (no tape)."""
+    kv, kvbs = _act3(kv, "K|V")
+    q, qbs = _act3(q, "Q")
+    B, d2, N = kv.shape
+    d = q.shape[1]
+    rq = torch.empty((B, 2 * d, T), dtype=_F32, device=q.device)
+    _lib.call("ssv_attention_apply", ctypes.c_void_p(kv.data_ptr() + 4 * d * N), kvbs, _p(a_buf), a_buf.shape[2],
+              _p(rq), 2 * d * T, B, d, N, T, _stream())
+    _lib.call("ssv_copy_rows", _p(q), qbs, ctypes.c_void_p(rq.data_ptr() + 4 * d * T), 2 * d * T, B, d * T, _stream())
+    return rq
+
+
+# ------------------------------------------------------------------------------------------- deconv
+class DeconvK2S2Fn(torch.autograd.Function):
+    """nn.ConvTranspose1d(C, C, kernel_size=2, stride=2), models/TTSModel.py:309,314."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, xbs = _act3(x, "deconv input")
+        B, Cin, L = x.shape
+        w, bias = _c(w), _c(bias)
+        Cout = w.shape[1]
+        if w.shape[0] != Cin or w.shape[2] != 2:
+            raise RuntimeError("deconv: weight %s does not match input channels %d / kernel 2" % (tuple(w.shape), Cin))
+        y = torch.empty((B, Cout, 2 * L), dtype=_F32, device=x.device)
+        _lib.call("ssv_deconv1d_k2s2_fwd", _p(x), xbs, _p(w), _p(bias), _p(y), Cout * 2 * L, B, Cin, Cout, L, _stream())
+        if _needs_grad(ctx):
+            ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        x, xbs = _act3(x)
+        dy, dybs = _act3(dy, "grad")
+        B, Cin, L = x.shape
+        Cout = w.shape[1]
+        dx = torch.empty((B, Cin, L), dtype=_F32, device=x.device)
+        dw = torch.empty_like(w)
+        db = torch.empty((Cout,), dtype=_F32, device=x.device)
+        nb = _lib.query("ssv_deconv1d_k2s2_bwd_workspace", B, Cin, Cout)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, _p(x), xbs, _p(w), _p(dx), Cin * L, _p(dw), _p(db),
+                  B, Cin, Cout, L, _p(ws), nb, _stream())
+        return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------- losses
+class SpecLossFn(torch.autograd.Function):
+    """train/ordinary.py:230-231 / :249-250: returns a 2-vector (mean |gt - y|, binary divergence)."""
+
+    @staticmethod
+    def forward(ctx, y, gt):
+        y, gt = _c(y), _c(gt)
+        if y.shape != gt.shape:
+            raise RuntimeError("spec loss: prediction %s vs target %s" % (tuple(y.shape), tuple(gt.shape)))
+        n = y.numel()
+        out = torch.empty((2,), dtype=_F32, device=y.device)
+        nb = _lib.query("ssv_spec_losses_workspace", n)
+        ws = _ws(nb, y.device)
+        _lib.call("ssv_spec_losses_fwd", _p(y), _p(gt), n, _p(out), _p(ws), nb, _stream())
+        ctx.save_for_backward(y, gt)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, gt = ctx.saved_tensors
+        gout = _c(gout)
+        dy = torch.empty_like(y)
+        _lib.call("ssv_spec_losses_bwd", _p(y), _p(gt), y.numel(), _p(gout), _p(dy), _stream())
+        return dy, None
+
+
+class GuidedAttLossFn(torch.autograd.Function):
+    """train/ordinary.py:232-234: sum(A * W[:N, :T]) / (B*N*T) as a 1-vector."""
+
+    @staticmethod
+    def forward(ctx, a, gaw):
+        a, gaw = _c(a), _c(gaw)
+        B, N, T = a.shape
+        if gaw.shape[0] < N or gaw.shape[1] < T:
+            raise RuntimeError("guided attention: weight %s smaller than attention %s" % (tuple(gaw.shape), tuple(a.shape)))
+        out = torch.empty((1,), dtype=_F32, device=a.device)
+        nb = _lib.query("ssv_guided_att_loss_workspace", B, N, T)
+        ws = _ws(nb, a.device)
+        _lib.call("ssv_guided_att_loss_fwd", _p(a), _p(gaw), gaw.shape[1], _p(out), B, N, T, _p(ws), nb, _stream())
+        ctx.save_for_backward(gaw)
+        ctx.dims = (B, N, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (gaw,) = ctx.saved_tensors
+        B, N, T = ctx.dims
+        gout = _c(gout)
+        da = torch.empty((B, N, T), dtype=_F32, device=gaw.device)
+        _lib.call("ssv_guided_att_loss_bwd", _p(gaw), gaw.shape[1], _p(gout), _p(da), B, N, T, _stream())
+        return da, None
+
+
+# ------------------------------------------------------------------------------------------- functional
+def highway_conv1d(x, w, bias, g1, b1, g2, b2, k, dilation, causal):
+    return HighwayConvFn.apply(x, w, bias, g1, b1, g2, b2, k, dilation, causal)
+
+
+def pointwise_conv_ln_act(x, w, bias, gamma, beta, s=None, act=0):
+    return PointwiseConvLnActFn.apply(x, w, bias, gamma, beta, s, act)
+
+
+def conv1d(x, w, bias, k=1, dilation=1, causal=False):
+    return Conv1dFn.apply(x, w, bias, k, dilation, causal)
+
+
+def text_embed(ids, w, bias):
+    return TextEmbedFn.apply(ids, w, bias)
+
+
+def attention_train(kv, q):
+    return AttentionTrainFn.apply(kv, q)
+
+
+def deconv1d_k2s2(x, w, bias):
+    return DeconvK2S2Fn.apply(x, w, bias)
+
+
+def spec_losses(y, gt):
+    out = SpecLossFn.apply(y, gt)
+    return out[0], out[1]
+
+
+def guided_att_loss(a, gaw):
+    return GuidedAttLossFn.apply(a, gaw)[0]

@@ -1,0 +1,234 @@
+"""Training harness pieces on the HIP hot path: initialisation, guided-attention weights, fused Adam,
+synthetic VCTK-shaped batches, the per-iteration train steps of the reference's trainers and the
+one-process-per-GPU data-parallel wrapper.
+
+What each piece replaces in the reference:
+  init_weights           train/ordinary.py:16-19
+  guided_attention_mat   train/ordinary.py:21-28 (Python double loop -> one vectorised float64 pass)
+  FusedAdam              optim.Adam(params, ALPHA, (BETA_1, BETA_2), EPSILON), train/ordinary.py:182
+  text2mel_step          train/ordinary.py:221-238 (teacher-forced forward, 3 losses, backward, Adam)
+  ssrn_step              train/ordinary.py:240-254
+  DataParallelRanks      nn.DataParallel (train/ordinary.py:165-173) -> one rank per GPU, RCCL all-reduce
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib, ops
+from .ops import _p, _stream
+
+
+def init_weights(layer):
+    """He-normal on every weight with more than one dimension (train/ordinary.py:16-19)."""
+    if hasattr(layer, "weight"):
+        if len(layer.weight.shape) > 1:
+            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+
+
+def guided_attention_mat(max_text_len, max_frame_num, device=None, g=0.2):
+    """W[n, t] = 1 - exp(-(t/T - n/N)^2 / (2 g^2)) (train/ordinary.py:21-28), evaluated in float64 and
+    rounded once to float32 -- the same values the reference's per-entry Python arithmetic stores."""
+    n = torch.arange(max_text_len, dtype=torch.float64).unsqueeze(1) / max_text_len
+    t = torch.arange(max_frame_num, dtype=torch.float64).unsqueeze(0) / max_frame_num
+    W = (1 - torch.exp(-(t - n) ** 2 / (2 * g * g))).float()
+    return W.to(device) if device is not None else W
+
+
+# --------------------------------------------------------------------------------------------- Adam
+_CHUNK = 32768
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (no weight decay / amsgrad, as the reference uses it), all parameters
+    updated by ONE multi-tensor kernel launch (ssv_adam_multi).  State keys match torch's Adam
+    (``step``, ``exp_avg``, ``exp_avg_sq``) so optimizer state dicts interchange.
+
+    With ``capturable=True`` the step count lives on the device and advances inside the kernel, so a
+    captured hipGraph of the whole training step replays correctly.
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.capturable = capturable
+        self._table = None
+        self._key = None
+        self._step_dev = None
+        self._steps = 0
+
+    def _build(self, plist):
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+        if key == self._key:
+            return
+        rows = []
+        for p in plist:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
+                raise RuntimeError("FusedAdam needs dense float32 parameters and gradients")
+            n = p.numel()
+            for off in range(0, n, _CHUNK):
+                m = min(_CHUNK, n - off)
+                rows.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, st["exp_avg"].data_ptr() + 4 * off,
+                             st["exp_avg_sq"].data_ptr() + 4 * off, m))
+        arr = np.array(rows, dtype=np.int64)
+        assert ctypes.sizeof(_lib.AdamChunk) == 40
+        self._table = torch.from_numpy(arr).to(plist[0].device)
+        self._nchunks = len(rows)
+        self._key = key
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            ops._dev(plist[0], "parameter")
+            self._build(plist)
+            self._steps += 1
+            b1, b2 = group["betas"]
+            step_dev = None
+            if self.capturable:
+                if self._step_dev is None:
+                    self._step_dev = torch.zeros(1, dtype=torch.int32, device=plist[0].device)
+                step_dev = _p(self._step_dev)
+            _lib.call("ssv_adam_multi", _p(self._table), self._nchunks, float(group["lr"]), float(b1), float(b2),
+                      float(group["eps"]), self._steps, step_dev, _stream())
+            for p in plist:
+                self.state[p]["step"] += 1
+        return loss
+
+
+# --------------------------------------------------------------------------------------------- data
+def synthetic_text2mel_batch(B, N=186, T=325, freq_bins=80, spk_dim=200, vocab=34, seed=0, device=None):
+    """VCTK-shaped synthetic batch: mel in (0,1), ids in [2, vocab) ending in
+    'E'(1) and 'P'(0) as data/dataset.py:175-185 pads them, speaker codes in the 0.04-0.09 range of
+    spk_emb/*.npy."""
+    g = torch.Generator().manual_seed(seed)
+    mel = torch.rand(B, freq_bins, T, generator=g)
+    text = torch.randint(2, vocab, (B, 1, N), generator=g)
+    text[:, :, -2] = 1
+    text[:, :, -1] = 0
+    spk = 0.04 + 0.05 * torch.rand(B, spk_dim, 1, generator=g)
+    if device is not None:
+        mel, text, spk = mel.to(device), text.to(device), spk.to(device)
+    return mel, text, spk
+
+
+def synthetic_ssrn_batch(B, T=325, freq_bins=80, out_bins=513, seed=0, device=None):
+    g = torch.Generator().manual_seed(seed)
+    mel = torch.rand(B, freq_bins, T, generator=g)
+    lin = torch.rand(B, out_bins, 4 * T, generator=g)
+    if device is not None:
+        mel, lin = mel.to(device), lin.to(device)
+    return mel, lin
+
+
+def shift_right(mel_gt):
+    """Teacher forcing input: [0 | mel[:, :, :-1]] (train/ordinary.py:226)."""
+    return torch.cat((torch.zeros_like(mel_gt[:, :, :1]), mel_gt[:, :, :-1]), dim=-1)
+
+
+# --------------------------------------------------------------------------------------------- steps
+def text2mel_losses(pred, att, mel_gt, gaw):
+    """(l1, bin_div, att) of train/ordinary.py:230-236 on the HIP loss kernels."""
+    l1, bd = ops.spec_losses(pred, mel_gt)
+    return l1, bd, ops.guided_att_loss(att, gaw)
+
+
+def text2mel_step(model, optimizer, mel_gt, text_id, spk_emb, gaw, ddp=None):
+    """One non-adversarial Text2Mel iteration (train/ordinary.py:221-238).  Returns the loss terms."""
+    optimizer.zero_grad(set_to_none=True)
+    pred, att = model(shift_right(mel_gt), text_id, spk_emb)
+    l1, bd, la = text2mel_losses(pred, att, mel_gt, gaw)
+    loss = l1 + bd + la
+    loss.backward()
+    if ddp is not None:
+        ddp.all_reduce_grads()
+    optimizer.step()
+    return l1, bd, la, att
+
+
+def ssrn_step(model, optimizer, mel_gt, lin_gt, ddp=None):
+    """One non-adversarial SSRN iteration (train/ordinary.py:240-254)."""
+    optimizer.zero_grad(set_to_none=True)
+    pred = model(mel_gt)
+    l1, bd = ops.spec_losses(pred, lin_gt)
+    (l1 + bd).backward()
+    if ddp is not None:
+        ddp.all_reduce_grads()
+    optimizer.step()
+    return l1, bd
+
+
+# --------------------------------------------------------------------------------------------- DDP
+class DataParallelRanks:
+    """One process per GPU; utterances are sharded by rank and gradients are averaged with ONE flat
+    all-reduce per bucket over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in the CPU tests).
+
+    The reference's nn.DataParallel (train/ordinary.py:165-173) re-broadcasts all parameters every
+    iteration and reduces gradients to GPU 0; here replicas stay in sync because every rank applies the
+    same averaged gradient, so the only traffic is the gradient all-reduce (96.3 MB for Text2Mel).
+    Gradients are packed into a few large flat buckets because xGMI is point-to-point: large messages
+    keep each link busy, per-tensor all-reduces (214 tensors) would be launch/latency bound.
+    """
+
+    def __init__(self, params, bucket_mb=64, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = max(1, int(bucket_mb * 1024 * 1024 // 4))
+        self._flat = None
+
+    def broadcast_parameters(self, src=0):
+        """Make every replica start from rank `src`'s weights (what DataParallel's replicate does)."""
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for p in self.params:
+                dist.broadcast(p.data, src, group=self.group)
+
+    def _buckets(self):
+        buckets, cur, n = [], [], 0
+        for p in self.params:
+            if p.grad is None:
+                continue
+            if n + p.numel() > self.bucket_elems and cur:
+                buckets.append(cur)
+                cur, n = [], 0
+            cur.append(p)
+            n += p.numel()
+        if cur:
+            buckets.append(cur)
+        return buckets
+
+    @torch.no_grad()
+    def all_reduce_grads(self):
+        if self.world == 1:
+            return
+        for bucket in self._buckets():
+            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+
+    @torch.no_grad()
+    def all_reduce_mean(self, *scalars):
+        """Average loss scalars over ranks (global-batch semantics for the adaptive critic weight,
+        train/adversarial_wasserstein_gp.py:290)."""
+        if self.world == 1:
+            return scalars
+        v = torch.stack([s.detach().reshape(()) for s in scalars])
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        v /= self.world
+        return tuple(v[i] for i in range(len(scalars)))

@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's ``models/TTSModel.py`` module surface on the HIP hot path.
+
+Same class names, constructor signatures, sub-module names (hence identical ``state_dict()`` keys and
+tensor layouts, so the reference's checkpoints load unchanged) and the same ``forward`` contracts:
+
+  melSyn(vocab_len, condition, spkemb_dim, textemb_dim=128, freq_bins=80, hidden_dim=256)
+      .forward(melspec, textid, spkemb, K=None, V=None, A_last=None, pma=None)
+          train mode            -> (Y, A)                      (models/TTSModel.py:263-273)
+          eval mode, T == 1     -> (Y, A, pma, K, V)           (:276-298)
+          eval mode, T  > 1     -> (Y, A, pma)                 (:299-300)
+  SSRN(freq_bins, output_bins, ssrn_dim).forward(mel) -> linear spectrogram (:342-362)
+  highwayConv(dimension, kernel_size, dilation, causal=False)  (:43-84; also used by the critics)
+
+The ``nn.Conv1d`` / ``nn.LayerNorm`` / ``nn.Linear`` / ``nn.ConvTranspose1d`` children are parameter
+containers only (they give the reference's initialisation order and key names); their stock
+``forward`` is never called -- all compute goes through ``spoofsv_amd.ops`` into libssv_hip.so.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class textEmbedding(nn.Module):
+    def __init__(self, vocab_len, out_channels=128):
+        super().__init__()
+        self.vocab_len = vocab_len
+        self.W = nn.Linear(in_features=vocab_len, out_features=out_channels)
+
+    def forward(self, inputs):
+        return ops.text_embed(inputs, self.W.weight, self.W.bias)
+
+
+class highwayConv(nn.Module):
+    def __init__(self, dimension, kernel_size, dilation, causal=False):
+        super().__init__()
+        self.dimension = dimension
+        self.causal = causal
+        self.kernel_size = kernel_size
+        self.dilation = dilation
+        self.pad = dilation * (kernel_size - 1) // 2
+        self.conv = nn.Conv1d(in_channels=dimension, out_channels=2 * dimension, kernel_size=kernel_size,
+                              padding=0 if causal else self.pad, dilation=dilation)
+        self.ln1 = nn.LayerNorm(normalized_shape=dimension)
+        self.ln2 = nn.LayerNorm(normalized_shape=dimension)
+
+    def forward(self, inputs):
+        return ops.highway_conv1d(inputs, self.conv.weight, self.conv.bias, self.ln1.weight, self.ln1.bias,
+                                  self.ln2.weight, self.ln2.bias, self.kernel_size, self.dilation, self.causal)
+
+
+class highwayDilationIncrement(nn.Module):
+    def __init__(self, dimension, causal=False):
+        super().__init__()
+        self.hc1 = highwayConv(dimension=dimension, kernel_size=3, dilation=1, causal=causal)
+        self.hc2 = highwayConv(dimension=dimension, kernel_size=3, dilation=3, causal=causal)
+        self.hc3 = highwayConv(dimension=dimension, kernel_size=3, dilation=9, causal=causal)
+        self.hc4 = highwayConv(dimension=dimension, kernel_size=3, dilation=27, causal=causal)
+
+    def forward(self, inputs):
+        return self.hc4(self.hc3(self.hc2(self.hc1(inputs))))
+
+
+def _cla(x, conv, ln, s=None, act=0):
+    return ops.pointwise_conv_ln_act(x, conv.weight, conv.bias, ln.weight, ln.bias, s, act)
+
+
+class textEncoder(nn.Module):
+    def __init__(self, vocab_len, textemb_dim=128, hidden_dim=256):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.textemb_layer = textEmbedding(vocab_len=vocab_len, out_channels=textemb_dim)
+        self.conv1 = nn.Conv1d(in_channels=textemb_dim, out_channels=2 * hidden_dim, kernel_size=1)
+        self.ln1 = nn.LayerNorm(normalized_shape=2 * hidden_dim)
+        self.conv2 = nn.Conv1d(in_channels=2 * hidden_dim, out_channels=2 * hidden_dim, kernel_size=1)
+        self.ln2 = nn.LayerNorm(normalized_shape=2 * hidden_dim)
+        self.hci1 = highwayDilationIncrement(dimension=2 * hidden_dim)
+        self.hci2 = highwayDilationIncrement(dimension=2 * hidden_dim)
+        self.hc1 = highwayConv(dimension=2 * hidden_dim, kernel_size=3, dilation=1)
+        self.hc2 = highwayConv(dimension=2 * hidden_dim, kernel_size=3, dilation=1)
+        self.hc3 = highwayConv(dimension=2 * hidden_dim, kernel_size=1, dilation=1)
+        self.hc4 = highwayConv(dimension=2 * hidden_dim, kernel_size=1, dilation=1)
+
+    def encode(self, inputs):
+        """The un-split (B, 2*hidden, N) output; K is the first half, V the second (:138-139)."""
+        x = self.textemb_layer(inputs)
+        x = _cla(x, self.conv1, self.ln1, act=1)      # relu feeds conv2 (:130)
+        x = _cla(x, self.conv2, self.ln2)
+        x = self.hci2(self.hci1(x))
+        return self.hc4(self.hc3(self.hc2(self.hc1(x))))
+
+    def forward(self, inputs):
+        x = self.encode(inputs)
+        return x[:, :self.hidden_dim, :], x[:, self.hidden_dim:, :]
+
+
+class audioEncoder(nn.Module):
+    def __init__(self, freq_bins, hidden_dim=256, condition=False, spkemb_dim=None):
+        super().__init__()
+        self.condition = condition
+        if condition:
+            self.fc1 = nn.Linear(in_features=spkemb_dim, out_features=hidden_dim)
+            self.fc2 = nn.Linear(in_features=spkemb_dim, out_features=hidden_dim)
+        self.conv1 = nn.Conv1d(in_channels=freq_bins, out_channels=hidden_dim, kernel_size=1)
+        self.ln1 = nn.LayerNorm(normalized_shape=hidden_dim)
+        self.conv2 = nn.Conv1d(in_channels=hidden_dim, out_channels=hidden_dim, kernel_size=1)
+        self.ln2 = nn.LayerNorm(normalized_shape=hidden_dim)
+        self.conv3 = nn.Conv1d(in_channels=hidden_dim, out_channels=hidden_dim, kernel_size=1)
+        self.ln3 = nn.LayerNorm(normalized_shape=hidden_dim)
+        self.hci1 = highwayDilationIncrement(dimension=hidden_dim, causal=True)
+        self.hci2 = highwayDilationIncrement(dimension=hidden_dim, causal=True)
+        self.hc1 = highwayConv(dimension=hidden_dim, kernel_size=3, dilation=3, causal=True)
+        self.hc2 = highwayConv(dimension=hidden_dim, kernel_size=3, dilation=3, causal=True)
+
+    def forward(self, inputs, spk=None):
+        s = p = None
+        if self.condition:
+            # nn.Linear on the (B, D, 1) speaker code == a 1x1 convolution over a length-1 sequence
+            s = ops.conv1d(spk, self.fc1.weight.unsqueeze(-1), self.fc1.bias)
+            p = ops.conv1d(spk, self.fc2.weight.unsqueeze(-1), self.fc2.bias)
+        x = _cla(inputs, self.conv1, self.ln1, s, act=1)
+        x = _cla(x, self.conv2, self.ln2, act=1)
+        x = _cla(x, self.conv3, self.ln3, p)
+        x = self.hci2(self.hci1(x))
+        return self.hc2(self.hc1(x))
+
+
+class audioDecoder(nn.Module):
+    def __init__(self, freq_bins, hidden_dim=256):
+        super().__init__()
+        self.conv1 = nn.Conv1d(in_channels=2 * hidden_dim, out_channels=hidden_dim, kernel_size=1)
+        self.ln1 = nn.LayerNorm(normalized_shape=hidden_dim)
+        self.hci = highwayDilationIncrement(dimension=hidden_dim, causal=True)
+        self.hc1 = highwayConv(dimension=hidden_dim, kernel_size=3, dilation=1, causal=True)
+        self.hc2 = highwayConv(dimension=hidden_dim, kernel_size=3, dilation=1, causal=True)
+        self.conv2 = nn.Conv1d(in_channels=hidden_dim, out_channels=hidden_dim, kernel_size=1)
+        self.ln2 = nn.LayerNorm(normalized_shape=hidden_dim)
+        self.conv3 = nn.Conv1d(in_channels=hidden_dim, out_channels=hidden_dim, kernel_size=1)
+        self.ln3 = nn.LayerNorm(normalized_shape=hidden_dim)
+        self.conv4 = nn.Conv1d(in_channels=hidden_dim, out_channels=hidden_dim, kernel_size=1)
+        self.ln4 = nn.LayerNorm(normalized_shape=hidden_dim)
+        self.conv5 = nn.Conv1d(in_channels=hidden_dim, out_channels=freq_bins, kernel_size=1)
+        self.ln5 = nn.LayerNorm(normalized_shape=freq_bins)
+
+    def forward(self, inputs):
+        x = _cla(inputs, self.conv1, self.ln1)
+        x = self.hc2(self.hc1(self.hci(x)))
+        x = _cla(x, self.conv2, self.ln2, act=1)
+        x = _cla(x, self.conv3, self.ln3, act=1)
+        x = _cla(x, self.conv4, self.ln4, act=1)
+        return _cla(x, self.conv5, self.ln5, act=2)
+
+
+class melSyn(nn.Module):
+    def __init__(self, vocab_len, condition, spkemb_dim, textemb_dim=128, freq_bins=80, hidden_dim=256):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.text_encoder = textEncoder(vocab_len=vocab_len, textemb_dim=textemb_dim, hidden_dim=hidden_dim)
+        self.audio_encoder = audioEncoder(freq_bins=freq_bins, hidden_dim=hidden_dim, condition=condition, spkemb_dim=spkemb_dim)
+        self.audio_decoder = audioDecoder(freq_bins=freq_bins, hidden_dim=hidden_dim)
+
+    def forward(self, melspec, textid, spkemb, K=None, V=None, A_last=None, pma=None):
+        T = melspec.shape[-1]
+        if self.training:
+            kv = self.text_encoder.encode(textid)
+            Q = self.audio_encoder(melspec, spkemb)
+            RQ, A = ops.attention_train(kv, Q)
+            return self.audio_decoder(RQ), A
+
+        # ---- synthesis step (models/TTSModel.py:275-300) ---------------------------------------
+        d = self.hidden_dim
+        with torch.no_grad():
+            if T == 1:
+                kv = self.text_encoder.encode(textid)
+                K, V = kv[:, :d, :], kv[:, d:, :]
+            else:
+                kv = _as_kv(K, V)
+            N = kv.shape[-1]
+            Q = self.audio_encoder(melspec, spkemb)
+            B = Q.shape[0]
+            A = torch.empty((B, N, T), dtype=torch.float32, device=Q.device)
+            if T > 1:
+                A[:, :, :T - 1] = A_last                      # older columns are kept as they were (:289-290)
+            nxt = ops.attention_step(kv, Q, pma, A, T - 1)    # mask + softmax + arg-max of the new column
+            Y = self.audio_decoder(ops.attention_apply(kv, A, Q, T))
+        if T == 1:
+            return Y, A, nxt, K, V
+        return Y, A, nxt
+
+
+def _as_kv(K, V):
+    """K and V as returned by the first step are the two halves of one (B, 2d, N) tensor; recover it
+    without a copy when that is the case, otherwise concatenate."""
+    d = K.shape[1]
+    if (K.data_ptr() + 4 * d * K.shape[2] == V.data_ptr() and K.stride() == V.stride()
+            and K.stride(2) == 1 and K.stride(1) == K.shape[2] and K.stride(0) == 2 * d * K.shape[2]):
+        return torch.as_strided(K, (K.shape[0], 2 * d, K.shape[2]), K.stride(), K.storage_offset())
+    return torch.cat((K, V), dim=1)
+
+
+class upsampling(nn.Module):
+    def __init__(self, ssrn_dim):
+        super().__init__()
+        self.deconv = nn.ConvTranspose1d(in_channels=ssrn_dim, out_channels=ssrn_dim, kernel_size=2, stride=2)
+        self.hc1 = highwayConv(dimension=ssrn_dim, kernel_size=3, dilation=1)
+        self.hc2 = highwayConv(dimension=ssrn_dim, kernel_size=3, dilation=3)
+
+    def forward(self, inputs):
+        x = ops.deconv1d_k2s2(inputs, self.deconv.weight, self.deconv.bias)
+        return self.hc2(self.hc1(x))
+
+
+class SSRN(nn.Module):
+    def __init__(self, freq_bins, output_bins, ssrn_dim):
+        super().__init__()
+        self.conv1 = nn.Conv1d(in_channels=freq_bins, out_channels=ssrn_dim, kernel_size=1)
+        self.ln1 = nn.LayerNorm(normalized_shape=ssrn_dim)
+        self.hc1 = highwayConv(dimension=ssrn_dim, kernel_size=3, dilation=1)
+        self.hc2 = highwayConv(dimension=ssrn_dim, kernel_size=3, dilation=3)
+        self.ups1 = upsampling(ssrn_dim=ssrn_dim)
+        self.ups2 = upsampling(ssrn_dim=ssrn_dim)
+        self.conv2 = nn.Conv1d(in_channels=ssrn_dim, out_channels=2 * ssrn_dim, kernel_size=1)
+        self.ln2 = nn.LayerNorm(normalized_shape=2 * ssrn_dim)
+        self.hc3 = highwayConv(dimension=2 * ssrn_dim, kernel_size=3, dilation=1)
+        self.hc4 = highwayConv(dimension=2 * ssrn_dim, kernel_size=3, dilation=1)
+        self.conv3 = nn.Conv1d(in_channels=2 * ssrn_dim, out_channels=output_bins, kernel_size=1)
+        self.ln3 = nn.LayerNorm(normalized_shape=output_bins)
+        self.conv4 = nn.Conv1d(in_channels=output_bins, out_channels=output_bins, kernel_size=1)
+        self.ln4 = nn.LayerNorm(normalized_shape=output_bins)
+        self.conv5 = nn.Conv1d(in_channels=output_bins, out_channels=output_bins, kernel_size=1)
+        self.ln5 = nn.LayerNorm(normalized_shape=output_bins)
+        self.conv6 = nn.Conv1d(in_channels=output_bins, out_channels=output_bins, kernel_size=1)
+        self.ln6 = nn.LayerNorm(normalized_shape=output_bins)
+
+    def forward(self, inputs):
+        x = _cla(inputs, self.conv1, self.ln1)
+        x = self.hc2(self.hc1(x))
+        x = self.ups2(self.ups1(x))
+        x = _cla(x, self.conv2, self.ln2)
+        x = self.hc4(self.hc3(x))
+        x = _cla(x, self.conv3, self.ln3)             # no ReLU between ln3 and conv4 (:355)
+        x = _cla(x, self.conv4, self.ln4, act=1)
+        x = _cla(x, self.conv5, self.ln5, act=1)
+        return _cla(x, self.conv6, self.ln6, act=2)

@@ -1,0 +1,213 @@
+"""GPU parity tests: the HIP path (through the C ABI of libssv_hip.so) against the golden vectors of
+the reference and against the pinned CPU oracle on seeded inputs.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import load, sub, t, rel_err
+from oracle import ge2e_oracle as GO
+from oracle import tts_oracle as TO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+# fp32 MFMA is an exact fp32 fma chain; differences to the CPU come from summation order only.
+FWD_TOL = 2e-5
+BWD_TOL = 3e-4     # BASELINE.json north_star: 1e-3 relative on spectrograms
+
+
+def _load_module_sd(mod, sd):
+    mod.load_state_dict({k: v.clone() for k, v in sd.items()})
+    return mod.to(DEV)
+
+
+def test_highway_fwd_bwd_golden():
+    from spoofsv_amd.tts import highwayConv
+    g = load("highway.npz")
+    for i, (k, d, causal) in enumerate(g["configs"]):
+        pre = "c%d/" % i
+        m = _load_module_sd(highwayConv(16, int(k), int(d), causal=bool(causal)), sub(g, pre + "sd/"))
+        x = t(g[pre + "x"], DEV).requires_grad_(True)
+        y = m(x)
+        assert rel_err(y, t(g[pre + "y"])) < FWD_TOL, (i, rel_err(y, t(g[pre + "y"])))
+        y.backward(t(g[pre + "dy"], DEV))
+        assert rel_err(x.grad, t(g[pre + "dx"])) < BWD_TOL, ("dx", i, rel_err(x.grad, t(g[pre + "dx"])))
+        for n, gr in sub(g, pre + "grad/").items():
+            got = dict(m.named_parameters())[n].grad
+            assert rel_err(got, gr) < BWD_TOL, (n, i, rel_err(got, gr))
+
+
+def test_melsyn_train_golden():
+    from spoofsv_amd import ops
+    from spoofsv_amd.tts import melSyn
+    g = load("melsyn_train.npz")
+    hidden, temb, B, N, T = [int(v) for v in g["dims"]]
+    m = _load_module_sd(melSyn(34, True, 200, textemb_dim=temb, freq_bins=80, hidden_dim=hidden), sub(g, "sd/"))
+    m.train()
+    Y, A = m(t(g["mel_in"], DEV), t(g["text"], DEV), t(g["spk"], DEV))
+    assert rel_err(Y, t(g["Y"])) < FWD_TOL, rel_err(Y, t(g["Y"]))
+    assert rel_err(A, t(g["A"])) < FWD_TOL, rel_err(A, t(g["A"]))
+    gaw = t(g["gaw"], DEV)
+    l1, bd = ops.spec_losses(Y, t(g["mel_gt"], DEV))
+    att = ops.guided_att_loss(A, gaw)
+    for mine, ref in ((l1, "l1"), (bd, "bd"), (att, "att")):
+        assert abs(float(mine) - float(g[ref])) < 2e-6 * max(1.0, abs(float(g[ref]))), (ref, float(mine), float(g[ref]))
+    (l1 + bd + att).backward()
+    bad = {}
+    for n, gr in sub(g, "grad/").items():
+        e = rel_err(dict(m.named_parameters())[n].grad, gr)
+        if e > BWD_TOL:
+            bad[n] = e
+    assert not bad, bad
+
+
+def test_melsyn_eval_loop_golden_indices_exact():
+    from spoofsv_amd.tts import melSyn
+    g = load("melsyn_eval.npz")
+    hidden, temb, B, N = [int(v) for v in g["dims"]]
+    m = _load_module_sd(melSyn(34, True, 200, textemb_dim=temb, freq_bins=80, hidden_dim=hidden), sub(g, "sd/"))
+    m.eval()
+    text, spk = t(g["text"], DEV), t(g["spk"], DEV)
+    init = torch.zeros(B, 80, 1, device=DEV)
+    Y, A, pma, K, V = m(melspec=init, textid=text, spkemb=spk, pma=torch.zeros(B, device=DEV).long())
+    inputs = torch.cat((init, Y), dim=-1)
+    seq = [pma.clone()]
+    for _ in range(int(g["steps"])):
+        Y, A, pma = m(melspec=inputs, textid=None, spkemb=spk, K=K, V=V, A_last=A, pma=pma)
+        inputs = torch.cat((inputs, Y[:, :, -1:]), dim=-1)
+        seq.append(pma.clone())
+    assert torch.equal(torch.stack(seq).cpu(), t(g["pma"]))       # bit-exact attention indices
+    assert rel_err(Y, t(g["Y"])) < 1e-4
+    assert rel_err(A, t(g["A"])) < 1e-4
+
+
+def test_ssrn_small_golden():
+    from spoofsv_amd import ops
+    from spoofsv_amd.tts import SSRN
+    g = load("ssrn_small.npz")
+    m = _load_module_sd(SSRN(80, 65, 16), sub(g, "sd/"))
+    m.train()
+    mel = t(g["mel"], DEV).requires_grad_(True)
+    P = m(mel)
+    assert rel_err(P, t(g["P"])) < FWD_TOL, rel_err(P, t(g["P"]))
+    l1, bd = ops.spec_losses(P, t(g["lin"], DEV))
+    assert abs(float(l1) - float(g["l1"])) < 2e-6 and abs(float(bd) - float(g["bd"])) < 2e-6
+    (l1 + bd).backward()
+    assert rel_err(mel.grad, t(g["dmel"])) < BWD_TOL
+    bad = {}
+    for n, gr in sub(g, "grad/").items():
+        e = rel_err(dict(m.named_parameters())[n].grad, gr)
+        if e > BWD_TOL:
+            bad[n] = e
+    assert not bad, bad
+
+
+def test_ssrn_full_config1_golden():
+    """BASELINE config 1: SSRN forward on one synthetic mel (80 x 200), full size, vs the reference."""
+    from spoofsv_amd.tts import SSRN
+    from spoofsv_amd.train import init_weights
+    g = load("ssrn_full.npz")
+    torch.manual_seed(int(g["w_seed"]))
+    m = SSRN(80, 513, 256)
+    m.apply(init_weights)
+    m = m.to(DEV).eval()
+    torch.manual_seed(int(g["x_seed"]))
+    x = torch.rand(1, 80, 200)
+    with torch.no_grad():
+        y = m(x.to(DEV)).cpu()
+    assert tuple(y.shape) == (1, 513, 800)
+    assert rel_err(y[0, ::8, ::8], t(g["y_slice"])) < 1e-4
+    assert abs(float(y.double().sum()) - float(g["y_sum"])) < 1e-4 * float(g["y_abs"])
+
+
+@pytest.mark.parametrize("C,L,k,d,causal", [(256, 325, 3, 27, True), (512, 186, 3, 9, False), (256, 650, 3, 3, False),
+                                            (512, 186, 1, 1, False), (128, 77, 3, 1, True)])
+def test_highway_full_size_vs_oracle(C, L, k, d, causal):
+    from spoofsv_amd.tts import highwayConv
+    torch.manual_seed(C + L + d)
+    m = highwayConv(C, k, d, causal=causal)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn_like(p))
+    B = 3
+    x = torch.randn(B, C, L)
+    dy = torch.randn(B, C, L)
+    sd = {"hc." + n: v.detach().clone().requires_grad_(True) for n, v in m.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    yo = TO.highway_conv(xo, sd, "hc", k, d, causal)
+    yo.backward(dy)
+    m = m.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    yg = m(xg)
+    yg.backward(dy.to(DEV))
+    assert rel_err(yg, yo) < FWD_TOL, rel_err(yg, yo)
+    assert rel_err(xg.grad, xo.grad) < BWD_TOL, rel_err(xg.grad, xo.grad)
+    for n, p in m.named_parameters():
+        assert rel_err(p.grad, sd["hc." + n].grad) < BWD_TOL, (n, rel_err(p.grad, sd["hc." + n].grad))
+
+
+def test_pointwise_513_channels_vs_oracle():
+    """SSRN tail: 513 channels (not a multiple of any MFMA tile), 4T = 1300 columns."""
+    from spoofsv_amd import ops
+    torch.manual_seed(5)
+    B, C, L = 2, 513, 1300
+    w = torch.randn(C, C, 1) * 0.05
+    b = torch.randn(C) * 0.1
+    gam = 1 + 0.2 * torch.randn(C)
+    bet = 0.2 * torch.randn(C)
+    x = torch.randn(B, C, L)
+    dy = torch.randn(B, C, L)
+    leaves = [v.clone().requires_grad_(True) for v in (x, w, b, gam, bet)]
+    yo = torch.relu(TO._ln_channels(torch.nn.functional.conv1d(leaves[0], leaves[1], leaves[2]), leaves[3], leaves[4]))
+    yo.backward(dy)
+    gl = [v.to(DEV).requires_grad_(True) for v in (x, w, b, gam, bet)]
+    yg = ops.pointwise_conv_ln_act(gl[0], gl[1], gl[2], gl[3], gl[4], None, 1)
+    yg.backward(dy.to(DEV))
+    assert rel_err(yg, yo) < FWD_TOL
+    for a, o, n in zip(gl, leaves, "x w b gamma beta".split()):
+        assert rel_err(a.grad, o.grad) < BWD_TOL, (n, rel_err(a.grad, o.grad))
+
+
+def test_adam_multi_golden():
+    from spoofsv_amd.train import FusedAdam
+    g = load("adam.npz")
+    p = torch.nn.Parameter(t(g["p0"], DEV).clone())
+    opt = FusedAdam([p], 2e-4, (0.5, 0.9), 1e-6)
+    for s in (1, 2, 3):
+        p.grad = t(g["g%d" % s], DEV).clone()
+        opt.step()
+        assert rel_err(p, t(g["p%d" % s])) < 1e-6, s
+
+
+def test_ge2e_embedder_golden():
+    from spoofsv_amd.ge2e import SpeechEmbedder
+    g = load("ge2e_embedder.npz")
+    m = SpeechEmbedder(nmels=40, hidden=32, num_layer=3, proj=16)
+    m.load_state_dict(sub(g, "sd/"))
+    m = m.to(DEV)
+    e = m(t(g["x"], DEV))
+    assert rel_err(e, t(g["e"])) < 1e-4, rel_err(e, t(g["e"]))
+
+
+def test_ge2e_embedder_midsize_vs_oracle():
+    from spoofsv_amd.ge2e import SpeechEmbedder
+    torch.manual_seed(3)
+    m = SpeechEmbedder(nmels=40, hidden=96, num_layer=3, proj=64)
+    x = torch.randn(37, 21, 40)
+    with torch.no_grad():
+        eo = GO.speech_embedder(x, m.state_dict())
+    eg = m.to(DEV)(x.to(DEV))
+    assert rel_err(eg, eo) < 1e-4, rel_err(eg, eo)
+
+
+def test_ge2e_loss_golden_and_known_answer():
+    from spoofsv_amd.ge2e import GE2ELoss
+    g = load("ge2e_loss.npz")
+    L = GE2ELoss(DEV)
+    loss = L(t(g["emb"], DEV))
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    with torch.no_grad():
+        L.w.fill_(1.0); L.b.fill_(0.0)
+    kl, per = L(t(g["kat_emb"], DEV), return_per_embedding=True)
+    assert abs(float(kl) - 5.2501) < 1e-4                      # GE2E/utils.py:89-96
+    assert rel_err(per, t(g["kat_per"])) < 1e-5
