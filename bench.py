@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: mel-frames/s of Text2Mel + SSRN training on synthetic VCTK-shaped batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one optimizer iteration of train_text2mel AND one of train_ssrn (train/ordinary.py:221-254 of
+the reference) on a batch of 32 utterances per GPU (N=186 characters, T=325 mel frames, 513x1300 linear
+frames): forward, the reference's losses, backward, Adam -- nothing skipped.  value = mel frames consumed
+by all ranks per second of that combined step ("Text2Mel+SSRN").  Inputs are resident in
+HBM before the timed region.  Weak scaling: the per-GPU batch is fixed, gradients are averaged with a
+flat RCCL all-reduce per step.
+
+Rank 0 prints ONE JSON line with the driver's contract plus:
+  roofline      the dominant kernel (dilated Conv1d implicit GEMM, fp32 MFMA) timed with HIP events here
+  cpu_baseline  the CPU oracle (same stock-op sequence the reference runs) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU, N_TEXT, T_MEL = 32, 186, 325
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    return ap.parse_args()
+
+
+class Trainer:
+    """Holds model + optimizer + static batch; runs fwd+bwd (+Adam) eagerly or from a captured graph."""
+
+    def __init__(self, kind, batch, dev, rank, world, use_graph):
+        from spoofsv_amd import train
+        from spoofsv_amd.tts import SSRN, melSyn
+        self.kind, self.world, self.train = kind, world, train
+        torch.manual_seed(1234)
+        if kind == "text2mel":
+            self.model = melSyn(34, True, 200, textemb_dim=128, freq_bins=80, hidden_dim=256)
+            self.batch = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=rank, device=dev)
+            self.gaw = train.guided_attention_mat(186, 325, device=dev)
+        else:
+            self.model = SSRN(80, 513, 256)
+            self.batch = train.synthetic_ssrn_batch(batch, T_MEL, seed=rank, device=dev)
+        self.model.apply(train.init_weights)
+        self.model.to(dev).train()
+        self.params = [p for p in self.model.parameters()]
+        self.opt = train.FusedAdam(self.params, 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+        self.ddp = train.DataParallelRanks(self.params) if world > 1 else None
+        if self.ddp:
+            self.ddp.broadcast_parameters(0)
+        self.graph = None
+        self.use_graph = use_graph
+        self.losses = None
+
+    def _fwd_bwd(self):
+        t = self.train
+        self.opt.zero_grad(set_to_none=True)
+        if self.kind == "text2mel":
+            mel, text, spk = self.batch
+            pred, att = self.model(t.shift_right(mel), text, spk)
+            l1, bd, la = t.text2mel_losses(pred, att, mel, self.gaw)
+            loss = l1 + bd + la
+        else:
+            mel, lin = self.batch
+            l1, bd = t.ops.spec_losses(self.model(mel), lin)
+            loss = l1 + bd
+        loss.backward()
+        self.losses = loss
+
+    def _whole(self):
+        self._fwd_bwd()
+        if self.ddp:
+            self.ddp.all_reduce_grads()
+        self.opt.step()
+
+    def prepare(self):
+        """Warm the allocator on a side stream and capture the step.  Single GPU: forward, backward and
+        Adam in ONE graph.  Multi GPU: forward+backward is captured, the gradient all-reduce and Adam
+        are launched eagerly after the replay (RCCL collectives stay outside the capture)."""
+        if not self.use_graph:
+            return
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._whole()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            if self.ddp:
+                self._fwd_bwd()
+            else:
+                self._whole()
+
+    def step(self):
+        if self.graph is None:
+            self._whole()
+        else:
+            self.graph.replay()
+            if self.ddp:
+                self.ddp.all_reduce_grads()
+                self.opt.step()
+
+
+def kernel_roofline(dev):
+    """Average duration of the dominant kernel -- the k=3 dilated Conv1d implicit GEMM (gemm_nn_kernel)
+    at its most frequent launch shape in the step: highwayConv C=256 (M=2C=512), L=325, B=32 -- timed
+    with HIP events on the launch stream.  Algorithmic FLOPs per launch = 2*B*L*(2C)*C*k."""
+    import ctypes
+    from spoofsv_amd import _lib
+    B, C, L, k = 32, 256, 325, 3
+    x = torch.randn(B, C, L, device=dev)
+    w = torch.randn(2 * C, C, k, device=dev) * 0.05
+    bias = torch.randn(2 * C, device=dev)
+    y = torch.empty(B, 2 * C, L, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    run = lambda: _lib.call("ssv_conv1d_fwd", P(x), C * L, P(w), P(bias), None, P(y), 2 * C * L, B, C, 2 * C, L, k, 1, 1, st)
+    for _ in range(5):
+        run()
+    reps = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * B * L * (2 * C) * C * k
+    bytes_alg = 4.0 * (B * C * L + B * 2 * C * L + 2 * C * C * k + 2 * C)
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_nn_kernel<KT=3> (dilated Conv1d fwd, B=32 C=256->512 L=325)",
+            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
+            "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4), "traffic": None}
+
+
+def cpu_baseline():
+    """The CPU oracle (oracle/tts_oracle.py: the stock torch-CPU op sequence the reference itself runs),
+    one Text2Mel and one SSRN train step on a bounded sample (B=4 and B=2 utterances of the same shape),
+    all host threads torch gives us."""
+    from oracle import tts_oracle as TO
+    from spoofsv_amd import train
+    from spoofsv_amd.tts import SSRN, melSyn
+    torch.manual_seed(1234)
+    # use the cores this process may actually run on (the box's share), not every core of the host
+    cores = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    out = {"host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    times = {}
+    for kind, b in (("text2mel", 4), ("ssrn", 2)):
+        if kind == "text2mel":
+            m = melSyn(34, True, 200, 128, 80, 256)
+            mel, text, spk = train.synthetic_text2mel_batch(b, N_TEXT, T_MEL, seed=0)
+            gaw = train.guided_attention_mat(186, 325)
+        else:
+            m = SSRN(80, 513, 256)
+            mel, lin = train.synthetic_ssrn_batch(b, T_MEL, seed=0)
+        m.apply(train.init_weights)
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        plist = list(sd.values())
+        opt = torch.optim.Adam(plist, 2e-4, (0.5, 0.9), 1e-6)
+
+        def one():
+            opt.zero_grad()
+            if kind == "text2mel":
+                Y, A = TO.melsyn_train(train.shift_right(mel), text, spk, sd)
+                l1, bd, la = TO.text2mel_losses(Y, A, mel, gaw)
+                (l1 + bd + la).backward()
+            else:
+                l1, bd = TO.ssrn_losses(TO.ssrn(mel, sd), lin)
+                (l1 + bd).backward()
+            opt.step()
+        one()
+        t0 = time.time()
+        reps = 2
+        for _ in range(reps):
+            one()
+        times[kind] = (time.time() - t0) / reps / (b * T_MEL)     # seconds per mel frame
+    fps = 1.0 / (times["text2mel"] + times["ssrn"])
+    out.update({"value": round(fps, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "1 warm-up + 2 timed train steps each of Text2Mel (B=4) and SSRN (B=2), N=186, T=325, fp32, torch CPU ops",
+                "text2mel_fps": round(1.0 / times["text2mel"], 1), "ssrn_fps": round(1.0 / times["ssrn"], 1)})
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from spoofsv_amd import _lib
+    _lib.lib()
+
+    use_graph = not args.no_graph
+    t2m = Trainer("text2mel", args.batch, dev, rank, world, use_graph)
+    ssr = Trainer("ssrn", args.batch, dev, rank, world, use_graph)
+    t2m.prepare()
+    ssr.prepare()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        t2m.step()
+        ssr.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t2m.step()
+        ssr.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-model split (same number of steps, timed separately, not part of `value`)
+    split = {}
+    for name, tr in (("text2mel", t2m), ("ssrn", ssr)):
+        barrier()
+        s0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step()
+        barrier()
+        split[name] = (time.perf_counter() - s0) / args.steps
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0])
+    frames = args.batch * T_MEL * world * args.steps
+    loss_t2m, loss_ssrn = float(t2m.losses.detach()), float(ssr.losses.detach())
+    if not (loss_t2m == loss_t2m and loss_ssrn == loss_ssrn):
+        raise SystemExit("non-finite loss in the benchmark step")
+
+    if rank == 0:
+        res = {"metric": "mel-frames/sec (Text2Mel+SSRN train)", "value": round(frames / dt, 1), "unit": "mel-frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "train_text2mel + train_ssrn (train/ordinary.py step: fwd, l1+bin-div+guided-att losses, bwd, Adam), "
+                                      "batch %d utterances/GPU, N=186, T=325, 80 mel -> 513x1300 linear, hidden 256, random-init" % args.batch,
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                          "launch": "hipGraph replay" if use_graph else "eager",
+                          "text2mel_ms": round(split["text2mel"] * 1e3, 3), "ssrn_ms": round(split["ssrn"] * 1e3, 3),
+                          "text2mel_fps": round(args.batch * T_MEL * world / split["text2mel"], 1),
+                          "ssrn_fps": round(args.batch * T_MEL * world / split["ssrn"], 1),
+                          "final_loss": [round(loss_t2m, 5), round(loss_ssrn, 5)]}}
+        res["roofline"] = kernel_roofline(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+            res["config"]["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = capturable
         self._table = None
+        self._host_table = None
         self._key = None
         self._step_dev = None
         self._steps = 0
@@ -78,7 +79,14 @@ class FusedAdam(torch.optim.Optimizer):
                              st["exp_avg_sq"].data_ptr() + 4 * off, m))
         arr = np.array(rows, dtype=np.int64)
         assert ctypes.sizeof(_lib.AdamChunk) == 40
-        self._table = torch.from_numpy(arr).to(plist[0].device)
+        # Pinned staging buffer + async copy, both allocated once (sized for every parameter): refilling
+        # them is legal while a hipGraph is being captured (the copy becomes a memcpy node).
+        if self._host_table is None:
+            cap = sum((p.numel() + _CHUNK - 1) // _CHUNK for g in self.param_groups for p in g["params"])
+            self._host_table = torch.empty((cap, 5), dtype=torch.int64).pin_memory()
+            self._table = torch.empty((cap, 5), dtype=torch.int64, device=plist[0].device)
+        self._host_table[:len(rows)].copy_(torch.from_numpy(arr))
+        self._table.copy_(self._host_table, non_blocking=True)
         self._nchunks = len(rows)
         self._key = key
 
