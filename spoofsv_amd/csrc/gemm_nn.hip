@@ -17,6 +17,8 @@
 //   B fragment lane l reads Xs[(k = l>>4)][(n = l&15) + off]   -> XS = 16 (mod 32)
 // Global -> LDS goes through registers (issue the next chunk's loads, run this chunk's MFMAs, then
 // write), which hides HBM/L2 latency under the 32-cycle MFMAs with 2 workgroups per CU.
+#include <stdio.h>
+#include <stdlib.h>
 #include "ssv_common.h"
 
 template <int KT> struct NNCfg {
@@ -27,7 +29,7 @@ template <int KT> struct NNCfg {
 };
 
 template <int KT, int WM, int NT, bool AVEC>
-__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN p, const int mtiles, const int smin, const int span) {
+__global__ __launch_bounds__(256, (WM == 1 ? 3 : 2)) void gemm_nn_kernel(const GemmNN p, const int mtiles, const int smin, const int span) {
   using Cfg = NNCfg<KT>;
   constexpr int KCH = Cfg::KCH, KC = Cfg::KC, AS = Cfg::AS;
   constexpr int BM = 64 * WM, BN = 16 * NT;
@@ -184,23 +186,36 @@ static int launch_cfg(const GemmNN& g, hipStream_t st, int smin, int span) {
   return ssv_check_launch("gemm_nn");
 }
 
+// Tile choice.  Every workgroup of these grids is resident at once (<= 4 per CU), so the kernel lasts as long
+// as the most loaded CU: ceil(tiles / 256) workgroups, each costing about its MFMA count plus a per-chunk
+// staging/barrier overhead that grows with the tile perimeter.  SSV_NN_TILE="WM,NT" overrides (tuning knob).
+static void pick_tile(const GemmNN& g, int* wm_out, int* nt_out) {
+  static const int nts[] = {8, 7, 6, 4, 2};
+  if (const char* e = getenv("SSV_NN_TILE")) {
+    int wm = 0, nt = 0;
+    if (sscanf(e, "%d,%d", &wm, &nt) == 2 && (wm == 1 || wm == 2)) {
+      for (int c : nts) if (c == nt) { *wm_out = wm; *nt_out = nt; return; }
+    }
+  }
+  double best = 1e30;
+  for (int wm = 1; wm <= 2; ++wm)
+    for (int nt : nts) {
+      const long tiles = (long)ssv_cdiv(g.M, 64 * wm) * ssv_cdiv(g.N, 16 * nt) * g.B;
+      const double per_tile = (double)wm * nt + 0.35 * wm + 0.12 * nt + 0.6;
+      const double cost = (double)((tiles + 255) / 256) * per_tile;
+      if (cost < best) { best = cost; *wm_out = wm; *nt_out = nt; }
+    }
+}
+
 template <int KT, bool AVEC>
 static int launch_nt(const GemmNN& g, hipStream_t st, int smin, int span) {
-  // Pick the column-tile width with the least padding; prefer the widest on ties.
-  static const int cand[] = {8, 7, 6, 4, 2};
-  int best = 2;
-  long best_pad = -1;
-  for (int nt : cand) {
-    const long padded = (long)ssv_cdiv(g.N, 16 * nt) * 16 * nt;
-    if (best_pad < 0 || padded < best_pad) { best_pad = padded; best = nt; }
-  }
-  switch (best) {
-    case 8: return launch_cfg<KT, 2, 8, AVEC>(g, st, smin, span);
-    case 7: return launch_cfg<KT, 2, 7, AVEC>(g, st, smin, span);
-    case 6: return launch_cfg<KT, 2, 6, AVEC>(g, st, smin, span);
-    case 4: return launch_cfg<KT, 2, 4, AVEC>(g, st, smin, span);
-    default: return launch_cfg<KT, 2, 2, AVEC>(g, st, smin, span);
-  }
+  int wm = 2, nt = 8;
+  pick_tile(g, &wm, &nt);
+#define SSV_CASE(WM_, NT_) if (wm == WM_ && nt == NT_) return launch_cfg<KT, WM_, NT_, AVEC>(g, st, smin, span)
+  SSV_CASE(2, 8); SSV_CASE(2, 7); SSV_CASE(2, 6); SSV_CASE(2, 4); SSV_CASE(2, 2);
+  SSV_CASE(1, 8); SSV_CASE(1, 7); SSV_CASE(1, 6); SSV_CASE(1, 4); SSV_CASE(1, 2);
+#undef SSV_CASE
+  return ssv_fail(SSV_UNSUPPORTED, "gemm_nn: no tile %d,%d", wm, nt);
 }
 
 int ssv_launch_gemm_nn(const GemmNN& g, hipStream_t st) {

@@ -239,18 +239,39 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(
   }
 }
 
-// out[i] = sum over blocks of part[blk][i], i < n (n = rows*C), fixed order.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int nblk) {
+// Sum the per-workgroup partial rows part[blk][n] in two levels, in a fixed order (bitwise reproducible).
+// Level 1: workgroup (x, y) folds rows y, y+RED_ROWS, ... into row y IN PLACE (every element of row y is read
+// and written by the same thread, so no other workgroup touches it).  Level 2: out[i] = sum of rows 0..RED_ROWS-1.
+#define RED_ROWS 64
+__global__ __launch_bounds__(256) void reduce_partials_l1_kernel(float* __restrict__ part, int n, int nblk) {
+  const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (i >= n || y >= nblk) return;
+  float s0 = 0.f, s1 = 0.f;
+  int k = y;
+  for (; k + RED_ROWS < nblk; k += 2 * RED_ROWS) { s0 += part[(long)k * n + i]; s1 += part[(long)(k + RED_ROWS) * n + i]; }
+  if (k < nblk) s0 += part[(long)k * n + i];
+  part[(long)y * n + i] = s0 + s1;
+}
+__global__ __launch_bounds__(256) void reduce_partials_l2_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int rows) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int k = 0;
-  for (; k + 3 < nblk; k += 4) {
+  for (; k + 3 < rows; k += 4) {
     s0 += part[(long)k * n + i]; s1 += part[(long)(k + 1) * n + i];
     s2 += part[(long)(k + 2) * n + i]; s3 += part[(long)(k + 3) * n + i];
   }
-  for (; k < nblk; ++k) s0 += part[(long)k * n + i];
+  for (; k < rows; ++k) s0 += part[(long)k * n + i];
   out[i] = (s0 + s1) + (s2 + s3);
+}
+static int reduce_partials(float* part, float* out, int n, int nblk, hipStream_t st) {
+  const int rows = nblk < RED_ROWS ? nblk : RED_ROWS;
+  if (nblk > RED_ROWS) {
+    hipLaunchKernelGGL(reduce_partials_l1_kernel, dim3(ssv_cdiv(n, 256), RED_ROWS), dim3(256), 0, st, part, n, nblk);
+    SSV_TRY(ssv_check_launch("reduce_partials_l1"));
+  }
+  hipLaunchKernelGGL(reduce_partials_l2_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, (const float*)part, out, n, rows);
+  return ssv_check_launch("reduce_partials_l2");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,9 +306,7 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
   LN_DISPATCH(C, CALL);
 #undef CALL
   SSV_TRY(ssv_check_launch("ln_gate_bwd"));
-  const int n = 6 * C;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, part, pgrads, n, (int)(grid.x * grid.y));
-  return ssv_check_launch("reduce_partials");
+  return reduce_partials(part, pgrads, 6 * C, (int)(grid.x * grid.y), st);
 }
 
 int ssv_launch_ln_act_fwd(const float* X, long x_bs, const float* gam, const float* bet, float* Y, long y_bs, float* stats,
@@ -307,7 +326,5 @@ int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs
   LN_DISPATCH(C, CALL);
 #undef CALL
   SSV_TRY(ssv_check_launch("ln_act_bwd"));
-  const int n = 3 * C;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, part, pgrads, n, (int)(grid.x * grid.y));
-  return ssv_check_launch("reduce_partials");
+  return reduce_partials(part, pgrads, 3 * C, (int)(grid.x * grid.y), st);
 }
