@@ -1,0 +1,79 @@
+"""WGAN-GP critics of the reference (``models/discriminator.py:6-80``), on stock PyTorch-ROCm ops.
+
+NOT part of the hand-written HIP hot path: SURVEY.md section 8(f) ranks the critics as the first "next" row.
+They need double backward for the gradient penalty (train/adversarial_wasserstein_gp.py:300-308), which the
+generator kernels do not need, and cost 0.7 % of the generator's FLOPs.  They exist here so that the
+reference's adversarial iteration can run end to end and hand its dL/dY to the HIP generator path.
+Same sub-module names as the reference, so ``disc_state_dict`` checkpoints interchange.  Dropout (p=0.05) is
+active whenever the module is in training mode, as in the reference (which never calls ``disc.eval()``).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _HighwayConvDropout(nn.Module):
+    """highwayConv of models/TTSModel_dropout.py:37-84 (the variant the critics import, discriminator.py:4)."""
+
+    def __init__(self, dimension, kernel_size, dilation):
+        super().__init__()
+        self.dimension = dimension
+        pad = dilation * (kernel_size - 1) // 2
+        self.conv = nn.Conv1d(dimension, 2 * dimension, kernel_size, padding=pad, dilation=dilation)
+        self.ln1 = nn.LayerNorm(dimension)
+        self.ln2 = nn.LayerNorm(dimension)
+        self.dp = nn.Dropout(p=0.05)
+
+    def forward(self, x):
+        h = self.conv(x)
+        h1 = self.ln1(h[:, :self.dimension].permute(0, 2, 1)).permute(0, 2, 1)
+        h2 = self.ln2(h[:, self.dimension:].permute(0, 2, 1)).permute(0, 2, 1)
+        g = torch.sigmoid(h1)
+        return self.dp(g * h2 + (1 - g) * x)
+
+
+def _ln(x, ln):
+    return ln(x.permute(0, 2, 1)).permute(0, 2, 1)
+
+
+class _Disc(nn.Module):
+    def __init__(self, freq_bins, disc_dim, pool1, pool2, last):
+        super().__init__()
+        self.conv1 = nn.Conv1d(freq_bins, disc_dim, 1)
+        self.ln1 = nn.LayerNorm(disc_dim)
+        self.dp1 = nn.Dropout(p=0.05)
+        self.hc = _HighwayConvDropout(disc_dim, 3, 1)
+        self.conv2 = nn.Conv1d(disc_dim, 64, 1)
+        self.pl1 = nn.AvgPool1d(kernel_size=pool1)
+        self.ln2 = nn.LayerNorm(64)
+        self.dp2 = nn.Dropout(p=0.05)
+        self.conv3 = nn.Conv1d(64, 16, 1)
+        self.pl2 = nn.AvgPool1d(kernel_size=pool2)
+        self.ln3 = nn.LayerNorm(16)
+        self.conv4 = nn.Conv1d(16, last, 1)
+        self.ln4 = nn.LayerNorm(last)
+        self.conv5 = nn.Conv1d(last, 1, 1)
+        self.pl3 = nn.AdaptiveAvgPool1d(output_size=1)
+
+    def forward(self, inputs):
+        x = self.dp1(_ln(self.conv1(inputs), self.ln1))
+        x = self.hc(x)
+        x = _ln(self.pl1(self.conv2(x)), self.ln2)
+        x = self.dp2(F.leaky_relu(x, 0.05))
+        x = _ln(self.pl2(self.conv3(x)), self.ln3)
+        x = _ln(self.conv4(F.leaky_relu(x, 0.05)), self.ln4)
+        return self.pl3(self.conv5(F.leaky_relu(x, 0.05)))      # no sigmoid: Wasserstein critic
+
+
+class melDisc(_Disc):
+    """models/discriminator.py:6-42."""
+
+    def __init__(self, freq_bins, disc_dim):
+        super().__init__(freq_bins, disc_dim, pool1=4, pool2=2, last=4)
+
+
+class linDisc(_Disc):
+    """models/discriminator.py:44-80."""
+
+    def __init__(self, freq_bins, disc_dim):
+        super().__init__(freq_bins, disc_dim, pool1=8, pool2=4, last=8)

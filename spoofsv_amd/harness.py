@@ -1,0 +1,309 @@
+"""Drop-in trainers and synthesiser with the reference's call signatures, running the generator on the HIP
+hot path:
+
+  ordinary_train(train_step, train_pattern, cfg, spec_dir, resume_checkpoints, current_time)      train/ordinary.py:130-135
+  adversarial_train(...same...)                                          train/adversarial_wasserstein_gp.py:148-153
+  synthesize(pattern, cfg, spec_dir, current_time)                                                      synthesize.py:41
+
+``cfg`` is the reference's config.json dict (same keys).  Checkpoints are written with the reference's key
+names (``model_state_dict``, ``optimizer_state_dict`` / ``opt_state_dict_syn`` ... ) and
+file names (``text2mel_iteration_N.tar.pth``, ``*_best_model.tar.pth``) so that either code base resumes the
+other's runs.
+
+Data: the reference's VCTK feature extraction (librosa STFT etc., data/dataset.py) is CPU preprocessing outside
+the hot path and is not rebuilt.  Batches come from ``BatchSource``: synthetic VCTK-shaped tensors, or -- when
+``spec_dir`` holds the reference's own ``pXXX/pXXX_NNN_{mel,lin}.npy`` spectrogram cache (data/dataset.py:85-91)
+plus ``cfg['SPK_EMB_DIR']/pXXX.npy`` -- those files, zero-padded per batch like collate_pad_3 (:215-224).
+Two extra, optional config keys bound a run: ``MAX_ITERATIONS`` and ``SYNTHETIC_BATCHES_PER_EPOCH``.
+Griffin-Lim / wav writing (synthesize.py:138-147) is CPU post-processing: synthesize() stops
+at the linear spectrogram and stores it as .npy.
+"""
+import glob
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import ops, train
+from .critic import linDisc, melDisc
+from .tts import SSRN, melSyn
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("spoofsv_amd: no ROCm device visible; the HIP hot path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def text2id(text, vocabulary):
+    """data/dataset.py:175-185: lower-case, map through VOCABULARY (the double quote folds into the single
+    quote), append 'E'."""
+    text = text.lower().replace('"', "'") + "E"
+    table = {ch: i for i, ch in enumerate(vocabulary)}
+    return [table[ch] for ch in text if ch in table]
+
+
+class BatchSource:
+    """Yields the dicts the reference's collate functions produce: data_0 mel (B,80,T), data_1 text (B,1,N)
+    int64 or lin (B,513,4T), data_2 spk (B,200,1), data_3 lin (synthesis)."""
+
+    def __init__(self, cfg, step, batch_size, spec_dir=None, seed=0, rank=0, world=1):
+        self.cfg, self.step, self.B = cfg, step, batch_size
+        self.rank, self.world, self.seed = rank, world, seed
+        self.files = []
+        if spec_dir and os.path.isdir(spec_dir):
+            self.files = sorted(glob.glob(os.path.join(spec_dir, "p*", "*_mel.npy")))
+        self.n_synth = int(cfg.get("SYNTHETIC_BATCHES_PER_EPOCH", 8))
+        self.vocab = len(cfg["VOCABULARY"]) - 1
+        self.F = cfg["COARSE_MELSPEC"]["FREQ_BINS"]
+        self.bins = 1 + cfg["STFT"]["FFT_LENGTH"] // 2
+
+    def __len__(self):
+        if self.files:
+            return max(1, len(self.files) // (self.B * self.world))
+        return self.n_synth
+
+    def _synthetic(self, i):
+        seed = self.seed + 1000 * i + self.rank
+        if self.step == "train_ssrn":
+            mel, lin = train.synthetic_ssrn_batch(self.B, self.cfg["MAX_FRAME_NUM"], self.F, self.bins, seed)
+            return {"data_0": mel, "data_1": lin}
+        mel, text, spk = train.synthetic_text2mel_batch(self.B, self.cfg["MAX_TEXT_LEN"], self.cfg["MAX_FRAME_NUM"], self.F,
+                                                        self.cfg["SPK_EMB_DIM"], self.vocab, seed)
+        out = {"data_0": mel, "data_1": text, "data_2": spk}
+        if self.step == "synthesize":
+            out["data_3"] = train.synthetic_ssrn_batch(self.B, self.cfg["MAX_FRAME_NUM"], self.F, self.bins, seed)[1]
+        return out
+
+    def _cached(self, i):
+        idx = [(i * self.world + self.rank) * self.B + j for j in range(self.B)]
+        mels = [np.load(self.files[k % len(self.files)]) for k in idx]
+        T = max(m.shape[1] for m in mels)
+        mel = torch.zeros(self.B, self.F, T)
+        for j, m in enumerate(mels):
+            mel[j, :, :m.shape[1]] = torch.from_numpy(m)
+        if self.step == "train_ssrn":
+            lin = torch.zeros(self.B, self.bins, 4 * T)
+            for j, k in enumerate(idx):
+                l = np.load(self.files[k % len(self.files)].replace("_mel.npy", "_lin.npy"))
+                lin[j, :, :l.shape[1]] = torch.from_numpy(l)
+            return {"data_0": mel, "data_1": lin}
+        raise RuntimeError("cached text2mel batches need the corpus transcripts; use synthetic batches")
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self._cached(i) if (self.files and self.step == "train_ssrn") else self._synthetic(i)
+
+
+def _build(train_step, train_pattern, cfg, adversarial):
+    if train_step == "train_text2mel":
+        model = melSyn(vocab_len=len(cfg["VOCABULARY"]) - 1, condition=(train_pattern == "conditional"),
+                       spkemb_dim=cfg["SPK_EMB_DIM"], textemb_dim=cfg["TEXT_EMB_DIM"],
+                       freq_bins=cfg["COARSE_MELSPEC"]["FREQ_BINS"], hidden_dim=cfg["HIDDEN_DIM"])
+        disc = melDisc(cfg["COARSE_MELSPEC"]["FREQ_BINS"], cfg["DISC_DIM"]) if adversarial else None
+    else:
+        model = SSRN(freq_bins=cfg["COARSE_MELSPEC"]["FREQ_BINS"], output_bins=1 + cfg["STFT"]["FFT_LENGTH"] // 2,
+                     ssrn_dim=cfg["SSRN_DIM"])
+        disc = linDisc(1 + cfg["STFT"]["FFT_LENGTH"] // 2, cfg["DISC_DIM"]) if adversarial else None
+    return model, disc
+
+
+def _adam(params, cfg, fused=True):
+    a = cfg["ADAM"]
+    if fused:
+        return train.FusedAdam(params, a["ALPHA"], (a["BETA_1"], a["BETA_2"]), a["EPSILON"])
+    return torch.optim.Adam(params, a["ALPHA"], (a["BETA_1"], a["BETA_2"]), a["EPSILON"])
+
+
+def _free_run(model, text_id, spk_emb, frames, freq_bins):
+    """The reference's synthesis loop (synthesize.py:103-109, ordinary.py:59-65)."""
+    B = text_id.shape[0]
+    dev = text_id.device
+    init = torch.zeros((B, freq_bins, 1), device=dev)
+    Y, A, pma, K, V = model(melspec=init, textid=text_id, spkemb=spk_emb, pma=torch.zeros((B,), device=dev).long())
+    inputs = torch.cat((init, Y), dim=-1)
+    for _ in range(frames - 1):
+        Y, A, pma = model(melspec=inputs, textid=None, spkemb=spk_emb, K=K, V=V, A_last=A, pma=pma)
+        inputs = torch.cat((inputs, Y[:, :, -1:]), dim=-1)
+    return Y, A
+
+
+def _save(path, payload):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save(payload, path)
+
+
+def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpoints=None, current_time=None):
+    """Non-adversarial training, train/ordinary.py:130-293."""
+    dev = _device()
+    save_dir = os.path.join(cfg["SRC_ROOT_DIR"], "checkpoints", train_pattern, "not_adversarial", str(current_time))
+    model, _ = _build(train_step, train_pattern, cfg, False)
+    epoch = iteration = 0
+    loss_val_log = []
+    if resume_checkpoints is None:
+        model.apply(train.init_weights)
+        model.to(dev)
+        opt = _adam(model.parameters(), cfg)
+    else:
+        ck = torch.load(resume_checkpoints, map_location="cpu")
+        model.load_state_dict(ck["model_state_dict"])
+        model.to(dev)
+        opt = _adam(model.parameters(), cfg)
+        opt.load_state_dict(ck["optimizer_state_dict"])
+        epoch, iteration, loss_val_log = ck["epoch"], ck["iteration"], ck["loss_val_log"]
+    model.train()
+    src = BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir)
+    gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
+    max_iter = cfg.get("MAX_ITERATIONS")
+    history = []
+    while epoch < cfg["MAX_EPOCHS"]:
+        for i, sp in enumerate(src):
+            t0 = time.time()
+            mel_gt = sp["data_0"].to(dev)
+            if train_step == "train_text2mel":
+                l1, bd, la, att = train.text2mel_step(model, opt, mel_gt, sp["data_1"].to(dev), sp["data_2"].to(dev), gaw)
+                terms = (float(l1), float(bd), float(la))
+            else:
+                l1, bd = train.ssrn_step(model, opt, mel_gt, sp["data_1"].to(dev))
+                terms = (float(l1), float(bd))
+            history.append(sum(terms))
+            print("Iteration {}/{} for epoch {}, loss: {} {} global iteration {}".format(
+                i + 1, len(src), epoch + 1, " ".join(str(t) for t in terms), sum(terms), iteration + 1))
+            if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
+                loss_val_log.append(history[-1])
+                payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
+                           "optimizer_state_dict": opt.state_dict(), "loss_val_log": loss_val_log}
+                _save(os.path.join(save_dir, "{}_iteration_{}.tar.pth".format(train_step[6:], iteration + 1)), payload)
+                if loss_val_log.index(min(loss_val_log)) == len(loss_val_log) - 1:
+                    _save(os.path.join(save_dir, "{}_best_model.tar.pth".format(train_step[6:])), payload)
+            iteration += 1
+            print("Time elapsed {}s".format(time.time() - t0))
+            if max_iter is not None and iteration >= max_iter:
+                return model, history
+        epoch += 1
+    return model, history
+
+
+def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpoints=None, current_time=None):
+    """WGAN-GP training, train/adversarial_wasserstein_gp.py:148-450: one generator iteration, then RATIO critic
+    iterations (:267); the generator runs on the HIP path in all of them (:278, :329), the critic on stock ops."""
+    dev = _device()
+    save_dir = os.path.join(cfg["SRC_ROOT_DIR"], "checkpoints", train_pattern, "adversarial", str(current_time))
+    model, disc = _build(train_step, train_pattern, cfg, True)
+    epoch = iteration = 0
+    logs = {"wd_log": [], "loss_train_log_syn": [], "loss_train_log_syn_onlyfromD": [], "loss_train_log_disc": [], "loss_val_log": []}
+    if resume_checkpoints is None:
+        model.apply(train.init_weights)
+        disc.apply(train.init_weights)
+        model.to(dev)
+        disc.to(dev)
+        opt_syn = _adam(model.parameters(), cfg)
+        opt_disc = _adam(disc.parameters(), cfg, fused=False)
+    else:
+        ck = torch.load(resume_checkpoints, map_location="cpu")
+        epoch, iteration = ck["epoch"], ck["iteration"]
+        model.load_state_dict(ck["model_state_dict"])
+        disc.load_state_dict(ck["disc_state_dict"])
+        model.to(dev)
+        disc.to(dev)
+        opt_syn = _adam(model.parameters(), cfg)
+        opt_disc = _adam(disc.parameters(), cfg, fused=False)
+        opt_syn.load_state_dict(ck["opt_state_dict_syn"])
+        opt_disc.load_state_dict(ck["opt_state_dict_disc"])
+        for k in logs:
+            logs[k] = ck[k]
+    model.train()
+    disc.train()
+    src = BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir)
+    gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
+    max_iter = cfg.get("MAX_ITERATIONS")
+    while epoch < cfg["MAX_EPOCHS"]:
+        for i, sp in enumerate(src):
+            t0 = time.time()
+            opt_syn.zero_grad(set_to_none=True)
+            opt_disc.zero_grad(set_to_none=True)
+            target = "D" if iteration % (cfg["RATIO"] + 1) else "G"
+            mel_gt = sp["data_0"].to(dev)
+            if train_step == "train_text2mel":
+                gt = mel_gt
+                pred, att = model(train.shift_right(mel_gt), sp["data_1"].to(dev), sp["data_2"].to(dev))
+            else:
+                gt = sp["data_1"].to(dev)
+                pred, att = model(mel_gt), None
+            B, C, T = gt.shape
+            if target == "G":
+                disc_syn = disc(pred)
+                l1, bd = ops.spec_losses(pred, gt)
+                base = l1 + bd
+                if att is not None:
+                    base = base + ops.guided_att_loss(att, gaw)
+                loss_disc = torch.mean(-disc_syn)
+                # adaptive weight of the critic term (:290): plain Python floats, as the reference's .item() calls
+                loss = base + (float(base) / abs(float(loss_disc))) * loss_disc
+                loss.backward()
+                opt_syn.step()
+                logs["loss_train_log_syn"].append(float(loss))
+                logs["loss_train_log_syn_onlyfromD"].append(float(loss_disc))
+                print("training G  L1:{}, BD:{}, DISC:{}, ALL:{}".format(float(l1), float(bd), float(loss_disc), float(loss)))
+            else:
+                coeff = torch.rand(B).view(B, 1, 1).expand(B, C, T).to(dev)          # CPU RNG, as :300
+                mid = (coeff * gt.detach() + (1 - coeff) * pred.detach()).requires_grad_(True)
+                out_mid = disc(mid)
+                grads = torch.autograd.grad(outputs=out_mid, inputs=mid, grad_outputs=torch.ones_like(out_mid),
+                                            retain_graph=True, create_graph=True)[0]
+                loss_gp = torch.mean(cfg["LAMBDA"] * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
+                loss_gp.backward()
+                loss_D = torch.mean(disc(pred.detach()) - disc(gt.detach()))
+                loss_D.backward()
+                opt_disc.step()
+                logs["loss_train_log_disc"].append(float(loss_D) + float(loss_gp))
+                logs["wd_log"].append(-float(loss_D))
+                print("training D  DISC:{}, WD:{}".format(float(loss_D) + float(loss_gp), -float(loss_D)))
+            if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
+                payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
+                           "disc_state_dict": disc.state_dict(), "opt_state_dict_syn": opt_syn.state_dict(),
+                           "opt_state_dict_disc": opt_disc.state_dict()}
+                payload.update(logs)
+                _save(os.path.join(save_dir, "{}_iteration_{}.tar.pth".format(train_step[6:], iteration + 1)), payload)
+            iteration += 1
+            print("Time elapsed {}s.".format(time.time() - t0))
+            if max_iter is not None and iteration >= max_iter:
+                return model, disc, logs
+        epoch += 1
+    return model, disc, logs
+
+
+def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=None, max_frames=None):
+    """synthesize.py:41-147 up to the linear spectrogram: Text2Mel free-running loop, then SSRN.  Returns the
+    list of (mel, lin, attention) numpy triples and stores them under SRC_ROOT_DIR/samples/<time>/."""
+    dev = _device()
+    sample_dir = os.path.join(cfg["SRC_ROOT_DIR"], "samples", str(current_time))
+    os.makedirs(sample_dir, exist_ok=True)
+    m1 = melSyn(vocab_len=len(cfg["VOCABULARY"]) - 1, condition=(pattern == "conditional"), spkemb_dim=cfg["SPK_EMB_DIM"],
+                textemb_dim=cfg["TEXT_EMB_DIM"], freq_bins=cfg["COARSE_MELSPEC"]["FREQ_BINS"], hidden_dim=cfg["HIDDEN_DIM"])
+    m2 = SSRN(freq_bins=cfg["COARSE_MELSPEC"]["FREQ_BINS"], output_bins=1 + cfg["STFT"]["FFT_LENGTH"] // 2, ssrn_dim=cfg["SSRN_DIM"])
+    for m, key in ((m1, "INFERENCE_TEXT2MEL_MODEL"), (m2, "INFERENCE_SSRN_MODEL")):
+        path = cfg.get(key)
+        if path and os.path.exists(path):
+            m.load_state_dict(torch.load(path, map_location="cpu")["model_state_dict"])
+        else:   # no trained checkpoint available offline: seeded random weights
+            torch.manual_seed(1234)
+            m.apply(train.init_weights)
+        m.to(dev).eval()
+    if texts is None:
+        with open(cfg["TTS_TEXTS"]) as f:
+            texts = [ln.strip() for ln in f if ln.strip()][:1]
+    frames = max_frames or cfg["MAX_FRAME_NUM"]
+    outs = []
+    with torch.no_grad():
+        for k, text in enumerate(texts):
+            ids = torch.tensor(text2id(text, cfg["VOCABULARY"]), dtype=torch.long, device=dev).view(1, 1, -1)
+            spk = (spk_emb if spk_emb is not None else torch.full((1, cfg["SPK_EMB_DIM"], 1), 0.06)).to(dev).float()
+            Y, A = _free_run(m1, ids, spk, frames, cfg["COARSE_MELSPEC"]["FREQ_BINS"])
+            lin = m2(Y)
+            mel_np, lin_np, a_np = Y[0].cpu().numpy(), lin[0].cpu().numpy(), A[0].cpu().numpy()
+            np.save(os.path.join(sample_dir, "S{}_mel.npy".format(k + 1)), mel_np)
+            np.save(os.path.join(sample_dir, "S{}_lin.npy".format(k + 1)), lin_np)
+            outs.append((mel_np, lin_np, a_np))
+    return outs

@@ -1,0 +1,79 @@
+"""CPU-only checks of the C-ABI boundary: libssv_hip.so loads without a GPU, exports every symbol that
+include/ssv_hip.h declares, answers its host-side queries, and rejects bad arguments with the documented
+codes before touching the device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from spoofsv_amd import _lib
+
+
+def test_header_declares_expected_entry_points():
+    protos = _lib.parse_header()
+    must = ["ssv_version", "ssv_arch", "ssv_last_error", "ssv_conv1d_fwd", "ssv_conv1d_bwd_data", "ssv_conv1d_bwd_weight",
+            "ssv_channel_ln_act_fwd", "ssv_channel_ln_act_bwd", "ssv_highway_conv1d_fwd", "ssv_highway_conv1d_bwd",
+            "ssv_text_embed_fwd", "ssv_text_embed_bwd", "ssv_attention_train_fwd", "ssv_attention_train_bwd",
+            "ssv_attention_step", "ssv_attention_apply", "ssv_deconv1d_k2s2_fwd", "ssv_deconv1d_k2s2_bwd",
+            "ssv_spec_losses_fwd", "ssv_spec_losses_bwd", "ssv_guided_att_loss_fwd", "ssv_guided_att_loss_bwd",
+            "ssv_adam_multi", "ssv_lstm_fwd", "ssv_proj_l2norm_fwd", "ssv_ge2e_loss_fwd"]
+    for name in must:
+        assert name in protos, name
+    # every prototype in the header text was parsed (count `ssv_xxx(` occurrences outside comments)
+    src = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER).read(), flags=re.S)
+    names = set(re.findall(r"\b(ssv_\w+)\s*\(", src))
+    assert names == set(protos), names ^ set(protos)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()                      # raises if a declared symbol is missing
+    assert L.ssv_version() == 1
+    assert L.ssv_arch() == b"gfx950"
+    raw = ctypes.CDLL(_lib.LIBPATH)
+    for name in _lib.parse_header():
+        assert hasattr(raw, name), name
+
+
+def test_no_torch_types_in_signatures():
+    src = open(_lib.HEADER).read()
+    assert "torch" not in src.lower().replace("pytorch", "").replace("torch's", "").replace("torch layout", "").replace("on torch", "").replace("torch.cat", "")
+    assert "at::" not in src and "Tensor" not in src
+
+
+def test_workspace_queries_are_host_only():
+    q = _lib.query
+    B, C, L, k = 32, 256, 325, 3
+    assert q("ssv_conv1d_bwd_data_workspace", C, 2 * C, k) >= 4 * C * 2 * C * k
+    assert q("ssv_highway_conv1d_bwd_workspace", B, C, L, k) >= 4 * B * 2 * C * L
+    assert q("ssv_attention_train_bwd_workspace", B, 256, 186, 325) >= 4 * B * 186 * 325
+    assert q("ssv_lstm_fwd_workspace", 880, 120, 40, 768, 3) >= 4 * 120 * 4 * 768 * 880
+    assert q("ssv_ge2e_loss_fwd_workspace", 88, 10, 256) >= 4 * 88 * 256
+
+
+def test_bad_arguments_fail_before_the_device():
+    L = _lib.lib()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)           # non-null dummy, never dereferenced: the checks come first
+    # empty problem -> -1
+    rc = L.ssv_conv1d_fwd(one, 0, one, null, null, one, 0, 0, 4, 4, 8, 3, 1, 0, null)
+    assert rc == -1 and b"conv1d_fwd" in L.ssv_last_error()
+    # unsupported kernel size -> -2
+    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 5, 1, 0, null)
+    assert rc == -2 and b"kernel_size" in L.ssv_last_error()
+    # dilation halo beyond the staged tile -> -2
+    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 3, 28, 0, null)
+    assert rc == -2
+    # workspace too small -> -1
+    rc = L.ssv_conv1d_bwd_data(one, 64, one, null, one, 64, 1, 4, 4, 16, 3, 1, 0, one, 8, null)
+    assert rc == -1 and b"workspace" in L.ssv_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.call("ssv_ge2e_loss_fwd", one, one, one, one, null, 4, 1, 8, one, 1 << 20, null)   # M must be > 1
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    import torch
+    from spoofsv_amd.tts import SSRN
+    m = SSRN(80, 65, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 80, 8))

@@ -1,0 +1,111 @@
+"""GPU tests of the drop-in harness: the reference's main.py entry points run end to end on the HIP path."""
+import json
+import os
+
+import pytest
+import torch
+
+from _golden import rel_err
+from oracle import tts_oracle as TO
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(tmp_path, **over):
+    cfg = json.load(open(os.path.join(ROOT, "config.json")))
+    cfg.update(SRC_ROOT_DIR=str(tmp_path) + os.sep, BATCH_SIZE=2, MAX_TEXT_LEN=24, MAX_FRAME_NUM=40, HIDDEN_DIM=32,
+               TEXT_EMB_DIM=16, SSRN_DIM=32, DISC_DIM=16, VAL_EVERY_ITER=2, SYNTHETIC_BATCHES_PER_EPOCH=3,
+               TTS_TEXTS=os.path.join(ROOT, "tts_texts.txt"))
+    cfg["STFT"] = {"FFT_LENGTH": 128, "HOP_LENGTH": 32}
+    cfg.update(over)
+    return cfg
+
+
+def test_ordinary_text2mel_trains_and_checkpoints(tmp_path):
+    from spoofsv_amd import harness
+    cfg = _cfg(tmp_path, MAX_ITERATIONS=6)
+    model, hist = harness.ordinary_train("train_text2mel", "conditional", cfg, current_time="t")
+    assert len(hist) == 6 and all(h == h for h in hist)
+    ck = os.path.join(str(tmp_path), "checkpoints", "conditional", "not_adversarial", "t", "text2mel_iteration_3.tar.pth")
+    payload = torch.load(ck, map_location="cpu")
+    assert set(payload) == {"epoch", "iteration", "model_state_dict", "optimizer_state_dict", "loss_val_log"}
+    # resume from it (the reference's -R path) and keep going
+    cfg2 = _cfg(tmp_path, MAX_ITERATIONS=5)
+    harness.ordinary_train("train_text2mel", "conditional", cfg2, resume_checkpoints=ck, current_time="t2")
+
+
+def test_ordinary_step_matches_cpu_oracle_step(tmp_path):
+    """One full optimizer iteration (fwd, losses, bwd, Adam) on the HIP path equals the oracle's."""
+    from spoofsv_amd import train
+    from spoofsv_amd.tts import melSyn
+    torch.manual_seed(7)
+    m = melSyn(34, True, 200, textemb_dim=16, freq_bins=80, hidden_dim=32)
+    m.apply(train.init_weights)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    mel, text, spk = train.synthetic_text2mel_batch(3, N=24, T=40, seed=2)
+    gaw = train.guided_attention_mat(186, 325)
+    opt_o = torch.optim.Adam(list(sd.values()), 2e-4, (0.5, 0.9), 1e-6)
+    Y, A = TO.melsyn_train(train.shift_right(mel), text, spk, sd)
+    l = TO.text2mel_losses(Y, A, mel, gaw)
+    sum(l).backward()
+    opt_o.step()
+    m = m.to("cuda:0").train()
+    opt = train.FusedAdam(m.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    l1, bd, la, _ = train.text2mel_step(m, opt, mel.cuda(), text.cuda(), spk.cuda(), gaw.cuda())
+    for mine, ref in zip((l1, bd, la), l):
+        assert abs(float(mine) - float(ref)) < 1e-5 * max(1, abs(float(ref)))
+    # Adam's first step moves every weight by ~lr*sign(g): compare the UPDATE, which is what the step computed
+    worst = 0.0
+    for k, p in m.state_dict().items():
+        worst = max(worst, float((p.cpu() - sd[k].detach()).abs().max()))
+    assert worst < 2e-5, worst          # lr = 2e-4: a sign flip of one update would show as 4e-4
+
+
+def test_adversarial_ssrn_and_text2mel_iterations(tmp_path):
+    from spoofsv_amd import harness
+    for step in ("train_text2mel", "train_ssrn"):
+        cfg = _cfg(tmp_path, MAX_ITERATIONS=7, RATIO=2)
+        model, disc, logs = harness.adversarial_train(step, "conditional", cfg, current_time="adv_" + step)
+        assert len(logs["loss_train_log_syn"]) == 3 and len(logs["loss_train_log_disc"]) == 4
+        assert all(v == v for v in logs["loss_train_log_syn"] + logs["loss_train_log_disc"])
+        ck = os.path.join(str(tmp_path), "checkpoints", "conditional", "adversarial", "adv_" + step,
+                          "{}_iteration_3.tar.pth".format(step[6:]))
+        keys = set(torch.load(ck, map_location="cpu"))
+        assert {"model_state_dict", "disc_state_dict", "opt_state_dict_syn", "opt_state_dict_disc", "wd_log"} <= keys
+
+
+def test_generator_accepts_critic_gradient_like_oracle():
+    """dL/dY coming from a stock-op critic flows through the HIP generator exactly as through the oracle."""
+    from spoofsv_amd import train
+    from spoofsv_amd.critic import linDisc
+    from spoofsv_amd.tts import SSRN
+    torch.manual_seed(11)
+    g = SSRN(80, 65, 16)
+    g.apply(train.init_weights)
+    d = linDisc(65, 16).eval()                     # eval: no dropout, so both arms see the same critic
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in g.state_dict().items()}
+    mel = torch.rand(2, 80, 16)
+    (-d(TO.ssrn(mel, sd))).mean().backward()
+    g = g.to("cuda:0").train()
+    d = d.to("cuda:0")
+    (-d(g(mel.cuda()))).mean().backward()
+    bad = {k: rel_err(p.grad, sd[k].grad) for k, p in g.named_parameters() if rel_err(p.grad, sd[k].grad) > 3e-4}
+    assert not bad, bad
+
+
+def test_main_cli_synthesize(tmp_path):
+    import main as cli_main
+    cfg = _cfg(tmp_path)
+    path = os.path.join(str(tmp_path), "cfg.json")
+    json.dump(cfg, open(path, "w"))
+
+    class A:
+        step, pattern, resume, configuration, adversarial, save_spectrogram, current_time = \
+            "synthesize", "conditional", None, path, False, False, "syn"
+    cfg["MAX_FRAME_NUM"] = 12
+    json.dump(cfg, open(path, "w"))
+    outs = cli_main.run(A)
+    mel, lin, att = outs[0]
+    assert mel.shape == (80, 12) and lin.shape == (65, 48) and att.shape == (43, 12)
+    assert os.path.exists(os.path.join(str(tmp_path), "samples", "syn", "S1_lin.npy"))

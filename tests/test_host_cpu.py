@@ -1,0 +1,112 @@
+"""CPU-only tests of the host logic: the module mirror (names, state-dict keys, initialisation order),
+the guided-attention matrix, synthetic batches and the data-parallel wrapper over gloo (world_size 2)."""
+import hashlib
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from _golden import load, sub
+from spoofsv_amd import train
+from spoofsv_amd.ge2e import GE2ELoss, SpeechEmbedder
+from spoofsv_amd.tts import SSRN, highwayConv, melSyn
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def test_state_dict_keys_match_reference():
+    g = load("melsyn_train.npz")
+    hidden, temb = int(g["dims"][0]), int(g["dims"][1])
+    m = melSyn(34, True, 200, textemb_dim=temb, freq_bins=80, hidden_dim=hidden)
+    ref = sub(g, "sd/")
+    assert list(m.state_dict().keys()) == list(ref.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(ref[k].shape), k
+    s = SSRN(80, 65, 16)
+    ref = sub(load("ssrn_small.npz"), "sd/")
+    assert list(s.state_dict().keys()) == list(ref.keys())
+    e = SpeechEmbedder(40, 32, 3, 16)
+    ref = sub(load("ge2e_embedder.npz"), "sd/")
+    assert list(e.state_dict().keys()) == list(ref.keys())
+    hc = highwayConv(16, 3, 9, causal=True)
+    assert list(hc.state_dict().keys()) == ["conv.weight", "conv.bias", "ln1.weight", "ln1.bias", "ln2.weight", "ln2.bias"]
+    L = GE2ELoss(torch.device("cpu"))
+    assert float(L.w) == 10.0 and float(L.b) == -5.0
+
+
+def test_full_size_init_reproduces_reference_checksums():
+    """G9: manual_seed -> construct -> apply(init_weights) gives the reference's weights bit for bit, so
+    full-size parity runs need no shipped checkpoints."""
+    g = load("init_pin.npz")
+    for tag, ctor in (("t2m", lambda: melSyn(34, True, 200, 128, 80, 256)), ("ssrn", lambda: SSRN(80, 513, 256))):
+        torch.manual_seed(1234)
+        m = ctor()
+        m.apply(train.init_weights)
+        sd = m.state_dict()
+        assert list(sd.keys()) == [str(n) for n in g[tag + "/names"]]
+        assert sum(p.numel() for p in m.parameters()) == int(g[tag + "/numel"])
+        for k, sha in zip(sd.keys(), g[tag + "/sha"]):
+            assert _sha(sd[k].numpy()) == str(sha), k
+
+
+def test_guided_attention_matrix_matches_reference_loop():
+    g = load("gaw.npz")
+    W = train.guided_attention_mat(186, 325)
+    assert np.array_equal(W.numpy()[g["n"], g["t"]], g["w"])
+    assert np.array_equal(W.numpy()[93], g["row93"])
+
+
+def test_synthetic_batches_and_shift():
+    mel, text, spk = train.synthetic_text2mel_batch(3, N=20, T=17, seed=5)
+    assert mel.shape == (3, 80, 17) and text.shape == (3, 1, 20) and spk.shape == (3, 200, 1)
+    assert text.dtype == torch.int64 and int(text.min()) >= 0 and int(text.max()) < 34
+    assert torch.all(text[:, :, -1] == 0) and torch.all(text[:, :, -2] == 1)
+    s = train.shift_right(mel)
+    assert torch.all(s[:, :, 0] == 0) and torch.equal(s[:, :, 1:], mel[:, :, :-1])
+    mel2, lin = train.synthetic_ssrn_batch(2, T=9, seed=1)
+    assert lin.shape == (2, 513, 36)
+    a, _, _ = train.synthetic_text2mel_batch(3, N=20, T=17, seed=5)
+    assert torch.equal(a, mel)          # deterministic per seed (rank)
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # replicas start DIFFERENT on purpose
+    params = [torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(300)), torch.nn.Parameter(torch.randn(3))]
+    ddp = train.DataParallelRanks(params, bucket_mb=0.001)   # tiny buckets -> several all-reduces
+    ddp.broadcast_parameters(0)
+    after_bcast = [p.detach().clone() for p in params]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    params[2].grad = None if False else params[2].grad
+    ddp.all_reduce_grads()
+    l = ddp.all_reduce_mean(torch.tensor(float(rank)), torch.tensor(10.0 * rank))
+    q.put((rank, [p.numpy() for p in after_bcast], [p.grad.numpy() for p in params], [float(v) for v in l]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_ranks_gloo_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, w0, g0, l0), (r1, w1, g1, l1) = res
+    for a, b in zip(w0, w1):                             # broadcast made the replicas identical
+        assert np.array_equal(a, b)
+    for i, (a, b) in enumerate(zip(g0, g1)):             # gradients averaged: (1 + 2)/2 * (i+1)
+        assert np.allclose(a, 1.5 * (i + 1)) and np.array_equal(a, b)
+    assert l0 == l1 == [0.5, 5.0]
