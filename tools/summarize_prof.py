@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output (kernel_stats.csv, optional FETCH_SIZE / WRITE_SIZE counter passes) into a short text table."""
+import csv, glob, sys, collections
+def stats(path, top=25):
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    out = ["%7s %7s %11s  %s" % ("time%", "calls", "avg_us", "kernel")]
+    for r in rows[:top]:
+        out.append("%6.2f%% %7s %11.1f  %s" % (100 * float(r["TotalDurationNs"]) / tot, r["Calls"], float(r["AverageNs"]) / 1e3, r["Name"][:120]))
+    out.append("total kernel time: %.3f ms over %d kernels" % (tot / 1e6, len(rows)))
+    return "\n".join(out)
+def counters(path, name):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name: continue
+        k = r["Kernel_Name"]
+        acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    return acc
+if __name__ == "__main__":
+    d = sys.argv[1]
+    print(stats(glob.glob(d + "/*/*kernel_stats.csv")[0]))
+    if len(sys.argv) > 3:
+        f = counters(glob.glob(sys.argv[2] + "/*/*counter_collection.csv")[0], "FETCH_SIZE")
+        w = counters(glob.glob(sys.argv[3] + "/*/*counter_collection.csv")[0], "WRITE_SIZE")
+        print("\nPMC (separate passes; units as reported by rocprofv3 = KiB; per-launch averages)")
+        print("%12s %12s %7s  %s" % ("FETCH_KiB", "WRITE_KiB", "calls", "kernel"))
+        for k in sorted(f, key=lambda k: -f[k][0])[:14]:
+            print("%12.1f %12.1f %7d  %s" % (f[k][0] / f[k][1], w[k][0] / max(1, w[k][1]), f[k][1], k[:110]))
