@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU, N_TEXT, T_MEL = 32, 186, 325
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparse figure)
 
 
 def parse():
@@ -40,6 +41,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="conv GEMM arithmetic: split-bf16 MFMA (default, ~1e-5 rel) or exact fp32 MFMA")
     return ap.parse_args()
 
 
@@ -133,7 +136,9 @@ def kernel_roofline(dev):
     y = torch.empty(B, 2 * C, L, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
-    run = lambda: _lib.call("ssv_conv1d_fwd", P(x), C * L, P(w), P(bias), None, P(y), 2 * C * L, B, C, 2 * C, L, k, 1, 1, st)
+    nb = _lib.query("ssv_conv1d_fwd_workspace", C, 2 * C, k)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    run = lambda: _lib.call("ssv_conv1d_fwd", P(x), C * L, P(w), P(bias), None, P(y), 2 * C * L, B, C, 2 * C, L, k, 1, 1, P(ws), nb, st)
     for _ in range(5):
         run()
     reps = 50
@@ -147,8 +152,14 @@ def kernel_roofline(dev):
     flops = 2.0 * B * L * (2 * C) * C * k
     bytes_alg = 4.0 * (B * C * L + B * 2 * C * L + 2 * C * C * k + 2 * C)
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_nn_kernel<KT=3> (dilated Conv1d fwd, B=32 C=256->512 L=325)",
-            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+    split = _lib.lib().ssv_set_precision(1) == 1      # read the mode (set_precision returns the previous one) ...
+    _lib.lib().ssv_set_precision(1 if split else 0)   # ... and restore it
+    # split-bf16 mode executes 3 bf16 MFMAs per algorithmic fp32 product: the roof for ALGORITHMIC flops is peak/3
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+    name = "gemm_nn_bf3_kernel<KT=3> (split-bf16 MFMA, 3 bf16 MFMAs per fp32 product)" if split else "gemm_nn_kernel<KT=3> (fp32 MFMA)"
+    return {"bound": "mfma", "kernel": name + ", dilated Conv1d fwd B=32 C=256->512 L=325",
+            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "peak_note": "bf16 dense 2500 TFLOP/s / 3" if split else "fp32-input MFMA dense",
             "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
             "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4), "traffic": None}
 
@@ -224,6 +235,9 @@ def main():
     _lib.lib()
 
     use_graph = not args.no_graph
+    import spoofsv_amd
+    spoofsv_amd.set_precision(args.precision)
+    use_bf3_mode = args.precision == "bf16x3"
     t2m = Trainer("text2mel", args.batch, dev, rank, world, use_graph)
     ssr = Trainer("ssrn", args.batch, dev, rank, world, use_graph)
     t2m.prepare()
@@ -265,7 +279,7 @@ def main():
     if rank == 0:
         res = {"metric": "mel-frames/sec (Text2Mel+SSRN train)", "value": round(frames / dt, 1), "unit": "mel-frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (conv GEMMs: split-bf16 hi+lo operands, fp32 accumulate)" if use_bf3_mode else "f32", "data": "synthetic",
                "config": {"workload": "train_text2mel + train_ssrn (train/ordinary.py step: fwd, l1+bin-div+guided-att losses, bwd, Adam), "
                                       "batch %d utterances/GPU, N=186, T=325, 80 mel -> 513x1300 linear, hidden 256, random-init" % args.batch,
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,

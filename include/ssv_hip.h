@@ -32,6 +32,10 @@ typedef void* ssv_stream_t; /* hipStream_t */
 int ssv_version(void);            /* ABI version, currently 1 */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
+/* Arithmetic of the conv GEMMs: 0 = fp32-in MFMA (bit-exact fp32 fma chains), 1 = split-bf16 MFMA (each fp32
+ * operand as bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate; ~1e-5 relative; default; env
+ * SSV_PRECISION=fp32 selects 0 at load).  Returns the previous mode.  Process-wide. */
+int ssv_set_precision(int mode);
 
 /* ---- Conv1d (stride 1, kernel 1 or 3, dilated, "same" or causal zero padding) -------------------
  * Replaces nn.Conv1d as used at models/TTSModel.py:59,78 (highway), :115-117, :154-158, :203-214,
@@ -39,9 +43,10 @@ const char* ssv_last_error(void); /* thread-local, valid until the next failing 
  * y(b,o,t) = bias[o] + bias_b[b*Cout+o] + sum_{c,j} w[o,c,j] * x(b,c,t + (j-j0)*dilation),
  * j0 = (k-1)/2 ("same", :57-59) or k-1 (causal: 2*pad zeros on the left, :72-74).
  * bias and bias_b (the broadcast speaker term of :175,:180) may be NULL. */
+size_t ssv_conv1d_fwd_workspace(int Cin, int Cout, int k);   /* holds the pre-split weights */
 int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b,
                    float* y, long y_bs, int B, int Cin, int Cout, int L, int k, int dilation, int causal,
-                   ssv_stream_t stream);
+                   void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* dx = conv1d_transpose(dy, w) [+ dx_add if non-NULL, same layout as dx]; ws holds w transposed. */
 size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k);
 int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const float* dx_add, float* dx, long dx_bs,
@@ -78,10 +83,12 @@ int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_b
  * Replaces highwayConv.forward, models/TTSModel.py:63-84:
  *   h = conv(x) (2C channels); y = sigmoid(LN1(h[:C])) * LN2(h[C:]) + (1 - sigmoid(LN1(h[:C]))) * x.
  * h (B,2C,L) dense and stats (B,4,L) = mean1, rstd1, mean2, rstd2 are saved for backward. */
+size_t ssv_highway_conv1d_fwd_workspace(int C, int k);
 int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias,
                            const float* g1, const float* b1, const float* g2, const float* b2,
                            float* h, float* stats, float* y, long y_bs,
-                           int B, int C, int L, int k, int dilation, int causal, ssv_stream_t stream);
+                           int B, int C, int L, int k, int dilation, int causal,
+                           void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_highway_conv1d_bwd_workspace(int B, int C, int L, int k);
 /* Outputs: dx (B,C,L), dw (2C,C,k), pgrads (6,C) = dgamma1, dbeta1, dgamma2, dbeta2, dbias[:C], dbias[C:]. */
 int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w,

@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 #include "ssv_common.h"
 #include "../../include/ssv_hip.h"
 
@@ -21,6 +23,19 @@ int ssv_check_launch(const char* what) {
   if (e == hipSuccess) return 0;
   ssv_fail(0, "%s: launch failed: %s", what, hipGetErrorString(e));
   return -(int)e;
+}
+static int g_precision = -1;
+int ssv_precision() {
+  if (g_precision < 0) {
+    const char* e = getenv("SSV_PRECISION");
+    g_precision = (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) ? 0 : 1;
+  }
+  return g_precision;
+}
+extern "C" int ssv_set_precision(int mode) {
+  const int prev = ssv_precision();
+  g_precision = mode ? 1 : 0;
+  return prev;
 }
 extern "C" int ssv_version(void) { return 1; }
 extern "C" const char* ssv_arch(void) { return "gfx950"; }
@@ -72,42 +87,77 @@ static GemmNT nt_zero() {
 }
 
 // ---- Conv1d ----------------------------------------------------------------------------------------
-extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b, float* y, long y_bs,
-                              int B, int Cin, int Cout, int L, int k, int dilation, int causal, ssv_stream_t stream) {
-  SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_fwd: bad argument B=%d Cin=%d Cout=%d L=%d", B, Cin, Cout, L);
-  SSV_CHECK(x_bs >= (long)Cin * L && y_bs >= (long)Cout * L, SSV_BAD_SHAPE, "conv1d_fwd: batch stride smaller than C*L");
+static inline int pad32(int n) { return (n + 31) & ~31; }
+static inline size_t split_bytes(int rows, int K, int k) { return align256((size_t)k * rows * pad32(K) * sizeof(unsigned short)); }
+static inline bool use_bf3(int B, int L, int Cin, int Cout) { return ssv_precision() == 1 && (long)B * L >= 128 && Cin >= 8 && Cout >= 16; }
+
+// y = conv(x, w): shared by forward (rows = Cout) and data gradient (rows = Cin, transposed weights, negated shifts)
+static int conv_nn(const float* x, long x_bs, const float* w, long w_sm, long w_sk, const float* bias, const float* bias_b,
+                   const float* r, long r_bs, float* y, long y_bs, int B, int K, int M, int L, int k, const int* shift,
+                   bool bf3, void* ws, hipStream_t st) {
+  if (bf3) {
+    const int Kpad = pad32(K);
+    unsigned short* hi = (unsigned short*)ws;
+    unsigned short* lo = (unsigned short*)((char*)ws + split_bytes(M, K, k));
+    SSV_TRY(ssv_launch_pack_split(w, hi, lo, M, K, Kpad, k, w_sm, w_sk, 1, st));
+    GemmNNB g;
+    g.Ahi = hi; g.Alo = lo; g.Kpad = Kpad;
+    g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
+    g.C = y; g.scb = y_bs; g.scm = L;
+    g.bias = bias; g.bias_b = bias_b; g.sbb = M;
+    g.R = r; g.srb = r_bs; g.srm = L;
+    g.M = M; g.N = L; g.Kc = K; g.KT = k; g.B = B;
+    for (int j = 0; j < 3; ++j) g.shift[j] = shift[j];
+    return ssv_launch_gemm_nn_bf3(g, st);
+  }
   GemmNN g = nn_zero();
-  SSV_TRY(conv_shifts(k, dilation, causal, g.shift));
-  g.A = w; g.sam = (long)Cin * k; g.sac = k; g.saj = 1;
+  for (int j = 0; j < 3; ++j) g.shift[j] = shift[j];
+  const float* a = w;
+  if (w_sk != k) {                                   // transposed operand for the data gradient: wt[c][o][j] = w[o][c][j]
+    SSV_TRY(ssv_launch_pack_wt(w, (float*)ws, K, M, k, st));
+    a = (const float*)ws;
+  }
+  g.A = a; g.sam = (long)K * k; g.sac = k; g.saj = 1;
   g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
   g.C = y; g.scb = y_bs; g.scm = L;
-  g.bias = bias; g.bias_b = bias_b; g.sbb = Cout;
-  g.M = Cout; g.N = L; g.Kc = Cin; g.KT = k; g.B = B;
-  return ssv_launch_gemm_nn(g, (hipStream_t)stream);
+  g.bias = bias; g.bias_b = bias_b; g.sbb = M;
+  if (r) { g.R = r; g.srb = r_bs; g.srm = L; }
+  g.M = M; g.N = L; g.Kc = K; g.KT = k; g.B = B;
+  return ssv_launch_gemm_nn(g, st);
 }
 
-extern "C" size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k) { return align256((size_t)Cin * Cout * k * sizeof(float)); }
+extern "C" size_t ssv_conv1d_fwd_workspace(int Cin, int Cout, int k) { return 2 * split_bytes(Cout, Cin, k); }
+extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b, float* y, long y_bs,
+                              int B, int Cin, int Cout, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes,
+                              ssv_stream_t stream) {
+  SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_fwd: bad argument B=%d Cin=%d Cout=%d L=%d", B, Cin, Cout, L);
+  SSV_CHECK(x_bs >= (long)Cin * L && y_bs >= (long)Cout * L, SSV_BAD_SHAPE, "conv1d_fwd: batch stride smaller than C*L");
+  int shift[3];
+  SSV_TRY(conv_shifts(k, dilation, causal, shift));
+  const bool bf3 = use_bf3(B, L, Cin, Cout);
+  if (bf3) SSV_CHECK(ws && ws_bytes >= ssv_conv1d_fwd_workspace(Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_fwd: workspace too small");
+  return conv_nn(x, x_bs, w, (long)Cin * k, k, bias, bias_b, nullptr, 0, y, y_bs, B, Cin, Cout, L, k, shift, bf3, ws, (hipStream_t)stream);
+}
+
+extern "C" size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k) {
+  const size_t a = align256((size_t)Cin * Cout * k * sizeof(float)), b = 2 * split_bytes(Cin, Cout, k);
+  return a > b ? a : b;
+}
 extern "C" int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const float* dx_add, float* dx, long dx_bs,
                                    int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                                    void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dy && w && dx && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_data: bad argument");
   SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_data_workspace(Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_bwd_data: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  GemmNN g = nn_zero();
-  SSV_TRY(conv_shifts(k, dilation, causal, g.shift));
-  for (int j = 0; j < 3; ++j) g.shift[j] = -g.shift[j];
-  float* wt = (float*)ws;                                 // wt[c][o][j] = w[o][c][j]
-  SSV_TRY(ssv_launch_pack_wt(w, wt, Cout, Cin, k, st));
-  g.A = wt; g.sam = (long)Cout * k; g.sac = k; g.saj = 1;
-  g.X = dy; g.sxb = dy_bs; g.sxc = L; g.Lx = L;
-  g.C = dx; g.scb = dx_bs; g.scm = L;
-  if (dx_add) { g.R = dx_add; g.srb = dx_bs; g.srm = L; }
-  g.M = Cin; g.N = L; g.Kc = Cout; g.KT = k; g.B = B;
-  return ssv_launch_gemm_nn(g, st);
+  int shift[3];
+  SSV_TRY(conv_shifts(k, dilation, causal, shift));
+  for (int j = 0; j < 3; ++j) shift[j] = -shift[j];
+  // rows = input channels c, reduction over output channels o: element (c, o, j) = w[o][c][j]
+  return conv_nn(dy, dy_bs, w, k, (long)Cin * k, nullptr, nullptr, dx_add, dx_bs, dx, dx_bs, B, Cout, Cin, L, k, shift,
+                 use_bf3(B, L, Cout, Cin), ws, (hipStream_t)stream);
 }
 
 static int dw_splits(int B, int M, int Nc, int k) {
-  const int nch = (k == 3) ? 32 : (Nc > 48 ? 96 : 32);
+  const int nch = ssv_nt_bf3_channels_per_tile(k, Nc);
   const int tiles = ssv_cdiv(M, 128) * ssv_cdiv(Nc, nch);
   int z = ssv_cdiv(512, tiles);
   if (z > B) z = B;
@@ -131,7 +181,8 @@ extern "C" int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* x
   g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
   g.C = (Z == 1) ? dw : (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = k; g.scj = 1;
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
-  SSV_TRY(ssv_launch_gemm_nt(g, st));
+  if (ssv_precision() == 1 && (long)B * L >= 256) SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
+  else SSV_TRY(ssv_launch_gemm_nt(g, st));
   if (Z > 1) SSV_TRY(ssv_launch_reduce_slabs((const float*)ws, dw, n, Z, n, st));
   return 0;
 }
@@ -152,11 +203,12 @@ extern "C" int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* 
 }
 
 // ---- highwayConv ---------------------------------------------------------------------------------------
+extern "C" size_t ssv_highway_conv1d_fwd_workspace(int C, int k) { return ssv_conv1d_fwd_workspace(C, 2 * C, k); }
 extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* g1, const float* b1,
                                       const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
-                                      int B, int C, int L, int k, int dilation, int causal, ssv_stream_t stream) {
+                                      int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w && g1 && b1 && g2 && b2 && h && y, SSV_BAD_SHAPE, "highway_conv1d_fwd: null argument");
-  SSV_TRY(ssv_conv1d_fwd(x, x_bs, w, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, stream));
+  SSV_TRY(ssv_conv1d_fwd(x, x_bs, w, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
   return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
 }
 

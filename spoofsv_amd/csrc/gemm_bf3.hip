@@ -1,0 +1,391 @@
+// Split-bf16 ("bf16x3") implicit-GEMM kernels for gfx950: fp32 operands are split as x = hi + lo with
+// hi = bf16(x), lo = bf16(x - hi); a product is accumulated in fp32 as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  on
+// v_mfma_f32_16x16x32_bf16 (the dropped lo*lo term is 2^-18 relative).  Three bf16 MFMAs cover 16x16x32 MACs in
+// 48 cycles where the fp32 MFMA needs 8 x 32 = 256: 5.3x the matrix-core rate at ~1e-5 relative error, inside
+// the 1e-3 budget of the hot path.  ssv_set_precision(0) switches every caller back to the exact fp32 MFMA kernels.
+//
+// Operand fragments of the 16x16x32 MFMA hold 8 consecutive k per lane (16 bytes).  Both LDS images are laid out
+// [k-group of 8][row][8 x bf16]: a fragment read is one ds_read_b128 at (kg*rows + row)*16 -- consecutive rows are
+// consecutive 16-byte slots, and because every k-group plane is a multiple of 256 bytes the four 16-lane groups of
+// ds_read_b128 hit disjoint banks (conflict-free for any row offset, hence for any dilation shift).
+//
+//   gemm_nn_bf3: Conv1d forward / data gradient.  Weights arrive pre-split in tap-major order [tap][row][k] (bf16 hi
+//     and lo planes written by pack_split_kernel), the input tile is split while it is staged (one fp32 global read
+//     per element; 8 channels of one column form a slot), taps address the same slots at column offsets.
+//   gemm_nt_bf3: Conv1d weight gradient.  The reduction runs over time, so a dilation shift would be a misaligned
+//     shift along k; instead each tap gets its own staged copy of the input rows at its exact shift.
+#include <stdio.h>
+#include <stdlib.h>
+#include "ssv_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned 16-byte load
+
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+  bf16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 t = (__bf16)v[i];
+    h[i] = t;
+    l[i] = (__bf16)(v[i] - (float)t);
+  }
+  hi = __builtin_bit_cast(uint4, h);
+  lo = __builtin_bit_cast(uint4, l);
+}
+
+// ---- weight pre-split: out[j][m][k] (k padded to Kpad with zeros) from w[m*sm + k*sk + j*sj] ----------------------
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                                         int M, int K, int Kpad, int KT, long sm, long sk, long sj) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)KT * M * Kpad;
+  if (i >= n) return;
+  const int k = (int)(i % Kpad);
+  const int m = (int)((i / Kpad) % M), j = (int)(i / ((long)Kpad * M));
+  const float v = k < K ? w[(long)m * sm + (long)k * sk + (long)j * sj] : 0.f;
+  const __bf16 h = (__bf16)v;
+  hi[i] = h;
+  lo[i] = (__bf16)(v - (float)h);
+}
+int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, hipStream_t st) {
+  const long n = (long)KT * M * Kpad;
+  hipLaunchKernelGGL(pack_split_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, (__bf16*)hi, (__bf16*)lo, M, K, Kpad, KT, sm, sk, sj);
+  return ssv_check_launch("pack_split");
+}
+
+// ---- NN ---------------------------------------------------------------------------------------------------------------
+template <int KT, int WM, int NT>
+__global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
+  constexpr int BM = 64 * WM, BN = 16 * NT;
+  constexpr int HALO = (KT == 1) ? 0 : 54;
+  constexpr int WX = ((BN + HALO + 15) / 16) * 16;         // staged columns, plane = WX*16 B = multiple of 256 B
+  constexpr int A_SLOTS = KT * 4 * BM;                      // 16-byte slots per hi (or lo) weight image
+  constexpr int X_SLOTS = 4 * WX;
+  constexpr int NA = A_SLOTS / 256;
+  constexpr int NX = (X_SLOTS + 255) / 256;
+  __shared__ uint4 lds[2 * A_SLOTS + 2 * X_SLOTS];
+  uint4* Ah = lds;
+  uint4* Al = lds + A_SLOTS;
+  uint4* Xh = lds + 2 * A_SLOTS;
+  uint4* Xl = Xh + X_SLOTS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mt = blockIdx.x % mtiles, ntile = blockIdx.x / mtiles, b = blockIdx.y;
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const float* __restrict__ Xb = p.X + (long)b * p.sxb;
+  const int W = BN + span;
+  const int nchunks = p.Kpad / 32;
+
+  f32x4 acc[WM][NT];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 rah[NA], ral[NA];
+  float rx[NX][8];
+
+  auto prefetch = [&](int ch) {
+    const int c0 = ch * 32;
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+      const int f = tid + 256 * r;                 // kg fastest: 4 lanes read 64 contiguous bytes of one weight row
+      const int kg = f & 3, m = (f >> 2) % BM, j = f / (4 * BM);
+      const int gm = m0 + m;
+      uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
+      if (gm < p.M) {
+        const long off = ((long)j * p.M + gm) * p.Kpad + c0 + 8 * kg;
+        h = *reinterpret_cast<const uint4*>(p.Ahi + off);
+        l = *reinterpret_cast<const uint4*>(p.Alo + off);
+      }
+      rah[r] = h; ral[r] = l;
+    }
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+      const int e = tid + 256 * r;
+      const int kg = e / WX, col = e % WX;
+      const int gcol = n0 + smin + col;
+      const bool cv = e < X_SLOTS && col < W && gcol >= 0 && gcol < p.Lx;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + 8 * kg + i;
+        rx[r][i] = (cv && c < p.Kc) ? Xb[(long)c * p.sxc + gcol] : 0.f;
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+      const int f = tid + 256 * r;
+      const int kg = f & 3, m = (f >> 2) % BM, j = f / (4 * BM);
+      const int slot = (j * 4 + kg) * BM + m;
+      Ah[slot] = rah[r]; Al[slot] = ral[r];
+    }
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+      const int e = tid + 256 * r;
+      if (e < X_SLOTS) {
+        uint4 h, l;
+        split8(rx[r], h, l);
+        Xh[e] = h; Xl[e] = l;            // slot index = kg*WX + col = e
+      }
+    }
+  };
+
+  int offj[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) offj[j] = p.shift[j] - smin;
+  const int kq = lane >> 4, nq = lane & 15;
+  const int arow = kq * BM + wave * WM * 16 + nq;
+
+  prefetch(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (ch + 1 < nchunks) prefetch(ch + 1);
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      bf16x8 ah[WM], al[WM];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        ah[i] = __builtin_bit_cast(bf16x8, Ah[j * 4 * BM + arow + i * 16]);
+        al[i] = __builtin_bit_cast(bf16x8, Al[j * 4 * BM + arow + i * 16]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int xs = kq * WX + t * 16 + nq + offj[j];
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  float* __restrict__ Cb = p.C + (long)b * p.scb;
+  const float* __restrict__ Rb = p.R ? p.R + (long)b * p.srb : nullptr;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gm = m0 + wave * WM * 16 + i * 16 + kq * 4 + r;
+      if (gm >= p.M) continue;
+      float add = 0.f;
+      if (p.bias) add += p.bias[gm];
+      if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gm];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int gn = n0 + t * 16 + nq;
+        if (gn >= p.N) continue;
+        float v = acc[i][t][r] + add;
+        if (Rb) v += Rb[(long)gm * p.srm + gn];
+        Cb[(long)gm * p.scm + gn] = v;
+      }
+    }
+}
+
+template <int KT, int WM, int NT>
+static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
+  const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT);
+  hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+  return ssv_check_launch("gemm_nn_bf3");
+}
+
+template <int KT>
+static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
+  static const int nts[] = {7, 6, 4, 2};
+  int wm = 2, nt = 7;
+  bool forced = false;
+  if (const char* e = getenv("SSV_NNB_TILE")) {
+    int a = 0, c = 0;
+    if (sscanf(e, "%d,%d", &a, &c) == 2 && (a == 1 || a == 2)) for (int x : nts) if (x == c) { wm = a; nt = c; forced = true; }
+  }
+  if (!forced) {
+    double best = 1e30;
+    for (int a = 1; a <= 2; ++a)
+      for (int c : nts) {
+        const long tiles = (long)ssv_cdiv(g.M, 64 * a) * ssv_cdiv(g.N, 16 * c) * g.B;
+        const double per_tile = (double)a * c + 0.9 * a + 0.25 * c + 1.0;
+        const double cost = (double)((tiles + 255) / 256) * per_tile;
+        if (cost < best) { best = cost; wm = a; nt = c; }
+      }
+  }
+#define SSV_CASE(A_, C_) if (wm == A_ && nt == C_) return launch_nnb<KT, A_, C_>(g, st, smin, span)
+  SSV_CASE(2, 7); SSV_CASE(2, 6); SSV_CASE(2, 4); SSV_CASE(2, 2);
+  SSV_CASE(1, 7); SSV_CASE(1, 6); SSV_CASE(1, 4); SSV_CASE(1, 2);
+#undef SSV_CASE
+  return ssv_fail(SSV_UNSUPPORTED, "gemm_nn_bf3: no tile %d,%d", wm, nt);
+}
+
+int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
+  SSV_CHECK(g.M > 0 && g.N > 0 && g.Kc > 0 && g.B > 0 && g.Kpad % 32 == 0 && g.Kpad >= g.Kc, SSV_BAD_SHAPE, "gemm_nn_bf3: bad problem");
+  SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nn_bf3: kernel_size %d", g.KT);
+  SSV_CHECK(g.B <= 65535, SSV_UNSUPPORTED, "gemm_nn_bf3: batch %d exceeds grid.y", g.B);
+  int smin = g.shift[0], smax = g.shift[0];
+  for (int j = 1; j < g.KT; ++j) { smin = g.shift[j] < smin ? g.shift[j] : smin; smax = g.shift[j] > smax ? g.shift[j] : smax; }
+  const int span = smax - smin;
+  SSV_CHECK(span <= 54, SSV_UNSUPPORTED, "gemm_nn_bf3: dilation halo %d exceeds 54", span);
+  return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
+}
+
+// ---- NT (weight gradient) -------------------------------------------------------------------------------------------------
+//   C(z,m,c,j) = sum_{b = z, z+bstep, ..} sum_t A(b,m,t) * X(b,c,t+shift[j]);  rows contiguous in t for both operands.
+template <int KT, int WM, int NTC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
+  constexpr int KB = 64, KG = KB / 8;                       // time steps per chunk, k-groups
+  constexpr int BM = 64 * WM, NCH = 16 * NTC;
+  constexpr int A_SLOTS = KG * BM, X_SLOTS = KT * KG * NCH;
+  constexpr int NA = A_SLOTS / 256, NX = (X_SLOTS + 255) / 256;
+  __shared__ uint4 lds[2 * A_SLOTS + 2 * X_SLOTS];
+  uint4* Ah = lds;
+  uint4* Al = lds + A_SLOTS;
+  uint4* Xh = lds + 2 * A_SLOTS;
+  uint4* Xl = Xh + X_SLOTS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mt = blockIdx.x % mtiles, ct = blockIdx.x / mtiles, z = blockIdx.z;
+  const int m0 = mt * BM, c0 = ct * NCH;
+  const int tchunks = (p.La + KB - 1) / KB;
+
+  f32x4 acc[WM][KT][NTC];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+      for (int q = 0; q < NTC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float ra[NA][8], rx[NX][8];
+
+  // 8 consecutive time steps of one row, zero outside [0, len)
+  auto load8 = [&](const float* __restrict__ row, int t, int len, float (&v)[8]) {
+    if (t >= 0 && t + 8 <= len) {
+      const f4u a = *reinterpret_cast<const f4u*>(row + t);
+      const f4u c = *reinterpret_cast<const f4u*>(row + t + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int tt = t + i; v[i] = (tt >= 0 && tt < len) ? row[tt] : 0.f; }
+    }
+  };
+  auto prefetch = [&](int b, int tc) {
+    const float* __restrict__ Ab = p.A + (long)b * p.sab;
+    const float* __restrict__ Xb = p.X + (long)b * p.sxb;
+    const int t0 = tc * KB;
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+      const int f = tid + 256 * r;                   // kg fastest: a wave reads 8 rows x 256 contiguous bytes
+      const int kg = f % KG, m = f / KG;
+      const int gm = m0 + m;
+      if (gm < p.M) load8(Ab + (long)gm * p.sam, t0 + 8 * kg, p.La, ra[r]);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ra[r][i] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+      const int f = tid + 256 * r;
+      const int kg = f % KG, c = (f / KG) % NCH, j = f / (KG * NCH);
+      const int gc = c0 + c;
+      if (f < X_SLOTS && gc < p.Nc) load8(Xb + (long)gc * p.sxc, t0 + 8 * kg + p.shift[j < KT ? j : 0], p.Lx, rx[r]);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rx[r][i] = 0.f;
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+      const int f = tid + 256 * r;
+      const int kg = f % KG, m = f / KG;
+      uint4 h, l;
+      split8(ra[r], h, l);
+      Ah[kg * BM + m] = h; Al[kg * BM + m] = l;
+    }
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+      const int f = tid + 256 * r;
+      if (f < X_SLOTS) {
+        const int kg = f % KG, c = (f / KG) % NCH, j = f / (KG * NCH);
+        uint4 h, l;
+        split8(rx[r], h, l);
+        Xh[(j * KG + kg) * NCH + c] = h; Xl[(j * KG + kg) * NCH + c] = l;
+      }
+    }
+  };
+
+  const int kq = lane >> 4, nq = lane & 15;
+  const int nb = (p.B - z + p.bstep - 1) / p.bstep;
+  const int total = nb * tchunks;
+  if (total > 0) prefetch(z, 0);
+  for (int it = 0; it < total; ++it) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (it + 1 < total) { const int nx = it + 1; prefetch(z + (nx / tchunks) * p.bstep, nx % tchunks); }
+#pragma unroll
+    for (int s = 0; s < KB / 32; ++s) {
+      const int kg = s * 4 + kq;
+      bf16x8 ah[WM], al[WM];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        ah[i] = __builtin_bit_cast(bf16x8, Ah[kg * BM + wave * WM * 16 + i * 16 + nq]);
+        al[i] = __builtin_bit_cast(bf16x8, Al[kg * BM + wave * WM * 16 + i * 16 + nq]);
+      }
+#pragma unroll
+      for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int q = 0; q < NTC; ++q) {
+          const int xs = (j * KG + kg) * NCH + q * 16 + nq;
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
+#pragma unroll
+          for (int i = 0; i < WM; ++i) {
+            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j][q], 0, 0, 0);
+            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j][q], 0, 0, 0);
+            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j][q], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  float* __restrict__ Cz = p.C + (long)z * p.scz;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gm = m0 + wave * WM * 16 + i * 16 + kq * 4 + r;
+      if (gm >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int q = 0; q < NTC; ++q) {
+          const int gc = c0 + q * 16 + nq;
+          if (gc < p.Nc) Cz[(long)gm * p.scm + (long)gc * p.scc + (long)j * p.scj] = acc[i][j][q][r];
+        }
+    }
+}
+
+int ssv_nt_bf3_channels_per_tile(int KT, int Nc) { return (KT == 3) ? 32 : (Nc > 48 ? 96 : 32); }
+
+int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
+  SSV_CHECK(g.M > 0 && g.Nc > 0 && g.La > 0 && g.B > 0 && g.Z > 0 && g.bstep > 0, SSV_BAD_SHAPE, "gemm_nt_bf3: empty problem");
+  SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nt_bf3: kernel_size %d", g.KT);
+  SSV_CHECK(g.sat == 1 && g.sxn == 1, SSV_UNSUPPORTED, "gemm_nt_bf3: rows must be contiguous in time");
+  SSV_CHECK(g.Z <= 65535, SSV_UNSUPPORTED, "gemm_nt_bf3: Z=%d exceeds grid.z", g.Z);
+  const int mtiles = ssv_cdiv(g.M, 128);
+  if (g.KT == 3) {
+    hipLaunchKernelGGL((gemm_nt_bf3_kernel<3, 2, 2>), dim3(mtiles * ssv_cdiv(g.Nc, 32), 1, g.Z), dim3(256), 0, st, g, mtiles);
+  } else if (g.Nc > 48) {
+    hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 6>), dim3(mtiles * ssv_cdiv(g.Nc, 96), 1, g.Z), dim3(256), 0, st, g, mtiles);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 2>), dim3(mtiles * ssv_cdiv(g.Nc, 32), 1, g.Z), dim3(256), 0, st, g, mtiles);
+  }
+  return ssv_check_launch("gemm_nt_bf3");
+}

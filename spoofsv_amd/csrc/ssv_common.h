@@ -45,6 +45,23 @@ struct GemmNT {
 };
 int ssv_launch_gemm_nt(const GemmNT& g, hipStream_t st);
 
+// ---- split-bf16 variants (gemm_bf3.hip): same contracts, unit column strides, weights pre-split --------------
+struct GemmNNB {
+  const unsigned short* Ahi; const unsigned short* Alo; int Kpad;   // [KT][M][Kpad] bf16 planes (hi, lo)
+  const float* X; long sxb, sxc; int Lx;
+  float* C; long scb, scm;
+  const float* bias;
+  const float* bias_b; long sbb;
+  const float* R; long srb, srm;
+  int M, N, Kc, KT, B;
+  int shift[3];
+};
+int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
+int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
+int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, hipStream_t st);
+int ssv_nt_bf3_channels_per_tile(int KT, int Nc);
+int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA (default)
+
 // ---- small helpers (misc.hip) ---------------------------------------------------------
 int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long slab_stride, hipStream_t st);
 int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hipStream_t st);

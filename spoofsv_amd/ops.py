@@ -80,8 +80,10 @@ class HighwayConvFn(torch.autograd.Function):
         y = torch.empty((B, C, L), dtype=_F32, device=x.device)
         h = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
         stats = torch.empty((B, 4, L), dtype=_F32, device=x.device) if train else None
+        nb = _lib.query("ssv_highway_conv1d_fwd_workspace", C, k)
+        ws = _ws(nb, x.device)
         _lib.call("ssv_highway_conv1d_fwd", _p(x), xbs, _p(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
-                  _p(h), _p(stats), _p(y), C * L, B, C, L, k, dilation, int(causal), _stream())
+                  _p(h), _p(stats), _p(y), C * L, B, C, L, k, dilation, int(causal), _p(ws), nb, _stream())
         if train:
             ctx.save_for_backward(x, w, g1, b1, g2, b2, h, stats)
             ctx.cfg = (k, dilation, int(causal))
@@ -108,8 +110,10 @@ class HighwayConvFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------- conv
 def _conv_fwd(x, xbs, w, bias, bias_b, y, ybs, k, dilation, causal):
     B, Cin, L = x.shape
+    nb = _lib.query("ssv_conv1d_fwd_workspace", Cin, w.shape[0], k)
+    ws = _ws(nb, x.device)
     _lib.call("ssv_conv1d_fwd", _p(x), xbs, _p(w), _p(bias), _p(bias_b), _p(y), ybs, B, Cin, w.shape[0], L,
-              k, dilation, int(causal), _stream())
+              k, dilation, int(causal), _p(ws), nb, _stream())
 
 
 def _conv_bwd_data(dy, dybs, w, Cin, L, k=1, dilation=1, causal=0):

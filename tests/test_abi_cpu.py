@@ -12,7 +12,7 @@ from spoofsv_amd import _lib
 
 def test_header_declares_expected_entry_points():
     protos = _lib.parse_header()
-    must = ["ssv_version", "ssv_arch", "ssv_last_error", "ssv_conv1d_fwd", "ssv_conv1d_bwd_data", "ssv_conv1d_bwd_weight",
+    must = ["ssv_version", "ssv_arch", "ssv_last_error", "ssv_set_precision", "ssv_conv1d_fwd", "ssv_conv1d_bwd_data", "ssv_conv1d_bwd_weight",
             "ssv_channel_ln_act_fwd", "ssv_channel_ln_act_bwd", "ssv_highway_conv1d_fwd", "ssv_highway_conv1d_bwd",
             "ssv_text_embed_fwd", "ssv_text_embed_bwd", "ssv_attention_train_fwd", "ssv_attention_train_bwd",
             "ssv_attention_step", "ssv_attention_apply", "ssv_deconv1d_k2s2_fwd", "ssv_deconv1d_k2s2_bwd",
@@ -30,6 +30,8 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()                      # raises if a declared symbol is missing
     assert L.ssv_version() == 1
     assert L.ssv_arch() == b"gfx950"
+    prev = L.ssv_set_precision(0)
+    assert L.ssv_set_precision(prev) == 0
     raw = ctypes.CDLL(_lib.LIBPATH)
     for name in _lib.parse_header():
         assert hasattr(raw, name), name
@@ -56,13 +58,13 @@ def test_bad_arguments_fail_before_the_device():
     null = ctypes.c_void_p(0)
     one = ctypes.c_void_p(16)           # non-null dummy, never dereferenced: the checks come first
     # empty problem -> -1
-    rc = L.ssv_conv1d_fwd(one, 0, one, null, null, one, 0, 0, 4, 4, 8, 3, 1, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 0, one, null, null, one, 0, 0, 4, 4, 8, 3, 1, 0, null, 0, null)
     assert rc == -1 and b"conv1d_fwd" in L.ssv_last_error()
     # unsupported kernel size -> -2
-    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 5, 1, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 5, 1, 0, null, 0, null)
     assert rc == -2 and b"kernel_size" in L.ssv_last_error()
     # dilation halo beyond the staged tile -> -2
-    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 3, 28, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 3, 28, 0, null, 0, null)
     assert rc == -2
     # workspace too small -> -1
     rc = L.ssv_conv1d_bwd_data(one, 64, one, null, one, 64, 1, 4, 4, 16, 3, 1, 0, one, 8, null)

@@ -10,9 +10,20 @@ from oracle import tts_oracle as TO
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-# fp32 MFMA is an exact fp32 fma chain; differences to the CPU come from summation order only.
-FWD_TOL = 2e-5
-BWD_TOL = 3e-4     # BASELINE.json north_star: 1e-3 relative on spectrograms
+# BASELINE.json north_star: 1e-3 relative on spectrograms.  "fp32": fp32-input MFMA, an exact fp32 fma chain
+# (differences to the CPU come from summation order only).  "bf16x3": split-bf16 MFMA, ~2^-17 per product.
+TOLS = {"fp32": (2e-5, 3e-4), "bf16x3": (1e-4, 5e-4)}
+FWD_TOL, BWD_TOL = TOLS["bf16x3"]
+
+
+@pytest.fixture(autouse=True, params=["bf16x3", "fp32"])
+def precision(request):
+    import spoofsv_amd
+    global FWD_TOL, BWD_TOL
+    prev = spoofsv_amd.set_precision(request.param)
+    FWD_TOL, BWD_TOL = TOLS[request.param]
+    yield request.param
+    spoofsv_amd.set_precision(prev)
 
 
 def _load_module_sd(mod, sd):
@@ -146,8 +157,14 @@ def test_highway_full_size_vs_oracle(C, L, k, d, causal):
         assert rel_err(p.grad, sd["hc." + n].grad) < BWD_TOL, (n, rel_err(p.grad, sd["hc." + n].grad))
 
 
-def test_pointwise_513_channels_vs_oracle():
-    """SSRN tail: 513 channels (not a multiple of any MFMA tile), 4T = 1300 columns."""
+@pytest.mark.parametrize("act", [2, 1])
+def test_pointwise_513_channels_vs_oracle(act):
+    """SSRN tail: 513 channels (not a multiple of any MFMA tile), 4T = 1300 columns.
+
+    act=2 (sigmoid) is smooth: max-norm comparison.  act=1 (ReLU) is discontinuous at 0: a pre-activation within
+    rounding of zero may take the other branch than on the CPU, which moves single entries of dL/dpre by O(1) --
+    in ANY implementation that does not share the CPU's summation order -- so gradients are compared in the L2
+    norm there (a wrong kernel would be off by O(1) in L2 as well)."""
     from spoofsv_amd import ops
     torch.manual_seed(5)
     B, C, L = 2, 513, 1300
@@ -158,14 +175,19 @@ def test_pointwise_513_channels_vs_oracle():
     x = torch.randn(B, C, L)
     dy = torch.randn(B, C, L)
     leaves = [v.clone().requires_grad_(True) for v in (x, w, b, gam, bet)]
-    yo = torch.relu(TO._ln_channels(torch.nn.functional.conv1d(leaves[0], leaves[1], leaves[2]), leaves[3], leaves[4]))
+    pre = TO._ln_channels(torch.nn.functional.conv1d(leaves[0], leaves[1], leaves[2]), leaves[3], leaves[4])
+    yo = torch.relu(pre) if act == 1 else torch.sigmoid(pre)
     yo.backward(dy)
     gl = [v.to(DEV).requires_grad_(True) for v in (x, w, b, gam, bet)]
-    yg = ops.pointwise_conv_ln_act(gl[0], gl[1], gl[2], gl[3], gl[4], None, 1)
+    yg = ops.pointwise_conv_ln_act(gl[0], gl[1], gl[2], gl[3], gl[4], None, act)
     yg.backward(dy.to(DEV))
     assert rel_err(yg, yo) < FWD_TOL
     for a, o, n in zip(gl, leaves, "x w b gamma beta".split()):
-        assert rel_err(a.grad, o.grad) < BWD_TOL, (n, rel_err(a.grad, o.grad))
+        if act == 1:
+            e = float((a.grad.cpu().double() - o.grad.double()).norm() / o.grad.double().norm())
+            assert e < 2e-3, (n, e)
+        else:
+            assert rel_err(a.grad, o.grad) < BWD_TOL, (n, rel_err(a.grad, o.grad))
 
 
 def test_adam_multi_golden():

@@ -12,16 +12,19 @@ SHAPES = [  # B, Cin, Cout, L, k
 ]
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 dev = "cuda:0"
+_lib.lib().ssv_set_precision(0 if os.environ.get("SWEEP_FP32") else 1)
 for (B, Cin, Cout, L, k) in SHAPES:
     x = torch.randn(B, Cin, L, device=dev); w = torch.randn(Cout, Cin, k, device=dev) * 0.05
     y = torch.empty(B, Cout, L, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nb = _lib.query("ssv_conv1d_fwd_workspace", Cin, Cout, k)
+    ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
     flops = 2.0 * B * L * Cout * Cin * k
     res = []
     for cfg in ["auto"] + ["%d,%d" % (wm, nt) for wm in (1, 2) for nt in (2, 4, 6, 7, 8)]:
-        if cfg == "auto": os.environ.pop("SSV_NN_TILE", None)
-        else: os.environ["SSV_NN_TILE"] = cfg
-        run = lambda: _lib.call("ssv_conv1d_fwd", P(x), Cin * L, P(w), None, None, P(y), Cout * L, B, Cin, Cout, L, k, 1, 0, st)
+        if cfg == "auto": os.environ.pop("SSV_NN_TILE", None); os.environ.pop("SSV_NNB_TILE", None)
+        else: os.environ["SSV_NN_TILE"] = cfg; os.environ["SSV_NNB_TILE"] = cfg
+        run = lambda: _lib.call("ssv_conv1d_fwd", P(x), Cin * L, P(w), None, None, P(y), Cout * L, B, Cin, Cout, L, k, 1, 0, P(ws), nb, st)
         for _ in range(3): run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
