@@ -53,20 +53,20 @@ int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int 
 }
 
 // ---- NN ---------------------------------------------------------------------------------------------------------------
+// Waves split the M axis, so a weight row is only ever used by ONE wave: weight fragments go straight from global memory
+// (L2-resident, pre-split, fragment-shaped 16-byte loads) into MFMA operand registers, one K chunk ahead (two register
+// sets, the chunk loop is unrolled by two).  Only the input tile, which all four waves share, is staged in LDS -- this
+// removes 2/3 of the LDS writes and 1/4 of the LDS reads of a version that staged both operands.
 template <int KT, int WM, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int BM = 64 * WM, BN = 16 * NT;
   constexpr int HALO = (KT == 1) ? 0 : 54;
   constexpr int WX = ((BN + HALO + 15) / 16) * 16;         // staged columns, plane = WX*16 B = multiple of 256 B
-  constexpr int A_SLOTS = KT * 4 * BM;                      // 16-byte slots per hi (or lo) weight image
   constexpr int X_SLOTS = 4 * WX;
-  constexpr int NA = A_SLOTS / 256;
   constexpr int NX = (X_SLOTS + 255) / 256;
-  __shared__ uint4 lds[2 * A_SLOTS + 2 * X_SLOTS];
-  uint4* Ah = lds;
-  uint4* Al = lds + A_SLOTS;
-  uint4* Xh = lds + 2 * A_SLOTS;
-  uint4* Xl = Xh + X_SLOTS;
+  __shared__ uint4 lds[2 * X_SLOTS];
+  uint4* Xh = lds;
+  uint4* Xl = lds + X_SLOTS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mt = blockIdx.x % mtiles, ntile = blockIdx.x / mtiles, b = blockIdx.y;
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   const float* __restrict__ Xb = p.X + (long)b * p.sxb;
   const int W = BN + span;
   const int nchunks = p.Kpad / 32;
+  const int kq = lane >> 4, nq = lane & 15;
 
   f32x4 acc[WM][NT];
 #pragma unroll
@@ -81,51 +82,58 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 rah[NA], ral[NA];
+  // Weight fragments.  KT == 3: one register set; tap j of the NEXT chunk is re-loaded into its registers right after
+  // tap j's MFMAs of the current chunk have been issued (2/3 of a chunk of lead time).  KT == 1: two sets, alternating.
+  constexpr int NSET = (KT == 1) ? 2 : 1;
+  uint4 Ah_[NSET][KT][WM], Al_[NSET][KT][WM];
   float rx[NX][8];
 
-  auto prefetch = [&](int ch) {
-    const int c0 = ch * 32;
+  // this lane's weight-fragment rows: row = m0 + wave*WM*16 + i*16 + (lane & 15), k = chunk*32 + 8*(lane >> 4) .. +7
+  long arow[WM];
 #pragma unroll
-    for (int r = 0; r < NA; ++r) {
-      const int f = tid + 256 * r;                 // kg fastest: 4 lanes read 64 contiguous bytes of one weight row
-      const int kg = f & 3, m = (f >> 2) % BM, j = f / (4 * BM);
-      const int gm = m0 + m;
-      uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
-      if (gm < p.M) {
-        const long off = ((long)j * p.M + gm) * p.Kpad + c0 + 8 * kg;
-        h = *reinterpret_cast<const uint4*>(p.Ahi + off);
-        l = *reinterpret_cast<const uint4*>(p.Alo + off);
-      }
-      rah[r] = h; ral[r] = l;
+  for (int i = 0; i < WM; ++i) {
+    const int gm = m0 + wave * WM * 16 + i * 16 + nq;
+    arow[i] = (long)(gm < p.M ? gm : 0) * p.Kpad + 8 * kq;
+  }
+  const long aplane = (long)p.M * p.Kpad;
+
+  auto loadA = [&](int set, int j, int ch) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      // rows past M read row 0 (always legal): they only feed accumulator rows that the epilogue never stores
+      const long off = j * aplane + arow[i] + ch * 32;
+      Ah_[set][j][i] = *reinterpret_cast<const uint4*>(p.Ahi + off);
+      Al_[set][j][i] = *reinterpret_cast<const uint4*>(p.Alo + off);
     }
+  };
+  // Input staging, two halves.  prefetchX only ISSUES loads (raw values, addresses clamped into the batch item so every
+  // load is legal); validity masks are applied in commitX one chunk later, right before the split.  A mask applied at
+  // load time would make hipcc wait for each load (or branch around it), serialising 24 L2 round trips per chunk.
+  const int Lrow = (int)p.sxc;
+  const int maxoff = (p.Kc - 1) * Lrow + p.Lx - 1;
+  auto prefetchX = [&](int ch) {
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       const int e = tid + 256 * r;
       const int kg = e / WX, col = e % WX;
-      const int gcol = n0 + smin + col;
-      const bool cv = e < X_SLOTS && col < W && gcol >= 0 && gcol < p.Lx;
+      const int base = (ch * 32 + 8 * kg) * Lrow + n0 + smin + col;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + 8 * kg + i;
-        rx[r][i] = (cv && c < p.Kc) ? Xb[(long)c * p.sxc + gcol] : 0.f;
-      }
+      for (int i = 0; i < 8; ++i) rx[r][i] = Xb[(unsigned)min(max(base + i * Lrow, 0), maxoff)];
     }
   };
-  auto commit = [&]() {
-#pragma unroll
-    for (int r = 0; r < NA; ++r) {
-      const int f = tid + 256 * r;
-      const int kg = f & 3, m = (f >> 2) % BM, j = f / (4 * BM);
-      const int slot = (j * 4 + kg) * BM + m;
-      Ah[slot] = rah[r]; Al[slot] = ral[r];
-    }
+  auto commitX = [&](int ch) {
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       const int e = tid + 256 * r;
       if (e < X_SLOTS) {
+        const int kg = e / WX, col = e % WX;
+        const int gcol = n0 + smin + col;
+        const bool cv = col < W && gcol >= 0 && gcol < p.Lx;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (cv && ch * 32 + 8 * kg + i < p.Kc) ? rx[r][i] : 0.f;
         uint4 h, l;
-        split8(rx[r], h, l);
+        split8(v, h, l);
         Xh[e] = h; Xl[e] = l;            // slot index = kg*WX + col = e
       }
     }
@@ -134,34 +142,55 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   int offj[KT];
 #pragma unroll
   for (int j = 0; j < KT; ++j) offj[j] = p.shift[j] - smin;
-  const int kq = lane >> 4, nq = lane & 15;
-  const int arow = kq * BM + wave * WM * 16 + nq;
 
-  prefetch(0);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (ch + 1 < nchunks) prefetch(ch + 1);
+  auto tap = [&](int set, int j) {
 #pragma unroll
-    for (int j = 0; j < KT; ++j) {
-      bf16x8 ah[WM], al[WM];
+    for (int t = 0; t < NT; ++t) {
+      const int xs = kq * WX + t * 16 + nq + offj[j];
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
-        ah[i] = __builtin_bit_cast(bf16x8, Ah[j * 4 * BM + arow + i * 16]);
-        al[i] = __builtin_bit_cast(bf16x8, Al[j * 4 * BM + arow + i * 16]);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, Ah_[set][j][i]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, Al_[set][j][i]);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[i][t], 0, 0, 0);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[i][t], 0, 0, 0);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[i][t], 0, 0, 0);
       }
+    }
+  };
+
+  if constexpr (KT == 1) {
+    loadA(0, 0, 0);
+    prefetchX(0);
+    for (int ch = 0; ch < nchunks; ch += 2) {
+      __syncthreads();
+      commitX(ch);
+      __syncthreads();
+      if (ch + 1 < nchunks) { prefetchX(ch + 1); loadA(1, 0, ch + 1); }
+      tap(0, 0);
+      if (ch + 1 >= nchunks) break;
+      __syncthreads();
+      commitX(ch + 1);
+      __syncthreads();
+      if (ch + 2 < nchunks) { prefetchX(ch + 2); loadA(0, 0, ch + 2); }
+      tap(1, 0);
+    }
+  } else {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int xs = kq * WX + t * 16 + nq + offj[j];
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
+    for (int j = 0; j < KT; ++j) loadA(0, j, 0);
+    prefetchX(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      __syncthreads();
+      commitX(ch);
+      __syncthreads();
+      const bool more = ch + 1 < nchunks;
+      if (more) prefetchX(ch + 1);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][t], 0, 0, 0);
-          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][t], 0, 0, 0);
-          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][t], 0, 0, 0);
-        }
+      for (int j = 0; j < KT; ++j) {
+        tap(0, j);
+        __builtin_amdgcn_sched_barrier(0);      // keep the re-load behind this tap's MFMAs, and later taps' LDS reads behind it
+        if (more) loadA(0, j, ch + 1);
       }
     }
   }

@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256, (WM == 1 ? 3 : 2)) void gemm_nn_kernel(const G
         const int f = tid + 256 * r;
         const int row = f / (KC / 4), q = f % (KC / 4);
         const int gm = m0 + row, gk = c0 * KT + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gm < p.M && gk < p.Kc * KT) v = *reinterpret_cast<const float4*>(Ab + (long)gm * p.sam + gk);
-        ra4[r] = v;
+        // raw load on a clamped, always-legal address; the validity mask is applied in commit(), one chunk later
+        // (masking here would make hipcc wait for -- or branch around -- every load)
+        ra4[r] = *reinterpret_cast<const float4*>(Ab + (long)min(gm, p.M - 1) * p.sam + min(gk, p.Kc * KT - 4));
       }
     } else {
 #pragma unroll
@@ -80,9 +80,7 @@ __global__ __launch_bounds__(256, (WM == 1 ? 3 : 2)) void gemm_nn_kernel(const G
         int row, kk;
         if (a_mfast) { kk = e / BM; row = e % BM; } else { row = e / KC; kk = e % KC; }
         const int c = c0 + kk / KT, j = kk % KT, gm = m0 + row;
-        float v = 0.f;
-        if (gm < p.M && c < p.Kc) v = Ab[(long)gm * p.sam + (long)c * p.sac + (long)j * p.saj];
-        ra1[r] = v;
+        ra1[r] = Ab[(long)min(gm, p.M - 1) * p.sam + (long)min(c, p.Kc - 1) * p.sac + (long)j * p.saj];
       }
     }
 #pragma unroll
@@ -90,21 +88,21 @@ __global__ __launch_bounds__(256, (WM == 1 ? 3 : 2)) void gemm_nn_kernel(const G
       const int e = tid + 256 * r;
       const int kr = e / XS, col = e % XS;
       const int c = c0 + kr, gcol = n0 + smin + col;
-      float v = 0.f;
-      if (kr < KCH && col < W && c < p.Kc && gcol >= 0 && gcol < p.Lx) v = Xb[(long)c * p.sxc + (long)gcol * p.sxn];
-      rx[r] = v;
+      rx[r] = Xb[(long)min(c, p.Kc - 1) * p.sxc + (long)min(max(gcol, 0), p.Lx - 1) * p.sxn];
     }
   };
 
-  auto commit = [&]() {
+  auto commit = [&](int ch) {
+    const int c0 = ch * KCH;
     if constexpr (AVEC) {
 #pragma unroll
       for (int r = 0; r < NA4; ++r) {
         const int f = tid + 256 * r;
         const int row = f / (KC / 4), q = f % (KC / 4);
+        const bool ok = m0 + row < p.M && c0 * KT + 4 * q < p.Kc * KT;
         float2* dst = reinterpret_cast<float2*>(As + row * AS + 4 * q);   // AS even -> 8-byte aligned
-        dst[0] = make_float2(ra4[r].x, ra4[r].y);
-        dst[1] = make_float2(ra4[r].z, ra4[r].w);
+        dst[0] = ok ? make_float2(ra4[r].x, ra4[r].y) : make_float2(0.f, 0.f);
+        dst[1] = ok ? make_float2(ra4[r].z, ra4[r].w) : make_float2(0.f, 0.f);
       }
     } else {
 #pragma unroll
@@ -112,13 +110,15 @@ __global__ __launch_bounds__(256, (WM == 1 ? 3 : 2)) void gemm_nn_kernel(const G
         const int e = tid + 256 * r;
         int row, kk;
         if (a_mfast) { kk = e / BM; row = e % BM; } else { row = e / KC; kk = e % KC; }
-        As[row * AS + kk] = ra1[r];
+        As[row * AS + kk] = (m0 + row < p.M && c0 + kk / KT < p.Kc) ? ra1[r] : 0.f;
       }
     }
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       const int e = tid + 256 * r;
-      if (e < KCH * XS) Xs[e] = rx[r];
+      const int kr = e / XS, col = e % XS;
+      const int gcol = n0 + smin + col;
+      if (e < KCH * XS) Xs[e] = (col < W && c0 + kr < p.Kc && gcol >= 0 && gcol < p.Lx) ? rx[r] : 0.f;
     }
   };
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, (WM == 1 ? 3 : 2)) void gemm_nn_kernel(const G
   prefetch(0);
   for (int ch = 0; ch < nchunks; ++ch) {
     __syncthreads();            // every wave is done reading the previous chunk
-    commit();
+    commit(ch);
     __syncthreads();
     if (ch + 1 < nchunks) prefetch(ch + 1);
 #pragma unroll

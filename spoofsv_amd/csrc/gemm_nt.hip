@@ -50,30 +50,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p, const i
       const int e = tid + 256 * r;
       const int row = e / KB, tt = e % KB;
       const int gm = m0 + row, gt = t0 + tt;
-      float v = 0.f;
-      if (gm < p.M && gt < p.La) v = Ab[(long)gm * p.sam + (long)gt * p.sat];
-      ra[r] = v;
+      ra[r] = Ab[(long)min(gm, p.M - 1) * p.sam + (long)min(gt, p.La - 1) * p.sat];   // raw; masked in commit()
     }
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       const int e = tid + 256 * r;
       const int cr = e / XS, col = e % XS;
       const int gc = c0 + cr, gcol = t0 + smin + col;
-      float v = 0.f;
-      if (cr < NCH && col < W && gc < p.Nc && gcol >= 0 && gcol < p.Lx) v = Xb[(long)gc * p.sxc + (long)gcol * p.sxn];
-      rx[r] = v;
+      rx[r] = Xb[(long)min(gc, p.Nc - 1) * p.sxc + (long)min(max(gcol, 0), p.Lx - 1) * p.sxn];
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int tc) {       // validity masks are applied here, one chunk after the loads were issued
+    const int t0 = tc * KB;
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
       const int e = tid + 256 * r;
-      As[(e / KB) * AS + (e % KB)] = ra[r];
+      As[(e / KB) * AS + (e % KB)] = (m0 + e / KB < p.M && t0 + e % KB < p.La) ? ra[r] : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       const int e = tid + 256 * r;
-      if (e < NCH * XS) Xs[e] = rx[r];
+      const int cr = e / XS, col = e % XS;
+      const int gcol = t0 + smin + col;
+      if (e < NCH * XS) Xs[e] = (col < W && c0 + cr < p.Nc && gcol >= 0 && gcol < p.Lx) ? rx[r] : 0.f;
     }
   };
 
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p, const i
   if (total > 0) prefetch(z, 0);
   for (int it = 0; it < total; ++it) {
     __syncthreads();
-    commit();
+    commit(it % tchunks);
     __syncthreads();
     if (it + 1 < total) {
       const int nx = it + 1;
