@@ -263,22 +263,24 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
 
 // ---- NT (weight gradient) -------------------------------------------------------------------------------------------------
 //   C(z,m,c,j) = sum_{b = z, z+bstep, ..} sum_t A(b,m,t) * X(b,c,t+shift[j]);  rows contiguous in t for both operands.
+// As in the NN kernel the waves split M, so the A rows (dL/dH) of a wave are private to it: its fragments are loaded
+// from global memory straight into registers (8 consecutive time steps per lane = two 16-byte loads), split there, and
+// never touch LDS.  The input rows X are shared by the four waves and staged in LDS, one exact-shift copy per tap.
 template <int KT, int WM, int NTC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
-  constexpr int KB = 64, KG = KB / 8;                       // time steps per chunk, k-groups
-  constexpr int BM = 64 * WM, NCH = 16 * NTC;
-  constexpr int A_SLOTS = KG * BM, X_SLOTS = KT * KG * NCH;
-  constexpr int NA = A_SLOTS / 256, NX = (X_SLOTS + 255) / 256;
-  __shared__ uint4 lds[2 * A_SLOTS + 2 * X_SLOTS];
-  uint4* Ah = lds;
-  uint4* Al = lds + A_SLOTS;
-  uint4* Xh = lds + 2 * A_SLOTS;
-  uint4* Xl = Xh + X_SLOTS;
+  constexpr int KB = 64, KG = KB / 8, KS = KB / 32;         // time steps per chunk, k-groups, MFMA k-steps
+  constexpr int NCH = 16 * NTC;
+  constexpr int X_SLOTS = KT * KG * NCH;
+  constexpr int NX = (X_SLOTS + 255) / 256;
+  __shared__ uint4 lds[2 * X_SLOTS];
+  uint4* Xh = lds;
+  uint4* Xl = lds + X_SLOTS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mt = blockIdx.x % mtiles, ct = blockIdx.x / mtiles, z = blockIdx.z;
-  const int m0 = mt * BM, c0 = ct * NCH;
+  const int m0 = mt * 64 * WM, c0 = ct * NCH;
   const int tchunks = (p.La + KB - 1) / KB;
+  const int kq = lane >> 4, nq = lane & 15;
 
   f32x4 acc[WM][KT][NTC];
 #pragma unroll
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
       for (int q = 0; q < NTC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float ra[NA][8], rx[NX][8];
+  float ra[WM][KS][8], rx[NX][8];
 
   // 8 consecutive time steps of one row, zero outside [0, len)
   auto load8 = [&](const float* __restrict__ row, int t, int len, float (&v)[8]) {
@@ -306,14 +308,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     const float* __restrict__ Xb = p.X + (long)b * p.sxb;
     const int t0 = tc * KB;
 #pragma unroll
-    for (int r = 0; r < NA; ++r) {
-      const int f = tid + 256 * r;                   // kg fastest: a wave reads 8 rows x 256 contiguous bytes
-      const int kg = f % KG, m = f / KG;
-      const int gm = m0 + m;
-      if (gm < p.M) load8(Ab + (long)gm * p.sam, t0 + 8 * kg, p.La, ra[r]);
-      else {
+    for (int i = 0; i < WM; ++i) {
+      const int gm = m0 + wave * WM * 16 + i * 16 + nq;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ra[r][i] = 0.f;
+      for (int s2 = 0; s2 < KS; ++s2) {
+        if (gm < p.M) load8(Ab + (long)gm * p.sam, t0 + s2 * 32 + 8 * kq, p.La, ra[i][s2]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ra[i][s2][e] = 0.f;
+        }
       }
     }
 #pragma unroll
@@ -328,15 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       }
     }
   };
-  auto commit = [&]() {
-#pragma unroll
-    for (int r = 0; r < NA; ++r) {
-      const int f = tid + 256 * r;
-      const int kg = f % KG, m = f / KG;
-      uint4 h, l;
-      split8(ra[r], h, l);
-      Ah[kg * BM + m] = h; Al[kg * BM + m] = l;
-    }
+  auto commitX = [&]() {
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       const int f = tid + 256 * r;
@@ -349,24 +344,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
   };
 
-  const int kq = lane >> 4, nq = lane & 15;
   const int nb = (p.B - z + p.bstep - 1) / p.bstep;
   const int total = nb * tchunks;
   if (total > 0) prefetch(z, 0);
   for (int it = 0; it < total; ++it) {
     __syncthreads();
-    commit();
+    commitX();
     __syncthreads();
+    uint4 ah[WM][KS], al[WM][KS];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) split8(ra[i][s2], ah[i][s2], al[i][s2]);
     if (it + 1 < total) { const int nx = it + 1; prefetch(z + (nx / tchunks) * p.bstep, nx % tchunks); }
 #pragma unroll
-    for (int s = 0; s < KB / 32; ++s) {
-      const int kg = s * 4 + kq;
-      bf16x8 ah[WM], al[WM];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        ah[i] = __builtin_bit_cast(bf16x8, Ah[kg * BM + wave * WM * 16 + i * 16 + nq]);
-        al[i] = __builtin_bit_cast(bf16x8, Al[kg * BM + wave * WM * 16 + i * 16 + nq]);
-      }
+    for (int s2 = 0; s2 < KS; ++s2) {
+      const int kg = s2 * 4 + kq;
 #pragma unroll
       for (int j = 0; j < KT; ++j)
 #pragma unroll
@@ -376,9 +369,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
           const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
 #pragma unroll
           for (int i = 0; i < WM; ++i) {
-            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j][q], 0, 0, 0);
-            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j][q], 0, 0, 0);
-            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j][q], 0, 0, 0);
+            const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[i][s2]);
+            const bf16x8 a_l = __builtin_bit_cast(bf16x8, al[i][s2]);
+            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, bh, acc[i][j][q], 0, 0, 0);
+            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, bl, acc[i][j][q], 0, 0, 0);
+            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, bh, acc[i][j][q], 0, 0, 0);
           }
         }
     }
