@@ -396,7 +396,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
 }
 
-int ssv_nt_bf3_channels_per_tile(int KT, int Nc) { return (KT == 3) ? 32 : (Nc > 48 ? 96 : 32); }
+static int nt_ntc3() { const char* e = getenv("SSV_NT_NTC"); return (e && atoi(e) == 2) ? 2 : 4; }
+int ssv_nt_bf3_channels_per_tile(int KT, int Nc) { return (KT == 3) ? 16 * nt_ntc3() : (Nc > 48 ? 96 : 32); }
 
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
   SSV_CHECK(g.M > 0 && g.Nc > 0 && g.La > 0 && g.B > 0 && g.Z > 0 && g.bstep > 0, SSV_BAD_SHAPE, "gemm_nt_bf3: empty problem");
@@ -404,7 +405,9 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
   SSV_CHECK(g.sat == 1 && g.sxn == 1, SSV_UNSUPPORTED, "gemm_nt_bf3: rows must be contiguous in time");
   SSV_CHECK(g.Z <= 65535, SSV_UNSUPPORTED, "gemm_nt_bf3: Z=%d exceeds grid.z", g.Z);
   const int mtiles = ssv_cdiv(g.M, 128);
-  if (g.KT == 3) {
+  if (g.KT == 3 && nt_ntc3() == 4) {
+    hipLaunchKernelGGL((gemm_nt_bf3_kernel<3, 2, 4>), dim3(mtiles * ssv_cdiv(g.Nc, 64), 1, g.Z), dim3(256), 0, st, g, mtiles);
+  } else if (g.KT == 3) {
     hipLaunchKernelGGL((gemm_nt_bf3_kernel<3, 2, 2>), dim3(mtiles * ssv_cdiv(g.Nc, 32), 1, g.Z), dim3(256), 0, st, g, mtiles);
   } else if (g.Nc > 48) {
     hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 6>), dim3(mtiles * ssv_cdiv(g.Nc, 96), 1, g.Z), dim3(256), 0, st, g, mtiles);
