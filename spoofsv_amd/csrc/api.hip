@@ -361,7 +361,7 @@ extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* x
 }
 
 // ---- GE2E speaker embedder ---------------------------------------------------------------------------------
-struct LstmWs { size_t xt, xp, seq0, seq1, g, c, total; };
+struct LstmWs { size_t xt, xp, seq0, seq1, g, c, wih, whh, total; };
 static LstmWs lstm_ws(int Bn, int T, int F, int H) {
   LstmWs s;
   s.xt = 0;
@@ -370,8 +370,35 @@ static LstmWs lstm_ws(int Bn, int T, int F, int H) {
   s.seq1 = s.seq0 + align256((size_t)T * H * Bn * sizeof(float));
   s.g = s.seq1 + align256((size_t)T * H * Bn * sizeof(float));
   s.c = s.g + align256((size_t)4 * H * Bn * sizeof(float));
-  s.total = s.c + align256((size_t)H * Bn * sizeof(float));
+  s.wih = s.c + align256((size_t)H * Bn * sizeof(float));
+  s.whh = s.wih + 2 * split_bytes(4 * H, F > H ? F : H, 1);        // pre-split weights (hi, lo planes)
+  s.total = s.whh + 2 * split_bytes(4 * H, H, 1);
   return s;
+}
+// C = A X (+ bias + bias_b + R) with A (M x K) row-major weights and X, C as [rows][Bn] activations; "batch" of nb
+// independent problems strided by sxb / scb.  Split-bf16 when enabled (weights pre-split into `pk`), else fp32 MFMA.
+static int lstm_gemm(const float* A, const unsigned short* pk_hi, const unsigned short* pk_lo, bool bf3, const float* X, long sxb,
+                     float* C, long scb, const float* bias, const float* bias_b, const float* R, int M, int K, int Bn, int nb,
+                     hipStream_t st) {
+  if (bf3) {
+    GemmNNB g;
+    g.Ahi = pk_hi; g.Alo = pk_lo; g.Kpad = pad32(K);
+    g.X = X; g.sxb = sxb; g.sxc = Bn; g.Lx = Bn;
+    g.C = C; g.scb = scb; g.scm = Bn;
+    g.bias = bias; g.bias_b = bias_b; g.sbb = 0;
+    g.R = R; g.srb = 0; g.srm = Bn;
+    g.M = M; g.N = Bn; g.Kc = K; g.KT = 1; g.B = nb;
+    g.shift[0] = g.shift[1] = g.shift[2] = 0;
+    return ssv_launch_gemm_nn_bf3(g, st);
+  }
+  GemmNN g = nn_zero();
+  g.A = A; g.sam = K; g.sac = 1; g.saj = 1;
+  g.X = X; g.sxb = sxb; g.sxc = Bn; g.Lx = Bn;
+  g.C = C; g.scb = scb; g.scm = Bn;
+  g.bias = bias; g.bias_b = bias_b; g.sbb = 0;
+  if (R) { g.R = R; g.srm = Bn; }
+  g.M = M; g.N = Bn; g.Kc = K; g.B = nb;
+  return ssv_launch_gemm_nn(g, st);
 }
 extern "C" size_t ssv_lstm_fwd_workspace(int Bn, int T, int F, int H, int layers) { (void)layers; return lstm_ws(Bn, T, F, H).total; }
 extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
@@ -388,31 +415,27 @@ extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const floa
   float* seq[2] = {(float*)(base + s.seq0), (float*)(base + s.seq1)};
   float* gbuf = (float*)(base + s.g);
   float* cbuf = (float*)(base + s.c);
+  const bool bf3 = ssv_precision() == 1 && Bn >= 64 && H >= 32;
   SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));    // [T][F][Bn]
   const float* in = xt;
   int Fin = F;
   float* out = nullptr;
   for (int l = 0; l < layers; ++l) {
     out = seq[l & 1];
-    {  // input projection for every frame at once: xp[t] = W_ih in[t] + b_ih + b_hh    ("batch" = frame)
-      GemmNN g = nn_zero();
-      g.A = w_ih[l]; g.sam = Fin; g.sac = 1; g.saj = 1;
-      g.X = in; g.sxb = (long)Fin * Bn; g.sxc = Bn; g.Lx = Bn;
-      g.C = xp; g.scb = (long)4 * H * Bn; g.scm = Bn;
-      g.bias = b_ih[l]; g.bias_b = b_hh[l]; g.sbb = 0;
-      g.M = 4 * H; g.N = Bn; g.Kc = Fin; g.B = T;
-      SSV_TRY(ssv_launch_gemm_nn(g, st));
+    unsigned short* ih_hi = (unsigned short*)(base + s.wih);
+    unsigned short* ih_lo = (unsigned short*)(base + s.wih + split_bytes(4 * H, Fin, 1));
+    unsigned short* hh_hi = (unsigned short*)(base + s.whh);
+    unsigned short* hh_lo = (unsigned short*)(base + s.whh + split_bytes(4 * H, H, 1));
+    if (bf3) {   // the weights of a layer are used by T + 1 products: split them once
+      SSV_TRY(ssv_launch_pack_split(w_ih[l], ih_hi, ih_lo, 4 * H, Fin, pad32(Fin), 1, Fin, 1, 1, st));
+      SSV_TRY(ssv_launch_pack_split(w_hh[l], hh_hi, hh_lo, 4 * H, H, pad32(H), 1, H, 1, 1, st));
     }
+    // input projection for every frame at once: xp[t] = W_ih in[t] + b_ih + b_hh    ("batch" = frame)
+    SSV_TRY(lstm_gemm(w_ih[l], ih_hi, ih_lo, bf3, in, (long)Fin * Bn, xp, (long)4 * H * Bn, b_ih[l], b_hh[l], nullptr, 4 * H, Fin, Bn, T, st));
     for (int t = 0; t < T; ++t) {
       const float* gates = xp + (long)t * 4 * H * Bn;
       if (t > 0) {  // gates = W_hh h_{t-1} + xp[t]
-        GemmNN g = nn_zero();
-        g.A = w_hh[l]; g.sam = H; g.sac = 1; g.saj = 1;
-        g.X = out + (long)(t - 1) * H * Bn; g.sxc = Bn; g.Lx = Bn;
-        g.C = gbuf; g.scm = Bn;
-        g.R = gates; g.srm = Bn;
-        g.M = 4 * H; g.N = Bn; g.Kc = H; g.B = 1;
-        SSV_TRY(ssv_launch_gemm_nn(g, st));
+        SSV_TRY(lstm_gemm(w_hh[l], hh_hi, hh_lo, bf3, out + (long)(t - 1) * H * Bn, 0, gbuf, 0, nullptr, nullptr, gates, 4 * H, H, Bn, 1, st));
         gates = gbuf;
       }
       SSV_TRY(ssv_launch_lstm_cell(gates, cbuf, out + (long)t * H * Bn, H, Bn, t == 0, st));
