@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adversarial", action="store_true", help="skip the extra WGAN-GP cycle timing")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="conv GEMM arithmetic: split-bf16 MFMA (default, ~1e-5 rel) or exact fp32 MFMA")
@@ -123,6 +124,59 @@ class Trainer:
                 self.opt.step()
 
 
+def adversarial_cycle_ms(kind, batch, dev, cycles=2):
+    """One full WGAN-GP cycle of the reference (1 generator + RATIO=5 critic iterations,
+    train/adversarial_wasserstein_gp.py:261-322): generator forward on the HIP path in all six, generator backward
+    + Adam in one, critic (stock torch ops) with gradient penalty in five.  Eager launches (the
+    reference's .item()-based loss weight forces a host sync per G iteration).  Returns ms per ITERATION."""
+    from spoofsv_amd import ops, train
+    from spoofsv_amd.critic import linDisc, melDisc
+    from spoofsv_amd.tts import SSRN, melSyn
+    torch.manual_seed(1234)
+    if kind == "text2mel":
+        model, disc = melSyn(34, True, 200, 128, 80, 256), melDisc(80, 128)
+        mel, text, spk = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=0, device=dev)
+        gaw = train.guided_attention_mat(186, 325, device=dev)
+        gt = mel
+    else:
+        model, disc = SSRN(80, 513, 256), linDisc(513, 128)
+        mel, gt = train.synthetic_ssrn_batch(batch, T_MEL, seed=0, device=dev)
+    model.apply(train.init_weights); disc.apply(train.init_weights)
+    model.to(dev).train(); disc.to(dev).train()
+    og = train.FusedAdam(model.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    od = torch.optim.Adam(disc.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+
+    def iteration(it):
+        og.zero_grad(set_to_none=True); od.zero_grad(set_to_none=True)
+        if kind == "text2mel":
+            pred, att = model(train.shift_right(mel), text, spk)
+        else:
+            pred, att = model(mel), None
+        B, C, T = gt.shape
+        if it % 6 == 0:
+            l1, bd = ops.spec_losses(pred, gt)
+            base = l1 + bd + (ops.guided_att_loss(att, gaw) if att is not None else 0.0)
+            ld = torch.mean(-disc(pred))
+            (base + (float(base) / abs(float(ld))) * ld).backward()
+            og.step()
+        else:
+            coeff = torch.rand(B).view(B, 1, 1).expand(B, C, T).to(dev)
+            mid = (coeff * gt + (1 - coeff) * pred.detach()).requires_grad_(True)
+            out = disc(mid)
+            g = torch.autograd.grad(out, mid, torch.ones_like(out), retain_graph=True, create_graph=True)[0]
+            (torch.mean(10 * (torch.norm(g, p=2, dim=(1, 2)) - 1) ** 2)).backward()
+            torch.mean(disc(pred.detach()) - disc(gt)).backward()
+            od.step()
+    for it in range(6):
+        iteration(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(6 * cycles):
+        iteration(it)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (6 * cycles) * 1e3
+
+
 def kernel_roofline(dev):
     """Average duration of the dominant kernel -- the k=3 dilated Conv1d implicit GEMM (gemm_nn_kernel)
     at its most frequent launch shape in the step: highwayConv C=256 (M=2C=512), L=325, B=32 -- timed
@@ -161,7 +215,10 @@ def kernel_roofline(dev):
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "peak_note": "bf16 dense 2500 TFLOP/s / 3" if split else "fp32-input MFMA dense",
             "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
-            "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4), "traffic": None}
+            "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4),
+            # PMC: FETCH_SIZE + WRITE_SIZE per launch of this kernel instantiation, separate rocprofv3 --pmc passes (not collected live)
+            "traffic": (47985.8 + 20899.8) * 1024 if split else (45959.9 + 20878.8) * 1024,
+            "traffic_source": "profiles/round1_bench_kernel_stats_v2_bf16x3.txt" if split else "profiles/round1_bench_kernel_stats_v1_fp32.txt"}
 
 
 def cpu_baseline():
@@ -289,6 +346,13 @@ def main():
                           "ssrn_fps": round(args.batch * T_MEL * world / split["ssrn"], 1),
                           "final_loss": [round(loss_t2m, 5), round(loss_ssrn, 5)]}}
         res["roofline"] = kernel_roofline(dev)
+        if world == 1 and not args.no_adversarial:
+            # BASELINE config 3 (--adversarial): reported beside the headline, never inside `value`
+            a1, a2 = adversarial_cycle_ms("text2mel", args.batch, dev), adversarial_cycle_ms("ssrn", args.batch, dev)
+            res["config"]["adversarial"] = {"text2mel_ms_per_iter": round(a1, 3), "ssrn_ms_per_iter": round(a2, 3),
+                                            "text2mel_fps": round(args.batch * T_MEL / a1 * 1e3, 1), "ssrn_fps": round(args.batch * T_MEL / a2 * 1e3, 1),
+                                            "combined_fps": round(args.batch * T_MEL / (a1 + a2) * 1e3, 1),
+                                            "note": "1 G : 5 D cycle average, critic on stock torch ops, eager"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["config"]["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
