@@ -111,6 +111,7 @@ class Trainer:
         with torch.cuda.graph(self.graph):
             if self.ddp:
                 self._fwd_bwd()
+                self.graph_grads = [p.grad for p in self.params]      # the tensors every replay writes
             else:
                 self._whole()
 
@@ -120,7 +121,7 @@ class Trainer:
         else:
             self.graph.replay()
             if self.ddp:
-                self.ddp.all_reduce_grads()
+                self.ddp.all_reduce_grads(self.graph_grads)
                 self.opt.step()
 
 
@@ -283,11 +284,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # rehearsal on fewer GPUs than ranks (SSV_DIST_BACKEND=gloo); identity on a full node
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("SSV_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from spoofsv_amd import _lib
     _lib.lib()
 

@@ -202,32 +202,45 @@ class DataParallelRanks:
             for p in self.params:
                 dist.broadcast(p.data, src, group=self.group)
 
-    def _buckets(self):
+    def _buckets(self, grads):
         buckets, cur, n = [], [], 0
-        for p in self.params:
-            if p.grad is None:
+        for p, g in zip(self.params, grads):
+            if g is None:
                 continue
-            if n + p.numel() > self.bucket_elems and cur:
+            if n + g.numel() > self.bucket_elems and cur:
                 buckets.append(cur)
                 cur, n = [], 0
-            cur.append(p)
-            n += p.numel()
+            cur.append((p, g))
+            n += g.numel()
         if cur:
             buckets.append(cur)
         return buckets
 
     @torch.no_grad()
-    def all_reduce_grads(self):
+    def all_reduce_grads(self, grads=None):
+        """Average gradients over ranks.  ``grads`` defaults to each parameter's ``.grad`` (pass the tensors a
+        captured hipGraph writes when replaying one).  Gradients are packed into persistent flat buckets (one
+        ``cat`` kernel each), each bucket is all-reduced asynchronously so packing bucket i+1 overlaps the
+        collective of bucket i, and afterwards every ``p.grad`` is re-pointed at its averaged slice of the bucket --
+        no copy back, and the optimizer's pointer table stays stable from step to step."""
         if self.world == 1:
             return
-        for bucket in self._buckets():
-            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.div_(self.world)
+        if grads is None:
+            grads = [p.grad for p in self.params]
+        buckets = self._buckets(grads)
+        if self._flat is None or len(self._flat) != len(buckets):
+            self._flat = [torch.empty(sum(g.numel() for _, g in b), dtype=b[0][1].dtype, device=b[0][1].device) for b in buckets]
+        works = []
+        for flat, bucket in zip(self._flat, buckets):
+            torch.cat([g.reshape(-1) for _, g in bucket], out=flat)
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for flat, bucket, w in zip(self._flat, buckets, works):
+            w.wait()
+            flat.mul_(1.0 / self.world)
             off = 0
-            for p in bucket:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            for p, g in bucket:
+                n = g.numel()
+                p.grad = flat[off:off + n].view_as(g)
                 off += n
 
     @torch.no_grad()
