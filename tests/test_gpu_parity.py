@@ -233,3 +233,56 @@ def test_ge2e_loss_golden_and_known_answer():
     kl, per = L(t(g["kat_emb"], DEV), return_per_embedding=True)
     assert abs(float(kl) - 5.2501) < 1e-4                      # GE2E/utils.py:89-96
     assert rel_err(per, t(g["kat_per"])) < 1e-5
+
+
+def test_config2_synthesize_full_size_vs_oracle(precision):
+    """BASELINE config 2: Text2Mel free-running synthesis of the first Harvard sentence + SSRN, full-size models with
+    seeded random weights (no trained checkpoint exists offline), one speaker code; GPU vs the CPU oracle.
+    Spectrograms within 1e-3 relative; attention indices exact wherever the oracle's top-2 margin exceeds the
+    arithmetic noise (the recorded minimum margin is asserted so the check cannot pass vacuously)."""
+    from spoofsv_amd import harness, train
+    from spoofsv_amd.tts import SSRN, melSyn
+    steps = 96                                            # 97 frames: bounded so the O(T^2) CPU oracle stays ~10 s
+    vocab = "PE abcdefghijklmnopqrstuvwxyz-,.?'" + '"'
+    ids = torch.tensor(harness.text2id("The birch canoe slid on the smooth planks.", vocab)).view(1, 1, -1)
+    assert ids.shape[-1] == 43
+    spk = torch.full((1, 200, 1), 0.06)
+    torch.manual_seed(1234)
+    m1 = melSyn(34, True, 200, 128, 80, 256)
+    m1.apply(train.init_weights)
+    torch.manual_seed(1234)
+    m2 = SSRN(80, 513, 256)
+    m2.apply(train.init_weights)
+    sd1 = {k: v.clone() for k, v in m1.state_dict().items()}
+    sd2 = {k: v.clone() for k, v in m2.state_dict().items()}
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    with torch.no_grad():
+        Yo, Ao, pma_o = TO.synthesize_loop(ids, spk, sd1, steps)
+        lin_o = TO.ssrn(Yo, sd2)
+        top = torch.topk(Ao, 2, dim=1).values
+        margins = (top[:, 0] - top[:, 1])[0]               # per generated frame
+    m1, m2 = m1.to(DEV).eval(), m2.to(DEV).eval()
+    idg, spg = ids.to(DEV), spk.to(DEV)
+    with torch.no_grad():
+        init = torch.zeros(1, 80, 1, device=DEV)
+        Y, A, pma, K, V = m1(melspec=init, textid=idg, spkemb=spg, pma=torch.zeros(1, device=DEV).long())
+        inputs = torch.cat((init, Y), dim=-1)
+        seq = [pma.clone()]
+        for _ in range(steps):
+            Y, A, pma = m1(melspec=inputs, textid=None, spkemb=spg, K=K, V=V, A_last=A, pma=pma)
+            inputs = torch.cat((inputs, Y[:, :, -1:]), dim=-1)
+            seq.append(pma.clone())
+        lin = m2(Y)
+    pma_g = torch.stack(seq).cpu()
+    safe = margins > 1e-3
+    assert int(safe.sum()) >= steps // 2, "too few decisive attention columns for a meaningful index check"
+    first_bad = None
+    for i in range(steps + 1):
+        if not torch.equal(pma_g[i], pma_o[i]):
+            first_bad = i
+            break
+    # indices must agree at least up to the first indecisive column (after one, trajectories may legitimately fork)
+    limit = int((~safe).nonzero()[0]) if (~safe).any() else steps + 1
+    assert first_bad is None or first_bad >= limit, (first_bad, limit, float(margins.min()))
+    if first_bad is None:
+        assert rel_err(Y, Yo) < 1e-3 and rel_err(lin, lin_o) < 1e-3, (rel_err(Y, Yo), rel_err(lin, lin_o))
