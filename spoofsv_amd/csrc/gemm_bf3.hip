@@ -109,29 +109,55 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   // Input staging, two halves.  prefetchX only ISSUES loads (raw values, addresses clamped into the batch item so every
   // load is legal); validity masks are applied in commitX one chunk later, right before the split.  A mask applied at
   // load time would make hipcc wait for each load (or branch around it), serialising 24 L2 round trips per chunk.
+  // Address arithmetic is hoisted: element (chunk ch, slot channel 8*kg+i, column) lives at
+  //   [Xb + (ch*32 + i)*L]  (wave-uniform, scalar ALU)  +  [8*kg*L + column]  (per thread, computed once),
+  // and the column mask is computed once; only a ragged last chunk (Kc % 32 != 0) needs per-channel clamps and masks.
   const int Lrow = (int)p.sxc;
-  const int maxoff = (p.Kc - 1) * Lrow + p.Lx - 1;
+  unsigned voff[NX];
+  bool cvs[NX];
+#pragma unroll
+  for (int r = 0; r < NX; ++r) {
+    const int e = tid + 256 * r;
+    const int kg = e / WX, col = e % WX;
+    const int gcol = n0 + smin + col;
+    cvs[r] = e < X_SLOTS && col < W && gcol >= 0 && gcol < p.Lx;
+    voff[r] = (unsigned)((e < X_SLOTS ? 8 * kg : 0) * Lrow + min(max(gcol, 0), p.Lx - 1));
+  }
+  const bool ragged = (p.Kc & 31) != 0;
   auto prefetchX = [&](int ch) {
+    if (!ragged || ch + 1 < nchunks) {
 #pragma unroll
-    for (int r = 0; r < NX; ++r) {
-      const int e = tid + 256 * r;
-      const int kg = e / WX, col = e % WX;
-      const int base = (ch * 32 + 8 * kg) * Lrow + n0 + smin + col;
+      for (int i = 0; i < 8; ++i) {
+        const float* __restrict__ rowp = Xb + (long)(ch * 32 + i) * Lrow;     // uniform
 #pragma unroll
-      for (int i = 0; i < 8; ++i) rx[r][i] = Xb[(unsigned)min(max(base + i * Lrow, 0), maxoff)];
+        for (int r = 0; r < NX; ++r) rx[r][i] = rowp[voff[r]];
+      }
+    } else {                                                                   // last, partial chunk: clamp channels
+#pragma unroll
+      for (int r = 0; r < NX; ++r) {
+        const int e = tid + 256 * r;
+        const int kg = (e < X_SLOTS) ? e / WX : 0;
+        const unsigned colo = voff[r] - (unsigned)(8 * kg * Lrow);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rx[r][i] = Xb[(long)min(ch * 32 + 8 * kg + i, p.Kc - 1) * Lrow + colo];
+      }
     }
   };
   auto commitX = [&](int ch) {
+    const bool last_ragged = ragged && ch + 1 == nchunks;
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       const int e = tid + 256 * r;
       if (e < X_SLOTS) {
-        const int kg = e / WX, col = e % WX;
-        const int gcol = n0 + smin + col;
-        const bool cv = col < W && gcol >= 0 && gcol < p.Lx;
         float v[8];
+        if (!last_ragged) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (cv && ch * 32 + 8 * kg + i < p.Kc) ? rx[r][i] : 0.f;
+          for (int i = 0; i < 8; ++i) v[i] = cvs[r] ? rx[r][i] : 0.f;
+        } else {
+          const int kg = e / WX;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = (cvs[r] && ch * 32 + 8 * kg + i < p.Kc) ? rx[r][i] : 0.f;
+        }
         uint4 h, l;
         split8(v, h, l);
         Xh[e] = h; Xl[e] = l;            // slot index = kg*WX + col = e
