@@ -243,6 +243,183 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     }
 }
 
+// ---- NN, wide workgroup ------------------------------------------------------------------------------------------------
+// The 4-wave kernel above moves (A tile + X tile) bytes from L2 per chunk for only 128 x 112 outputs: at the bf16 MFMA rate
+// that is ~34 B/clk/CU, and an ablation (MFMAs removed: 356 of 503 us remain; loads removed: 167 us) shows it is bound by
+// L2->CU traffic, not by the matrix cores.  Here a workgroup has 4 x NWN waves (M x N): the NWN wave columns share one
+// weight tile, so both operands are staged in LDS once per workgroup and the L2 bytes per MAC drop by ~2x (128 x 336 tile:
+// 16 B/clk/CU at the full MFMA rate).  Same LDS image layout [k-group][row][8 x bf16] (conflict-free b128 reads), same
+// "issue raw loads, mask at commit" staging and hoisted addressing as above.
+template <int KT, int WM, int NT, int NWN>
+__global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
+  constexpr int T = 256 * NWN;
+  constexpr int BM = 64 * WM, BN = 16 * NT * NWN;
+  constexpr int HALO = (KT == 1) ? 0 : 54;
+  constexpr int WX = ((BN + HALO + 15) / 16) * 16;
+  constexpr int A_SLOTS = KT * 4 * BM, X_SLOTS = 4 * WX;
+  constexpr int NA = (A_SLOTS + T - 1) / T, NX = (X_SLOTS + T - 1) / T;
+  __shared__ uint4 lds[2 * A_SLOTS + 2 * X_SLOTS];
+  uint4* Ah = lds;
+  uint4* Al = lds + A_SLOTS;
+  uint4* Xh = lds + 2 * A_SLOTS;
+  uint4* Xl = Xh + X_SLOTS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int mt = blockIdx.x % mtiles, ntile = blockIdx.x / mtiles, b = blockIdx.y;
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const float* __restrict__ Xb = p.X + (long)b * p.sxb;
+  const int W = BN + span;
+  const int nchunks = p.Kpad / 32;
+  const int kq = lane >> 4, nq = lane & 15;
+
+  f32x4 acc[WM][NT];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 rah[NA], ral[NA];
+  float rx[NX][8];
+
+  // weight staging: slot f -> (tap j, row m, k-group kg), kg fastest so 4 lanes read 64 contiguous bytes of one row
+  auto a_off = [&](int r) -> long {
+    const int f = min(tid + T * r, A_SLOTS - 1);
+    const int kg = f & 3, m = (f >> 2) % BM, j = f / (4 * BM);
+    return ((long)j * p.M + min(m0 + m, p.M - 1)) * p.Kpad + 8 * kg;      // rows past M read row M-1: never stored
+  };
+  auto a_slot = [&](int r) -> int {
+    const int f = min(tid + T * r, A_SLOTS - 1);
+    const int kg = f & 3, m = (f >> 2) % BM, j = f / (4 * BM);
+    return (j * 4 + kg) * BM + m;
+  };
+  const int Lrow = (int)p.sxc;
+  unsigned voff[NX];
+  unsigned cvmask = 0;
+#pragma unroll
+  for (int r = 0; r < NX; ++r) {
+    const int e = tid + T * r;
+    const int kg = e / WX, col = e % WX;
+    const int gcol = n0 + smin + col;
+    if (e < X_SLOTS && col < W && gcol >= 0 && gcol < p.Lx) cvmask |= 1u << r;
+    voff[r] = (unsigned)((e < X_SLOTS ? 8 * kg : 0) * Lrow + min(max(gcol, 0), p.Lx - 1));
+  }
+  const bool ragged = (p.Kc & 31) != 0;
+
+  auto prefetch = [&](int ch) {
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+      const long o = a_off(r) + ch * 32;
+      rah[r] = *reinterpret_cast<const uint4*>(p.Ahi + o);
+      ral[r] = *reinterpret_cast<const uint4*>(p.Alo + o);
+    }
+    if (!ragged || ch + 1 < nchunks) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float* __restrict__ rowp = Xb + (long)(ch * 32 + i) * Lrow;     // wave-uniform
+#pragma unroll
+        for (int r = 0; r < NX; ++r) rx[r][i] = rowp[voff[r]];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NX; ++r) {
+        const int e = tid + T * r;
+        const int kg = (e < X_SLOTS) ? e / WX : 0;
+        const unsigned colo = voff[r] - (unsigned)(8 * kg * Lrow);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rx[r][i] = Xb[(long)min(ch * 32 + 8 * kg + i, p.Kc - 1) * Lrow + colo];
+      }
+    }
+  };
+  auto commit = [&](int ch) {
+#pragma unroll
+    for (int r = 0; r < NA; ++r)
+      if (tid + T * r < A_SLOTS) { const int sl = a_slot(r); Ah[sl] = rah[r]; Al[sl] = ral[r]; }
+    const bool last_ragged = ragged && ch + 1 == nchunks;
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+      const int e = tid + T * r;
+      if (e < X_SLOTS) {
+        float v[8];
+        if (!last_ragged) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = ((cvmask >> r) & 1) ? rx[r][i] : 0.f;
+        } else {
+          const int kg = e / WX;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = (((cvmask >> r) & 1) && ch * 32 + 8 * kg + i < p.Kc) ? rx[r][i] : 0.f;
+        }
+        uint4 h, l;
+        split8(v, h, l);
+        Xh[e] = h; Xl[e] = l;
+      }
+    }
+  };
+
+  int offj[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) offj[j] = p.shift[j] - smin;
+  const int arow = kq * BM + wm * WM * 16 + nq;
+  const int xcol = kq * WX + wn * NT * 16 + nq;
+
+  prefetch(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();
+    commit(ch);
+    __syncthreads();
+    if (ch + 1 < nchunks) prefetch(ch + 1);
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      bf16x8 ah[WM], al[WM];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        ah[i] = __builtin_bit_cast(bf16x8, Ah[j * 4 * BM + arow + i * 16]);
+        al[i] = __builtin_bit_cast(bf16x8, Al[j * 4 * BM + arow + i * 16]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int xs = xcol + t * 16 + offj[j];
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  float* __restrict__ Cb = p.C + (long)b * p.scb;
+  const float* __restrict__ Rb = p.R ? p.R + (long)b * p.srb : nullptr;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gm = m0 + wm * WM * 16 + i * 16 + kq * 4 + r;
+      if (gm >= p.M) continue;
+      float add = 0.f;
+      if (p.bias) add += p.bias[gm];
+      if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gm];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int gn = n0 + wn * NT * 16 + t * 16 + nq;
+        if (gn >= p.N) continue;
+        float v = acc[i][t][r] + add;
+        if (Rb) v += Rb[(long)gm * p.srm + gn];
+        Cb[(long)gm * p.scm + gn] = v;
+      }
+    }
+}
+
+template <int KT, int WM, int NT, int NWN>
+static int launch_nnbw(const GemmNNB& g, hipStream_t st, int smin, int span) {
+  const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT * NWN);
+  hipLaunchKernelGGL((gemm_nn_bf3w_kernel<KT, WM, NT, NWN>), dim3(mtiles * ntiles, g.B), dim3(256 * NWN), 0, st, g, mtiles, smin, span);
+  return ssv_check_launch("gemm_nn_bf3w");
+}
+
 template <int KT, int WM, int NT>
 static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT);
@@ -252,6 +429,18 @@ static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
 
 template <int KT>
 static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
+  {
+    int wm = 0, nt = 0, nwn = 0;
+    const char* e = getenv("SSV_NNB_WIDE");
+    if (e && sscanf(e, "%d,%d,%d", &wm, &nt, &nwn) == 3) {
+#define SSV_W(A_, C_, D_) if (wm == A_ && nt == C_ && nwn == D_) return launch_nnbw<KT, A_, C_, D_>(g, st, smin, span)
+      SSV_W(2, 7, 3); SSV_W(1, 7, 3); SSV_W(2, 7, 2); SSV_W(2, 6, 2); SSV_W(1, 6, 2); SSV_W(2, 4, 4); SSV_W(2, 7, 4);
+#undef SSV_W
+    }
+    // measured (tools/sweep_nn_tiles.py): the wide workgroup wins for kernel-size-1 convolutions over long sequences
+    // (SSRN's 513-channel layers: 150 -> 205 TFLOP/s); the k=3 layers are as fast or faster on the 4-wave kernel.
+    if (KT == 1 && !e && g.N >= 1024 && g.M >= 256 && g.Kc >= 256) return launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
+  }
   static const int nts[] = {7, 6, 4, 2};
   int wm = 2, nt = 7;
   bool forced = false;
