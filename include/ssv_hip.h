@@ -70,8 +70,10 @@ int ssv_copy_rows(const float* src, long src_bs, float* dst, long dst_bs, int B,
  * Replaces `ln(x.permute(0,2,1)).permute(0,2,1)` followed by F.relu / F.sigmoid,
  * models/TTSModel.py:129-131, :175-180, :219-231, :344-361.  act: 0 none, 1 relu, 2 sigmoid.
  * stats (B,2,L) = mean, rstd: saved for backward (may be NULL for inference). */
+size_t ssv_channel_ln_act_fwd_workspace(int B, int C, int L);
 int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const float* beta,
-                           float* y, long y_bs, float* stats, int B, int C, int L, int act, ssv_stream_t stream);
+                           float* y, long y_bs, float* stats, int B, int C, int L, int act,
+                           void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L);
 /* dx: gradient w.r.t. the pre-LN input; pgrads (3,C) = dgamma, dbeta, sum_{b,t} dx (bias gradient of
  * the producing conv). */
@@ -83,7 +85,7 @@ int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_b
  * Replaces highwayConv.forward, models/TTSModel.py:63-84:
  *   h = conv(x) (2C channels); y = sigmoid(LN1(h[:C])) * LN2(h[C:]) + (1 - sigmoid(LN1(h[:C]))) * x.
  * h (B,2C,L) dense and stats (B,4,L) = mean1, rstd1, mean2, rstd2 are saved for backward. */
-size_t ssv_highway_conv1d_fwd_workspace(int C, int k);
+size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k);
 int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias,
                            const float* g1, const float* b1, const float* g2, const float* b2,
                            float* h, float* stats, float* y, long y_bs,

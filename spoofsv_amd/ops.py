@@ -80,7 +80,7 @@ class HighwayConvFn(torch.autograd.Function):
         y = torch.empty((B, C, L), dtype=_F32, device=x.device)
         h = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
         stats = torch.empty((B, 4, L), dtype=_F32, device=x.device) if train else None
-        nb = _lib.query("ssv_highway_conv1d_fwd_workspace", C, k)
+        nb = _lib.query("ssv_highway_conv1d_fwd_workspace", B, C, L, k)
         ws = _ws(nb, x.device)
         _lib.call("ssv_highway_conv1d_fwd", _p(x), xbs, _p(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
                   _p(h), _p(stats), _p(y), C * L, B, C, L, k, dilation, int(causal), _p(ws), nb, _stream())
@@ -168,8 +168,10 @@ class PointwiseConvLnActFn(torch.autograd.Function):
         y = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
         stats = torch.empty((B, 2, L), dtype=_F32, device=x.device) if train else None
         _conv_fwd(x, xbs, w, bias, sb, pre, Cout * L, 1, 1, 0)
+        nbl = _lib.query("ssv_channel_ln_act_fwd_workspace", B, Cout, L)
+        wsl = _ws(nbl, x.device)
         _lib.call("ssv_channel_ln_act_fwd", _p(pre), Cout * L, _p(gamma), _p(beta), _p(y), Cout * L, _p(stats),
-                  B, Cout, L, act, _stream())
+                  B, Cout, L, act, _p(wsl), nbl, _stream())
         if train:
             ctx.save_for_backward(x, w, gamma, beta, pre, stats)
             ctx.act = act

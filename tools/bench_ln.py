@@ -19,7 +19,8 @@ for (B, C, L) in [(32, 513, 1300), (32, 512, 186), (32, 256, 325), (32, 256, 130
     stats = torch.empty(B, 2, L, device=dev); pg = torch.empty(3, C, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     nb = _lib.query("ssv_channel_ln_act_bwd_workspace", B, C, L); ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    f = lambda: _lib.call("ssv_channel_ln_act_fwd", P(x), C * L, P(g), P(b), P(y), C * L, P(stats), B, C, L, 1, st)
+    nbf = _lib.query("ssv_channel_ln_act_fwd_workspace", B, C, L); wsf = torch.empty(nbf, dtype=torch.uint8, device=dev)
+    f = lambda: _lib.call("ssv_channel_ln_act_fwd", P(x), C * L, P(g), P(b), P(y), C * L, P(stats), B, C, L, 1, P(wsf), nbf, st)
     bw = lambda: _lib.call("ssv_channel_ln_act_bwd", P(dy), C * L, P(x), C * L, P(stats), P(g), P(b), P(dx), C * L, P(pg), B, C, L, 1, P(ws), nb, st)
     tf, tb = timeit(f), timeit(bw)
     n = B * C * L * 4
