@@ -125,56 +125,41 @@ class Trainer:
                 self.opt.step()
 
 
-def adversarial_cycle_ms(kind, batch, dev, cycles=2):
+def adversarial_cycle_ms(kind, batch, dev, cycles=3):
     """One full WGAN-GP cycle of the reference (1 generator + RATIO=5 critic iterations,
-    train/adversarial_wasserstein_gp.py:261-322): generator forward on the HIP path in all six, generator backward
-    + Adam in one, critic (stock torch ops) with gradient penalty in five.  Eager launches (the
-    reference's .item()-based loss weight forces a host sync per G iteration).  Returns ms per ITERATION."""
-    from spoofsv_amd import ops, train
+    train/adversarial_wasserstein_gp.py:261-322): generator on the HIP path, critic on stock torch ops
+    with gradient penalty, both iterations replayed from captured hipGraphs (train.AdversarialGraphStep).
+    Returns ms per ITERATION averaged over the cycle."""
+    from spoofsv_amd import train
     from spoofsv_amd.critic import linDisc, melDisc
     from spoofsv_amd.tts import SSRN, melSyn
     torch.manual_seed(1234)
+    gaw = None
     if kind == "text2mel":
         model, disc = melSyn(34, True, 200, 128, 80, 256), melDisc(80, 128)
-        mel, text, spk = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=0, device=dev)
+        data = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=0, device=dev)
         gaw = train.guided_attention_mat(186, 325, device=dev)
-        gt = mel
     else:
         model, disc = SSRN(80, 513, 256), linDisc(513, 128)
-        mel, gt = train.synthetic_ssrn_batch(batch, T_MEL, seed=0, device=dev)
+        data = train.synthetic_ssrn_batch(batch, T_MEL, seed=0, device=dev)
     model.apply(train.init_weights); disc.apply(train.init_weights)
     model.to(dev).train(); disc.to(dev).train()
-    og = train.FusedAdam(model.parameters(), 2e-4, (0.5, 0.9), 1e-6)
-    od = torch.optim.Adam(disc.parameters(), 2e-4, (0.5, 0.9), 1e-6)
-
-    def iteration(it):
-        og.zero_grad(set_to_none=True); od.zero_grad(set_to_none=True)
-        if kind == "text2mel":
-            pred, att = model(train.shift_right(mel), text, spk)
-        else:
-            pred, att = model(mel), None
-        B, C, T = gt.shape
-        if it % 6 == 0:
-            l1, bd = ops.spec_losses(pred, gt)
-            base = l1 + bd + (ops.guided_att_loss(att, gaw) if att is not None else 0.0)
-            ld = torch.mean(-disc(pred))
-            (base + (float(base) / abs(float(ld))) * ld).backward()
-            og.step()
-        else:
-            coeff = torch.rand(B).view(B, 1, 1).expand(B, C, T).to(dev)
-            mid = (coeff * gt + (1 - coeff) * pred.detach()).requires_grad_(True)
-            out = disc(mid)
-            g = torch.autograd.grad(out, mid, torch.ones_like(out), retain_graph=True, create_graph=True)[0]
-            (torch.mean(10 * (torch.norm(g, p=2, dim=(1, 2)) - 1) ** 2)).backward()
-            torch.mean(disc(pred.detach()) - disc(gt)).backward()
-            od.step()
-    for it in range(6):
-        iteration(it)
+    og = train.FusedAdam(model.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+    od = train.FusedAdam(disc.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+    stepper = train.AdversarialGraphStep(kind, model, disc, og, od, data, gaw)
+    def cycle():
+        stepper.g_step()
+        for _ in range(5):
+            stepper.d_step()
+    cycle()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for it in range(6 * cycles):
-        iteration(it)
+    for _ in range(cycles):
+        cycle()
     torch.cuda.synchronize()
+    out = stepper.g_step()
+    if not all(float(v) == float(v) for v in out):
+        raise SystemExit("non-finite loss in the adversarial cycle")
     return (time.perf_counter() - t0) / (6 * cycles) * 1e3
 
 
@@ -359,7 +344,7 @@ def main():
             res["config"]["adversarial"] = {"text2mel_ms_per_iter": round(a1, 3), "ssrn_ms_per_iter": round(a2, 3),
                                             "text2mel_fps": round(args.batch * T_MEL / a1 * 1e3, 1), "ssrn_fps": round(args.batch * T_MEL / a2 * 1e3, 1),
                                             "combined_fps": round(args.batch * T_MEL / (a1 + a2) * 1e3, 1),
-                                            "note": "1 G : 5 D cycle average, critic on stock torch ops, eager"}
+                                            "note": "1 G : 5 D cycle average, critic on stock torch ops, both iterations replayed from hipGraphs"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["config"]["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)

@@ -218,6 +218,8 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
     src = BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir)
     gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
     max_iter = cfg.get("MAX_ITERATIONS")
+    if cfg.get("CAPTURE_GRAPHS") and resume_checkpoints is None and not src.files:
+        return _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter)
     while epoch < cfg["MAX_EPOCHS"]:
         for i, sp in enumerate(src):
             t0 = time.time()
@@ -260,6 +262,57 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
                 logs["loss_train_log_disc"].append(float(loss_D) + float(loss_gp))
                 logs["wd_log"].append(-float(loss_D))
                 print("training D  DISC:{}, WD:{}".format(float(loss_D) + float(loss_gp), -float(loss_D)))
+            if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
+                payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
+                           "disc_state_dict": disc.state_dict(), "opt_state_dict_syn": opt_syn.state_dict(),
+                           "opt_state_dict_disc": opt_disc.state_dict()}
+                payload.update(logs)
+                _save(os.path.join(save_dir, "{}_iteration_{}.tar.pth".format(train_step[6:], iteration + 1)), payload)
+            iteration += 1
+            print("Time elapsed {}s.".format(time.time() - t0))
+            if max_iter is not None and iteration >= max_iter:
+                return model, disc, logs
+        epoch += 1
+    return model, disc, logs
+
+
+def _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter):
+    """adversarial_train with both iteration kinds replayed from hipGraphs (optional config key CAPTURE_GRAPHS; needs
+    fixed batch shapes, i.e. the synthetic source).  Same schedule, losses, logs and checkpoints as the eager loop."""
+    a = cfg["ADAM"]
+    opt_syn = train.FusedAdam(model.parameters(), a["ALPHA"], (a["BETA_1"], a["BETA_2"]), a["EPSILON"], capturable=True)
+    opt_disc = train.FusedAdam(disc.parameters(), a["ALPHA"], (a["BETA_1"], a["BETA_2"]), a["EPSILON"], capturable=True)
+    w_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    w_disc = {k: v.detach().clone() for k, v in disc.state_dict().items()}
+    kind = "text2mel" if train_step == "train_text2mel" else "ssrn"
+
+    def pick(sp):
+        keys = ("data_0", "data_1", "data_2") if kind == "text2mel" else ("data_0", "data_1")
+        return [sp[k].to(dev) for k in keys]
+    first = pick(next(iter(src)))
+    stepper = train.AdversarialGraphStep(kind, model, disc, opt_syn, opt_disc, first, gaw, cfg["LAMBDA"])
+    # capturing ran warm-up iterations: put weights and optimizer state back to the start of training
+    model.load_state_dict(w_model)
+    disc.load_state_dict(w_disc)
+    for opt in (opt_syn, opt_disc):
+        for st in opt.state.values():
+            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+        opt._step_dev.zero_()
+    epoch = iteration = 0
+    while epoch < cfg["MAX_EPOCHS"]:
+        for sp in src:
+            t0 = time.time()
+            stepper.load(pick(sp))
+            if iteration % (cfg["RATIO"] + 1) == 0:
+                l1, bd, la, ld, tot = [float(v) for v in stepper.g_step()]
+                logs["loss_train_log_syn"].append(tot)
+                logs["loss_train_log_syn_onlyfromD"].append(ld)
+                print("training G  L1:{}, BD:{}, ATT:{}, DISC:{}, ALL:{}".format(l1, bd, la, ld, tot))
+            else:
+                ld, gp = [float(v) for v in stepper.d_step()]
+                logs["loss_train_log_disc"].append(ld + gp)
+                logs["wd_log"].append(-ld)
+                print("training D  DISC:{}, WD:{}".format(ld + gp, -ld))
             if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
                 payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
                            "disc_state_dict": disc.state_dict(), "opt_state_dict_syn": opt_syn.state_dict(),

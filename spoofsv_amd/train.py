@@ -253,3 +253,96 @@ class DataParallelRanks:
         dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
         v /= self.world
         return tuple(v[i] for i in range(len(scalars)))
+
+
+# --------------------------------------------------------------------------------------------- WGAN-GP
+class AdversarialGraphStep:
+    """The generator iteration and the critic iteration of the reference's WGAN-GP trainer
+    (train/adversarial_wasserstein_gp.py:261-322), each captured ONCE as a hipGraph over static input buffers and
+    replayed per iteration -- the eager form is host-bound (hundreds of small critic kernels, three critic forwards and a
+    double backward per D iteration, Python autograd glue), not GPU-bound.
+
+    Differences to the eager reference that make capture possible, none changing the mathematics:
+      * the adaptive weight of the critic term, (l1+bd+att).item()/|disc|.item() (:290, :338), is formed on the device
+        from detached tensors instead of through two host round trips;
+      * the interpolation coefficients of the gradient penalty (:300) come from the device RNG instead of the CPU RNG;
+      * D iterations run the generator forward without recording a tape (the reference records one and discards it:
+        only ``pred.detach()`` is used, :311-313).
+    ``kind``: "text2mel" (batch = mel, text, spk) or "ssrn" (batch = mel, lin).  Optimizers must be FusedAdam(capturable=True).
+    """
+
+    def __init__(self, kind, model, disc, opt_syn, opt_disc, batch, gaw=None, lam=10.0):
+        self.kind, self.model, self.disc, self.opt_syn, self.opt_disc = kind, model, disc, opt_syn, opt_disc
+        self.static = [b.clone() for b in batch]
+        self.gaw, self.lam = gaw, float(lam)
+        self.g_out = self.d_out = None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._g_iter()
+                self._d_iter()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.g_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_graph):
+            self.g_out = self._g_iter()
+        self.d_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.d_graph):
+            self.d_out = self._d_iter()
+
+    def _forward(self):
+        if self.kind == "text2mel":
+            mel, text, spk = self.static
+            pred, att = self.model(shift_right(mel), text, spk)
+            return pred, att, mel
+        mel, lin = self.static
+        return self.model(mel), None, lin
+
+    def _g_iter(self):
+        self.opt_syn.zero_grad(set_to_none=True)
+        self.opt_disc.zero_grad(set_to_none=True)
+        pred, att, gt = self._forward()
+        l1, bd = ops.spec_losses(pred, gt)
+        base = l1 + bd
+        la = None
+        if att is not None:
+            la = ops.guided_att_loss(att, self.gaw)
+            base = base + la
+        ld = torch.mean(-self.disc(pred))
+        loss = base + (base.detach() / ld.detach().abs()) * ld
+        loss.backward()
+        self.opt_syn.step()
+        return tuple(t.detach() for t in (l1, bd, la if la is not None else l1 * 0, ld, loss))
+
+    def _d_iter(self):
+        self.opt_syn.zero_grad(set_to_none=True)
+        self.opt_disc.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            pred, _, gt = self._forward()
+        B, C, T = gt.shape
+        coeff = torch.rand(B, 1, 1, device=gt.device)
+        mid = (coeff * gt + (1 - coeff) * pred).requires_grad_(True)
+        out = self.disc(mid)
+        grads = torch.autograd.grad(outputs=out, inputs=mid, grad_outputs=torch.ones_like(out), retain_graph=True, create_graph=True)[0]
+        loss_gp = torch.mean(self.lam * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
+        loss_gp.backward()
+        loss_d = torch.mean(self.disc(pred) - self.disc(gt))
+        loss_d.backward()
+        self.opt_disc.step()
+        return loss_d.detach(), loss_gp.detach()
+
+    def load(self, batch):
+        """Copy a new batch (same shapes) into the static buffers the graphs read."""
+        for dst, src in zip(self.static, batch):
+            dst.copy_(src, non_blocking=True)
+
+    def g_step(self):
+        """-> (l1, bin_div, att, disc, total) device scalars of this iteration."""
+        self.g_graph.replay()
+        return self.g_out
+
+    def d_step(self):
+        """-> (loss_D, loss_gp) device scalars (Wasserstein estimate = -loss_D)."""
+        self.d_graph.replay()
+        return self.d_out

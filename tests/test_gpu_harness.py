@@ -75,6 +75,16 @@ def test_adversarial_ssrn_and_text2mel_iterations(tmp_path):
         assert {"model_state_dict", "disc_state_dict", "opt_state_dict_syn", "opt_state_dict_disc", "wd_log"} <= keys
 
 
+def test_adversarial_train_captured_graphs(tmp_path):
+    from spoofsv_amd import harness
+    cfg = _cfg(tmp_path, MAX_ITERATIONS=7, RATIO=2, CAPTURE_GRAPHS=True)
+    model, disc, logs = harness.adversarial_train("train_text2mel", "conditional", cfg, current_time="cap")
+    assert len(logs["loss_train_log_syn"]) == 3 and len(logs["loss_train_log_disc"]) == 4
+    assert all(v == v for v in logs["loss_train_log_syn"] + logs["loss_train_log_disc"])
+    ck = os.path.join(str(tmp_path), "checkpoints", "conditional", "adversarial", "cap", "text2mel_iteration_3.tar.pth")
+    assert os.path.exists(ck)
+
+
 def test_generator_accepts_critic_gradient_like_oracle():
     """dL/dY coming from a stock-op critic flows through the HIP generator exactly as through the oracle."""
     from spoofsv_amd import train
@@ -109,3 +119,52 @@ def test_main_cli_synthesize(tmp_path):
     mel, lin, att = outs[0]
     assert mel.shape == (80, 12) and lin.shape == (65, 48) and att.shape == (43, 12)
     assert os.path.exists(os.path.join(str(tmp_path), "samples", "syn", "S1_lin.npy"))
+
+
+def test_adversarial_graph_step_matches_eager_generator_iteration():
+    """The captured G iteration equals the eager one (same weights, same batch, critic in eval so no dropout RNG)."""
+    from spoofsv_amd import ops, train
+    from spoofsv_amd.critic import melDisc
+    from spoofsv_amd.tts import melSyn
+    dev = "cuda:0"
+
+    def build():
+        torch.manual_seed(21)
+        m = melSyn(34, True, 200, textemb_dim=16, freq_bins=80, hidden_dim=32)
+        d = melDisc(80, 16)
+        m.apply(train.init_weights); d.apply(train.init_weights)
+        return m.to(dev).train(), d.to(dev).eval()
+    batch = train.synthetic_text2mel_batch(2, N=24, T=40, seed=4, device=dev)
+    gaw = train.guided_attention_mat(186, 325, device=dev)
+    # eager, as the reference spells it (host-side adaptive weight)
+    m, d = build()
+    opt = train.FusedAdam(m.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    mel, text, spk = batch
+    pred, att = m(train.shift_right(mel), text, spk)
+    l1, bd = ops.spec_losses(pred, mel)
+    la = ops.guided_att_loss(att, gaw)
+    ld = torch.mean(-d(pred))
+    loss = l1 + bd + la + (float(l1) + float(bd) + float(la)) / abs(float(ld)) * ld
+    loss.backward()
+    opt.step()
+    ref = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    # captured
+    m2, d2 = build()
+    og = train.FusedAdam(m2.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+    od = train.FusedAdam(d2.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+    w0 = {k: v.detach().clone() for k, v in m2.state_dict().items()}
+    c0 = {k: v.detach().clone() for k, v in d2.state_dict().items()}
+    stepper = train.AdversarialGraphStep("text2mel", m2, d2, og, od, batch, gaw)
+    # construction ran warm-up iterations of both kinds: restore the initial weights (generator AND critic) and the
+    # generator's optimizer moments, then replay ONE G step
+    m2.load_state_dict(w0)
+    d2.load_state_dict(c0)
+    for st in og.state.values():
+        st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+    og._step_dev.zero_()
+    out = stepper.g_step()
+    assert abs(float(out[4]) - float(loss)) < 1e-4 * abs(float(loss))
+    worst = max(float((m2.state_dict()[k] - ref[k]).abs().max()) for k in ref)
+    assert worst < 2e-5, worst
+    ld_, gp_ = stepper.d_step()
+    assert float(ld_) == float(ld_) and float(gp_) == float(gp_)
