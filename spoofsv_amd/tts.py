@@ -162,8 +162,18 @@ class melSyn(nn.Module):
     def forward(self, melspec, textid, spkemb, K=None, V=None, A_last=None, pma=None):
         T = melspec.shape[-1]
         if self.training:
-            kv = self.text_encoder.encode(textid)
+            # The text encoder and the audio encoder are independent until the attention: run the text branch on a
+            # second HIP stream so that its (small) kernels fill the CUs the audio branch leaves idle.  autograd replays
+            # each branch's backward on the stream of its forward, so the backward pass overlaps the same way, and a
+            # hipGraph capture records the fork/join as parallel branches.
+            cur = torch.cuda.current_stream()
+            side = _side_stream(melspec.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                kv = self.text_encoder.encode(textid)
             Q = self.audio_encoder(melspec, spkemb)
+            cur.wait_stream(side)
+            kv.record_stream(cur)
             RQ, A = ops.attention_train(kv, Q)
             return self.audio_decoder(RQ), A
 
@@ -186,6 +196,16 @@ class melSyn(nn.Module):
         if T == 1:
             return Y, A, nxt, K, V
         return Y, A, nxt
+
+
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 def _as_kv(K, V):
