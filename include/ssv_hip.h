@@ -99,6 +99,15 @@ int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_b
                            int B, int C, int L, int k, int dilation, int causal,
                            void* ws, size_t ws_bytes, ssv_stream_t stream);
 
+/* Building block of the above: only the gate + two LayerNorm backward.  dh (B,2C,L) dense = dL/dh (the conv output
+ * gradient), dxres = dy*(1-gate) (the residual-path part of dL/dx), pgrads (6,C) as above.  A caller can then run
+ * ssv_conv1d_bwd_data(dh, ..., dx_add = dxres) and ssv_conv1d_bwd_weight(dh, x, ...) on two different streams. */
+size_t ssv_highway_gate_bwd_workspace(int B, int C, int L);
+int ssv_highway_gate_bwd(const float* dy, long dy_bs, const float* x, long x_bs,
+                         const float* g1, const float* b1, const float* g2, const float* b2,
+                         const float* h, const float* stats, float* dh, float* dxres, long dx_bs, float* pgrads,
+                         int B, int C, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
+
 /* ---- textEmbedding -------------------------------------------------------------------------------
  * Replaces textEmbedding.forward, models/TTSModel.py:25-35 (one-hot scatter + Linear):
  * y(b,e,n) = w[e, ids(b,0,n)] + bias[e]; w is the nn.Linear weight (E, vocab).  ids int64 (B,1,N);

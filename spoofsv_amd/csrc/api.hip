@@ -238,6 +238,19 @@ extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w,
   return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
 }
 
+// ---- highway gate alone (building block: lets a caller overlap the two conv gradients on different streams) ---------------
+extern "C" size_t ssv_highway_gate_bwd_workspace(int B, int C, int L) {
+  return zmax(align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float)), ssv_lnr_use(B, C, L) ? ssv_lnr_bwd_ws(B, C, L, 4) : 0);
+}
+extern "C" int ssv_highway_gate_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* g1, const float* b1,
+                                    const float* g2, const float* b2, const float* h, const float* stats, float* dh, float* dxres,
+                                    long dx_bs, float* pgrads, int B, int C, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dy && x && g1 && b1 && g2 && b2 && h && stats && dh && dxres && pgrads && B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_gate_bwd: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_highway_gate_bwd_workspace(B, C, L), SSV_BAD_SHAPE, "highway_gate_bwd: workspace too small");
+  if (ssv_lnr_use(B, C, L)) return ssv_lnr_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dxres, dx_bs, ws, pgrads, B, C, L, (hipStream_t)stream);
+  return ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dxres, dx_bs, (float*)ws, pgrads, B, C, L, (hipStream_t)stream);
+}
+
 struct HwWs { size_t dh, part, wt, slabs, total; };
 static HwWs hw_ws(int B, int C, int L, int k) {
   HwWs s;

@@ -172,8 +172,7 @@ class melSyn(nn.Module):
             with torch.cuda.stream(side):
                 kv = self.text_encoder.encode(textid)
             Q = self.audio_encoder(melspec, spkemb)
-            cur.wait_stream(side)
-            kv.record_stream(cur)
+            cur.wait_stream(side)     # join; kv stays alive until backward, no record_stream (illegal under capture) needed
             RQ, A = ops.attention_train(kv, Q)
             return self.audio_decoder(RQ), A
 
