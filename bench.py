@@ -116,13 +116,30 @@ class Trainer:
                 self._whole()
 
     def step(self):
+        self.step_begin()
+        self.step_end()
+
+    # Two halves, so that with N > 1 the gradient all-reduce of one model overlaps the other model's compute:
+    #   begin = forward + backward (+ start of the asynchronous all-reduce);  end = wait + Adam.
+    def step_begin(self):
+        self._pending = None
+        if self.ddp is None:
+            if self.graph is None:
+                self._whole()
+            else:
+                self.graph.replay()
+            return
         if self.graph is None:
-            self._whole()
+            self._fwd_bwd()
+            self._pending = self.ddp.all_reduce_grads_begin()
         else:
             self.graph.replay()
-            if self.ddp:
-                self.ddp.all_reduce_grads(self.graph_grads)
-                self.opt.step()
+            self._pending = self.ddp.all_reduce_grads_begin(self.graph_grads)
+
+    def step_end(self):
+        if self.ddp is not None:
+            self.ddp.all_reduce_grads_end(self._pending)
+            self.opt.step()
 
 
 def adversarial_cycle_ms(kind, batch, dev, cycles=3):
@@ -297,14 +314,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Leave each model's gradient all-reduce in flight while the other model computes (RCCL runs collectives on its own
+    # stream).  Only with the RCCL backend: gloo's CUDA path synchronises with the host and the overlap backfires.
+    pipeline = world > 1 and os.environ.get("SSV_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("SSV_DDP_PIPELINE", "1") != "0"
+
+    def both():
+        # one "step" of the benchmark: a Text2Mel iteration and an SSRN iteration (independent models)
+        if pipeline:
+            t2m.step_begin()
+            ssr.step_begin()
+            t2m.step_end()
+            ssr.step_end()
+        else:
+            t2m.step()
+            ssr.step()
+
     for _ in range(args.warmup):
-        t2m.step()
-        ssr.step()
+        both()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        t2m.step()
-        ssr.step()
+        both()
     barrier()
     dt = time.perf_counter() - t0
     # per-model split (same number of steps, timed separately, not part of `value`)
@@ -333,6 +363,8 @@ def main():
                                       "batch %d utterances/GPU, N=186, T=325, 80 mel -> 513x1300 linear, hidden 256, random-init" % args.batch,
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "launch": "hipGraph replay" if use_graph else "eager",
+                          "ddp": ("flat-bucket RCCL all-reduce, pipelined under the other model's step" if pipeline else
+                                  ("flat-bucket all-reduce" if world > 1 else "none")),
                           "text2mel_ms": round(split["text2mel"] * 1e3, 3), "ssrn_ms": round(split["ssrn"] * 1e3, 3),
                           "text2mel_fps": round(args.batch * T_MEL * world / split["text2mel"], 1),
                           "ssrn_fps": round(args.batch * T_MEL * world / split["ssrn"], 1),

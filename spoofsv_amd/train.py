@@ -217,14 +217,14 @@ class DataParallelRanks:
         return buckets
 
     @torch.no_grad()
-    def all_reduce_grads(self, grads=None):
-        """Average gradients over ranks.  ``grads`` defaults to each parameter's ``.grad`` (pass the tensors a
-        captured hipGraph writes when replaying one).  Gradients are packed into persistent flat buckets (one
-        ``cat`` kernel each), each bucket is all-reduced asynchronously so packing bucket i+1 overlaps the
-        collective of bucket i, and afterwards every ``p.grad`` is re-pointed at its averaged slice of the bucket --
-        no copy back, and the optimizer's pointer table stays stable from step to step."""
+    def all_reduce_grads_begin(self, grads=None):
+        """Start averaging gradients over ranks and return a handle for ``all_reduce_grads_end``.  ``grads`` defaults
+        to each parameter's ``.grad`` (pass the tensors a captured hipGraph writes when replaying one).  Gradients are
+        packed into persistent flat buckets (one ``cat`` kernel each) and every bucket is all-reduced asynchronously:
+        packing bucket i+1 overlaps the collective of bucket i, and whatever the caller enqueues before calling
+        ``..._end`` (e.g. the other model's step) overlaps the collectives on RCCL's own stream."""
         if self.world == 1:
-            return
+            return None
         if grads is None:
             grads = [p.grad for p in self.params]
         buckets = self._buckets(grads)
@@ -234,6 +234,15 @@ class DataParallelRanks:
         for flat, bucket in zip(self._flat, buckets):
             torch.cat([g.reshape(-1) for _, g in bucket], out=flat)
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return buckets, works
+
+    @torch.no_grad()
+    def all_reduce_grads_end(self, handle):
+        """Wait for the collectives, scale by 1/world and re-point every ``p.grad`` at its averaged slice of the
+        bucket -- no copy back, and the optimizer's pointer table stays stable from step to step."""
+        if handle is None:
+            return
+        buckets, works = handle
         for flat, bucket, w in zip(self._flat, buckets, works):
             w.wait()
             flat.mul_(1.0 / self.world)
@@ -242,6 +251,9 @@ class DataParallelRanks:
                 n = g.numel()
                 p.grad = flat[off:off + n].view_as(g)
                 off += n
+
+    def all_reduce_grads(self, grads=None):
+        self.all_reduce_grads_end(self.all_reduce_grads_begin(grads))
 
     @torch.no_grad()
     def all_reduce_mean(self, *scalars):
