@@ -19,6 +19,7 @@ Fixtures (names follow SURVEY.md section 8c):
   ge2e_loss.npz      G7  GE2ELoss random case + the utils.py:89-96 known-answer case
   init_pin.npz       G9  seed -> construct -> apply(init_weights): per-parameter checksums
   adam.npz           a13 three torch.optim.Adam steps with the config.json hyper-parameters
+  adversarial_iter.npz G8 one G and one D iteration with the reference's melSyn + melDisc (critic dropout off)
 """
 import argparse
 import hashlib
@@ -277,6 +278,62 @@ def gen_ge2e(ref):
                         kat_emb=_np(kat), kat_cossim=_np(kc), kat_loss=_np(kl), kat_per=_np(kper))
 
 
+def gen_adversarial(TTS, ref):
+    """G8: one generator iteration and one critic iteration of train/adversarial_wasserstein_gp.py:261-322, executed
+    with the reference's own melSyn and melDisc modules and its loss expressions, at reduced dims.  The critic is put in
+    eval mode (dropout off) and the gradient-penalty coefficients are stored, so the iteration is reproducible by another
+    implementation; Adam as configured in config.json."""
+    import torch.nn.functional as F
+    import importlib
+    D = importlib.import_module("models.discriminator")
+    torch.manual_seed(31)
+    hidden, temb, B, N, T = 16, 8, 2, 12, 20
+    m = TTS.melSyn(vocab_len=34, condition=True, spkemb_dim=200, textemb_dim=temb, freq_bins=80, hidden_dim=hidden)
+    d = D.melDisc(freq_bins=80, disc_dim=16)
+    m.apply(init_weights); d.apply(init_weights)
+    m.train(); d.eval()
+    sd_m0, sd_d0 = {k: v.clone() for k, v in m.state_dict().items()}, {k: v.clone() for k, v in d.state_dict().items()}
+    opt_syn = torch.optim.Adam(m.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    opt_disc = torch.optim.Adam(d.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    mel_gt, text, spk = _t2m_inputs(B, N, T, seed=17)
+    gaw = _guided(24, 32)
+    spec_inputs = torch.cat((torch.zeros_like(mel_gt[:, :, :1]), mel_gt[:, :, :-1]), dim=-1)
+    # ---- G iteration (:278-297)
+    pred, att = m(spec_inputs, text, spk)
+    disc_syn = d(pred)
+    l1 = torch.mean(torch.abs(mel_gt - pred))
+    bd = torch.mean(-mel_gt * torch.log(pred + 1e-8) - (1 - mel_gt) * torch.log(1 - pred + 1e-8))
+    aug = F.pad(att, (0, 32 - att.size()[-1], 0, 24 - att.size()[-2]), value=-1)
+    la = torch.sum(torch.ne(aug, -1).float() * aug * gaw) / torch.sum(torch.ne(aug, -1).float())
+    ld = torch.mean(-disc_syn)
+    loss = l1 + bd + la + (l1.item() + bd.item() + la.item()) / (abs(ld.item())) * ld
+    loss.backward()
+    opt_syn.step()
+    out = dict(mel_gt=_np(mel_gt), text=_np(text), spk=_np(spk), gaw=_np(gaw),
+               g_l1=_np(l1), g_bd=_np(bd), g_att=_np(la), g_disc=_np(ld), g_all=_np(loss),
+               dims=np.array([hidden, temb, B, N, T], dtype=np.int64))
+    out.update(_sd_np(sd_m0, "m0/")); out.update(_sd_np(sd_d0, "d0/"))
+    out.update(_sd_np(m.state_dict(), "m1/"))
+    # ---- D iteration (:299-322) on the updated generator
+    opt_syn.zero_grad(); opt_disc.zero_grad()
+    pred, att = m(spec_inputs, text, spk)
+    coeff_b = torch.rand(B)
+    C = mel_gt.shape[1]
+    coeff = torch.stack(T * [torch.stack(C * [coeff_b], dim=1)], dim=2)
+    mid = coeff * mel_gt.detach() + (1 - coeff) * pred.detach()
+    mid.requires_grad = True
+    out_mid = d(mid)
+    grads = torch.autograd.grad(outputs=out_mid, inputs=mid, grad_outputs=torch.ones(out_mid.size()), retain_graph=True, create_graph=True)[0]
+    gp = torch.mean(10 * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
+    gp.backward()
+    loss_D = torch.mean(d(pred.detach()) - d(mel_gt.detach()))
+    loss_D.backward()
+    opt_disc.step()
+    out.update(dict(coeff=_np(coeff_b), d_gp=_np(gp), d_loss=_np(loss_D)))
+    out.update(_sd_np(d.state_dict(), "d1/"))
+    np.savez_compressed(os.path.join(OUT, "adversarial_iter.npz"), **out)
+
+
 def gen_init_pin(TTS):
     out = {}
     for tag, ctor in (("t2m", lambda: TTS.melSyn(vocab_len=34, condition=True, spkemb_dim=200, textemb_dim=128,
@@ -326,6 +383,7 @@ def main():
     gen_gaw()
     gen_init_pin(TTS)
     gen_adam()
+    gen_adversarial(TTS, args.ref)
     gen_ge2e(args.ref)
     for f in sorted(os.listdir(OUT)):
         print("%-22s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))

@@ -168,3 +168,65 @@ def test_adversarial_graph_step_matches_eager_generator_iteration():
     assert worst < 2e-5, worst
     ld_, gp_ = stepper.d_step()
     assert float(ld_) == float(ld_) and float(gp_) == float(gp_)
+
+# Biases that feed a LayerNorm have an exactly-zero true gradient; what autograd returns for them is rounding noise, and
+# Adam's first step turns noise into +-lr.  They are excluded; every other parameter's update must agree element-wise
+# (a handful of near-zero gradients may still flip sign, hence a 5 % allowance instead of a max-norm bound).
+_ZERO_GRAD = ("conv1.bias", "hc.conv.bias", "conv2.bias", "conv3.bias", "conv4.bias", "conv5.bias")
+
+
+def _critic_updates_agree(got, before, want):
+    for k in want:
+        if k in _ZERO_GRAD:
+            continue
+        bad = ((got[k] - want[k]).abs() > 2e-5).float().mean()
+        assert float(bad) <= 0.05, (k, float(bad))
+        moved = ((want[k] - before[k]).abs() > 1e-5).float().mean()
+        assert float(moved) > 0.5, (k, "fixture update unexpectedly empty")
+
+
+def test_adversarial_iteration_golden_gpu():
+    """G8 on the GPU: HIP generator + stock-op critic reproduce the reference's G and D iterations (losses, weights)."""
+    from _golden import load, sub, t
+    from spoofsv_amd import ops, train
+    from spoofsv_amd.critic import melDisc
+    from spoofsv_amd.tts import melSyn
+    g = load("adversarial_iter.npz")
+    hidden, temb, B, N, T = [int(v) for v in g["dims"]]
+    dev = "cuda:0"
+    m = melSyn(34, True, 200, textemb_dim=temb, freq_bins=80, hidden_dim=hidden)
+    m.load_state_dict(sub(g, "m0/"))
+    d = melDisc(80, 16)
+    d.load_state_dict(sub(g, "d0/"))
+    m, d = m.to(dev).train(), d.to(dev).eval()
+    mel, text, spk, gaw = t(g["mel_gt"], dev), t(g["text"], dev), t(g["spk"], dev), t(g["gaw"], dev)
+    opt = train.FusedAdam(m.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    pred, att = m(train.shift_right(mel), text, spk)
+    l1, bd = ops.spec_losses(pred, mel)
+    la = ops.guided_att_loss(att, gaw)
+    ld = torch.mean(-d(pred))
+    loss = l1 + bd + la + (float(l1) + float(bd) + float(la)) / abs(float(ld)) * ld
+    for mine, ref in ((l1, "g_l1"), (bd, "g_bd"), (la, "g_att"), (ld, "g_disc"), (loss, "g_all")):
+        assert abs(float(mine) - float(g[ref])) < 1e-5 * max(1.0, abs(float(g[ref]))), (ref, float(mine), float(g[ref]))
+    loss.backward()
+    opt.step()
+    m1 = sub(g, "m1/")
+    worst = max(float((m.state_dict()[k].cpu() - m1[k]).abs().max()) for k in m1)
+    assert worst < 5e-5, worst                       # one Adam step moves weights by ~2e-4
+    od = torch.optim.Adam(d.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    m.load_state_dict(m1)
+    with torch.no_grad():
+        pred, _ = m(train.shift_right(mel), text, spk)
+    coeff = t(g["coeff"], dev).view(-1, 1, 1)
+    mid = (coeff * mel + (1 - coeff) * pred).requires_grad_(True)
+    out = d(mid)
+    grads = torch.autograd.grad(out, mid, torch.ones_like(out), retain_graph=True, create_graph=True)[0]
+    gp = torch.mean(10 * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
+    gp.backward()
+    loss_d = torch.mean(d(pred) - d(mel))
+    loss_d.backward()
+    od.step()
+    assert abs(float(gp) - float(g["d_gp"])) < 1e-3 * max(1.0, abs(float(g["d_gp"])))
+    assert abs(float(loss_d) - float(g["d_loss"])) < 1e-4 * max(1.0, abs(float(g["d_loss"])))
+    d1 = sub(g, "d1/")
+    _critic_updates_agree({k: v.cpu() for k, v in d.state_dict().items()}, sub(g, "d0/"), d1)

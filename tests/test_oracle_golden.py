@@ -110,3 +110,60 @@ def test_ge2e_loss_and_known_answer():
     assert rel_err(GO.ge2e_cossim(t(g["kat_emb"])), t(g["kat_cossim"])) < 1e-6
     assert abs(float(kl) - 5.2501) < 1e-4 and abs(float(kl) - float(g["kat_loss"])) < 1e-5
     assert rel_err(kper, t(g["kat_per"])) < 1e-5
+
+# Biases that feed a LayerNorm have an exactly-zero true gradient; what autograd returns for them is rounding noise, and
+# Adam's first step turns noise into +-lr.  They are excluded; every other parameter's update must agree element-wise
+# (a handful of near-zero gradients may still flip sign, hence a 5 % allowance instead of a max-norm bound).
+_ZERO_GRAD = ("conv1.bias", "hc.conv.bias", "conv2.bias", "conv3.bias", "conv4.bias", "conv5.bias")
+
+
+def _critic_updates_agree(got, before, want):
+    for k in want:
+        if k in _ZERO_GRAD:
+            continue
+        bad = ((got[k] - want[k]).abs() > 2e-5).float().mean()
+        assert float(bad) <= 0.05, (k, float(bad))
+        moved = ((want[k] - before[k]).abs() > 1e-5).float().mean()
+        assert float(moved) > 0.5, (k, "fixture update unexpectedly empty")
+
+
+def test_adversarial_iteration_golden_cpu():
+    """G8: the oracle generator + this repo's critic (stock ops) reproduce the reference's G and D iterations."""
+    import torch.nn.functional as F
+    from spoofsv_amd.critic import melDisc
+    g = load("adversarial_iter.npz")
+    sd = {n: v.clone().requires_grad_(True) for n, v in sub(g, "m0/").items()}
+    d = melDisc(80, 16)
+    d.load_state_dict(sub(g, "d0/"))
+    d.eval()
+    mel, text, spk, gaw = t(g["mel_gt"]), t(g["text"]), t(g["spk"]), t(g["gaw"])
+    mel_in = torch.cat((torch.zeros_like(mel[:, :, :1]), mel[:, :, :-1]), dim=-1)
+    opt = torch.optim.Adam(list(sd.values()), 2e-4, (0.5, 0.9), 1e-6)
+    pred, att = TO.melsyn_train(mel_in, text, spk, sd)
+    l1, bd, la = TO.text2mel_losses(pred, att, mel, gaw)
+    ld = torch.mean(-d(pred))
+    loss = l1 + bd + la + (l1.item() + bd.item() + la.item()) / abs(ld.item()) * ld
+    for mine, ref in ((l1, "g_l1"), (bd, "g_bd"), (la, "g_att"), (ld, "g_disc"), (loss, "g_all")):
+        assert abs(float(mine) - float(g[ref])) < 2e-6 * max(1.0, abs(float(g[ref]))), ref
+    loss.backward()
+    opt.step()
+    m1 = sub(g, "m1/")
+    assert max(float((sd[k].detach() - m1[k]).abs().max()) for k in m1) < 1e-5      # 5 % of one Adam step (lr 2e-4)
+    # D iteration with the stored interpolation coefficients
+    od = torch.optim.Adam(d.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    sd1 = {k: v.clone() for k, v in m1.items()}
+    with torch.no_grad():
+        pred, _ = TO.melsyn_train(mel_in, text, spk, sd1)
+    coeff = t(g["coeff"]).view(-1, 1, 1)
+    mid = (coeff * mel + (1 - coeff) * pred).requires_grad_(True)
+    out = d(mid)
+    grads = torch.autograd.grad(out, mid, torch.ones_like(out), retain_graph=True, create_graph=True)[0]
+    gp = torch.mean(10 * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
+    gp.backward()
+    loss_d = torch.mean(d(pred) - d(mel))
+    loss_d.backward()
+    od.step()
+    assert abs(float(gp) - float(g["d_gp"])) < 1e-5 * max(1.0, abs(float(g["d_gp"])))
+    assert abs(float(loss_d) - float(g["d_loss"])) < 1e-6 * max(1.0, abs(float(g["d_loss"])))
+    d1 = sub(g, "d1/")
+    _critic_updates_agree(d.state_dict(), sub(g, "d0/"), d1)
