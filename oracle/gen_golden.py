@@ -328,6 +328,7 @@ def gen_adversarial(TTS, ref):
     gp.backward()
     loss_D = torch.mean(d(pred.detach()) - d(mel_gt.detach()))
     loss_D.backward()
+    out.update(_grads_np(d, "dgrad/"))          # critic gradients (gradient penalty + Wasserstein terms) before the step
     opt_disc.step()
     out.update(dict(coeff=_np(coeff_b), d_gp=_np(gp), d_loss=_np(loss_D)))
     out.update(_sd_np(d.state_dict(), "d1/"))

@@ -169,20 +169,18 @@ def test_adversarial_graph_step_matches_eager_generator_iteration():
     ld_, gp_ = stepper.d_step()
     assert float(ld_) == float(ld_) and float(gp_) == float(gp_)
 
-# Biases that feed a LayerNorm have an exactly-zero true gradient; what autograd returns for them is rounding noise, and
-# Adam's first step turns noise into +-lr.  They are excluded; every other parameter's update must agree element-wise
-# (a handful of near-zero gradients may still flip sign, hence a 5 % allowance instead of a max-norm bound).
+# Biases that feed a LayerNorm have an exactly-zero true gradient; what autograd returns for them is rounding noise.
+# They are excluded; every other critic gradient must agree in the relative L2 norm.  (Post-step WEIGHTS are not
+# compared for the critic: Adam's first step maps every gradient to +-lr, so near-zero entries flip on rounding noise.)
 _ZERO_GRAD = ("conv1.bias", "hc.conv.bias", "conv2.bias", "conv3.bias", "conv4.bias", "conv5.bias")
 
 
-def _critic_updates_agree(got, before, want):
-    for k in want:
+def _critic_grads_agree(module, want, tol):
+    for k, p in module.named_parameters():
         if k in _ZERO_GRAD:
             continue
-        bad = ((got[k] - want[k]).abs() > 2e-5).float().mean()
-        assert float(bad) <= 0.05, (k, float(bad))
-        moved = ((want[k] - before[k]).abs() > 1e-5).float().mean()
-        assert float(moved) > 0.5, (k, "fixture update unexpectedly empty")
+        a, b = p.grad.detach().cpu().double(), want[k].double()
+        assert float((a - b).norm() / b.norm()) < tol, (k, float((a - b).norm() / b.norm()))
 
 
 def test_adversarial_iteration_golden_gpu():
@@ -217,6 +215,7 @@ def test_adversarial_iteration_golden_gpu():
     m.load_state_dict(m1)
     with torch.no_grad():
         pred, _ = m(train.shift_right(mel), text, spk)
+    d.zero_grad()          # the G iteration left gradients on the critic; the reference zeroes both optimizers (:264-265)
     coeff = t(g["coeff"], dev).view(-1, 1, 1)
     mid = (coeff * mel + (1 - coeff) * pred).requires_grad_(True)
     out = d(mid)
@@ -225,8 +224,6 @@ def test_adversarial_iteration_golden_gpu():
     gp.backward()
     loss_d = torch.mean(d(pred) - d(mel))
     loss_d.backward()
-    od.step()
     assert abs(float(gp) - float(g["d_gp"])) < 1e-3 * max(1.0, abs(float(g["d_gp"])))
     assert abs(float(loss_d) - float(g["d_loss"])) < 1e-4 * max(1.0, abs(float(g["d_loss"])))
-    d1 = sub(g, "d1/")
-    _critic_updates_agree({k: v.cpu() for k, v in d.state_dict().items()}, sub(g, "d0/"), d1)
+    _critic_grads_agree(d, sub(g, "dgrad/"), 2e-3)
