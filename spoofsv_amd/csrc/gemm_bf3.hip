@@ -454,7 +454,12 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
       for (int c : nts) {
         const long tiles = (long)ssv_cdiv(g.M, 64 * a) * ssv_cdiv(g.N, 16 * c) * g.B;
         const double per_tile = (double)a * c + 0.9 * a + 0.25 * c + 1.0;
-        const double cost = (double)((tiles + 255) / 256) * per_tile;
+        // The most loaded CU runs n workgroups.  For kernel-size-1 products a K chunk carries a third of the MFMAs per
+        // staged byte, so co-resident workgroups are needed to cover each other's staging (measured: the LSTM step
+        // 3072 x 880 x 768 runs 2x faster on 672 small tiles than on 192 large ones); k=3 chunks are long enough.
+        const long n = (tiles + 255) / 256;
+        const double overlap = (KT == 1) ? (n >= 3 ? 1.8 : (n == 2 ? 1.5 : 1.0)) : 1.0;
+        const double cost = (double)n * per_tile / overlap;
         if (cost < best) { best = cost; wm = a; nt = c; }
       }
   }
