@@ -110,8 +110,9 @@ static int conv_nn(const float* x, long x_bs, const float* w, long w_sm, long w_
     const int Kpad = pad32(K);
     unsigned short* hi = (unsigned short*)ws;
     unsigned short* lo = (unsigned short*)((char*)ws + split_bytes(M, K, k));
-    SSV_TRY(ssv_launch_pack_split(w, hi, lo, M, K, Kpad, k, w_sm, w_sk, 1, st));
+    SSV_TRY(ssv_launch_pack_split(w, hi, lo, M, K, Kpad, k, w_sm, w_sk, 1, 0, st));
     GemmNNB g;
+    g.perm_h = 0; g.epi = 0; g.first = 0; g.cstate = nullptr;
     g.Ahi = hi; g.Alo = lo; g.Kpad = Kpad;
     g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
     g.C = y; g.scb = y_bs; g.scm = L;
@@ -416,21 +417,9 @@ static LstmWs lstm_ws(int Bn, int T, int F, int H) {
   return s;
 }
 // C = A X (+ bias + bias_b + R) with A (M x K) row-major weights and X, C as [rows][Bn] activations; "batch" of nb
-// independent problems strided by sxb / scb.  Split-bf16 when enabled (weights pre-split into `pk`), else fp32 MFMA.
-static int lstm_gemm(const float* A, const unsigned short* pk_hi, const unsigned short* pk_lo, bool bf3, const float* X, long sxb,
-                     float* C, long scb, const float* bias, const float* bias_b, const float* R, int M, int K, int Bn, int nb,
-                     hipStream_t st) {
-  if (bf3) {
-    GemmNNB g;
-    g.Ahi = pk_hi; g.Alo = pk_lo; g.Kpad = pad32(K);
-    g.X = X; g.sxb = sxb; g.sxc = Bn; g.Lx = Bn;
-    g.C = C; g.scb = scb; g.scm = Bn;
-    g.bias = bias; g.bias_b = bias_b; g.sbb = 0;
-    g.R = R; g.srb = 0; g.srm = Bn;
-    g.M = M; g.N = Bn; g.Kc = K; g.KT = 1; g.B = nb;
-    g.shift[0] = g.shift[1] = g.shift[2] = 0;
-    return ssv_launch_gemm_nn_bf3(g, st);
-  }
+// independent problems strided by sxb / scb.  fp32 MFMA path (the split-bf16 path is spelled out in ssv_lstm_fwd).
+static int lstm_gemm_f32(const float* A, const float* X, long sxb, float* C, long scb, const float* bias, const float* bias_b,
+                         const float* R, int M, int K, int Bn, int nb, hipStream_t st) {
   GemmNN g = nn_zero();
   g.A = A; g.sam = K; g.sac = 1; g.saj = 1;
   g.X = X; g.sxb = sxb; g.sxc = Bn; g.Lx = Bn;
@@ -457,28 +446,56 @@ extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const floa
   float* cbuf = (float*)(base + s.c);
   const bool bf3 = ssv_precision() == 1 && Bn >= 64 && H >= 32;
   SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));    // [T][F][Bn]
+  if (bf3) SSV_TRY(ssv_launch_fill(gbuf, 0.f, (long)H * Bn, st));
   const float* in = xt;
   int Fin = F;
   float* out = nullptr;
   for (int l = 0; l < layers; ++l) {
     out = seq[l & 1];
-    unsigned short* ih_hi = (unsigned short*)(base + s.wih);
-    unsigned short* ih_lo = (unsigned short*)(base + s.wih + split_bytes(4 * H, Fin, 1));
-    unsigned short* hh_hi = (unsigned short*)(base + s.whh);
-    unsigned short* hh_lo = (unsigned short*)(base + s.whh + split_bytes(4 * H, H, 1));
-    if (bf3) {   // the weights of a layer are used by T + 1 products: split them once
-      SSV_TRY(ssv_launch_pack_split(w_ih[l], ih_hi, ih_lo, 4 * H, Fin, pad32(Fin), 1, Fin, 1, 1, st));
-      SSV_TRY(ssv_launch_pack_split(w_hh[l], hh_hi, hh_lo, 4 * H, H, pad32(H), 1, H, 1, 1, st));
-    }
-    // input projection for every frame at once: xp[t] = W_ih in[t] + b_ih + b_hh    ("batch" = frame)
-    SSV_TRY(lstm_gemm(w_ih[l], ih_hi, ih_lo, bf3, in, (long)Fin * Bn, xp, (long)4 * H * Bn, b_ih[l], b_hh[l], nullptr, 4 * H, Fin, Bn, T, st));
-    for (int t = 0; t < T; ++t) {
-      const float* gates = xp + (long)t * 4 * H * Bn;
-      if (t > 0) {  // gates = W_hh h_{t-1} + xp[t]
-        SSV_TRY(lstm_gemm(w_hh[l], hh_hi, hh_lo, bf3, out + (long)(t - 1) * H * Bn, 0, gbuf, 0, nullptr, nullptr, gates, 4 * H, H, Bn, 1, st));
-        gates = gbuf;
+    if (!bf3) {
+      // input projection for every frame at once: xp[t] = W_ih in[t] + b_ih + b_hh    ("batch" = frame)
+      SSV_TRY(lstm_gemm_f32(w_ih[l], in, (long)Fin * Bn, xp, (long)4 * H * Bn, b_ih[l], b_hh[l], nullptr, 4 * H, Fin, Bn, T, st));
+      for (int t = 0; t < T; ++t) {
+        const float* gates = xp + (long)t * 4 * H * Bn;
+        if (t > 0) {  // gates = W_hh h_{t-1} + xp[t]
+          SSV_TRY(lstm_gemm_f32(w_hh[l], out + (long)(t - 1) * H * Bn, 0, gbuf, 0, nullptr, nullptr, gates, 4 * H, H, Bn, 1, st));
+          gates = gbuf;
+        }
+        SSV_TRY(ssv_launch_lstm_cell(gates, cbuf, out + (long)t * H * Bn, H, Bn, t == 0, st));
       }
-      SSV_TRY(ssv_launch_lstm_cell(gates, cbuf, out + (long)t * H * Bn, H, Bn, t == 0, st));
+    } else {
+      // Split-bf16 path.  The layer's weights are used by T + 1 products: split them once, with the 4H output rows
+      // re-ordered gate-interleaved (row 4u + gate) so that the recurrent product can finish the cell in its epilogue.
+      unsigned short* ih_hi = (unsigned short*)(base + s.wih);
+      unsigned short* ih_lo = (unsigned short*)(base + s.wih + split_bytes(4 * H, Fin, 1));
+      unsigned short* hh_hi = (unsigned short*)(base + s.whh);
+      unsigned short* hh_lo = (unsigned short*)(base + s.whh + split_bytes(4 * H, H, 1));
+      SSV_TRY(ssv_launch_pack_split(w_ih[l], ih_hi, ih_lo, 4 * H, Fin, pad32(Fin), 1, Fin, 1, 1, H, st));
+      SSV_TRY(ssv_launch_pack_split(w_hh[l], hh_hi, hh_lo, 4 * H, H, pad32(H), 1, H, 1, 1, H, st));
+      GemmNNB g;
+      g.X = in; g.sxb = (long)Fin * Bn; g.sxc = Bn; g.Lx = Bn;
+      g.bias_b = nullptr; g.sbb = 0; g.R = nullptr; g.srb = 0; g.srm = Bn;
+      g.M = 4 * H; g.N = Bn; g.KT = 1;
+      g.shift[0] = g.shift[1] = g.shift[2] = 0;
+      g.perm_h = H; g.first = 0; g.cstate = nullptr;
+      // input projection for every frame at once, biases left to the cell: xp[t] = W_ih in[t]  (gate-interleaved rows)
+      g.Ahi = ih_hi; g.Alo = ih_lo; g.Kpad = pad32(Fin); g.Kc = Fin;
+      g.C = xp; g.scb = (long)4 * H * Bn; g.scm = Bn; g.bias = nullptr; g.B = T; g.epi = 0;
+      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+      // recurrent product with the cell finished in its epilogue: h_t, c_t from W_hh h_{t-1} + xp[t] + b_ih + b_hh.
+      // t = 0 has no recurrent term; it runs the same kernel on an all-zero h_{-1} (gbuf, zeroed above; one product in T).
+      g.Ahi = hh_hi; g.Alo = hh_lo; g.Kpad = pad32(H); g.Kc = H;
+      g.sxb = 0; g.scb = 0; g.scm = Bn;
+      g.bias = b_ih[l]; g.bias_b = b_hh[l]; g.sbb = 0;
+      g.srb = 0; g.srm = Bn;
+      g.B = 1; g.epi = 1; g.cstate = cbuf;
+      for (int t = 0; t < T; ++t) {
+        g.X = (t > 0) ? out + (long)(t - 1) * H * Bn : gbuf;
+        g.C = out + (long)t * H * Bn;
+        g.R = xp + (long)t * 4 * H * Bn;
+        g.first = (t == 0);
+        SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+      }
     }
     in = out;
     Fin = H;

@@ -35,20 +35,21 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
 
 // ---- weight pre-split: out[j][m][k] (k padded to Kpad with zeros) from w[m*sm + k*sk + j*sj] ----------------------
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
-                                                         int M, int K, int Kpad, int KT, long sm, long sk, long sj) {
+                                                         int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long n = (long)KT * M * Kpad;
   if (i >= n) return;
   const int k = (int)(i % Kpad);
   const int m = (int)((i / Kpad) % M), j = (int)(i / ((long)Kpad * M));
-  const float v = k < K ? w[(long)m * sm + (long)k * sk + (long)j * sj] : 0.f;
+  const int ms = perm_h ? (m & 3) * perm_h + (m >> 2) : m;       // LSTM: gate-interleaved output rows
+  const float v = k < K ? w[(long)ms * sm + (long)k * sk + (long)j * sj] : 0.f;
   const __bf16 h = (__bf16)v;
   hi[i] = h;
   lo[i] = (__bf16)(v - (float)h);
 }
-int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, hipStream_t st) {
+int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st) {
   const long n = (long)KT * M * Kpad;
-  hipLaunchKernelGGL(pack_split_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, (__bf16*)hi, (__bf16*)lo, M, K, Kpad, KT, sm, sk, sj);
+  hipLaunchKernelGGL(pack_split_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, (__bf16*)hi, (__bf16*)lo, M, K, Kpad, KT, sm, sk, sj, perm_h);
   return ssv_check_launch("pack_split");
 }
 
@@ -57,7 +58,7 @@ int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int 
 // (L2-resident, pre-split, fragment-shaped 16-byte loads) into MFMA operand registers, one K chunk ahead (two register
 // sets, the chunk loop is unrolled by two).  Only the input tile, which all four waves share, is staged in LDS -- this
 // removes 2/3 of the LDS writes and 1/4 of the LDS reads of a version that staged both operands.
-template <int KT, int WM, int NT>
+template <int KT, int WM, int NT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int BM = 64 * WM, BN = 16 * NT;
   constexpr int HALO = (KT == 1) ? 0 : 54;
@@ -223,15 +224,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
 
   float* __restrict__ Cb = p.C + (long)b * p.scb;
   const float* __restrict__ Rb = p.R ? p.R + (long)b * p.srb : nullptr;
+  if constexpr (EPI == 1) {
+    // Fused LSTM cell (torch gate order i, f, g, o).  Rows were packed gate-interleaved, so the four accumulator rows a
+    // lane holds for a 16-row tile (rows kq*4 .. kq*4+3) are the four gates of ONE hidden unit at column nq.
+    const int H = p.perm_h;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int row0 = m0 + wave * WM * 16 + i * 16 + kq * 4;       // = 4 * unit
+      const int u = row0 >> 2;
+      if (u >= H) continue;
+      float add[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) add[r] = (p.bias ? p.bias[r * H + u] : 0.f) + (p.bias_b ? p.bias_b[r * H + u] : 0.f);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int gn = n0 + t * 16 + nq;
+        if (gn >= p.N) continue;
+        float gte[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gte[r] = acc[i][t][r] + add[r] + (Rb ? Rb[(long)(row0 + r) * p.srm + gn] : 0.f);
+        const float gi = 1.f / (1.f + expf(-gte[0])), gf = 1.f / (1.f + expf(-gte[1]));
+        const float gg = tanhf(gte[2]), go = 1.f / (1.f + expf(-gte[3]));
+        const long ci = (long)u * p.N + gn;
+        const float cn = (p.first ? 0.f : gf * p.cstate[ci]) + gi * gg;
+        p.cstate[ci] = cn;
+        Cb[(long)u * p.scm + gn] = go * tanhf(cn);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gm = m0 + wave * WM * 16 + i * 16 + kq * 4 + r;
       if (gm >= p.M) continue;
+      const int gb = p.perm_h ? (gm & 3) * p.perm_h + (gm >> 2) : gm;   // bias index in the caller's (torch) row order
       float add = 0.f;
-      if (p.bias) add += p.bias[gm];
-      if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gm];
+      if (p.bias) add += p.bias[gb];
+      if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gb];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int gn = n0 + t * 16 + nq;
@@ -423,7 +454,13 @@ static int launch_nnbw(const GemmNNB& g, hipStream_t st, int smin, int span) {
 template <int KT, int WM, int NT>
 static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT);
-  hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+  if constexpr (KT == 1) {
+    if (g.epi == 1) {
+      hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 1>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+      return ssv_check_launch("gemm_nn_bf3_lstm");
+    }
+  }
+  hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
   return ssv_check_launch("gemm_nn_bf3");
 }
 
@@ -439,7 +476,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
     }
     // measured (tools/sweep_nn_tiles.py): the wide workgroup wins for kernel-size-1 convolutions over long sequences
     // (SSRN's 513-channel layers: 150 -> 205 TFLOP/s); the k=3 layers are as fast or faster on the 4-wave kernel.
-    if (KT == 1 && !e && g.N >= 1024 && g.M >= 256 && g.Kc >= 256) return launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
+    if (KT == 1 && !e && !g.epi && !g.perm_h && g.N >= 1024 && g.M >= 256 && g.Kc >= 256) return launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
   }
   static const int nts[] = {7, 6, 4, 2};
   int wm = 2, nt = 7;
@@ -474,6 +511,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(g.M > 0 && g.N > 0 && g.Kc > 0 && g.B > 0 && g.Kpad % 32 == 0 && g.Kpad >= g.Kc, SSV_BAD_SHAPE, "gemm_nn_bf3: bad problem");
   SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nn_bf3: kernel_size %d", g.KT);
   SSV_CHECK(g.B <= 65535, SSV_UNSUPPORTED, "gemm_nn_bf3: batch %d exceeds grid.y", g.B);
+  SSV_CHECK(!g.epi || (g.KT == 1 && g.perm_h > 0 && g.M == 4 * g.perm_h && g.cstate && g.B == 1), SSV_BAD_SHAPE, "gemm_nn_bf3: bad LSTM epilogue request");
   int smin = g.shift[0], smax = g.shift[0];
   for (int j = 1; j < g.KT; ++j) { smin = g.shift[j] < smin ? g.shift[j] : smin; smax = g.shift[j] > smax ? g.shift[j] : smax; }
   const int span = smax - smin;

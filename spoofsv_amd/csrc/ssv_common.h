@@ -55,10 +55,16 @@ struct GemmNNB {
   const float* R; long srb, srm;
   int M, N, Kc, KT, B;
   int shift[3];
+  // LSTM support.  perm_h = H > 0: output row m is gate (m % 4) of hidden unit (m / 4), i.e. row (m % 4) * H + m / 4 of
+  // the torch layout -- the weights were packed in that order and the bias vectors are indexed through the same map.
+  // epi = 1: fused cell epilogue -- the 4 accumulator rows of a lane are the (i, f, g, o) pre-activations of one unit;
+  // the kernel adds R (the input projection) and the biases, updates cstate [H][N] in place and writes h to C [H][N].
+  int perm_h, epi, first;
+  float* cstate;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
-int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, hipStream_t st);
+int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st);
 int ssv_nt_bf3_channels_per_tile(int KT, int Nc);
 int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA (default)
 
