@@ -99,7 +99,7 @@ static GemmNT nt_zero() {
 
 // ---- Conv1d ----------------------------------------------------------------------------------------
 static inline int pad32(int n) { return (n + 31) & ~31; }
-static inline size_t split_bytes(int rows, int K, int k) { return align256((size_t)k * rows * pad32(K) * sizeof(unsigned short)); }
+static inline size_t split_bytes(int rows, int K, int k) { return align256((size_t)k * ((rows + 15) / 16 * 16) * pad32(K) * sizeof(unsigned short)); }
 static inline bool use_bf3(int B, int L, int Cin, int Cout) { return ssv_precision() == 1 && (long)B * L >= 128 && Cin >= 8 && Cout >= 16; }
 
 // y = conv(x, w): shared by forward (rows = Cout) and data gradient (rows = Cin, transposed weights, negated shifts)

@@ -33,22 +33,30 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
   lo = __builtin_bit_cast(uint4, l);
 }
 
-// ---- weight pre-split: out[j][m][k] (k padded to Kpad with zeros) from w[m*sm + k*sk + j*sj] ----------------------
+// ---- weight pre-split ---------------------------------------------------------------------------------------------
+// Source w[m*sm + k*sk + j*sj] (M x K per tap j).  Output: bf16 hi / lo planes in MFMA FRAGMENT ORDER,
+//   [tap j][row block mb = m/16][chunk ch = k/32][k-group kg = (k/8)%4][row m%16][8 x bf16],
+// rows padded to a multiple of 16 and k to Kpad (zeros).  One (mb, ch) block is 1 KB and is exactly what a wave's
+// 64 lanes load as one A fragment (lane = kg*16 + m%16, 16 bytes each): the load covers 8 whole cache lines.  With the
+// plain [row][k] order the same fragment touched 16 lines and used half of each, doubling L2->L1 traffic for weights.
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
                                                          int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long n = (long)KT * M * Kpad;
+  const int MB = (M + 15) >> 4, NCH = Kpad >> 5;
+  const long n = (long)KT * MB * NCH * 512;
   if (i >= n) return;
-  const int k = (int)(i % Kpad);
-  const int m = (int)((i / Kpad) % M), j = (int)(i / ((long)Kpad * M));
+  const int e = (int)(i & 7), r16 = (int)((i >> 3) & 15), kg = (int)((i >> 7) & 3);
+  const long blk = i >> 9;
+  const int ch = (int)(blk % NCH), mb = (int)((blk / NCH) % MB), j = (int)(blk / ((long)NCH * MB));
+  const int m = mb * 16 + r16, k = ch * 32 + kg * 8 + e;
   const int ms = perm_h ? (m & 3) * perm_h + (m >> 2) : m;       // LSTM: gate-interleaved output rows
-  const float v = k < K ? w[(long)ms * sm + (long)k * sk + (long)j * sj] : 0.f;
+  const float v = (m < M && k < K) ? w[(long)ms * sm + (long)k * sk + (long)j * sj] : 0.f;
   const __bf16 h = (__bf16)v;
   hi[i] = h;
   lo[i] = (__bf16)(v - (float)h);
 }
 int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st) {
-  const long n = (long)KT * M * Kpad;
+  const long n = (long)KT * ((M + 15) / 16 * 16) * Kpad;
   hipLaunchKernelGGL(pack_split_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, (__bf16*)hi, (__bf16*)lo, M, K, Kpad, KT, sm, sk, sj, perm_h);
   return ssv_check_launch("pack_split");
 }
@@ -89,20 +97,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   uint4 Ah_[NSET][KT][WM], Al_[NSET][KT][WM];
   float rx[NX][8];
 
-  // this lane's weight-fragment rows: row = m0 + wave*WM*16 + i*16 + (lane & 15), k = chunk*32 + 8*(lane >> 4) .. +7
+  // this lane's weight fragments: row block (m0 + wave*WM*16 + i*16) / 16, 16 bytes at lane*16 of each 1 KB (mb, chunk) block
+  const int MB = (p.M + 15) >> 4;
   long arow[WM];
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
-    const int gm = m0 + wave * WM * 16 + i * 16 + nq;
-    arow[i] = (long)(gm < p.M ? gm : 0) * p.Kpad + 8 * kq;
+    const int mb = (m0 + wave * WM * 16 + i * 16) >> 4;
+    arow[i] = (long)min(mb, MB - 1) * nchunks * 512 + lane * 8;     // blocks past M re-read the last one: never stored
   }
-  const long aplane = (long)p.M * p.Kpad;
+  const long aplane = (long)MB * nchunks * 512;
 
   auto loadA = [&](int set, int j, int ch) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-      // rows past M read row 0 (always legal): they only feed accumulator rows that the epilogue never stores
-      const long off = j * aplane + arow[i] + ch * 32;
+      const long off = j * aplane + arow[i] + ch * 512;
       Ah_[set][j][i] = *reinterpret_cast<const uint4*>(p.Ahi + off);
       Al_[set][j][i] = *reinterpret_cast<const uint4*>(p.Alo + off);
     }
@@ -313,16 +321,18 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
   uint4 rah[NA], ral[NA];
   float rx[NX][8];
 
-  // weight staging: slot f -> (tap j, row m, k-group kg), kg fastest so 4 lanes read 64 contiguous bytes of one row
+  // weight staging: slot f -> (tap j, row block, k-group kg, row%16) in the packed fragment order, so a wave reads 1 KB
+  // of contiguous global memory per load
+  const int MB = (p.M + 15) >> 4;
   auto a_off = [&](int r) -> long {
     const int f = min(tid + T * r, A_SLOTS - 1);
-    const int kg = f & 3, m = (f >> 2) % BM, j = f / (4 * BM);
-    return ((long)j * p.M + min(m0 + m, p.M - 1)) * p.Kpad + 8 * kg;      // rows past M read row M-1: never stored
+    const int r16 = f & 15, kg = (f >> 4) & 3, mbl = (f >> 6) % (BM / 16), j = f / (4 * BM);
+    return (((long)j * MB + min((m0 >> 4) + mbl, MB - 1)) * nchunks) * 512 + (kg * 16 + r16) * 8;
   };
   auto a_slot = [&](int r) -> int {
     const int f = min(tid + T * r, A_SLOTS - 1);
-    const int kg = f & 3, m = (f >> 2) % BM, j = f / (4 * BM);
-    return (j * 4 + kg) * BM + m;
+    const int r16 = f & 15, kg = (f >> 4) & 3, mbl = (f >> 6) % (BM / 16), j = f / (4 * BM);
+    return (j * 4 + kg) * BM + mbl * 16 + r16;
   };
   const int Lrow = (int)p.sxc;
   unsigned voff[NX];
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
   auto prefetch = [&](int ch) {
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
-      const long o = a_off(r) + ch * 32;
+      const long o = a_off(r) + ch * 512;
       rah[r] = *reinterpret_cast<const uint4*>(p.Ahi + o);
       ral[r] = *reinterpret_cast<const uint4*>(p.Alo + o);
     }

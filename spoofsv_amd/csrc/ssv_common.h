@@ -47,7 +47,7 @@ int ssv_launch_gemm_nt(const GemmNT& g, hipStream_t st);
 
 // ---- split-bf16 variants (gemm_bf3.hip): same contracts, unit column strides, weights pre-split --------------
 struct GemmNNB {
-  const unsigned short* Ahi; const unsigned short* Alo; int Kpad;   // [KT][M][Kpad] bf16 planes (hi, lo)
+  const unsigned short* Ahi; const unsigned short* Alo; int Kpad;   // bf16 planes (hi, lo) in fragment order, see pack_split_kernel
   const float* X; long sxb, sxc; int Lx;
   float* C; long scb, scm;
   const float* bias;
