@@ -37,6 +37,19 @@ __device__ __forceinline__ float col_sum(float v) {
   return v;
 }
 
+
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private L2.  A
+// column tile is only 16 floats = 64 B of every channel row, so with the natural order the two tiles that share each
+// 128-byte line (and the tiles that share a DRAM page) always land on different XCDs.  Re-number so that every XCD
+// walks one contiguous range of tiles: co-running workgroups of an XCD then touch adjacent 64-byte pieces of the same rows.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
+  const unsigned gx = gridDim.x, total = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+  const unsigned xcd = lin & 7, idx = lin >> 3, q = total >> 3, r = total & 7;
+  const unsigned nl = xcd * q + (xcd < r ? xcd : r) + idx;
+  bx = (int)(nl % gx);
+  by = (int)(nl / gx);
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int CPT>
 __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(
@@ -45,7 +58,9 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(
     float* __restrict__ Y, long y_bs, float* __restrict__ stats, int C, int L) {
   __shared__ float red[256];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int t = blockIdx.x * 16 + col, b = blockIdx.y;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
   const float* Hb = H + (long)b * h_bs + t;
   float h1[CPT], h2[CPT];
@@ -98,7 +113,9 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
     float* __restrict__ dH, float* __restrict__ dXres, long dx_bs, float* __restrict__ part, int C, int L) {
   __shared__ float red[256];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int t = blockIdx.x * 16 + col, b = blockIdx.y;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
   const long hb = (long)b * 2 * C * L + t;
   float mu1 = 0.f, r1 = 0.f, mu2 = 0.f, r2 = 0.f;
@@ -107,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
     mu1 = sb[0]; r1 = sb[L]; mu2 = sb[2L * L]; r2 = sb[3L * L];
   }
   float xh1[CPT], xh2[CPT], a1[CPT], a2[CPT];
-  float* pblk = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 6 * C;
+  float* pblk = part + ((long)by * gridDim.x + bx) * 6 * C;
   float sa1 = 0.f, sah1 = 0.f, sa2 = 0.f, sah2 = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
@@ -156,7 +173,9 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(
     float* __restrict__ Y, long y_bs, float* __restrict__ stats, int C, int L, int act) {
   __shared__ float red[256];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int t = blockIdx.x * 16 + col, b = blockIdx.y;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
   const float* Xb = X + (long)b * x_bs + t;
   float x[CPT];
@@ -199,12 +218,14 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(
     float* __restrict__ dX, long dx_bs, float* __restrict__ part, int C, int L, int act) {
   __shared__ float red[256];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int t = blockIdx.x * 16 + col, b = blockIdx.y;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
   float mu = 0.f, r = 0.f;
   if (tv) { mu = stats[(long)b * 2 * L + t]; r = stats[(long)b * 2 * L + L + t]; }
   float xh[CPT], a[CPT];
-  float* pblk = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 3 * C;
+  float* pblk = part + ((long)by * gridDim.x + bx) * 3 * C;
   float sa = 0.f, sah = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
