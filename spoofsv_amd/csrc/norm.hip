@@ -28,14 +28,9 @@ __device__ __forceinline__ float group_sum(float v, float* red, int col, int g) 
   return s;
 }
 
-// Sum over the 16 columns (16 consecutive lanes share one channel group).
-__device__ __forceinline__ float col_sum(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
-  return v;
-}
+// Sum over the 16 columns (16 consecutive lanes share one channel group = one DPP row): VALU only, no LDS traffic
+// (the backward kernels make 3 of these per element).
+__device__ __forceinline__ float col_sum(float v) { return ssv_row16_sum(v); }
 
 
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private L2.  A

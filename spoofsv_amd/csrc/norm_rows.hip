@@ -26,9 +26,7 @@ template <int NQ>
 __device__ __forceinline__ void row_reduce(const float (&v)[NQ], float* rowred, int r) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    float s = v[q];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float s = ssv_wave_sum(v[q]);
     if ((threadIdx.x & 63) == 0) rowred[(r * NQ + q) * 4 + (threadIdx.x >> 6)] = s;
   }
 }

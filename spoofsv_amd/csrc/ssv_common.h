@@ -74,3 +74,24 @@ int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hip
 int ssv_launch_fill(float* p, float v, long n, hipStream_t st);
 
 static inline int ssv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- cross-lane sums on the VALU (DPP) ---------------------------------------------------
+// hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS-pipe instruction); inside a DPP row of 16 lanes the same
+// butterfly is four v_add_f32_dpp.  Pairing (hence rounding) is that of a xor-butterfly over 1, 2, 4, 8.
+template <int CTRL>
+__device__ __forceinline__ float ssv_dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float ssv_row16_sum(float v) {   // every lane gets the sum over its aligned group of 16 lanes
+  v += ssv_dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += ssv_dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += ssv_dpp_mov<0x141>(v);    // row_half_mirror: the other quad of this half row
+  v += ssv_dpp_mov<0x140>(v);    // row_mirror: the other half row
+  return v;
+}
+__device__ __forceinline__ float ssv_wave_sum(float v) {    // every lane gets the sum over the 64 lanes
+  v = ssv_row16_sum(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
