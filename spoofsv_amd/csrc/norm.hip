@@ -57,15 +57,18 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(
   xcd_tile(bx, by);
   const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
-  const float* Hb = H + (long)b * h_bs + t;
+  // addressing: wave-uniform 64-bit bases + one 32-bit per-thread offset (c = g, column t), stepped by 16 rows
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = 16u * (unsigned)L;
+  const float* __restrict__ Hb1 = H + (long)b * h_bs;
+  const float* __restrict__ Hb2 = Hb1 + (long)C * L;
   float h1[CPT], h2[CPT];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = g + 16 * i;
     const bool v = tv && c < C;
-    h1[i] = v ? Hb[(long)c * L] : 0.f;
-    h2[i] = v ? Hb[(long)(C + c) * L] : 0.f;
+    h1[i] = v ? Hb1[o0 + i * ostep] : 0.f;
+    h2[i] = v ? Hb2[o0 + i * ostep] : 0.f;
     s1 += h1[i]; s2 += h2[i];
   }
   const float inv = 1.f / (float)C;
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(
     float* sb = stats + (long)b * 4 * L + t;
     sb[0] = mu1; sb[L] = r1; sb[2L * L] = mu2; sb[3L * L] = r2;
   }
-  const float* Xb = X + (long)b * x_bs + t;
-  float* Yb = Y + (long)b * y_bs + t;
+  const float* __restrict__ Xb = X + (long)b * x_bs;
+  float* __restrict__ Yb = Y + (long)b * y_bs;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = g + 16 * i;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(
       const float n1 = (h1[i] - mu1) * r1 * g1[c] + b1[c];
       const float n2 = (h2[i] - mu2) * r2 * g2[c] + b2[c];
       const float s = sigmoidf_(n1);
-      Yb[(long)c * L] = s * n2 + (1.f - s) * Xb[(long)c * L];
+      Yb[o0 + i * ostep] = s * n2 + (1.f - s) * Xb[o0 + i * ostep];
     }
   }
 }
@@ -112,7 +115,14 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
   xcd_tile(bx, by);
   const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
-  const long hb = (long)b * 2 * C * L + t;
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = 16u * (unsigned)L;
+  const float* __restrict__ Hb1 = H + (long)b * 2 * C * L;
+  const float* __restrict__ Hb2 = Hb1 + (long)C * L;
+  float* __restrict__ dHb1 = dH + (long)b * 2 * C * L;
+  float* __restrict__ dHb2 = dHb1 + (long)C * L;
+  const float* __restrict__ dYb = dY + (long)b * dy_bs;
+  const float* __restrict__ Xb = X + (long)b * x_bs;
+  float* __restrict__ dXb = dXres + (long)b * dx_bs;
   float mu1 = 0.f, r1 = 0.f, mu2 = 0.f, r2 = 0.f;
   if (tv) {
     const float* sb = stats + (long)b * 4 * L + t;
@@ -128,17 +138,17 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
     float dn1 = 0.f, dn2 = 0.f, gg1 = 0.f, gg2 = 0.f;
     xh1[i] = 0.f; xh2[i] = 0.f;
     if (v) {
-      const float dy = dY[(long)b * dy_bs + (long)c * L + t];
-      const float x = X[(long)b * x_bs + (long)c * L + t];
+      const float dy = dYb[o0 + i * ostep];
+      const float x = Xb[o0 + i * ostep];
       gg1 = g1[c]; gg2 = g2[c];
-      xh1[i] = (H[hb + (long)c * L] - mu1) * r1;
-      xh2[i] = (H[hb + (long)(C + c) * L] - mu2) * r2;
+      xh1[i] = (Hb1[o0 + i * ostep] - mu1) * r1;
+      xh2[i] = (Hb2[o0 + i * ostep] - mu2) * r2;
       const float n1 = xh1[i] * gg1 + b1[c];
       const float n2 = xh2[i] * gg2 + b2[c];
       const float s = sigmoidf_(n1);
       dn2 = dy * s;
       dn1 = dy * (n2 - x) * s * (1.f - s);
-      dXres[(long)b * dx_bs + (long)c * L + t] = dy * (1.f - s);
+      dXb[o0 + i * ostep] = dy * (1.f - s);
     }
     // per-channel parameter-gradient partials over this block's 16 columns
     const float p0 = col_sum(dn1 * xh1[i]), p1 = col_sum(dn1), p2 = col_sum(dn2 * xh2[i]), p3 = col_sum(dn2);
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
     const bool v = tv && c < C;
     const float d1 = v ? r1 * (a1[i] - m1 - xh1[i] * mh1) : 0.f;
     const float d2 = v ? r2 * (a2[i] - m2 - xh2[i] * mh2) : 0.f;
-    if (v) { dH[hb + (long)c * L] = d1; dH[hb + (long)(C + c) * L] = d2; }
+    if (v) { dHb1[o0 + i * ostep] = d1; dHb2[o0 + i * ostep] = d2; }
     const float q0 = col_sum(d1), q1 = col_sum(d2);
     if (col == 0 && c < C) { pblk[4 * C + c] = q0; pblk[5 * C + c] = q1; }
   }
@@ -172,13 +182,14 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(
   xcd_tile(bx, by);
   const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
-  const float* Xb = X + (long)b * x_bs + t;
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = 16u * (unsigned)L;
+  const float* __restrict__ Xb = X + (long)b * x_bs;
   float x[CPT];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = g + 16 * i;
-    x[i] = (tv && c < C) ? Xb[(long)c * L] : 0.f;
+    x[i] = (tv && c < C) ? Xb[o0 + i * ostep] : 0.f;
     s += x[i];
   }
   const float inv = 1.f / (float)C;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(
   const float r = rsqrtf(group_sum(q, red, col, g) * inv + LN_EPS);
   if (!tv) return;
   if (g == 0 && stats) { stats[(long)b * 2 * L + t] = mu; stats[(long)b * 2 * L + L + t] = r; }
-  float* Yb = Y + (long)b * y_bs + t;
+  float* __restrict__ Yb = Y + (long)b * y_bs;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = g + 16 * i;
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(
       float n = (x[i] - mu) * r * gam[c] + bet[c];
       if (act == 1) n = fmaxf(n, 0.f);
       else if (act == 2) n = sigmoidf_(n);
-      Yb[(long)c * L] = n;
+      Yb[o0 + i * ostep] = n;
     }
   }
 }
@@ -219,6 +230,10 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(
   const bool tv = t < L;
   float mu = 0.f, r = 0.f;
   if (tv) { mu = stats[(long)b * 2 * L + t]; r = stats[(long)b * 2 * L + L + t]; }
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = 16u * (unsigned)L;
+  const float* __restrict__ dYb = dY + (long)b * dy_bs;
+  const float* __restrict__ Xb = X + (long)b * x_bs;
+  float* __restrict__ dXb = dX + (long)b * dx_bs;
   float xh[CPT], a[CPT];
   float* pblk = part + ((long)by * gridDim.x + bx) * 3 * C;
   float sa = 0.f, sah = 0.f;
@@ -229,9 +244,9 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(
     float dn = 0.f, gg = 0.f;
     xh[i] = 0.f;
     if (v) {
-      const float dy = dY[(long)b * dy_bs + (long)c * L + t];
+      const float dy = dYb[o0 + i * ostep];
       gg = gam[c];
-      xh[i] = (X[(long)b * x_bs + (long)c * L + t] - mu) * r;
+      xh[i] = (Xb[o0 + i * ostep] - mu) * r;
       const float n = xh[i] * gg + bet[c];
       if (act == 1) dn = n > 0.f ? dy : 0.f;
       else if (act == 2) { const float s = sigmoidf_(n); dn = dy * s * (1.f - s); }
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(
     const int c = g + 16 * i;
     const bool v = tv && c < C;
     const float d = v ? r * (a[i] - m - xh[i] * mh) : 0.f;
-    if (v) dX[(long)b * dx_bs + (long)c * L + t] = d;
+    if (v) dXb[o0 + i * ostep] = d;
     const float q0 = col_sum(d);
     if (col == 0 && c < C) pblk[2 * C + c] = q0;
   }
@@ -294,9 +309,10 @@ static int reduce_partials(float* part, float* out, int n, int nblk, hipStream_t
 #define LN_DISPATCH(C, CALL)                                            \
   do {                                                                  \
     const int _cpt = ((C) + 15) / 16;                                   \
+    if ((long)(2 * (C) + 32) * (long)L >= (1L << 31)) return ssv_fail(SSV_UNSUPPORTED, "LayerNorm: one batch item exceeds 2^31 elements"); \
     if (_cpt <= 2) { CALL(2); } else if (_cpt <= 4) { CALL(4); }        \
     else if (_cpt <= 8) { CALL(8); } else if (_cpt <= 16) { CALL(16); } \
-    else if (_cpt <= 33) { CALL(33); } else if (_cpt <= 64) { CALL(64); } \
+    else if (_cpt <= 32) { CALL(32); } else if (_cpt <= 33) { CALL(33); } else if (_cpt <= 64) { CALL(64); } \
     else return ssv_fail(SSV_UNSUPPORTED, "LayerNorm over %d channels not supported (max 1024)", (C)); \
   } while (0)
 
