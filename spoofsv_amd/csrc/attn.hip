@@ -40,11 +40,96 @@ __global__ __launch_bounds__(256) void softmax_cols_bwd_kernel(const float* __re
   }
 }
 
+// Tiled versions for N <= 256 text positions (the configured maximum is 186): a workgroup owns 32 columns of one batch
+// item, its 8 row groups hold rows rg, rg+8, ... in registers, and the column max / sums are combined through LDS in a fixed
+// order.  B*ceil(T/32) workgroups instead of B*T/256, one read and one write per element.
+template <int NR>
+__global__ __launch_bounds__(256) void softmax_cols_tile_kernel(float* __restrict__ s, int N, int T) {
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + col, b = blockIdx.y;
+  const bool tv = t < T;
+  float* __restrict__ p = s + (long)b * N * T;
+  const unsigned o0 = (unsigned)rg * T + t, ostep = 8u * T;
+  float v[NR];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    v[i] = (tv && rg + 8 * i < N) ? p[o0 + i * ostep] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  red[rg][col] = mx;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) mx = fmaxf(mx, red[r][col]);
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    v[i] = (tv && rg + 8 * i < N) ? expf(v[i] - mx) : 0.f;
+    sum += v[i];
+  }
+  red[rg][col] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) tot += red[r][col];
+  const float inv = 1.f / tot;
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+    if (tv && rg + 8 * i < N) p[o0 + i * ostep] = v[i] * inv;
+}
+template <int NR>
+__global__ __launch_bounds__(256) void softmax_cols_bwd_tile_kernel(const float* __restrict__ a, float* __restrict__ da,
+                                                                    const float* __restrict__ da_ext, float scale, int N, int T) {
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + col, b = blockIdx.y;
+  const bool tv = t < T;
+  const long base = (long)b * N * T;
+  const float* __restrict__ ab = a + base;
+  float* __restrict__ db = da + base;
+  const float* __restrict__ eb = da_ext ? da_ext + base : nullptr;
+  const unsigned o0 = (unsigned)rg * T + t, ostep = 8u * T;
+  float av[NR], g[NR];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const bool v = tv && rg + 8 * i < N;
+    av[i] = v ? ab[o0 + i * ostep] : 0.f;
+    g[i] = v ? db[o0 + i * ostep] : 0.f;
+    if (eb && v) g[i] += eb[o0 + i * ostep];
+    dot += av[i] * g[i];
+  }
+  red[rg][col] = dot;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) tot += red[r][col];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+    if (tv && rg + 8 * i < N) db[o0 + i * ostep] = av[i] * (g[i] - tot) * scale;
+}
+
 int ssv_launch_softmax_cols(float* s, int B, int N, int T, hipStream_t st) {
+  if (N <= 256 && B <= 65535 && (long)N * T < (1L << 31)) {
+    dim3 grid(ssv_cdiv(T, 32), B);
+    if (N <= 64) hipLaunchKernelGGL(softmax_cols_tile_kernel<8>, grid, dim3(256), 0, st, s, N, T);
+    else if (N <= 192) hipLaunchKernelGGL(softmax_cols_tile_kernel<24>, grid, dim3(256), 0, st, s, N, T);
+    else hipLaunchKernelGGL(softmax_cols_tile_kernel<32>, grid, dim3(256), 0, st, s, N, T);
+    return ssv_check_launch("softmax_cols_tile");
+  }
   hipLaunchKernelGGL(softmax_cols_kernel, dim3(ssv_cdiv((long)B * T, 256)), dim3(256), 0, st, s, B, N, T);
   return ssv_check_launch("softmax_cols");
 }
 int ssv_launch_softmax_cols_bwd(const float* a, float* da, const float* da_ext, float scale, int B, int N, int T, hipStream_t st) {
+  if (N <= 256 && B <= 65535 && (long)N * T < (1L << 31)) {
+    dim3 grid(ssv_cdiv(T, 32), B);
+    if (N <= 64) hipLaunchKernelGGL(softmax_cols_bwd_tile_kernel<8>, grid, dim3(256), 0, st, a, da, da_ext, scale, N, T);
+    else if (N <= 192) hipLaunchKernelGGL(softmax_cols_bwd_tile_kernel<24>, grid, dim3(256), 0, st, a, da, da_ext, scale, N, T);
+    else hipLaunchKernelGGL(softmax_cols_bwd_tile_kernel<32>, grid, dim3(256), 0, st, a, da, da_ext, scale, N, T);
+    return ssv_check_launch("softmax_cols_bwd_tile");
+  }
   hipLaunchKernelGGL(softmax_cols_bwd_kernel, dim3(ssv_cdiv((long)B * T, 256)), dim3(256), 0, st, a, da, da_ext, scale, B, N, T);
   return ssv_check_launch("softmax_cols_bwd");
 }

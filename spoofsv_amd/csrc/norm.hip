@@ -295,7 +295,35 @@ __global__ __launch_bounds__(256) void reduce_partials_l2_kernel(const float* __
   for (; k < rows; ++k) s0 += part[(long)k * n + i];
   out[i] = (s0 + s1) + (s2 + s3);
 }
+// One launch for moderate block counts: a workgroup owns 32 outputs; its 8 row groups each fold rows rg, rg+8, ... and
+// the eight sums are combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void reduce_partials_1_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int nblk) {
+  __shared__ float red[8][32];
+  const int li = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + li;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int k = rg;
+    for (; k + 24 < nblk; k += 32) {
+      s0 += part[(long)k * n + i]; s1 += part[(long)(k + 8) * n + i];
+      s2 += part[(long)(k + 16) * n + i]; s3 += part[(long)(k + 24) * n + i];
+    }
+    for (; k < nblk; k += 8) s0 += part[(long)k * n + i];
+  }
+  red[rg][li] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][li];
+    out[i] = t;
+  }
+}
 static int reduce_partials(float* part, float* out, int n, int nblk, hipStream_t st) {
+  if (nblk <= 768) {
+    hipLaunchKernelGGL(reduce_partials_1_kernel, dim3(ssv_cdiv(n, 32)), dim3(256), 0, st, (const float*)part, out, n, nblk);
+    return ssv_check_launch("reduce_partials_1");
+  }
   const int rows = nblk < RED_ROWS ? nblk : RED_ROWS;
   if (nblk > RED_ROWS) {
     hipLaunchKernelGGL(reduce_partials_l1_kernel, dim3(ssv_cdiv(n, 256), RED_ROWS), dim3(256), 0, st, part, n, nblk);
