@@ -12,7 +12,7 @@ import re
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "ssv_hip.h")
-LIBPATH = os.path.join(_PKG, "libssv_hip.so")
+LIBPATH = os.environ.get("SSV_HIP_LIB") or os.path.join(_PKG, "libssv_hip.so")   # override: tuning builds only
 
 
 class AdamChunk(ctypes.Structure):

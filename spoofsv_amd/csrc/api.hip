@@ -168,10 +168,12 @@ extern "C" int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, 
                  use_bf3(B, L, Cout, Cin), ws, (hipStream_t)stream);
 }
 
+// Number of batch slabs the weight gradient is split into: enough workgroups to fill the chip (2 per CU), no more --
+// every slab is an extra copy of the output written and read back.  SSV_NT_Z forces a count (tuning aid).
 static int dw_splits(int B, int M, int Nc, int k) {
-  const int nch = ssv_nt_bf3_channels_per_tile(k, Nc);
-  const int tiles = ssv_cdiv(M, 128) * ssv_cdiv(Nc, nch);
+  const int tiles = ssv_nt_bf3_tiles(k == 3 ? 3 : 1, M, Nc);
   int z = ssv_cdiv(512, tiles);
+  if (const char* e = getenv("SSV_NT_Z")) { const int v = atoi(e); if (v > 0) z = v; }
   if (z > B) z = B;
   if (z < 1) z = 1;
   return z;
@@ -191,11 +193,12 @@ extern "C" int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* x
   const long n = (long)Cout * Cin * k;
   g.A = dy; g.sab = dy_bs; g.sam = L; g.La = L;
   g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
-  g.C = (Z == 1) ? dw : (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = k; g.scj = 1;
+  if (Z == 1) { g.C = dw; g.scz = n; g.scm = (long)Cin * k; g.scc = k; g.scj = 1; }
+  else { g.C = (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = 1; g.scj = Cin; }     // slabs [z][m][j][c]
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
-  if (ssv_precision() == 1 && (long)B * L >= 256) SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
+  if (ssv_precision() == 1 && (long)B * L >= 256 && ssv_nt_bf3_fits(g)) SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
   else SSV_TRY(ssv_launch_gemm_nt(g, st));
-  if (Z > 1) SSV_TRY(ssv_launch_reduce_slabs((const float*)ws, dw, n, Z, n, st));
+  if (Z > 1) SSV_TRY(ssv_launch_reduce_slabs_perm((const float*)ws, dw, Cout, Cin, k, Z, st));
   return 0;
 }
 

@@ -15,8 +15,12 @@
 //   gemm_nt_bf3: Conv1d weight gradient.  The reduction runs over time, so a dilation shift would be a misaligned
 //     shift along k; instead each tap gets its own staged copy of the input rows at its exact shift.
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 #include "ssv_common.h"
+#ifndef SSV_ABL
+#define SSV_ABL 0      // tuning builds only: 1 = weight-gradient kernel without its MFMAs
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned 16-byte load
@@ -78,7 +82,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   uint4* Xl = lds + X_SLOTS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mt = blockIdx.x % mtiles, ntile = blockIdx.x / mtiles, b = blockIdx.y;
+  const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);   // see ssv_xcd_order
+  const int bxx = (int)(wg % gridDim.x), b = (int)(wg / gridDim.x);
+  const int mt = bxx % mtiles, ntile = bxx / mtiles;
   const int m0 = mt * BM, n0 = ntile * BN;
   const float* __restrict__ Xb = p.X + (long)b * p.sxb;
   const int W = BN + span;
@@ -305,7 +311,9 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
-  const int mt = blockIdx.x % mtiles, ntile = blockIdx.x / mtiles, b = blockIdx.y;
+  const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);   // see ssv_xcd_order
+  const int bxx = (int)(wg % gridDim.x), b = (int)(wg / gridDim.x);
+  const int mt = bxx % mtiles, ntile = bxx / mtiles;
   const int m0 = mt * BM, n0 = ntile * BN;
   const float* __restrict__ Xb = p.X + (long)b * p.sxb;
   const int W = BN + span;
@@ -531,21 +539,32 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
 
 // ---- NT (weight gradient) -------------------------------------------------------------------------------------------------
 //   C(z,m,c,j) = sum_{b = z, z+bstep, ..} sum_t A(b,m,t) * X(b,c,t+shift[j]);  rows contiguous in t for both operands.
-// As in the NN kernel the waves split M, so the A rows (dL/dH) of a wave are private to it: its fragments are loaded
-// from global memory straight into registers (8 consecutive time steps per lane = two 16-byte loads), split there, and
-// never touch LDS.  The input rows X are shared by the four waves and staged in LDS, one exact-shift copy per tap.
+// The reduction runs over time, so a tap's dilation shift is a misaligned shift along k: every tap needs its own staged
+// copy of the input rows.  The kernel therefore steps over (batch item, 64-step chunk, tap), tap fastest:
+//   * the waves split M, so a wave's A rows (dL/dH) are private: its fragments go global -> registers (two 16-byte loads
+//     per 8 time steps), are split there once per chunk and reused by the KT taps -- A never touches LDS;
+//   * per step only ONE tap's input tile (16*NTC channels x 64 steps) is split and staged, into one of two LDS buffers:
+//     the step's MFMAs read buffer s while the next step's tile is written to buffer s^1 -- one barrier per step, and
+//     16 staging registers instead of 48 (staging all taps at once put the 128 x 64 x 3 tile at 256 VGPRs with spills,
+//     and every scratch reload waits for vmcnt(0), i.e. for the whole prefetch in flight).
+// Loads are issued raw, one step (input) or one chunk (A) ahead, with no branch in the prefetch (see load8/fix8).
 template <int KT, int WM, int NTC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
   constexpr int KB = 64, KG = KB / 8, KS = KB / 32;         // time steps per chunk, k-groups, MFMA k-steps
   constexpr int NCH = 16 * NTC;
-  constexpr int X_SLOTS = KT * KG * NCH;
-  constexpr int NX = (X_SLOTS + 255) / 256;
-  __shared__ uint4 lds[2 * X_SLOTS];
-  uint4* Xh = lds;
-  uint4* Xl = lds + X_SLOTS;
+  constexpr int X_SLOTS = KG * NCH;                         // 16-byte slots of one tap's tile (multiple of 256)
+  constexpr int NX = X_SLOTS / 256;
+  static_assert(X_SLOTS % 256 == 0, "tile slots must be a multiple of the workgroup size");
+  // [buffer][hi plane | lo plane], slot = kg*NCH + (channel ^ kg).  The staging threads take kg fastest (8 lanes = 256
+  // contiguous bytes of one channel row in global memory), so without the XOR the 8 lanes of a ds_write_b128 group would
+  // write slots 1 KB apart -- one bank set, an 8-way conflict that cost more than the step's MFMAs.  With it they land on
+  // 8 distinct 16-byte bank groups, and the fragment reads (16 consecutive channels per quarter wave) stay conflict-free.
+  __shared__ uint4 lds[2][2 * X_SLOTS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mt = blockIdx.x % mtiles, ct = blockIdx.x / mtiles, z = blockIdx.z;
+  const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);   // a slab's tiles share an XCD
+  const int bxx = (int)(wg % gridDim.x), z = (int)(wg / gridDim.x);
+  const int mt = bxx % mtiles, ct = bxx / mtiles;
   const int m0 = mt * 64 * WM, c0 = ct * NCH;
   const int tchunks = (p.La + KB - 1) / KB;
   const int kq = lane >> 4, nq = lane & 15;
@@ -558,92 +577,208 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
       for (int q = 0; q < NTC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float ra[WM][KS][8], rx[NX][8];
+  float ra[WM][KS][8], rx[2][NX][8];   // rx: two sets, the tile of step s travels in set s & 1
+  int ma[WM][KS], mx[2][NX];           // edge windows only: validity bits (low 8) | offset clamp distance << 8
+  uint4 ah[WM][KS], al[WM][KS];
 
-  // 8 consecutive time steps of one row, zero outside [0, len)
-  auto load8 = [&](const float* __restrict__ row, int t, int len, float (&v)[8]) {
-    if (t >= 0 && t + 8 <= len) {
-      const f4u a = *reinterpret_cast<const f4u*>(row + t);
-      const f4u c = *reinterpret_cast<const f4u*>(row + t + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+  // A window = 8 consecutive time steps of one row, at any alignment.  Element offsets are 32-bit (the launcher checks
+  // that both tensors span < 2^30 elements): a per-thread row offset, fixed for the whole kernel, plus a wave-uniform
+  // (batch item, chunk, tap) offset.  Two kinds of chunk / step, told apart by a wave-uniform test:
+  //   interior -- every window of the tile lies inside its row: plain loads, plain split; nothing else on the VALU;
+  //   edge     -- a window may start before 0 or run past the row (first/last chunk, ragged tile): it is still loaded RAW
+  //     by two 16-byte loads at its true offset (an edge window simply runs into the neighbouring row) and the validity
+  //     bits are applied when the values are split, a step later.  Masking at load time makes hipcc branch around each
+  //     load and wait for it.  Only a window that would leave the TENSOR (head of its first row, tail of its last) has
+  //     its offset clamped; the clamp distance travels with the mask and the split shifts the values back into place.
+  const int a_span = (int)((long)(p.B - 1) * p.sab + (long)(p.M - 1) * p.sam + p.La) - 8;     // last legal window start
+  const int x_span = (int)((long)(p.B - 1) * p.sxb + (long)(p.Nc - 1) * p.sxc + p.Lx) - 8;
+  int arow[WM], xrow[NX];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) arow[i] = min(m0 + wave * WM * 16 + i * 16 + nq, p.M - 1) * (int)p.sam + 8 * kq;
+#pragma unroll
+  for (int r = 0; r < NX; ++r) {
+    const int f = tid + 256 * r;
+    xrow[r] = min(c0 + f / KG, p.Nc - 1) * (int)p.sxc + 8 * (f % KG);
+  }
+  const bool rows_in_m = m0 + 64 * WM <= p.M, rows_in_c = c0 + NCH <= p.Nc;
+
+  auto load8 = [&](const float* __restrict__ base, int off, float (&v)[8]) {
+    const f4u a = *reinterpret_cast<const f4u*>(base + (unsigned)off);
+    const f4u c = *reinterpret_cast<const f4u*>(base + (unsigned)off + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+  };
+  auto load8_edge = [&](const float* __restrict__ base, int off, int span, int t, int len, bool row_ok, float (&v)[8]) -> int {
+    const int oc = min(max(off, 0), span);
+    load8(base, oc, v);
+    const int sl = min(max(-t, 0), 8), sh = min(max(t + 8 - len, 0), 8);
+    const int m = row_ok ? (int)((0xFFu << sl) & (0xFFu >> sh) & 0xFFu) : 0;
+    return m | ((off - oc) << 8);
+  };
+  auto split_edge = [&](const float (&raw)[8], int meta, uint4& h, uint4& l) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = raw[i];
+    const int d = meta >> 8;
+    // wave-uniform test: a scalar branch hipcc cannot turn into straight-line selects (128 VALU instructions per window)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(d != 0) != 0ull, 0)) {   // v[i] must be the element at offset oc + (i + d)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r = (i + d == k) ? raw[k] : r;
+        v[i] = r;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = ((meta >> i) & 1) ? v[i] : 0.f;
+    split8(v, h, l);
+  };
+
+  // chunk cursors (wave-uniform): batch item and first time step of chunks n .. n+3
+  const int nb = (p.B - z + p.bstep - 1) / p.bstep;
+  const int total = nb * tchunks;                                           // chunks this workgroup reduces over
+  int cb[4], ct0[4];
+  cb[0] = z; ct0[0] = 0;
+  auto next_chunk = [&](int b, int t0, int& nb_, int& nt0) __attribute__((always_inline)) {
+    nt0 = t0 + KB; nb_ = b;
+    if (nt0 >= tchunks * KB) { nt0 = 0; nb_ = b + p.bstep; }
+  };
+#pragma unroll
+  for (int k = 1; k < 4; ++k) next_chunk(cb[k - 1], ct0[k - 1], cb[k], ct0[k]);
+  auto a_edge = [&](int t0) __attribute__((always_inline)) -> bool { return !(rows_in_m && t0 + KB <= p.La); };
+  auto x_edge = [&](int t0, int j) __attribute__((always_inline)) -> bool { return !(rows_in_c && t0 + p.shift[j] >= 0 && t0 + KB + p.shift[j] <= p.Lx); };
+
+  auto loadA = [&](int b, int t0) __attribute__((always_inline)) {                                         // -> ra (/ ma)
+    const int base = b * (int)p.sab + t0;
+    if (!a_edge(t0)) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) load8(p.A, base + arow[i] + s2 * 32, ra[i][s2]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int tt = t + i; v[i] = (tt >= 0 && tt < len) ? row[tt] : 0.f; }
+      for (int i = 0; i < WM; ++i) {
+        const bool ok = m0 + wave * WM * 16 + i * 16 + nq < p.M;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2)
+          ma[i][s2] = load8_edge(p.A, base + arow[i] + s2 * 32, a_span, t0 + s2 * 32 + 8 * kq, p.La, ok, ra[i][s2]);
+      }
     }
   };
-  auto prefetch = [&](int b, int tc) {
-    const float* __restrict__ Ab = p.A + (long)b * p.sab;
-    const float* __restrict__ Xb = p.X + (long)b * p.sxb;
-    const int t0 = tc * KB;
+  auto splitA = [&](int t0) __attribute__((always_inline)) {
+    if (!a_edge(t0)) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      const int gm = m0 + wave * WM * 16 + i * 16 + nq;
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) split8(ra[i][s2], ah[i][s2], al[i][s2]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) split_edge(ra[i][s2], ma[i][s2], ah[i][s2], al[i][s2]);
+    }
+  };
+  auto loadX = [&](auto set, int b, int t0, int j) __attribute__((always_inline)) {                        // -> rx[set] (/ mx[set])
+    constexpr int S = decltype(set)::value;
+    const int base = b * (int)p.sxb + t0 + p.shift[j];
+    if (!x_edge(t0, j)) {
+#pragma unroll
+      for (int r = 0; r < NX; ++r) load8(p.X, base + xrow[r], rx[S][r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < NX; ++r) {
+        const int f = tid + 256 * r;
+        mx[S][r] = load8_edge(p.X, base + xrow[r], x_span, t0 + p.shift[j] + 8 * (f % KG), p.Lx, c0 + f / KG < p.Nc, rx[S][r]);
+      }
+    }
+  };
+  auto commitX = [&](auto set, int t0, int j) __attribute__((always_inline)) {                             // rx[set] -> LDS buffer `set`
+    constexpr int S = decltype(set)::value;
+    uint4* Xh = lds[S];
+    uint4* Xl = lds[S] + X_SLOTS;
+    const bool edge = x_edge(t0, j);
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+      const int f = tid + 256 * r;
+      const int kg = f % KG, c = f / KG;
+      uint4 h, l;
+      if (!edge) split8(rx[S][r], h, l);
+      else split_edge(rx[S][r], mx[S][r], h, l);
+      Xh[kg * NCH + (c ^ kg)] = h; Xl[kg * NCH + (c ^ kg)] = l;          // XOR swizzle, see the slot comment above
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  const int steps = total * KT;
+
+  // One chunk = KT steps (tap fastest); step s = n*KT + j uses LDS buffer and staging set s & 1.  In step s:
+  //   MFMAs of step s on buffer s&1  |  tile s+1 (loaded two steps ago) is split into buffer (s+1)&1  |  the loads of
+  //   tile s+3 are issued into the set just freed  ->  a tile's loads have two steps (~100 MFMAs per wave) to land.
+  auto chunk = [&](auto par, int n) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par)::value;                               // parity of this chunk's first step
+    const bool more = n + 1 < total;
+    if (more) loadA(cb[1], ct0[1]);                                         // lands during this chunk's KT steps
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const int q_ = (PAR + j) & 1;
+      const uint4* Xh = lds[q_];
+      const uint4* Xl = lds[q_] + X_SLOTS;
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) {
-        if (gm < p.M) load8(Ab + (long)gm * p.sam, t0 + s2 * 32 + 8 * kq, p.La, ra[i][s2]);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ra[i][s2][e] = 0.f;
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < NX; ++r) {
-      const int f = tid + 256 * r;
-      const int kg = f % KG, c = (f / KG) % NCH, j = f / (KG * NCH);
-      const int gc = c0 + c;
-      if (f < X_SLOTS && gc < p.Nc) load8(Xb + (long)gc * p.sxc, t0 + 8 * kg + p.shift[j < KT ? j : 0], p.Lx, rx[r]);
-      else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rx[r][i] = 0.f;
-      }
-    }
-  };
-  auto commitX = [&]() {
-#pragma unroll
-    for (int r = 0; r < NX; ++r) {
-      const int f = tid + 256 * r;
-      if (f < X_SLOTS) {
-        const int kg = f % KG, c = (f / KG) % NCH, j = f / (KG * NCH);
-        uint4 h, l;
-        split8(rx[r], h, l);
-        Xh[(j * KG + kg) * NCH + c] = h; Xl[(j * KG + kg) * NCH + c] = l;
-      }
-    }
-  };
-
-  const int nb = (p.B - z + p.bstep - 1) / p.bstep;
-  const int total = nb * tchunks;
-  if (total > 0) prefetch(z, 0);
-  for (int it = 0; it < total; ++it) {
-    __syncthreads();
-    commitX();
-    __syncthreads();
-    uint4 ah[WM][KS], al[WM][KS];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) split8(ra[i][s2], ah[i][s2], al[i][s2]);
-    if (it + 1 < total) { const int nx = it + 1; prefetch(z + (nx / tchunks) * p.bstep, nx % tchunks); }
-#pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-      const int kg = s2 * 4 + kq;
-#pragma unroll
-      for (int j = 0; j < KT; ++j)
+        const int kg = s2 * 4 + kq;
 #pragma unroll
         for (int q = 0; q < NTC; ++q) {
-          const int xs = (j * KG + kg) * NCH + q * 16 + nq;
+          const int xs = kg * NCH + ((q * 16 + nq) ^ kg);
           const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
           const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
 #pragma unroll
           for (int i = 0; i < WM; ++i) {
             const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[i][s2]);
             const bf16x8 a_l = __builtin_bit_cast(bf16x8, al[i][s2]);
+#if SSV_ABL == 1
+            acc[i][j][q][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a_l).x ^ __builtin_bit_cast(uint4, bh).x ^ __builtin_bit_cast(uint4, a_h).y ^ __builtin_bit_cast(uint4, bl).y);
+#else
             acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, bh, acc[i][j][q], 0, 0, 0);
             acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, bl, acc[i][j][q], 0, 0, 0);
             acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, bh, acc[i][j][q], 0, 0, 0);
+#endif
           }
         }
+      }
+      const int c1 = (j + 1) / KT, j1 = (j + 1) % KT;                       // step s+1: chunk n + c1, tap j1
+      const int c3 = (j + 3) / KT, j3 = (j + 3) % KT;                       // step s+3
+      const int s = n * KT + j;
+      if (((PAR + j) & 1) == 0) {
+        if (s + 1 < steps) commitX(P1{}, ct0[c1], j1);
+        if (s + 3 < steps) loadX(P1{}, cb[c3], ct0[c3], j3);
+      } else {
+        if (s + 1 < steps) commitX(P0{}, ct0[c1], j1);
+        if (s + 3 < steps) loadX(P0{}, cb[c3], ct0[c3], j3);
+      }
+      if (j == KT - 1 && more) splitA(ct0[1]);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { cb[k] = cb[k + 1]; ct0[k] = ct0[k + 1]; }
+    next_chunk(cb[2], ct0[2], cb[3], ct0[3]);
+  };
+
+  if (total > 0) {
+    // prologue: A of chunk 0 split, tile 0 staged, tiles 1 and 2 in flight
+    loadA(cb[0], ct0[0]);
+    loadX(P0{}, cb[0], ct0[0], 0);
+    if (steps > 1) loadX(P1{}, cb[1 / KT], ct0[1 / KT], 1 % KT);
+    splitA(ct0[0]);
+    commitX(P0{}, ct0[0], 0);
+    if (steps > 2) loadX(P0{}, cb[2 / KT], ct0[2 / KT], 2 % KT);
+    __syncthreads();
+    if constexpr ((KT & 1) == 0) {
+      for (int n = 0; n < total; ++n) chunk(P0{}, n);
+    } else {
+      for (int n = 0; n < total; n += 2) {
+        chunk(P0{}, n);
+        if (n + 1 < total) chunk(P1{}, n + 1);
+      }
     }
   }
 
@@ -664,23 +799,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
 }
 
-static int nt_ntc3() { const char* e = getenv("SSV_NT_NTC"); return (e && atoi(e) == 2) ? 2 : 4; }
-int ssv_nt_bf3_channels_per_tile(int KT, int Nc) { return (KT == 3) ? 16 * nt_ntc3() : (Nc > 48 ? 96 : 32); }
+// Tile plan for the weight gradient.  The output (M x Nc x KT) is small, so the reduction axis (batch x time) is cut into
+// Z slabs that are summed afterwards; slab traffic (Z x output, written and read back) competes with the operand reads,
+// so smaller tiles with fewer slabs win when the output is small.  SSV_NT_PLAN="wm,ntc" forces a tile (tuning aid).
+void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
+  int a = 0, c = 0;
+  if (const char* e = getenv("SSV_NT_PLAN")) {
+    if (sscanf(e, "%d,%d", &a, &c) == 2 && (a == 1 || a == 2) && (c == 2 || c == 4 || c == 6)) {
+      if (KT == 3 && c == 6) c = 4;
+      *wm = a; *ntc = c;
+      return;
+    }
+  }
+  if (KT == 3) { *wm = 2; *ntc = 4; }
+  else { *wm = 2; *ntc = (Nc > 48) ? 6 : 2; }
+}
+int ssv_nt_bf3_tiles(int KT, int M, int Nc) {
+  int wm, ntc;
+  ssv_nt_bf3_tile(KT, M, Nc, &wm, &ntc);
+  return ssv_cdiv(M, 64 * wm) * ssv_cdiv(Nc, 16 * ntc);
+}
 
+// the kernel addresses both operands with 32-bit element offsets
+bool ssv_nt_bf3_fits(const GemmNT& g) {
+  const long lim = 1L << 30;
+  return (long)(g.B - 1) * g.sab + (long)(g.M - 1) * g.sam + g.La < lim && (long)(g.B - 1) * g.sxb + (long)(g.Nc - 1) * g.sxc + g.Lx < lim &&
+         (long)g.B * g.sab < lim && (long)g.B * g.sxb < lim && g.La >= 8 && g.Lx >= 8;
+}
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
   SSV_CHECK(g.M > 0 && g.Nc > 0 && g.La > 0 && g.B > 0 && g.Z > 0 && g.bstep > 0, SSV_BAD_SHAPE, "gemm_nt_bf3: empty problem");
   SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nt_bf3: kernel_size %d", g.KT);
   SSV_CHECK(g.sat == 1 && g.sxn == 1, SSV_UNSUPPORTED, "gemm_nt_bf3: rows must be contiguous in time");
   SSV_CHECK(g.Z <= 65535, SSV_UNSUPPORTED, "gemm_nt_bf3: Z=%d exceeds grid.z", g.Z);
-  const int mtiles = ssv_cdiv(g.M, 128);
-  if (g.KT == 3 && nt_ntc3() == 4) {
-    hipLaunchKernelGGL((gemm_nt_bf3_kernel<3, 2, 4>), dim3(mtiles * ssv_cdiv(g.Nc, 64), 1, g.Z), dim3(256), 0, st, g, mtiles);
-  } else if (g.KT == 3) {
-    hipLaunchKernelGGL((gemm_nt_bf3_kernel<3, 2, 2>), dim3(mtiles * ssv_cdiv(g.Nc, 32), 1, g.Z), dim3(256), 0, st, g, mtiles);
-  } else if (g.Nc > 48) {
-    hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 6>), dim3(mtiles * ssv_cdiv(g.Nc, 96), 1, g.Z), dim3(256), 0, st, g, mtiles);
-  } else {
-    hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 2>), dim3(mtiles * ssv_cdiv(g.Nc, 32), 1, g.Z), dim3(256), 0, st, g, mtiles);
-  }
-  return ssv_check_launch("gemm_nt_bf3");
+  SSV_CHECK(ssv_nt_bf3_fits(g), SSV_UNSUPPORTED, "gemm_nt_bf3: an operand spans 2^30 elements or more");
+  int wm, ntc;
+  ssv_nt_bf3_tile(g.KT, g.M, g.Nc, &wm, &ntc);
+  const int mtiles = ssv_cdiv(g.M, 64 * wm);
+  const dim3 grid(mtiles * ssv_cdiv(g.Nc, 16 * ntc), 1, g.Z);
+#define SSV_NT(K_, A_, C_) if (g.KT == K_ && wm == A_ && ntc == C_) { hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_>), grid, dim3(256), 0, st, g, mtiles); return ssv_check_launch("gemm_nt_bf3"); }
+  SSV_NT(3, 2, 4) SSV_NT(3, 2, 2) SSV_NT(3, 1, 4) SSV_NT(3, 1, 2)
+  SSV_NT(1, 2, 6) SSV_NT(1, 2, 4) SSV_NT(1, 2, 2) SSV_NT(1, 1, 6) SSV_NT(1, 1, 4) SSV_NT(1, 1, 2)
+#undef SSV_NT
+  return ssv_fail(SSV_UNSUPPORTED, "gemm_nt_bf3: no tile %d,%d for kernel size %d", wm, ntc, g.KT);
 }

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256, (WM == 1 ? 3 : 2)) void gemm_nn_kernel(const G
   float* Xs = lds + BM * AS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mt = blockIdx.x % mtiles, ntile = blockIdx.x / mtiles, b = blockIdx.y;
+  const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);   // see ssv_xcd_order
+  const int bxx = (int)(wg % gridDim.x), b = (int)(wg / gridDim.x);
+  const int mt = bxx % mtiles, ntile = bxx / mtiles;
   const int m0 = mt * BM, n0 = ntile * BN;
   const float* __restrict__ Ab = p.A + (long)b * p.sab;
   const float* __restrict__ Xb = p.X + (long)b * p.sxb;

@@ -27,7 +27,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p, const i
   float* Xs = lds + BM * AS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mt = blockIdx.x % mtiles, ct = blockIdx.x / mtiles, z = blockIdx.z;
+  const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);   // a slab's tiles share an XCD
+  const int bxx = (int)(wg % gridDim.x), z = (int)(wg / gridDim.x);
+  const int mt = bxx % mtiles, ct = bxx / mtiles;
   const int m0 = mt * BM, c0 = ct * NCH;
   const int W = KB + span;
   const int tchunks = (p.La + KB - 1) / KB;

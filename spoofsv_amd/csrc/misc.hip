@@ -16,6 +16,27 @@ int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long 
   return ssv_check_launch("reduce_slabs");
 }
 
+// Slabs stored [z][m][j][c] (channels contiguous: the weight-gradient kernel's lanes write 64-byte runs), output in the
+// weight layout out[m][c][j] = sum_z slab[z][m][j][c].  Threads walk the slab order, so the Z large reads are coalesced.
+__global__ __launch_bounds__(256) void reduce_slabs_perm_kernel(const float* __restrict__ s, float* __restrict__ out, int Nc, int KT, long n, int Z) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a0 = 0.f, a1 = 0.f;
+  int z = 0;
+  for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + i]; a1 += s[(long)(z + 1) * n + i]; }
+  if (z < Z) a0 += s[(long)z * n + i];
+  const int c = (int)(i % Nc);
+  const long mj = i / Nc;
+  const int j = (int)(mj % KT);
+  const long m = mj / KT;
+  out[(m * Nc + c) * KT + j] = a0 + a1;
+}
+int ssv_launch_reduce_slabs_perm(const float* slabs, float* out, int M, int Nc, int KT, int Z, hipStream_t st) {
+  const long n = (long)M * Nc * KT;
+  hipLaunchKernelGGL(reduce_slabs_perm_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, slabs, out, Nc, KT, n, Z);
+  return ssv_check_launch("reduce_slabs_perm");
+}
+
 // ---- wt[c][o][j] = w[o][c][j]: weights for the data gradient ---------------------------------------
 __global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int KT) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index into wt

@@ -64,16 +64,28 @@ struct GemmNNB {
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
+bool ssv_nt_bf3_fits(const GemmNT& g);          // operands addressable with the kernel's 32-bit element offsets
 int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st);
-int ssv_nt_bf3_channels_per_tile(int KT, int Nc);
+int ssv_nt_bf3_tiles(int KT, int M, int Nc);   // output tiles of the weight-gradient kernel for this problem
 int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA (default)
 
 // ---- small helpers (misc.hip) ---------------------------------------------------------
 int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long slab_stride, hipStream_t st);
+int ssv_launch_reduce_slabs_perm(const float* slabs, float* out, int M, int Nc, int KT, int Z, hipStream_t st);
 int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hipStream_t st);
 int ssv_launch_fill(float* p, float v, long n, hipStream_t st);
 
 static inline int ssv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- XCD-aware workgroup order ----------------------------------------------------------------
+// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8, x fastest), each with a private 4 MB L2.  In launch
+// order, the workgroups that share an operand tile (the M tiles of one column tile, the tiles of one batch slab) are
+// neighbours, i.e. they land on 8 different XCDs and each L2 fetches that tile from HBM again.  Re-numbered so that
+// XCD k walks the contiguous range [k*total/8, (k+1)*total/8), neighbours in the problem are neighbours in one L2.
+__device__ __forceinline__ unsigned ssv_xcd_order(unsigned lin, unsigned total) {
+  const unsigned xcd = lin & 7u, idx = lin >> 3, q = total >> 3, r = total & 7u;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+}
 
 // ---- cross-lane sums on the VALU (DPP) ---------------------------------------------------
 // hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS-pipe instruction); inside a DPP row of 16 lanes the same
