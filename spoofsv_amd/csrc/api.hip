@@ -172,7 +172,7 @@ extern "C" int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, 
 // every slab is an extra copy of the output written and read back.  SSV_NT_Z forces a count (tuning aid).
 static int dw_splits(int B, int M, int Nc, int k) {
   const int tiles = ssv_nt_bf3_tiles(k == 3 ? 3 : 1, M, Nc);
-  int z = ssv_cdiv(512, tiles);
+  int z = ssv_cdiv(ssv_nt_bf3_target(k == 3 ? 3 : 1, M, Nc), tiles);
   if (const char* e = getenv("SSV_NT_Z")) { const int v = atoi(e); if (v > 0) z = v; }
   if (z > B) z = B;
   if (z < 1) z = 1;

@@ -811,8 +811,18 @@ void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
       return;
     }
   }
+  // measured (tools/sweep_nt.py): k=3 -- the largest tile wins at every hot shape; k=1 carries a third of the MFMAs per
+  // staged byte, so only large outputs (513 x 513) keep the 128 x 96 tile, smaller ones take 64 x 64 tiles with fewer slabs
   if (KT == 3) { *wm = 2; *ntc = 4; }
-  else { *wm = 2; *ntc = (Nc > 48) ? 6 : 2; }
+  else if (Nc <= 48) { *wm = 2; *ntc = 2; }
+  else if ((long)M * Nc >= (1L << 18)) { *wm = 2; *ntc = 6; }
+  else { *wm = 1; *ntc = 4; }
+}
+// workgroups to aim for when choosing the number of batch slabs
+int ssv_nt_bf3_target(int KT, int M, int Nc) {
+  int wm, ntc;
+  ssv_nt_bf3_tile(KT, M, Nc, &wm, &ntc);
+  return (KT == 1 && wm == 2 && ntc == 6) ? 1024 : 512;
 }
 int ssv_nt_bf3_tiles(int KT, int M, int Nc) {
   int wm, ntc;

@@ -66,7 +66,8 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
 bool ssv_nt_bf3_fits(const GemmNT& g);          // operands addressable with the kernel's 32-bit element offsets
 int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st);
-int ssv_nt_bf3_tiles(int KT, int M, int Nc);   // output tiles of the weight-gradient kernel for this problem
+int ssv_nt_bf3_tiles(int KT, int M, int Nc);
+int ssv_nt_bf3_target(int KT, int M, int Nc);  // workgroups to aim for when choosing the slab count   // output tiles of the weight-gradient kernel for this problem
 int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA (default)
 
 // ---- small helpers (misc.hip) ---------------------------------------------------------
