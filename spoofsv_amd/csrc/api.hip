@@ -56,15 +56,6 @@ int ssv_launch_l2norm_rows(const float*, float*, int, int, hipStream_t);
 
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-// row-chunk LayerNorm path for large tensors (norm_rows.hip)
-bool ssv_lnr_use(int B, int C, int L);       // backward
-bool ssv_lnr_use_fwd(int B, int C, int L);   // forward
-size_t ssv_lnr_fwd_ws(int B, int C, int L, int nln);
-size_t ssv_lnr_bwd_ws(int B, int C, int L, int nq);
-int ssv_lnr_gate_fwd(const float*, long, const float*, long, const float*, const float*, const float*, const float*, float*, long, float*, void*, int, int, int, hipStream_t);
-int ssv_lnr_act_fwd(const float*, long, const float*, const float*, float*, long, float*, void*, int, int, int, int, hipStream_t);
-int ssv_lnr_gate_bwd(const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*, const float*, float*, float*, long, void*, float*, int, int, int, hipStream_t);
-int ssv_lnr_act_bwd(const float*, long, const float*, long, const float*, const float*, const float*, float*, long, void*, float*, int, int, int, int, hipStream_t);
 static inline size_t zmax(size_t a, size_t b) { return a > b ? a : b; }
 
 static int conv_shifts(int k, int dilation, int causal, int* shift) {
@@ -203,55 +194,46 @@ extern "C" int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* x
 }
 
 // ---- LayerNorm over channels ------------------------------------------------------------------------
-extern "C" size_t ssv_channel_ln_act_fwd_workspace(int B, int C, int L) { return ssv_lnr_use_fwd(B, C, L) ? ssv_lnr_fwd_ws(B, C, L, 1) : 256; }
+extern "C" size_t ssv_channel_ln_act_fwd_workspace(int B, int C, int L) { (void)B; (void)C; (void)L; return 256; }   // none needed; kept in the ABI
 extern "C" int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const float* beta, float* y, long y_bs, float* stats,
                                       int B, int C, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && gamma && beta && y && B > 0 && C > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "channel_ln_act_fwd: bad argument");
   SSV_CHECK(B <= 65535, SSV_UNSUPPORTED, "channel_ln_act_fwd: batch %d exceeds grid.y", B);
-  if (ssv_lnr_use_fwd(B, C, L)) {
-    SSV_CHECK(ws && ws_bytes >= ssv_lnr_fwd_ws(B, C, L, 1), SSV_BAD_SHAPE, "channel_ln_act_fwd: workspace too small");
-    return ssv_lnr_act_fwd(x, x_bs, gamma, beta, y, y_bs, stats, ws, B, C, L, act, (hipStream_t)stream);
-  }
+  (void)ws; (void)ws_bytes;
   return ssv_launch_ln_act_fwd(x, x_bs, gamma, beta, y, y_bs, stats, B, C, L, act, (hipStream_t)stream);
 }
 extern "C" size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L) {
-  return zmax(align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * C * sizeof(float)), ssv_lnr_use(B, C, L) ? ssv_lnr_bwd_ws(B, C, L, 2) : 0);
+  return align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * C * sizeof(float));
 }
 extern "C" int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* stats, const float* gamma, const float* beta,
                                       float* dx, long dx_bs, float* pgrads, int B, int C, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dy && x && stats && gamma && beta && dx && pgrads && B > 0 && C > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "channel_ln_act_bwd: bad argument");
   SSV_CHECK(ws && ws_bytes >= ssv_channel_ln_act_bwd_workspace(B, C, L), SSV_BAD_SHAPE, "channel_ln_act_bwd: workspace too small");
-  if (ssv_lnr_use(B, C, L)) return ssv_lnr_act_bwd(dy, dy_bs, x, x_bs, stats, gamma, beta, dx, dx_bs, ws, pgrads, B, C, L, act, (hipStream_t)stream);
   return ssv_launch_ln_act_bwd(dy, dy_bs, x, x_bs, stats, gamma, beta, dx, dx_bs, (float*)ws, pgrads, B, C, L, act, (hipStream_t)stream);
 }
 
 // ---- highwayConv ---------------------------------------------------------------------------------------
 extern "C" size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k) {
-  return ssv_conv1d_fwd_workspace(C, 2 * C, k) + (ssv_lnr_use_fwd(B, C, L) ? ssv_lnr_fwd_ws(B, C, L, 2) : 0);
+  (void)B; (void)L;
+  return ssv_conv1d_fwd_workspace(C, 2 * C, k);
 }
 extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* g1, const float* b1,
                                       const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
                                       int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w && g1 && b1 && g2 && b2 && h && y, SSV_BAD_SHAPE, "highway_conv1d_fwd: null argument");
   SSV_TRY(ssv_conv1d_fwd(x, x_bs, w, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
-  if (ssv_lnr_use_fwd(B, C, L)) {
-    const size_t cw = ssv_conv1d_fwd_workspace(C, 2 * C, k);
-    SSV_CHECK(ws && ws_bytes >= cw + ssv_lnr_fwd_ws(B, C, L, 2), SSV_BAD_SHAPE, "highway_conv1d_fwd: workspace too small");
-    return ssv_lnr_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, (char*)ws + cw, B, C, L, (hipStream_t)stream);
-  }
   return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
 }
 
 // ---- highway gate alone (building block: lets a caller overlap the two conv gradients on different streams) ---------------
 extern "C" size_t ssv_highway_gate_bwd_workspace(int B, int C, int L) {
-  return zmax(align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float)), ssv_lnr_use(B, C, L) ? ssv_lnr_bwd_ws(B, C, L, 4) : 0);
+  return align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float));
 }
 extern "C" int ssv_highway_gate_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* g1, const float* b1,
                                     const float* g2, const float* b2, const float* h, const float* stats, float* dh, float* dxres,
                                     long dx_bs, float* pgrads, int B, int C, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dy && x && g1 && b1 && g2 && b2 && h && stats && dh && dxres && pgrads && B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_gate_bwd: bad argument");
   SSV_CHECK(ws && ws_bytes >= ssv_highway_gate_bwd_workspace(B, C, L), SSV_BAD_SHAPE, "highway_gate_bwd: workspace too small");
-  if (ssv_lnr_use(B, C, L)) return ssv_lnr_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dxres, dx_bs, ws, pgrads, B, C, L, (hipStream_t)stream);
   return ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dxres, dx_bs, (float*)ws, pgrads, B, C, L, (hipStream_t)stream);
 }
 
@@ -260,7 +242,7 @@ static HwWs hw_ws(int B, int C, int L, int k) {
   HwWs s;
   s.dh = 0;
   s.part = s.dh + align256((size_t)B * 2 * C * L * sizeof(float));
-  s.wt = s.part + zmax(align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float)), ssv_lnr_use(B, C, L) ? ssv_lnr_bwd_ws(B, C, L, 4) : 0);
+  s.wt = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float));
   s.slabs = s.wt + ssv_conv1d_bwd_data_workspace(C, 2 * C, k);
   s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, C, 2 * C, k);
   return s;
@@ -277,8 +259,7 @@ extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* 
   char* base = (char*)ws;
   float* dH = (float*)(base + s.dh);
   // gate + both LayerNorms backward: dH (B,2C,L), the residual-path gradient dy*(1-g) into dx, parameter partials
-  if (ssv_lnr_use(B, C, L)) SSV_TRY(ssv_lnr_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, base + s.part, pgrads, B, C, L, (hipStream_t)stream));
-  else SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, (float*)(base + s.part), pgrads, B, C, L, (hipStream_t)stream));
+  SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, (float*)(base + s.part), pgrads, B, C, L, (hipStream_t)stream));
   // dx += conv^T(dH)
   SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, w, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
   return ssv_conv1d_bwd_weight(dH, (long)2 * C * L, x, x_bs, dw, B, C, 2 * C, L, k, dilation, causal, base + s.slabs, s.total - s.slabs, stream);

@@ -292,7 +292,7 @@ def test_config2_synthesize_full_size_vs_oracle(precision):
     (1, 8, 1, 1, 1, False),        # length-1 sequence (the Linear-on-speaker-code case)
     (1, 24, 7, 3, 1, True),        # shorter than one tile, channels not a multiple of 16
     (5, 40, 97, 3, 9, False),      # odd batch / length, dilation halo larger than the tail tile
-    (2, 72, 1601, 3, 27, True),    # longer than 1536 columns: two column blocks in the row-chunk LayerNorm path
+    (2, 72, 1601, 3, 27, True),    # a very long row: > 100 column tiles per batch item
     (3, 136, 333, 1, 1, False),    # k=1, C = 8*17
     (2, 264, 130, 3, 3, False),    # C not a multiple of 32 (ragged last K chunk in the split-bf16 kernel)
 ])
@@ -321,32 +321,21 @@ def test_highway_ragged_shapes_vs_oracle(B, C, L, k, d, causal):
         assert rel_err(p.grad, sd["hc." + n].grad) < BWD_TOL, (n, rel_err(p.grad, sd["hc." + n].grad))
 
 
-@pytest.mark.parametrize("lnr", ["all", "off"])
-def test_layernorm_paths_agree_with_oracle(lnr, monkeypatch):
-    """Both LayerNorm decompositions (column tiles, row chunks) against the oracle, forced via SSV_LNR."""
-    import subprocess, sys, os, textwrap
-    code = textwrap.dedent('''
-        import sys, torch
-        sys.path.insert(0, %r); sys.path.insert(0, %r)
-        from _golden import rel_err
-        from oracle import tts_oracle as TO
-        from spoofsv_amd import ops
-        torch.manual_seed(3)
-        B, C, L = 3, 200, 700
-        w = torch.randn(C, C, 1) * 0.07; b = torch.randn(C) * 0.1
-        gam = 1 + 0.2 * torch.randn(C); bet = 0.2 * torch.randn(C)
-        x = torch.randn(B, C, L); dy = torch.randn(B, C, L)
-        lv = [v.clone().requires_grad_(True) for v in (x, w, b, gam, bet)]
-        yo = torch.sigmoid(TO._ln_channels(torch.nn.functional.conv1d(lv[0], lv[1], lv[2]), lv[3], lv[4]))
-        yo.backward(dy)
-        gl = [v.cuda().requires_grad_(True) for v in (x, w, b, gam, bet)]
-        yg = ops.pointwise_conv_ln_act(gl[0], gl[1], gl[2], gl[3], gl[4], None, 2)
-        yg.backward(dy.cuda())
-        assert rel_err(yg, yo) < 1e-4, rel_err(yg, yo)
-        for a, o in zip(gl, lv):
-            assert rel_err(a.grad, o.grad) < 5e-4, rel_err(a.grad, o.grad)
-        print("ok")
-    ''') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SSV_LNR=lnr)
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+def test_pointwise_conv_layernorm_long_rows_vs_oracle():
+    """1x1 conv + channel LayerNorm + sigmoid at a long, ragged shape (C not a multiple of 16, L not of the 16-column tile)."""
+    from oracle import tts_oracle as TO
+    from spoofsv_amd import ops
+    torch.manual_seed(3)
+    B, C, L = 3, 200, 700
+    w = torch.randn(C, C, 1) * 0.07; b = torch.randn(C) * 0.1
+    gam = 1 + 0.2 * torch.randn(C); bet = 0.2 * torch.randn(C)
+    x = torch.randn(B, C, L); dy = torch.randn(B, C, L)
+    lv = [v.clone().requires_grad_(True) for v in (x, w, b, gam, bet)]
+    yo = torch.sigmoid(TO._ln_channels(torch.nn.functional.conv1d(lv[0], lv[1], lv[2]), lv[3], lv[4]))
+    yo.backward(dy)
+    gl = [v.to(DEV).requires_grad_(True) for v in (x, w, b, gam, bet)]
+    yg = ops.pointwise_conv_ln_act(gl[0], gl[1], gl[2], gl[3], gl[4], None, 2)
+    yg.backward(dy.to(DEV))
+    assert rel_err(yg, yo) < FWD_TOL, rel_err(yg, yo)
+    for a, o in zip(gl, lv):
+        assert rel_err(a.grad, o.grad) < BWD_TOL, rel_err(a.grad, o.grad)
