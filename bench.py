@@ -162,7 +162,7 @@ def adversarial_cycle_ms(kind, batch, dev, cycles=3):
     model.apply(train.init_weights); disc.apply(train.init_weights)
     model.to(dev).train(); disc.to(dev).train()
     og = train.FusedAdam(model.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
-    od = train.FusedAdam(disc.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+    od = train.FusedAdam(disc.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True, resident=False)
     stepper = train.AdversarialGraphStep(kind, model, disc, og, od, data, gaw)
     def cycle():
         stepper.g_step()
@@ -195,7 +195,7 @@ def kernel_roofline(dev):
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     nb = _lib.query("ssv_conv1d_fwd_workspace", C, 2 * C, k)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    run = lambda: _lib.call("ssv_conv1d_fwd", P(x), C * L, P(w), P(bias), None, P(y), 2 * C * L, B, C, 2 * C, L, k, 1, 1, P(ws), nb, st)
+    run = lambda: _lib.call("ssv_conv1d_fwd", P(x), C * L, P(w), None, P(bias), None, P(y), 2 * C * L, B, C, 2 * C, L, k, 1, 1, P(ws), nb, st)
     for _ in range(5):
         run()
     reps = 50

@@ -43,13 +43,16 @@ int ssv_set_precision(int mode);
  * y(b,o,t) = bias[o] + bias_b[b*Cout+o] + sum_{c,j} w[o,c,j] * x(b,c,t + (j-j0)*dilation),
  * j0 = (k-1)/2 ("same", :57-59) or k-1 (causal: 2*pad zeros on the left, :72-74).
  * bias and bias_b (the broadcast speaker term of :175,:180) may be NULL. */
+/* w_packed (every entry that takes it): NULL, or the weight's resident pre-split planes written by
+ * ssv_conv_pack_multi (see "Resident pre-split weights" below) -- then the call skips its own weight split.  The
+ * caller vouches that the planes are current for w. */
 size_t ssv_conv1d_fwd_workspace(int Cin, int Cout, int k);   /* holds the pre-split weights */
-int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b,
+int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const void* w_packed, const float* bias, const float* bias_b,
                    float* y, long y_bs, int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                    void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* dx = conv1d_transpose(dy, w) [+ dx_add if non-NULL, same layout as dx]; ws holds w transposed. */
 size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k);
-int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const float* dx_add, float* dx, long dx_bs,
+int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* dx_add, float* dx, long dx_bs,
                         int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                         void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* dw(o,c,j) = sum_{b,t} dy(b,o,t) x(b,c,t+(j-j0)*dilation); split over the batch into slabs, summed
@@ -86,14 +89,14 @@ int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_b
  *   h = conv(x) (2C channels); y = sigmoid(LN1(h[:C])) * LN2(h[C:]) + (1 - sigmoid(LN1(h[:C]))) * x.
  * h (B,2C,L) dense and stats (B,4,L) = mean1, rstd1, mean2, rstd2 are saved for backward. */
 size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k);
-int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias,
+int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const void* w_packed, const float* bias,
                            const float* g1, const float* b1, const float* g2, const float* b2,
                            float* h, float* stats, float* y, long y_bs,
                            int B, int C, int L, int k, int dilation, int causal,
                            void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_highway_conv1d_bwd_workspace(int B, int C, int L, int k);
 /* Outputs: dx (B,C,L), dw (2C,C,k), pgrads (6,C) = dgamma1, dbeta1, dgamma2, dbeta2, dbias[:C], dbias[C:]. */
-int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w,
+int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
                            const float* g1, const float* b1, const float* g2, const float* b2,
                            const float* h, const float* stats, float* dx, long dx_bs, float* dw, float* pgrads,
                            int B, int C, int L, int k, int dilation, int causal,
@@ -166,6 +169,21 @@ int ssv_guided_att_loss_fwd(const float* a, const float* gaw, int gaw_T, float* 
                             void* ws, size_t ws_bytes, ssv_stream_t stream);
 int ssv_guided_att_loss_bwd(const float* gaw, int gaw_T, const float* gscale, float* da, int B, int N, int T,
                             ssv_stream_t stream);
+
+/* ---- Resident pre-split weights ------------------------------------------------------------------
+ * The split-bf16 conv kernels read weights as bf16 hi/lo planes in MFMA fragment order.  Splitting a weight costs one
+ * small launch per conv call (forward order for the forward, transposed order for the data gradient): ~100 launches
+ * per training step.  Instead a trainer can keep one caller-owned buffer of ssv_conv_pack_bytes() per weight and
+ * refresh ALL of them with one launch after each optimizer step; the conv entry points then take that buffer as
+ * w_packed.  A job table is planned once on the host (ssv_conv_pack_plan), copied to the device by the caller, and
+ * replayed by ssv_conv_pack_multi (safe inside hipGraph capture). */
+typedef struct { const float* w; void* planes; int M, K, Kpad, KT; long sm, sk; int first_block, pad_; } ssv_pack_job;
+size_t ssv_conv_pack_bytes(int Cout, int Cin, int k);   /* forward + transposed planes of one weight (Cout,Cin,k) */
+/* Fills 2*n HOST jobs (forward, transposed per weight) for weights w[i] (DEVICE pointers, torch layout (Cout,Cin,k))
+ * and their DEVICE buffers planes[i]; returns the number of workgroups ssv_conv_pack_multi must launch, or < 0. */
+int ssv_conv_pack_plan(int n, const float* const* w, void* const* planes, const int* Cout, const int* Cin, const int* k,
+                       ssv_pack_job* jobs_host);
+int ssv_conv_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, ssv_stream_t stream);
 
 /* ---- Adam -------------------------------------------------------------------------------------------
  * Replaces optim.Adam(...).step(), train/ordinary.py:182,238 (config.json:41-46), for many tensors in

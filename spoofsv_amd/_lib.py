@@ -21,6 +21,13 @@ class AdamChunk(ctypes.Structure):
                 ("v", ctypes.c_void_p), ("n", ctypes.c_long)]
 
 
+class PackJob(ctypes.Structure):
+    """Mirror of ``ssv_pack_job``."""
+    _fields_ = [("w", ctypes.c_void_p), ("planes", ctypes.c_void_p), ("M", ctypes.c_int), ("K", ctypes.c_int),
+                ("Kpad", ctypes.c_int), ("KT", ctypes.c_int), ("sm", ctypes.c_long), ("sk", ctypes.c_long),
+                ("first_block", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
 def _ctype(decl):
     d = decl.strip()
     if "*" in d:

@@ -94,14 +94,15 @@ static inline size_t split_bytes(int rows, int K, int k) { return align256((size
 static inline bool use_bf3(int B, int L, int Cin, int Cout) { return ssv_precision() == 1 && (long)B * L >= 128 && Cin >= 8 && Cout >= 16; }
 
 // y = conv(x, w): shared by forward (rows = Cout) and data gradient (rows = Cin, transposed weights, negated shifts)
-static int conv_nn(const float* x, long x_bs, const float* w, long w_sm, long w_sk, const float* bias, const float* bias_b,
+// `packed`: resident pre-split planes of this operand (hi plane, then lo plane), or null -> split into ws here.
+static int conv_nn(const float* x, long x_bs, const float* w, const void* packed, long w_sm, long w_sk, const float* bias, const float* bias_b,
                    const float* r, long r_bs, float* y, long y_bs, int B, int K, int M, int L, int k, const int* shift,
                    bool bf3, void* ws, hipStream_t st) {
   if (bf3) {
     const int Kpad = pad32(K);
-    unsigned short* hi = (unsigned short*)ws;
-    unsigned short* lo = (unsigned short*)((char*)ws + split_bytes(M, K, k));
-    SSV_TRY(ssv_launch_pack_split(w, hi, lo, M, K, Kpad, k, w_sm, w_sk, 1, 0, st));
+    const unsigned short* hi = (const unsigned short*)(packed ? packed : ws);
+    const unsigned short* lo = (const unsigned short*)((const char*)hi + split_bytes(M, K, k));
+    if (!packed) SSV_TRY(ssv_launch_pack_split(w, (void*)hi, (void*)lo, M, K, Kpad, k, w_sm, w_sk, 1, 0, st));
     GemmNNB g;
     g.perm_h = 0; g.epi = 0; g.first = 0; g.cstate = nullptr;
     g.Ahi = hi; g.Alo = lo; g.Kpad = Kpad;
@@ -130,7 +131,7 @@ static int conv_nn(const float* x, long x_bs, const float* w, long w_sm, long w_
 }
 
 extern "C" size_t ssv_conv1d_fwd_workspace(int Cin, int Cout, int k) { return 2 * split_bytes(Cout, Cin, k); }
-extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b, float* y, long y_bs,
+extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const void* w_packed, const float* bias, const float* bias_b, float* y, long y_bs,
                               int B, int Cin, int Cout, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes,
                               ssv_stream_t stream) {
   SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_fwd: bad argument B=%d Cin=%d Cout=%d L=%d", B, Cin, Cout, L);
@@ -138,25 +139,55 @@ extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const f
   int shift[3];
   SSV_TRY(conv_shifts(k, dilation, causal, shift));
   const bool bf3 = use_bf3(B, L, Cin, Cout);
-  if (bf3) SSV_CHECK(ws && ws_bytes >= ssv_conv1d_fwd_workspace(Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_fwd: workspace too small");
-  return conv_nn(x, x_bs, w, (long)Cin * k, k, bias, bias_b, nullptr, 0, y, y_bs, B, Cin, Cout, L, k, shift, bf3, ws, (hipStream_t)stream);
+  if (bf3 && !w_packed) SSV_CHECK(ws && ws_bytes >= ssv_conv1d_fwd_workspace(Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_fwd: workspace too small");
+  return conv_nn(x, x_bs, w, w_packed, (long)Cin * k, k, bias, bias_b, nullptr, 0, y, y_bs, B, Cin, Cout, L, k, shift, bf3, ws, (hipStream_t)stream);
 }
 
 extern "C" size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k) {
   const size_t a = align256((size_t)Cin * Cout * k * sizeof(float)), b = 2 * split_bytes(Cin, Cout, k);
   return a > b ? a : b;
 }
-extern "C" int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const float* dx_add, float* dx, long dx_bs,
+extern "C" int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* dx_add, float* dx, long dx_bs,
                                    int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                                    void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dy && w && dx && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_data: bad argument");
-  SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_data_workspace(Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_bwd_data: workspace too small");
+  SSV_CHECK(w_packed || (ws && ws_bytes >= ssv_conv1d_bwd_data_workspace(Cin, Cout, k)), SSV_BAD_SHAPE, "conv1d_bwd_data: workspace too small");
   int shift[3];
   SSV_TRY(conv_shifts(k, dilation, causal, shift));
   for (int j = 0; j < 3; ++j) shift[j] = -shift[j];
   // rows = input channels c, reduction over output channels o: element (c, o, j) = w[o][c][j]
-  return conv_nn(dy, dy_bs, w, k, (long)Cin * k, nullptr, nullptr, dx_add, dx_bs, dx, dx_bs, B, Cout, Cin, L, k, shift,
+  // the transposed planes follow the forward planes in a resident buffer (ssv_conv_pack_bytes)
+  const void* pk = w_packed ? (const char*)w_packed + 2 * split_bytes(Cout, Cin, k) : nullptr;
+  return conv_nn(dy, dy_bs, w, pk, k, (long)Cin * k, nullptr, nullptr, dx_add, dx_bs, dx, dx_bs, B, Cout, Cin, L, k, shift,
                  use_bf3(B, L, Cout, Cin), ws, (hipStream_t)stream);
+}
+
+// ---- resident pre-split weights ------------------------------------------------------------------------------------
+extern "C" size_t ssv_conv_pack_bytes(int Cout, int Cin, int k) { return 2 * split_bytes(Cout, Cin, k) + 2 * split_bytes(Cin, Cout, k); }
+extern "C" int ssv_conv_pack_plan(int n, const float* const* w, void* const* planes, const int* Cout, const int* Cin, const int* k,
+                                  ssv_pack_job* jobs) {
+  SSV_CHECK(n > 0 && w && planes && Cout && Cin && k && jobs, SSV_BAD_SHAPE, "conv_pack_plan: bad argument");
+  long blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    SSV_CHECK(w[i] && planes[i] && Cout[i] > 0 && Cin[i] > 0 && (k[i] == 1 || k[i] == 3), SSV_BAD_SHAPE, "conv_pack_plan: weight %d: bad shape", i);
+    for (int tr = 0; tr < 2; ++tr) {
+      ssv_pack_job& j = jobs[2 * i + tr];
+      const int M = tr ? Cin[i] : Cout[i], K = tr ? Cout[i] : Cin[i];
+      j.w = w[i];
+      j.planes = (char*)planes[i] + (tr ? 2 * split_bytes(Cout[i], Cin[i], k[i]) : 0);
+      j.M = M; j.K = K; j.Kpad = pad32(K); j.KT = k[i];
+      j.sm = tr ? k[i] : (long)Cin[i] * k[i];            // element (m, kk, tap) = w[m*sm + kk*sk + tap]
+      j.sk = tr ? (long)Cin[i] * k[i] : k[i];
+      j.first_block = (int)blocks; j.pad_ = 0;
+      blocks += ssv_pack_job_blocks(j);
+      SSV_CHECK(blocks < (1L << 30), SSV_UNSUPPORTED, "conv_pack_plan: too many elements");
+    }
+  }
+  return (int)blocks;
+}
+extern "C" int ssv_conv_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, ssv_stream_t stream) {
+  SSV_CHECK(jobs_dev && njobs > 0 && nblocks > 0, SSV_BAD_SHAPE, "conv_pack_multi: bad argument");
+  return ssv_launch_pack_multi(jobs_dev, njobs, nblocks, (hipStream_t)stream);
 }
 
 // Number of batch slabs the weight gradient is split into: enough workgroups to fill the chip (2 per CU), no more --
@@ -217,11 +248,11 @@ extern "C" size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k) {
   (void)B; (void)L;
   return ssv_conv1d_fwd_workspace(C, 2 * C, k);
 }
-extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* g1, const float* b1,
+extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const void* w_packed, const float* bias, const float* g1, const float* b1,
                                       const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
                                       int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w && g1 && b1 && g2 && b2 && h && y, SSV_BAD_SHAPE, "highway_conv1d_fwd: null argument");
-  SSV_TRY(ssv_conv1d_fwd(x, x_bs, w, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
+  SSV_TRY(ssv_conv1d_fwd(x, x_bs, w, w_packed, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
   return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
 }
 
@@ -248,7 +279,7 @@ static HwWs hw_ws(int B, int C, int L, int k) {
   return s;
 }
 extern "C" size_t ssv_highway_conv1d_bwd_workspace(int B, int C, int L, int k) { return hw_ws(B, C, L, k).total; }
-extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const float* g1, const float* b1,
+extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed, const float* g1, const float* b1,
                                       const float* g2, const float* b2, const float* h, const float* stats, float* dx, long dx_bs, float* dw,
                                       float* pgrads, int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes,
                                       ssv_stream_t stream) {
@@ -261,7 +292,7 @@ extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* 
   // gate + both LayerNorms backward: dH (B,2C,L), the residual-path gradient dy*(1-g) into dx, parameter partials
   SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, (float*)(base + s.part), pgrads, B, C, L, (hipStream_t)stream));
   // dx += conv^T(dH)
-  SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, w, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
+  SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
   return ssv_conv1d_bwd_weight(dH, (long)2 * C * L, x, x_bs, dw, B, C, 2 * C, L, k, dilation, causal, base + s.slabs, s.total - s.slabs, stream);
 }
 

@@ -65,6 +65,44 @@ int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int 
   return ssv_check_launch("pack_split");
 }
 
+// Many weights in one launch (resident pre-split weights, ssv_conv_pack_multi): workgroup -> job by binary search over
+// the jobs' first_block, then the same element map as pack_split_kernel, 1024 elements per workgroup.
+#define PACK_PER_BLOCK 1024
+__global__ __launch_bounds__(256) void pack_multi_kernel(const ssv_pack_job* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {                                   // last job with first_block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ssv_pack_job j = jobs[lo];
+  const int MB = (j.M + 15) >> 4, NCH = j.Kpad >> 5;
+  const long n = (long)j.KT * MB * NCH * 512;
+  __bf16* __restrict__ hip = (__bf16*)j.planes;
+  __bf16* __restrict__ lop = (__bf16*)((char*)j.planes + (((size_t)n * sizeof(__bf16) + 255) & ~(size_t)255));
+  const long base = (long)((int)blockIdx.x - j.first_block) * PACK_PER_BLOCK;
+#pragma unroll
+  for (int r = 0; r < PACK_PER_BLOCK / 256; ++r) {
+    const long i = base + r * 256 + threadIdx.x;
+    if (i >= n) break;
+    const int e = (int)(i & 7), r16 = (int)((i >> 3) & 15), kg = (int)((i >> 7) & 3);
+    const long blk = i >> 9;
+    const int ch = (int)(blk % NCH), mb = (int)((blk / NCH) % MB), tap = (int)(blk / ((long)NCH * MB));
+    const int m = mb * 16 + r16, k = ch * 32 + kg * 8 + e;
+    const float v = (m < j.M && k < j.K) ? j.w[(long)m * j.sm + (long)k * j.sk + tap] : 0.f;
+    const __bf16 h = (__bf16)v;
+    hip[i] = h;
+    lop[i] = (__bf16)(v - (float)h);
+  }
+}
+int ssv_pack_job_blocks(const ssv_pack_job& j) {
+  const long n = (long)j.KT * ((j.M + 15) / 16) * (j.Kpad / 32) * 512;
+  return (int)((n + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK);
+}
+int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, hipStream_t st) {
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs);
+  return ssv_check_launch("pack_multi");
+}
+
 // ---- NN ---------------------------------------------------------------------------------------------------------------
 // Waves split the M axis, so a weight row is only ever used by ONE wave: weight fragments go straight from global memory
 // (L2-resident, pre-split, fragment-shaped 16-byte loads) into MFMA operand registers, one K chunk ahead (two register

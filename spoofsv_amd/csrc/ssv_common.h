@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include "../../include/ssv_hip.h"
 
 // ---- error reporting (thread-local, see ssv_last_error in api.hip) -------------------
 int ssv_fail(int code, const char* fmt, ...);
@@ -69,6 +70,8 @@ int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int 
 int ssv_nt_bf3_tiles(int KT, int M, int Nc);
 int ssv_nt_bf3_target(int KT, int M, int Nc);  // workgroups to aim for when choosing the slab count   // output tiles of the weight-gradient kernel for this problem
 int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA (default)
+int ssv_pack_job_blocks(const ssv_pack_job& j);           // workgroups one job of ssv_conv_pack_multi takes
+int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, hipStream_t st);
 
 // ---- small helpers (misc.hip) ---------------------------------------------------------
 int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long slab_stride, hipStream_t st);

@@ -12,7 +12,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, resident
 
 _F32 = torch.float32
 
@@ -82,7 +82,7 @@ class HighwayConvFn(torch.autograd.Function):
         stats = torch.empty((B, 4, L), dtype=_F32, device=x.device) if train else None
         nb = _lib.query("ssv_highway_conv1d_fwd_workspace", B, C, L, k)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_highway_conv1d_fwd", _p(x), xbs, _p(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
+        _lib.call("ssv_highway_conv1d_fwd", _p(x), xbs, _p(w), resident.lookup(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
                   _p(h), _p(stats), _p(y), C * L, B, C, L, k, dilation, int(causal), _p(ws), nb, _stream())
         if train:
             ctx.save_for_backward(x, w, g1, b1, g2, b2, h, stats)
@@ -101,7 +101,7 @@ class HighwayConvFn(torch.autograd.Function):
         pg = torch.empty((6, C), dtype=_F32, device=x.device)
         nb = _lib.query("ssv_highway_conv1d_bwd_workspace", B, C, L, k)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_highway_conv1d_bwd", _p(dy), dybs, _p(x), xbs, _p(w), _p(g1), _p(b1), _p(g2), _p(b2),
+        _lib.call("ssv_highway_conv1d_bwd", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
                   _p(h), _p(stats), _p(dx), C * L, _p(dw), _p(pg), B, C, L, k, dilation, causal,
                   _p(ws), nb, _stream())
         return dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3], None, None, None
@@ -112,7 +112,7 @@ def _conv_fwd(x, xbs, w, bias, bias_b, y, ybs, k, dilation, causal):
     B, Cin, L = x.shape
     nb = _lib.query("ssv_conv1d_fwd_workspace", Cin, w.shape[0], k)
     ws = _ws(nb, x.device)
-    _lib.call("ssv_conv1d_fwd", _p(x), xbs, _p(w), _p(bias), _p(bias_b), _p(y), ybs, B, Cin, w.shape[0], L,
+    _lib.call("ssv_conv1d_fwd", _p(x), xbs, _p(w), resident.lookup(w), _p(bias), _p(bias_b), _p(y), ybs, B, Cin, w.shape[0], L,
               k, dilation, int(causal), _p(ws), nb, _stream())
 
 
@@ -121,7 +121,7 @@ def _conv_bwd_data(dy, dybs, w, Cin, L, k=1, dilation=1, causal=0):
     dx = torch.empty((B, Cin, L), dtype=_F32, device=dy.device)
     nb = _lib.query("ssv_conv1d_bwd_data_workspace", Cin, Cout, k)
     ws = _ws(nb, dy.device)
-    _lib.call("ssv_conv1d_bwd_data", _p(dy), dybs, _p(w), None, _p(dx), Cin * L, B, Cin, Cout, L, k, dilation,
+    _lib.call("ssv_conv1d_bwd_data", _p(dy), dybs, _p(w), resident.lookup(w), None, _p(dx), Cin * L, B, Cin, Cout, L, k, dilation,
               int(causal), _p(ws), nb, _stream())
     return dx
 

@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib, ops
+from . import resident as _resident
 from .ops import _p, _stream
 
 
@@ -50,7 +51,7 @@ class FusedAdam(torch.optim.Optimizer):
     captured hipGraph of the whole training step replays correctly.
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False, resident=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = capturable
         self._table = None
@@ -58,6 +59,18 @@ class FusedAdam(torch.optim.Optimizer):
         self._key = None
         self._step_dev = None
         self._steps = 0
+        self._resident = None
+        self.resident = resident           # False for models that do not run on the HIP conv path (the critics)
+
+    def refresh_resident_weights(self):
+        """(Re)write the resident pre-split planes of every conv weight this optimizer owns (one launch; see
+        ``spoofsv_amd.resident``).  ``step`` does it after every update; call it once before the first forward
+        -- and after anything that writes weights behind autograd's back -- so that step too finds current planes."""
+        if not self.resident:
+            return
+        if self._resident is None:
+            self._resident = _resident.ResidentWeights([p for g in self.param_groups for p in g["params"]])
+        self._resident.refresh(_stream())
 
     def _build(self, plist):
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
@@ -110,6 +123,7 @@ class FusedAdam(torch.optim.Optimizer):
                       float(group["eps"]), self._steps, step_dev, _stream())
             for p in plist:
                 self.state[p]["step"] += 1
+        self.refresh_resident_weights()
         return loss
 
 
@@ -201,6 +215,7 @@ class DataParallelRanks:
         with torch.no_grad():
             for p in self.params:
                 dist.broadcast(p.data, src, group=self.group)
+        _resident.invalidate(self.params)      # p.data writes do not bump the version the resident planes are checked against
 
     def _buckets(self, grads):
         buckets, cur, n = [], [], 0

@@ -58,16 +58,16 @@ def test_bad_arguments_fail_before_the_device():
     null = ctypes.c_void_p(0)
     one = ctypes.c_void_p(16)           # non-null dummy, never dereferenced: the checks come first
     # empty problem -> -1
-    rc = L.ssv_conv1d_fwd(one, 0, one, null, null, one, 0, 0, 4, 4, 8, 3, 1, 0, null, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 0, one, null, null, null, one, 0, 0, 4, 4, 8, 3, 1, 0, null, 0, null)
     assert rc == -1 and b"conv1d_fwd" in L.ssv_last_error()
     # unsupported kernel size -> -2
-    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 5, 1, 0, null, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, null, one, 64, 1, 4, 4, 16, 5, 1, 0, null, 0, null)
     assert rc == -2 and b"kernel_size" in L.ssv_last_error()
     # dilation halo beyond the staged tile -> -2
-    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 3, 28, 0, null, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, null, one, 64, 1, 4, 4, 16, 3, 28, 0, null, 0, null)
     assert rc == -2
     # workspace too small -> -1
-    rc = L.ssv_conv1d_bwd_data(one, 64, one, null, one, 64, 1, 4, 4, 16, 3, 1, 0, one, 8, null)
+    rc = L.ssv_conv1d_bwd_data(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 3, 1, 0, one, 8, null)
     assert rc == -1 and b"workspace" in L.ssv_last_error()
     with pytest.raises(RuntimeError):
         _lib.call("ssv_ge2e_loss_fwd", one, one, one, one, null, 4, 1, 8, one, 1 << 20, null)   # M must be > 1
@@ -79,3 +79,35 @@ def test_ops_fail_loudly_on_cpu_tensors():
     m = SSRN(80, 65, 16)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.rand(1, 80, 8))
+
+
+def test_conv_pack_plan_is_host_only_and_consistent():
+    """ssv_conv_pack_plan runs on the host: job table for two weights (forward + transposed order each)."""
+    import ctypes
+    from spoofsv_amd import _lib
+    L = _lib.lib()
+    n = 2
+    vp = ctypes.c_void_p
+    w = (vp * n)(0x1000, 0x2000)
+    pl = (vp * n)(0x100000, 0x200000)
+    co = (ctypes.c_int * n)(512, 80)
+    ci = (ctypes.c_int * n)(256, 513)
+    kk = (ctypes.c_int * n)(3, 1)
+    jobs = (_lib.PackJob * (2 * n))()
+    nblocks = L.ssv_conv_pack_plan(n, w, pl, co, ci, kk, jobs)
+    assert nblocks > 0
+    # forward job of weight 0: rows = Cout, K = Cin, element (m, c, tap) at w[m*Cin*k + c*k + tap]
+    j = jobs[0]
+    assert (j.M, j.K, j.Kpad, j.KT, j.sm, j.sk, j.first_block) == (512, 256, 256, 3, 768, 3, 0)
+    # transposed job: rows = Cin, K = Cout; its planes follow the forward planes inside the same buffer
+    t = jobs[1]
+    assert (t.M, t.K, t.KT, t.sm, t.sk) == (256, 512, 3, 3, 768)
+    fwd_bytes = 2 * 3 * 512 * 256 * 2
+    assert t.planes - j.planes == fwd_bytes
+    assert L.ssv_conv_pack_bytes(512, 256, 3) == 2 * fwd_bytes
+    # ragged weight: K padded to 32, rows to 16
+    r = jobs[2]
+    assert (r.M, r.K, r.Kpad, r.KT) == (80, 513, 544, 1)
+    firsts = [jobs[i].first_block for i in range(2 * n)]
+    assert firsts == sorted(firsts) and firsts[0] == 0 and firsts[-1] < nblocks
+    assert L.ssv_conv_pack_plan(1, w, pl, co, ci, (ctypes.c_int * 1)(2), jobs) < 0      # kernel size 2 is not a conv weight here

@@ -227,3 +227,53 @@ def test_adversarial_iteration_golden_gpu():
     assert abs(float(gp) - float(g["d_gp"])) < 1e-3 * max(1.0, abs(float(g["d_gp"])))
     assert abs(float(loss_d) - float(g["d_loss"])) < 1e-4 * max(1.0, abs(float(g["d_loss"])))
     _critic_grads_agree(d, sub(g, "dgrad/"), 2e-3)
+
+
+@pytest.mark.gpu
+def test_resident_weights_match_per_call_split_and_follow_weight_updates():
+    """Resident pre-split planes (one refresh launch) give bit-identical results to the per-call split, and a weight
+    changed through torch stops using them until the next refresh."""
+    from spoofsv_amd import resident, train
+    from spoofsv_amd.tts import highwayConv
+    torch.manual_seed(5)
+    m = highwayConv(64, 3, 3, causal=True).to("cuda")
+    x = torch.randn(4, 64, 200, device="cuda")
+    dy = torch.randn(4, 64, 200, device="cuda")
+
+    def run():
+        xg = x.clone().requires_grad_(True)
+        for p in m.parameters():
+            p.grad = None
+        y = m(xg)
+        y.backward(dy)
+        return [y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+
+    w = m.conv.weight
+    assert resident.lookup(w) is None
+    base = run()
+    opt = train.FusedAdam(m.parameters(), 1e-3)
+    opt.refresh_resident_weights()
+    assert resident.lookup(w) is not None
+    res = run()
+    for a, b in zip(base, res):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        w.mul_(1.5)                                   # in-place torch op: version bump -> planes are stale
+    assert resident.lookup(w) is None
+    changed = run()
+    assert not torch.equal(changed[0], base[0])
+    opt.refresh_resident_weights()
+    assert resident.lookup(w) is not None
+    again = run()
+    for a, b in zip(changed, again):
+        assert torch.equal(a, b)
+    for p in m.parameters():                          # an optimizer step keeps the planes current
+        p.grad = torch.randn_like(p)
+    opt.step()
+    assert resident.lookup(w) is not None
+    after = run()
+    resident.invalidate([w])
+    assert resident.lookup(w) is None
+    ref = run()
+    for a, b in zip(after, ref):
+        assert torch.equal(a, b)
