@@ -11,20 +11,22 @@
 //
 //   ln_gate_*: highwayConv epilogue  y = sigmoid(LN1(H1))*LN2(H2) + (1-sigmoid(LN1(H1)))*x
 //   ln_act_* : y = act(LN(x)), act in {none, relu, sigmoid}
+#include <stdlib.h>
 #include "ssv_common.h"
 
 #define LN_EPS 1e-5f
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
-// Sum `v` over the 16 channel groups of this thread's column. `red` is a [16][16] LDS array.
+// Sum `v` over the G channel groups of this thread's column. `red` is a [G][16] LDS array.
+template <int G>
 __device__ __forceinline__ float group_sum(float v, float* red, int col, int g) {
   __syncthreads();
   red[g * 16 + col] = v;
   __syncthreads();
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += red[i * 16 + col];
+  for (int i = 0; i < G; ++i) s += red[i * 16 + col];
   return s;
 }
 
@@ -46,43 +48,43 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CPT>
-__global__ __launch_bounds__(256) void ln_gate_fwd_kernel(
+template <int CPT, int G>
+__global__ __launch_bounds__(16 * G) void ln_gate_fwd_kernel(
     const float* __restrict__ H, long h_bs, const float* __restrict__ X, long x_bs,
     const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
     float* __restrict__ Y, long y_bs, float* __restrict__ stats, int C, int L) {
-  __shared__ float red[256];
+  __shared__ float red[16 * G];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
   const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
   // addressing: wave-uniform 64-bit bases + one 32-bit per-thread offset (c = g, column t), stepped by 16 rows
-  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = 16u * (unsigned)L;
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = (unsigned)G * (unsigned)L;
   const float* __restrict__ Hb1 = H + (long)b * h_bs;
   const float* __restrict__ Hb2 = Hb1 + (long)C * L;
   float h1[CPT], h2[CPT];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + 16 * i;
+    const int c = g + G * i;
     const bool v = tv && c < C;
     h1[i] = v ? Hb1[o0 + i * ostep] : 0.f;
     h2[i] = v ? Hb2[o0 + i * ostep] : 0.f;
     s1 += h1[i]; s2 += h2[i];
   }
   const float inv = 1.f / (float)C;
-  const float mu1 = group_sum(s1, red, col, g) * inv;
-  const float mu2 = group_sum(s2, red, col, g) * inv;
+  const float mu1 = group_sum<G>(s1, red, col, g) * inv;
+  const float mu2 = group_sum<G>(s2, red, col, g) * inv;
   float q1 = 0.f, q2 = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const bool v = (g + 16 * i) < C;
+    const bool v = (g + G * i) < C;
     const float d1 = v ? h1[i] - mu1 : 0.f, d2 = v ? h2[i] - mu2 : 0.f;
     q1 += d1 * d1; q2 += d2 * d2;
   }
-  const float r1 = rsqrtf(group_sum(q1, red, col, g) * inv + LN_EPS);
-  const float r2 = rsqrtf(group_sum(q2, red, col, g) * inv + LN_EPS);
+  const float r1 = rsqrtf(group_sum<G>(q1, red, col, g) * inv + LN_EPS);
+  const float r2 = rsqrtf(group_sum<G>(q2, red, col, g) * inv + LN_EPS);
   if (!tv) return;
   if (g == 0 && stats) {
     float* sb = stats + (long)b * 4 * L + t;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(
   float* __restrict__ Yb = Y + (long)b * y_bs;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + 16 * i;
+    const int c = g + G * i;
     if (c < C) {
       const float n1 = (h1[i] - mu1) * r1 * g1[c] + b1[c];
       const float n2 = (h2[i] - mu2) * r2 * g2[c] + b2[c];
@@ -103,19 +105,19 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(
 }
 
 // part layout: [block][6][C] = dgamma1, dbeta1, dgamma2, dbeta2, dbiasH1, dbiasH2
-template <int CPT>
-__global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
+template <int CPT, int G>
+__global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
     const float* __restrict__ dY, long dy_bs, const float* __restrict__ H, const float* __restrict__ X, long x_bs,
     const float* __restrict__ stats,
     const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
     float* __restrict__ dH, float* __restrict__ dXres, long dx_bs, float* __restrict__ part, int C, int L) {
-  __shared__ float red[256];
+  __shared__ float red[16 * G];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
   const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
-  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = 16u * (unsigned)L;
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = (unsigned)G * (unsigned)L;
   const float* __restrict__ Hb1 = H + (long)b * 2 * C * L;
   const float* __restrict__ Hb2 = Hb1 + (long)C * L;
   float* __restrict__ dHb1 = dH + (long)b * 2 * C * L;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
   float sa1 = 0.f, sah1 = 0.f, sa2 = 0.f, sah2 = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + 16 * i;
+    const int c = g + G * i;
     const bool v = tv && c < C;
     float dn1 = 0.f, dn2 = 0.f, gg1 = 0.f, gg2 = 0.f;
     xh1[i] = 0.f; xh2[i] = 0.f;
@@ -157,11 +159,11 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
     sa1 += a1[i]; sah1 += a1[i] * xh1[i]; sa2 += a2[i]; sah2 += a2[i] * xh2[i];
   }
   const float inv = 1.f / (float)C;
-  const float m1 = group_sum(sa1, red, col, g) * inv, mh1 = group_sum(sah1, red, col, g) * inv;
-  const float m2 = group_sum(sa2, red, col, g) * inv, mh2 = group_sum(sah2, red, col, g) * inv;
+  const float m1 = group_sum<G>(sa1, red, col, g) * inv, mh1 = group_sum<G>(sah1, red, col, g) * inv;
+  const float m2 = group_sum<G>(sa2, red, col, g) * inv, mh2 = group_sum<G>(sah2, red, col, g) * inv;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + 16 * i;
+    const int c = g + G * i;
     const bool v = tv && c < C;
     const float d1 = v ? r1 * (a1[i] - m1 - xh1[i] * mh1) : 0.f;
     const float d2 = v ? r2 * (a2[i] - m2 - xh2[i] * mh2) : 0.f;
@@ -172,41 +174,41 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CPT>
-__global__ __launch_bounds__(256) void ln_act_fwd_kernel(
+template <int CPT, int G>
+__global__ __launch_bounds__(16 * G) void ln_act_fwd_kernel(
     const float* __restrict__ X, long x_bs, const float* __restrict__ gam, const float* __restrict__ bet,
     float* __restrict__ Y, long y_bs, float* __restrict__ stats, int C, int L, int act) {
-  __shared__ float red[256];
+  __shared__ float red[16 * G];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
   const int t = bx * 16 + col, b = by;
   const bool tv = t < L;
-  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = 16u * (unsigned)L;
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = (unsigned)G * (unsigned)L;
   const float* __restrict__ Xb = X + (long)b * x_bs;
   float x[CPT];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + 16 * i;
+    const int c = g + G * i;
     x[i] = (tv && c < C) ? Xb[o0 + i * ostep] : 0.f;
     s += x[i];
   }
   const float inv = 1.f / (float)C;
-  const float mu = group_sum(s, red, col, g) * inv;
+  const float mu = group_sum<G>(s, red, col, g) * inv;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const float d = ((g + 16 * i) < C) ? x[i] - mu : 0.f;
+    const float d = ((g + G * i) < C) ? x[i] - mu : 0.f;
     q += d * d;
   }
-  const float r = rsqrtf(group_sum(q, red, col, g) * inv + LN_EPS);
+  const float r = rsqrtf(group_sum<G>(q, red, col, g) * inv + LN_EPS);
   if (!tv) return;
   if (g == 0 && stats) { stats[(long)b * 2 * L + t] = mu; stats[(long)b * 2 * L + L + t] = r; }
   float* __restrict__ Yb = Y + (long)b * y_bs;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + 16 * i;
+    const int c = g + G * i;
     if (c < C) {
       float n = (x[i] - mu) * r * gam[c] + bet[c];
       if (act == 1) n = fmaxf(n, 0.f);
@@ -217,12 +219,12 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(
 }
 
 // part layout: [block][3][C] = dgamma, dbeta, dbias (= column sums of dX)
-template <int CPT>
-__global__ __launch_bounds__(256) void ln_act_bwd_kernel(
+template <int CPT, int G>
+__global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
     const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs, const float* __restrict__ stats,
     const float* __restrict__ gam, const float* __restrict__ bet,
     float* __restrict__ dX, long dx_bs, float* __restrict__ part, int C, int L, int act) {
-  __shared__ float red[256];
+  __shared__ float red[16 * G];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(
   const bool tv = t < L;
   float mu = 0.f, r = 0.f;
   if (tv) { mu = stats[(long)b * 2 * L + t]; r = stats[(long)b * 2 * L + L + t]; }
-  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = 16u * (unsigned)L;
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = (unsigned)G * (unsigned)L;
   const float* __restrict__ dYb = dY + (long)b * dy_bs;
   const float* __restrict__ Xb = X + (long)b * x_bs;
   float* __restrict__ dXb = dX + (long)b * dx_bs;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(
   float sa = 0.f, sah = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + 16 * i;
+    const int c = g + G * i;
     const bool v = tv && c < C;
     float dn = 0.f, gg = 0.f;
     xh[i] = 0.f;
@@ -258,10 +260,10 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(
     sa += a[i]; sah += a[i] * xh[i];
   }
   const float inv = 1.f / (float)C;
-  const float m = group_sum(sa, red, col, g) * inv, mh = group_sum(sah, red, col, g) * inv;
+  const float m = group_sum<G>(sa, red, col, g) * inv, mh = group_sum<G>(sah, red, col, g) * inv;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + 16 * i;
+    const int c = g + G * i;
     const bool v = tv && c < C;
     const float d = v ? r * (a[i] - m - xh[i] * mh) : 0.f;
     if (v) dXb[o0 + i * ostep] = d;
@@ -334,23 +336,35 @@ static int reduce_partials(float* part, float* out, int n, int nblk, hipStream_t
 }
 
 // ------------------------------------------------------------------------------------------------
-#define LN_DISPATCH(C, CALL)                                            \
+// G = channel groups per 16-column tile (workgroup = 16 * G threads), CPT = channels per thread = ceil(C / G).
+// Measured (tools/bench_ln.py, B = 32): up to 256 channels 16 groups are best at every length; 512 channels run 15-25 %
+// faster on 32 groups (half the registers per thread: 224 -> ~130 VGPRs in the gate backward, so twice the waves per CU);
+// the 513-channel backward is fastest on 64 groups (113 -> 92 us at L = 1300), its forward on 16.
+// SSV_LN_GROUPS forces G (tuning aid).
+static int ln_groups(int C, bool bwd) {
+  if (const char* e = getenv("SSV_LN_GROUPS")) { const int g = atoi(e); if (g == 16 || g == 32 || g == 64) return g; }
+  if (C > 512) return bwd ? 64 : 16;
+  return C > 256 ? 32 : 16;
+}
+#define LN_CASE(G_, N_) if (_g == G_ && _cpt <= N_) { CALL(N_, G_); } else
+#define LN_DISPATCH(BWD, C, L, CALL)                                    \
   do {                                                                  \
-    const int _cpt = ((C) + 15) / 16;                                   \
-    if ((long)(2 * (C) + 32) * (long)L >= (1L << 31)) return ssv_fail(SSV_UNSUPPORTED, "LayerNorm: one batch item exceeds 2^31 elements"); \
-    if (_cpt <= 2) { CALL(2); } else if (_cpt <= 4) { CALL(4); }        \
-    else if (_cpt <= 8) { CALL(8); } else if (_cpt <= 16) { CALL(16); } \
-    else if (_cpt <= 32) { CALL(32); } else if (_cpt <= 33) { CALL(33); } else if (_cpt <= 64) { CALL(64); } \
-    else return ssv_fail(SSV_UNSUPPORTED, "LayerNorm over %d channels not supported (max 1024)", (C)); \
+    const int _g = ln_groups(C, BWD);                                   \
+    const int _cpt = ((C) + _g - 1) / _g;                               \
+    if ((long)(2 * (C) + 2 * _g) * (long)L >= (1L << 31)) return ssv_fail(SSV_UNSUPPORTED, "LayerNorm: one batch item exceeds 2^31 elements"); \
+    LN_CASE(16, 2) LN_CASE(16, 4) LN_CASE(16, 8) LN_CASE(16, 16) LN_CASE(16, 32) LN_CASE(16, 33) LN_CASE(16, 64) \
+    LN_CASE(32, 4) LN_CASE(32, 8) LN_CASE(32, 16) LN_CASE(32, 17) LN_CASE(32, 32)                               \
+    LN_CASE(64, 4) LN_CASE(64, 8) LN_CASE(64, 9) LN_CASE(64, 16)                                               \
+    return ssv_fail(SSV_UNSUPPORTED, "LayerNorm over %d channels not supported (max 1024)", (C)); \
   } while (0)
 
 int ssv_launch_ln_gate_fwd(const float* H, long h_bs, const float* X, long x_bs, const float* g1, const float* b1,
                            const float* g2, const float* b2, float* Y, long y_bs, float* stats, int B, int C, int L,
                            hipStream_t st) {
   dim3 grid(ssv_cdiv(L, 16), B);
-#define CALL(N) hipLaunchKernelGGL(ln_gate_fwd_kernel<N>, grid, dim3(256), 0, st, H, h_bs, X, x_bs, g1, b1, g2, b2, Y, y_bs, stats, C, L)
+#define CALL(N, G) hipLaunchKernelGGL((ln_gate_fwd_kernel<N, G>), grid, dim3(16 * G), 0, st, H, h_bs, X, x_bs, g1, b1, g2, b2, Y, y_bs, stats, C, L)
   if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
-  LN_DISPATCH(C, CALL);
+  LN_DISPATCH(false, C, L, CALL);
 #undef CALL
   return ssv_check_launch("ln_gate_fwd");
 }
@@ -361,9 +375,9 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
                            const float* g1, const float* b1, const float* g2, const float* b2, float* dH, float* dXres,
                            long dx_bs, float* part, float* pgrads /* [6][C] */, int B, int C, int L, hipStream_t st) {
   dim3 grid(ssv_cdiv(L, 16), B);
-#define CALL(N) hipLaunchKernelGGL(ln_gate_bwd_kernel<N>, grid, dim3(256), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, C, L)
+#define CALL(N, G) hipLaunchKernelGGL((ln_gate_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, C, L)
   if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
-  LN_DISPATCH(C, CALL);
+  LN_DISPATCH(true, C, L, CALL);
 #undef CALL
   SSV_TRY(ssv_check_launch("ln_gate_bwd"));
   return reduce_partials(part, pgrads, 6 * C, (int)(grid.x * grid.y), st);
@@ -372,8 +386,8 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
 int ssv_launch_ln_act_fwd(const float* X, long x_bs, const float* gam, const float* bet, float* Y, long y_bs, float* stats,
                           int B, int C, int L, int act, hipStream_t st) {
   dim3 grid(ssv_cdiv(L, 16), B);
-#define CALL(N) hipLaunchKernelGGL(ln_act_fwd_kernel<N>, grid, dim3(256), 0, st, X, x_bs, gam, bet, Y, y_bs, stats, C, L, act)
-  LN_DISPATCH(C, CALL);
+#define CALL(N, G) hipLaunchKernelGGL((ln_act_fwd_kernel<N, G>), grid, dim3(16 * G), 0, st, X, x_bs, gam, bet, Y, y_bs, stats, C, L, act)
+  LN_DISPATCH(false, C, L, CALL);
 #undef CALL
   return ssv_check_launch("ln_act_fwd");
 }
@@ -382,8 +396,8 @@ int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs
                           const float* bet, float* dX, long dx_bs, float* part, float* pgrads /* [3][C] */, int B, int C,
                           int L, int act, hipStream_t st) {
   dim3 grid(ssv_cdiv(L, 16), B);
-#define CALL(N) hipLaunchKernelGGL(ln_act_bwd_kernel<N>, grid, dim3(256), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, C, L, act)
-  LN_DISPATCH(C, CALL);
+#define CALL(N, G) hipLaunchKernelGGL((ln_act_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, C, L, act)
+  LN_DISPATCH(true, C, L, CALL);
 #undef CALL
   SSV_TRY(ssv_check_launch("ln_act_bwd"));
   return reduce_partials(part, pgrads, 3 * C, (int)(grid.x * grid.y), st);
