@@ -181,31 +181,40 @@ def adversarial_cycle_ms(kind, batch, dev, cycles=3):
 
 
 def kernel_roofline(dev):
-    """Average duration of the dominant kernel -- the k=3 dilated Conv1d implicit GEMM (gemm_nn_kernel)
-    at its most frequent launch shape in the step: highwayConv C=256 (M=2C=512), L=325, B=32 -- timed
-    with HIP events on the launch stream.  Algorithmic FLOPs per launch = 2*B*L*(2C)*C*k."""
+    """Average duration of the dominant kernel -- the k=3 dilated Conv1d implicit GEMM (gemm_nn_bf3_kernel / gemm_nn_kernel)
+    at its most frequent launch shape in the step: highwayConv C=256 (M=2C=512), L=325, B=32 -- timed with HIP events
+    on the launch stream, launched the way the training step launches it: weights resident in pre-split form (so the
+    timed region holds this kernel only) and every launch on its own activation tensors (20 rotating input/output sets,
+    640 MB > the 256 MB Infinity Cache), because in the step each layer reads and writes tensors of its own.
+    Algorithmic FLOPs per launch = 2*B*L*(2C)*C*k."""
     import ctypes
-    from spoofsv_amd import _lib
+    from spoofsv_amd import _lib, resident
     B, C, L, k = 32, 256, 325, 3
-    x = torch.randn(B, C, L, device=dev)
+    nset = 20
+    xs = [torch.randn(B, C, L, device=dev) for _ in range(nset)]
+    ys = [torch.empty(B, 2 * C, L, device=dev) for _ in range(nset)]
     w = torch.randn(2 * C, C, k, device=dev) * 0.05
     bias = torch.randn(2 * C, device=dev)
-    y = torch.empty(B, 2 * C, L, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rw = resident.ResidentWeights([w])
+    rw.refresh(st)
+    wp = resident.lookup(w)
     nb = _lib.query("ssv_conv1d_fwd_workspace", C, 2 * C, k)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    run = lambda: _lib.call("ssv_conv1d_fwd", P(x), C * L, P(w), None, P(bias), None, P(y), 2 * C * L, B, C, 2 * C, L, k, 1, 1, P(ws), nb, st)
-    for _ in range(5):
-        run()
-    reps = 50
+    run = lambda i: _lib.call("ssv_conv1d_fwd", P(xs[i]), C * L, P(w), wp, P(bias), None, P(ys[i]), 2 * C * L, B, C, 2 * C, L, k, 1, 1,
+                              P(ws), nb, st)
+    for i in range(nset):
+        run(i)
+    reps = 3 * nset
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        run()
+    for i in range(reps):
+        run(i % nset)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
+    resident.invalidate([w])
     flops = 2.0 * B * L * (2 * C) * C * k
     bytes_alg = 4.0 * (B * C * L + B * 2 * C * L + 2 * C * C * k + 2 * C)
     ach = flops / (ms * 1e-3) / 1e12
@@ -213,15 +222,15 @@ def kernel_roofline(dev):
     _lib.lib().ssv_set_precision(1 if split else 0)   # ... and restore it
     # split-bf16 mode executes 3 bf16 MFMAs per algorithmic fp32 product: the roof for ALGORITHMIC flops is peak/3
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-    name = "gemm_nn_bf3_kernel<KT=3> (split-bf16 MFMA, 3 bf16 MFMAs per fp32 product)" if split else "gemm_nn_kernel<KT=3> (fp32 MFMA)"
+    name = "gemm_nn_bf3_kernel<3,1,7,0> (split-bf16 MFMA, 3 bf16 MFMAs per fp32 product)" if split else "gemm_nn_kernel<KT=3> (fp32 MFMA)"
     return {"bound": "mfma", "kernel": name + ", dilated Conv1d fwd B=32 C=256->512 L=325",
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "peak_note": "bf16 dense 2500 TFLOP/s / 3" if split else "fp32-input MFMA dense",
             "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
             "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4),
             # PMC: FETCH_SIZE + WRITE_SIZE per launch of this kernel instantiation, separate rocprofv3 --pmc passes (not collected live)
-            "traffic": (47531.0 + 20869.7) * 1024 if split else (45959.9 + 20878.8) * 1024,
-            "traffic_source": "profiles/round1_bench_kernel_stats_v3_final.txt" if split else "profiles/round1_bench_kernel_stats_v1_fp32.txt"}
+            "traffic": (13117.1 + 20839.8) * 1024 if split else (45959.9 + 20878.8) * 1024,
+            "traffic_source": "profiles/round1_bench_kernel_stats_v4.txt" if split else "profiles/round1_bench_kernel_stats_v1_fp32.txt"}
 
 
 def cpu_baseline():
