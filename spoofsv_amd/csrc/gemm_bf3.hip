@@ -532,7 +532,10 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
     }
     // measured (tools/sweep_nn_tiles.py): the wide workgroup wins for kernel-size-1 convolutions over long sequences
     // (SSRN's 513-channel layers: 150 -> 205 TFLOP/s); the k=3 layers are as fast or faster on the 4-wave kernel.
-    if (KT == 1 && !e && !g.epi && !g.perm_h && g.N >= 1024 && g.M >= 256 && g.Kc >= 256) return launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
+    // 128 x 192 tiles (8 waves) are the faster wide shape (513 -> 512 channels: 104 -> 87 us, 256 -> 512: 60 -> 49 us) except
+    // when M leaves a nearly empty last row tile (M = 513), where the 16-wave 128 x 448 tile loses less (tools/sweep_wide.py)
+    if (KT == 1 && !e && !g.epi && !g.perm_h && g.N >= 1024 && g.M >= 256 && g.Kc >= 256)
+      return (g.M % 128 == 0) ? launch_nnbw<KT, 2, 6, 2>(g, st, smin, span) : launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
   }
   static const int nts[] = {7, 6, 4, 2};
   int wm = 2, nt = 7;
@@ -543,7 +546,11 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   }
   if (!forced) {
     double best = 1e30;
-    for (int a = 1; a <= 2; ++a)
+    // k=1 products carry a third of the MFMAs per weight byte: 64-row tiles (twice the weight traffic per MAC) lose at every
+    // conv shape measured (256 -> 256, L=650: 28 us on 64 x 112 tiles, 20 us on 128 x 64); only the single-"batch" LSTM
+    // product, short of workgroups, still wants them
+    const int a_min = (KT == 1 && g.B > 1 && g.M > 64) ? 2 : 1;
+    for (int a = a_min; a <= 2; ++a)
       for (int c : nts) {
         const long tiles = (long)ssv_cdiv(g.M, 64 * a) * ssv_cdiv(g.N, 16 * c) * g.B;
         const double per_tile = (double)a * c + 0.9 * a + 0.25 * c + 1.0;
