@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   constexpr int WX = ((BN + HALO + 15) / 16) * 16;         // staged columns, plane = WX*16 B = multiple of 256 B
   constexpr int X_SLOTS = 4 * WX;
   constexpr int NX = (X_SLOTS + 255) / 256;
-  __shared__ uint4 lds[2 * X_SLOTS];
-  uint4* Xh = lds;
-  uint4* Xl = lds + X_SLOTS;
+  // two images of the staged input tile: the MFMAs of chunk c read image c & 1 while chunk c+1 is split into the other
+  // one -- one barrier per chunk, and the split (VALU) runs under the MFMAs instead of between two barriers
+  __shared__ uint4 lds[2][2 * X_SLOTS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);   // see ssv_xcd_order
@@ -197,6 +197,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     }
   };
   auto commitX = [&](int ch) {
+    uint4* Xh = lds[ch & 1];
+    uint4* Xl = lds[ch & 1] + X_SLOTS;
     const bool last_ragged = ragged && ch + 1 == nchunks;
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
@@ -222,7 +224,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
 #pragma unroll
   for (int j = 0; j < KT; ++j) offj[j] = p.shift[j] - smin;
 
-  auto tap = [&](int set, int j) {
+  auto tap = [&](int set, int j, int ch) {
+    const uint4* Xh = lds[ch & 1];
+    const uint4* Xl = lds[ch & 1] + X_SLOTS;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int xs = kq * WX + t * 16 + nq + offj[j];
@@ -239,38 +243,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     }
   };
 
+  // Prologue: chunk 0 staged, chunk 1 in flight.  Chunk c: MFMAs on image c & 1 (weight fragments of chunk c+1 re-loaded
+  // tap by tap behind them), then chunk c+1 is split into the other image and the loads of chunk c+2 are issued.
   if constexpr (KT == 1) {
     loadA(0, 0, 0);
     prefetchX(0);
+    commitX(0);
+    if (nchunks > 1) { prefetchX(1); loadA(1, 0, 1); }
+    __syncthreads();
     for (int ch = 0; ch < nchunks; ch += 2) {
-      __syncthreads();
-      commitX(ch);
-      __syncthreads();
-      if (ch + 1 < nchunks) { prefetchX(ch + 1); loadA(1, 0, ch + 1); }
-      tap(0, 0);
+      tap(0, 0, ch);
       if (ch + 1 >= nchunks) break;
-      __syncthreads();
       commitX(ch + 1);
-      __syncthreads();
       if (ch + 2 < nchunks) { prefetchX(ch + 2); loadA(0, 0, ch + 2); }
-      tap(1, 0);
+      __syncthreads();
+      tap(1, 0, ch + 1);
+      if (ch + 2 < nchunks) {
+        commitX(ch + 2);
+        if (ch + 3 < nchunks) { prefetchX(ch + 3); loadA(1, 0, ch + 3); }
+      }
+      __syncthreads();
     }
   } else {
 #pragma unroll
     for (int j = 0; j < KT; ++j) loadA(0, j, 0);
     prefetchX(0);
+    commitX(0);
+    if (nchunks > 1) prefetchX(1);
+    __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
-      __syncthreads();
-      commitX(ch);
-      __syncthreads();
       const bool more = ch + 1 < nchunks;
-      if (more) prefetchX(ch + 1);
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
-        tap(0, j);
+        tap(0, j, ch);
         __builtin_amdgcn_sched_barrier(0);      // keep the re-load behind this tap's MFMAs, and later taps' LDS reads behind it
         if (more) loadA(0, j, ch + 1);
       }
+      if (more) {
+        commitX(ch + 1);
+        if (ch + 2 < nchunks) prefetchX(ch + 2);
+      }
+      __syncthreads();
     }
   }
 

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Time the free-running synthesis loop (reference: synthesize.py:103-109; config 2 of SURVEY.md 8d): 1 + 325 melSyn eval
+steps, each re-encoding the whole prefix as the reference does, then SSRN.  Reports mel frames per second."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spoofsv_amd import harness, train
+from spoofsv_amd.tts import melSyn, SSRN
+dev = "cuda:0"
+torch.manual_seed(1234)
+m = melSyn(34, True, 200); m.apply(train.init_weights); m = m.to(dev).eval()
+s = SSRN(80, 513, 256); s.apply(train.init_weights); s = s.to(dev).eval()
+for B, N in ((1, 43), (8, 43), (32, 186)):
+    text = torch.randint(2, 33, (B, 1, N), device=dev); text[:, :, -1] = 1
+    spk = 0.04 + 0.05 * torch.rand(B, 200, 1, device=dev)
+    frames = 326
+    with torch.no_grad():
+        harness._free_run(m, text, spk, 8, 80)              # warm-up
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        Y, A = harness._free_run(m, text, spk, frames, 80)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        lin = s(Y)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("B=%d N=%d: text2mel %d steps %.3f s (%.2f ms/step), ssrn %.1f ms -> %.0f mel frames/s" %
+          (B, N, frames, t1 - t0, (t1 - t0) / frames * 1e3, (t2 - t1) * 1e3, B * frames / (t2 - t0)), flush=True)
