@@ -249,13 +249,29 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const ssv_adam_chunk* _
   const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
   const float step_size = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   const ssv_adam_chunk ch = chunks[blockIdx.x];
-  for (long i = threadIdx.x; i < ch.n; i += 256) {
-    const float g = ch.g[i];
-    const float m = b1 * ch.m[i] + (1.f - b1) * g;
-    const float v = b2 * ch.v[i] + (1.f - b2) * g * g;
-    ch.m[i] = m; ch.v[i] = v;
-    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
-    ch.p[i] -= step_size * (m / denom);
+  auto upd = [&](float& p, float g, float& m, float& v) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+  };
+  long i0 = 0;
+  // 16-byte accesses when the four pointers allow it (28 B/param of pure streaming: this kernel is HBM-bound)
+  if ((((uintptr_t)ch.p | (uintptr_t)ch.g | (uintptr_t)ch.m | (uintptr_t)ch.v) & 15) == 0) {
+    const long n4 = ch.n >> 2;
+    float4* __restrict__ p4 = (float4*)ch.p; const float4* __restrict__ g4 = (const float4*)ch.g;
+    float4* __restrict__ m4 = (float4*)ch.m; float4* __restrict__ v4 = (float4*)ch.v;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      float4 p = p4[i], m = m4[i], v = v4[i];
+      const float4 g = g4[i];
+      upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+      p4[i] = p; m4[i] = m; v4[i] = v;
+    }
+    i0 = n4 << 2;
+  }
+  for (long i = i0 + threadIdx.x; i < ch.n; i += 256) {
+    float p = ch.p[i], m = ch.m[i], v = ch.v[i];
+    upd(p, ch.g[i], m, v);
+    ch.p[i] = p; ch.m[i] = m; ch.v[i] = v;
   }
 }
 __global__ void step_inc_kernel(int* step_dev) { step_dev[0] += 1; }
