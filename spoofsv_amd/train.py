@@ -117,14 +117,31 @@ class FusedAdam(torch.optim.Optimizer):
             step_dev = None
             if self.capturable:
                 if self._step_dev is None:
-                    self._step_dev = torch.zeros(1, dtype=torch.int32, device=plist[0].device)
+                    self._step_dev = torch.full((1,), self._steps - 1, dtype=torch.int32, device=plist[0].device)
                 step_dev = _p(self._step_dev)
             _lib.call("ssv_adam_multi", _p(self._table), self._nchunks, float(group["lr"]), float(b1), float(b2),
                       float(group["eps"]), self._steps, step_dev, _stream())
-            for p in plist:
-                self.state[p]["step"] += 1
         self.refresh_resident_weights()
         return loss
+
+    # The per-parameter ``step`` entries of torch's Adam state are only materialised when the state is exported (one
+    # host-side tensor op per parameter per iteration would cost more host time than the whole launch), and read back
+    # on import so that a resumed run continues the bias correction where the checkpoint left it.
+    def state_dict(self):
+        if self._step_dev is not None:
+            self._steps = int(self._step_dev.item())       # graph replays advance only the device counter
+        for st in self.state.values():
+            if "exp_avg" in st:
+                st["step"] = torch.tensor(float(self._steps))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = [int(st["step"]) for st in self.state.values() if "step" in st]
+        self._steps = max(steps) if steps else 0
+        if self._step_dev is not None:
+            self._step_dev.fill_(self._steps)
+        self._key = None                      # moment tensors were replaced: rebuild the chunk table
 
 
 # --------------------------------------------------------------------------------------------- data

@@ -277,3 +277,37 @@ def test_resident_weights_match_per_call_split_and_follow_weight_updates():
     ref = run()
     for a, b in zip(after, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("capturable", [False, True])
+def test_fused_adam_state_roundtrip_continues_bias_correction(capturable):
+    """A FusedAdam restored from its state_dict takes exactly the step the original would have taken next
+    (step count, moments), and its state_dict carries torch-Adam style ``step`` entries."""
+    from spoofsv_amd import train
+    torch.manual_seed(11)
+    p0 = torch.randn(1000, device="cuda")
+    grads = [torch.randn(1000, device="cuda") for _ in range(5)]
+
+    def make():
+        p = torch.nn.Parameter(p0.clone())
+        return p, train.FusedAdam([p], 1e-2, (0.5, 0.9), 1e-6, capturable=capturable)
+
+    pa, oa = make()
+    for g in grads:
+        pa.grad = g.clone()
+        oa.step()
+    pb, ob = make()
+    for g in grads[:3]:
+        pb.grad = g.clone()
+        ob.step()
+    sd = ob.state_dict()
+    assert float(sd["state"][0]["step"]) == 3.0
+    pc = torch.nn.Parameter(pb.detach().clone())
+    oc = train.FusedAdam([pc], 1e-2, (0.5, 0.9), 1e-6, capturable=capturable)
+    oc.load_state_dict(sd)
+    for g in grads[3:]:
+        pc.grad = g.clone()
+        oc.step()
+    assert torch.equal(pc, pa)
+    assert float(oc.state_dict()["state"][0]["step"]) == 5.0
