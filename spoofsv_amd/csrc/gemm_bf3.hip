@@ -572,7 +572,10 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
         // 3072 x 880 x 768 runs 2x faster on 672 small tiles than on 192 large ones); k=3 chunks are long enough.
         const long n = (tiles + 255) / 256;
         const double overlap = (KT == 1) ? (n >= 3 ? 1.8 : (n == 2 ? 1.5 : 1.0)) : 1.0;
-        const double cost = (double)n * per_tile / overlap;
+        // a single workgroup per CU (4 waves) cannot cover its own load latencies: measured +10 % on the data-gradient
+        // shapes that fit in 256 large tiles (C=256, L=325: 45 -> 41 us on 768 tiles of 64 x 64)
+        const double lonely = (tiles <= 256) ? 1.35 : 1.0;
+        const double cost = (double)n * per_tile * lonely / overlap;
         if (cost < best) { best = cost; wm = a; nt = c; }
       }
   }
