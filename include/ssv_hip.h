@@ -149,8 +149,9 @@ int ssv_attention_apply(const float* v, long kv_bs, const float* a, int a_T, flo
 /* ---- ConvTranspose1d(kernel 2, stride 2) ----------------------------------------------------------
  * Replaces upsampling.deconv, models/TTSModel.py:309,314.  w: (Cin, Cout, 2) as nn.ConvTranspose1d.
  * y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t). */
+size_t ssv_deconv1d_k2s2_fwd_workspace(int Cin, int Cout);   /* pre-split weights of both taps */
 int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
-                          int B, int Cin, int Cout, int L, ssv_stream_t stream);
+                          int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout);
 int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w,
                           float* dx, long dx_bs, float* dw, float* dbias,

@@ -93,6 +93,20 @@ static inline int pad32(int n) { return (n + 31) & ~31; }
 static inline size_t split_bytes(int rows, int K, int k) { return align256((size_t)k * ((rows + 15) / 16 * 16) * pad32(K) * sizeof(unsigned short)); }
 static inline bool use_bf3(int B, int L, int Cin, int Cout) { return ssv_precision() == 1 && (long)B * L >= 128 && Cin >= 8 && Cout >= 16; }
 
+static GemmNNB nnb_zero() {
+  GemmNNB g;
+  g.Ahi = g.Alo = nullptr; g.Kpad = 0;
+  g.X = nullptr; g.sxb = g.sxc = 0; g.Lx = 0;
+  g.C = nullptr; g.scb = g.scm = 0;
+  g.bias = g.bias_b = nullptr; g.sbb = 0;
+  g.R = nullptr; g.srb = g.srm = 0;
+  g.M = g.N = g.Kc = 0; g.KT = 1; g.B = 1;
+  g.shift[0] = g.shift[1] = g.shift[2] = 0;
+  g.sxn = g.scn = 1;
+  g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
+  return g;
+}
+
 // y = conv(x, w): shared by forward (rows = Cout) and data gradient (rows = Cin, transposed weights, negated shifts)
 // `packed`: resident pre-split planes of this operand (hi plane, then lo plane), or null -> split into ws here.
 static int conv_nn(const float* x, long x_bs, const float* w, const void* packed, long w_sm, long w_sk, const float* bias, const float* bias_b,
@@ -103,8 +117,7 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
     const unsigned short* hi = (const unsigned short*)(packed ? packed : ws);
     const unsigned short* lo = (const unsigned short*)((const char*)hi + split_bytes(M, K, k));
     if (!packed) SSV_TRY(ssv_launch_pack_split(w, (void*)hi, (void*)lo, M, K, Kpad, k, w_sm, w_sk, 1, 0, st));
-    GemmNNB g;
-    g.perm_h = 0; g.epi = 0; g.first = 0; g.cstate = nullptr;
+    GemmNNB g = nnb_zero();
     g.Ahi = hi; g.Alo = lo; g.Kpad = Kpad;
     g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
     g.C = y; g.scb = y_bs; g.scm = L;
@@ -366,9 +379,32 @@ extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float*
 }
 
 // ---- ConvTranspose1d(k=2, s=2) -----------------------------------------------------------------------------
+// Split-bf16 path of the two deconvolution halves: both taps' weights are split by ONE pack launch (tap-major planes);
+// tap j is a k=1 product whose output (forward) or input (data gradient) columns have stride 2.
+static size_t deconv_pack_bytes(int rows, int K) { return 2 * split_bytes(rows, K, 2); }
+extern "C" size_t ssv_deconv1d_k2s2_fwd_workspace(int Cin, int Cout) { return deconv_pack_bytes(Cout, Cin); }
 extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
-                                     int B, int Cin, int Cout, int L, ssv_stream_t stream) {
+                                     int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "deconv1d_k2s2_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (use_bf3(B, L, Cin, Cout)) {
+    SSV_CHECK(ws && ws_bytes >= ssv_deconv1d_k2s2_fwd_workspace(Cin, Cout), SSV_BAD_SHAPE, "deconv1d_k2s2_fwd: workspace too small");
+    const int Kpad = pad32(Cin);
+    const size_t tap = (size_t)((Cout + 15) / 16 * 16) * Kpad;                    // elements of one tap's plane
+    unsigned short* hi = (unsigned short*)ws;
+    unsigned short* lo = (unsigned short*)((char*)ws + split_bytes(Cout, Cin, 2));
+    SSV_TRY(ssv_launch_pack_split(w, hi, lo, Cout, Cin, Kpad, 2, 2, (long)2 * Cout, 1, 0, st));   // (m=o, k=c, tap j) = w[c][o][j]
+    for (int j = 0; j < 2; ++j) {               // y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t)
+      GemmNNB g = nnb_zero();
+      g.Ahi = hi + j * tap; g.Alo = lo + j * tap; g.Kpad = Kpad;
+      g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
+      g.C = y + j; g.scb = y_bs; g.scm = (long)2 * L; g.scn = 2;
+      g.bias = bias;
+      g.M = Cout; g.N = L; g.Kc = Cin; g.B = B;
+      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+    }
+    return 0;
+  }
   for (int j = 0; j < 2; ++j) {               // y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t)
     GemmNN g = nn_zero();
     g.A = w + j; g.sam = 2; g.sac = (long)2 * Cout;
@@ -376,13 +412,14 @@ extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* w, 
     g.C = y + j; g.scb = y_bs; g.scm = (long)2 * L; g.scn = 2;
     g.bias = bias;
     g.M = Cout; g.N = L; g.Kc = Cin; g.B = B;
-    SSV_TRY(ssv_launch_gemm_nn(g, (hipStream_t)stream));
+    SSV_TRY(ssv_launch_gemm_nn(g, st));
   }
   return 0;
 }
 static int deconv_splits(int B, int Cin, int Cout) { return dw_splits(B, Cin, Cout, 1); }
 extern "C" size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout) {
-  return align256((size_t)deconv_splits(B, Cin, Cout) * Cin * Cout * 2 * sizeof(float)) + align256((size_t)B * Cout * sizeof(float));
+  return align256((size_t)deconv_splits(B, Cin, Cout) * Cin * Cout * 2 * sizeof(float)) + align256((size_t)B * Cout * sizeof(float)) +
+         deconv_pack_bytes(Cin, Cout);
 }
 extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, float* dx, long dx_bs,
                                      float* dw, float* dbias, int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
@@ -393,14 +430,30 @@ extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* x
   const long n = (long)Cin * Cout * 2;
   float* slabs = (float*)ws;
   float* rs = (float*)((char*)ws + align256((size_t)Z * n * sizeof(float)));
+  const bool bf3 = use_bf3(B, L, Cout, Cin);
+  unsigned short* hi = (unsigned short*)((char*)rs + align256((size_t)B * Cout * sizeof(float)));
+  unsigned short* lo = (unsigned short*)((char*)hi + split_bytes(Cin, Cout, 2));
+  const int Kpad = pad32(Cout);
+  const size_t tap = (size_t)((Cin + 15) / 16 * 16) * Kpad;
+  if (bf3) SSV_TRY(ssv_launch_pack_split(w, hi, lo, Cin, Cout, Kpad, 2, (long)2 * Cout, 2, 1, 0, st));   // (m=c, k=o, tap j) = w[c][o][j]
   for (int j = 0; j < 2; ++j) {
-    GemmNN g = nn_zero();                      // dx(b,c,t) (+)= sum_o w[c,o,j] dy(b,o,2t+j)
-    g.A = w + j; g.sam = (long)2 * Cout; g.sac = 2;
-    g.X = dy + j; g.sxb = dy_bs; g.sxc = (long)2 * L; g.sxn = 2; g.Lx = L;
-    g.C = dx; g.scb = dx_bs; g.scm = L;
-    if (j == 1) { g.R = dx; g.srb = dx_bs; g.srm = L; }
-    g.M = Cin; g.N = L; g.Kc = Cout; g.B = B;
-    SSV_TRY(ssv_launch_gemm_nn(g, st));
+    if (bf3) {                                 // dx(b,c,t) (+)= sum_o w[c,o,j] dy(b,o,2t+j)
+      GemmNNB g = nnb_zero();
+      g.Ahi = hi + j * tap; g.Alo = lo + j * tap; g.Kpad = Kpad;
+      g.X = dy + j; g.sxb = dy_bs; g.sxc = (long)2 * L; g.sxn = 2; g.Lx = L;
+      g.C = dx; g.scb = dx_bs; g.scm = L;
+      if (j == 1) { g.R = dx; g.srb = dx_bs; g.srm = L; }
+      g.M = Cin; g.N = L; g.Kc = Cout; g.B = B;
+      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+    } else {
+      GemmNN g = nn_zero();
+      g.A = w + j; g.sam = (long)2 * Cout; g.sac = 2;
+      g.X = dy + j; g.sxb = dy_bs; g.sxc = (long)2 * L; g.sxn = 2; g.Lx = L;
+      g.C = dx; g.scb = dx_bs; g.scm = L;
+      if (j == 1) { g.R = dx; g.srb = dx_bs; g.srm = L; }
+      g.M = Cin; g.N = L; g.Kc = Cout; g.B = B;
+      SSV_TRY(ssv_launch_gemm_nn(g, st));
+    }
     GemmNT t = nt_zero();                      // dw[c,o,j] = sum_{b,t} x(b,c,t) dy(b,o,2t+j)
     t.A = x; t.sab = x_bs; t.sam = L; t.La = L;
     t.X = dy + j; t.sxb = dy_bs; t.sxc = (long)2 * L; t.sxn = 2; t.Lx = L;
@@ -487,7 +540,7 @@ extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const floa
       unsigned short* hh_lo = (unsigned short*)(base + s.whh + split_bytes(4 * H, H, 1));
       SSV_TRY(ssv_launch_pack_split(w_ih[l], ih_hi, ih_lo, 4 * H, Fin, pad32(Fin), 1, Fin, 1, 1, H, st));
       SSV_TRY(ssv_launch_pack_split(w_hh[l], hh_hi, hh_lo, 4 * H, H, pad32(H), 1, H, 1, 1, H, st));
-      GemmNNB g;
+      GemmNNB g = nnb_zero();
       g.X = in; g.sxb = (long)Fin * Bn; g.sxc = Bn; g.Lx = Bn;
       g.bias_b = nullptr; g.sbb = 0; g.R = nullptr; g.srb = 0; g.srm = Bn;
       g.M = 4 * H; g.N = Bn; g.KT = 1;

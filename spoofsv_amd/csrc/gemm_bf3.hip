@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     const int kg = e / WX, col = e % WX;
     const int gcol = n0 + smin + col;
     cvs[r] = e < X_SLOTS && col < W && gcol >= 0 && gcol < p.Lx;
-    voff[r] = (unsigned)((e < X_SLOTS ? 8 * kg : 0) * Lrow + min(max(gcol, 0), p.Lx - 1));
+    voff[r] = (unsigned)((e < X_SLOTS ? 8 * kg : 0) * Lrow + min(max(gcol, 0), p.Lx - 1) * p.sxn);
   }
   const bool ragged = (p.Kc & 31) != 0;
   auto prefetchX = [&](int ch) {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
         if (gn >= p.N) continue;
         float v = acc[i][t][r] + add;
         if (Rb) v += Rb[(long)gm * p.srm + gn];
-        Cb[(long)gm * p.scm + gn] = v;
+        Cb[(long)gm * p.scm + (long)gn * p.scn] = v;
       }
     }
 }
@@ -538,7 +538,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   {
     int wm = 0, nt = 0, nwn = 0;
     const char* e = getenv("SSV_NNB_WIDE");
-    if (e && sscanf(e, "%d,%d,%d", &wm, &nt, &nwn) == 3) {
+    if (e && g.sxn == 1 && g.scn == 1 && sscanf(e, "%d,%d,%d", &wm, &nt, &nwn) == 3) {
 #define SSV_W(A_, C_, D_) if (wm == A_ && nt == C_ && nwn == D_) return launch_nnbw<KT, A_, C_, D_>(g, st, smin, span)
       SSV_W(2, 7, 3); SSV_W(1, 7, 3); SSV_W(2, 7, 2); SSV_W(2, 6, 2); SSV_W(1, 6, 2); SSV_W(2, 4, 4); SSV_W(2, 7, 4);
 #undef SSV_W
@@ -547,7 +547,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
     // (SSRN's 513-channel layers: 150 -> 205 TFLOP/s); the k=3 layers are as fast or faster on the 4-wave kernel.
     // 128 x 192 tiles (8 waves) are the faster wide shape (513 -> 512 channels: 104 -> 87 us, 256 -> 512: 60 -> 49 us) except
     // when M leaves a nearly empty last row tile (M = 513), where the 16-wave 128 x 448 tile loses less (tools/sweep_wide.py)
-    if (KT == 1 && !e && !g.epi && !g.perm_h && g.N >= 1024 && g.M >= 256 && g.Kc >= 256)
+    if (KT == 1 && !e && !g.epi && !g.perm_h && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256)
       return (g.M % 128 == 0) ? launch_nnbw<KT, 2, 6, 2>(g, st, smin, span) : launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
   }
   static const int nts[] = {7, 6, 4, 2};
@@ -590,6 +590,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(g.M > 0 && g.N > 0 && g.Kc > 0 && g.B > 0 && g.Kpad % 32 == 0 && g.Kpad >= g.Kc, SSV_BAD_SHAPE, "gemm_nn_bf3: bad problem");
   SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nn_bf3: kernel_size %d", g.KT);
   SSV_CHECK(g.B <= 65535, SSV_UNSUPPORTED, "gemm_nn_bf3: batch %d exceeds grid.y", g.B);
+  SSV_CHECK(g.sxn >= 1 && g.scn >= 1 && (g.scn == 1 || (!g.R && !g.epi)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad column strides");
   SSV_CHECK(!g.epi || (g.KT == 1 && g.perm_h > 0 && g.M == 4 * g.perm_h && g.cstate && g.B == 1), SSV_BAD_SHAPE, "gemm_nn_bf3: bad LSTM epilogue request");
   int smin = g.shift[0], smax = g.shift[0];
   for (int j = 1; j < g.KT; ++j) { smin = g.shift[j] < smin ? g.shift[j] : smin; smax = g.shift[j] > smax ? g.shift[j] : smax; }

@@ -56,6 +56,7 @@ struct GemmNNB {
   const float* R; long srb, srm;
   int M, N, Kc, KT, B;
   int shift[3];
+  int sxn, scn;            // column strides of X and C (1 everywhere except the stride-2 deconvolution halves; R needs scn == 1)
   // LSTM support.  perm_h = H > 0: output row m is gate (m % 4) of hidden unit (m / 4), i.e. row (m % 4) * H + m / 4 of
   // the torch layout -- the weights were packed in that order and the bias vectors are indexed through the same map.
   // epi = 1: fused cell epilogue -- the 4 accumulator rows of a lane are the (i, f, g, o) pre-activations of one unit;

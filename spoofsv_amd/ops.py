@@ -353,7 +353,9 @@ class DeconvK2S2Fn(torch.autograd.Function):
         if w.shape[0] != Cin or w.shape[2] != 2:
             raise RuntimeError("deconv: weight %s does not match input channels %d / kernel 2" % (tuple(w.shape), Cin))
         y = torch.empty((B, Cout, 2 * L), dtype=_F32, device=x.device)
-        _lib.call("ssv_deconv1d_k2s2_fwd", _p(x), xbs, _p(w), _p(bias), _p(y), Cout * 2 * L, B, Cin, Cout, L, _stream())
+        nb = _lib.query("ssv_deconv1d_k2s2_fwd_workspace", Cin, Cout)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_deconv1d_k2s2_fwd", _p(x), xbs, _p(w), _p(bias), _p(y), Cout * 2 * L, B, Cin, Cout, L, _p(ws), nb, _stream())
         if _needs_grad(ctx):
             ctx.save_for_backward(x, w)
         return y

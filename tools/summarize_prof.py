@@ -16,9 +16,24 @@ def counters(path, name):
         k = r["Kernel_Name"]
         acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     return acc
+def by_shape(path, top=22):
+    """Kernel time per (kernel, grid): separates the launch shapes that share one template instantiation."""
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        k = (r["Kernel_Name"][:60], "%sx%sx%s" % (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"]))
+        acc[k][0] += 1
+        acc[k][1] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
+    tot = sum(v[1] for v in acc.values())
+    out = ["\nper launch shape (grid in threads):", "%7s %7s %11s  %s" % ("time%", "calls", "avg_us", "kernel  grid")]
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:top]:
+        out.append("%6.2f%% %7d %11.1f  %s  %s" % (100 * v[1] / tot, v[0], v[1] / v[0], k[0], k[1]))
+    return "\n".join(out)
 if __name__ == "__main__":
     d = sys.argv[1]
     print(stats(glob.glob(d + "/*/*kernel_stats.csv")[0]))
+    tr = glob.glob(d + "/*/*kernel_trace.csv")
+    if tr:
+        print(by_shape(tr[0]))
     if len(sys.argv) > 3:
         f = counters(glob.glob(sys.argv[2] + "/*/*counter_collection.csv")[0], "FETCH_SIZE")
         w = counters(glob.glob(sys.argv[3] + "/*/*counter_collection.csv")[0], "WRITE_SIZE")
