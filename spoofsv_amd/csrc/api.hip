@@ -104,6 +104,7 @@ static GemmNNB nnb_zero() {
   g.shift[0] = g.shift[1] = g.shift[2] = 0;
   g.sxn = g.scn = 1;
   g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
+  g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0;
   return g;
 }
 
@@ -497,16 +498,111 @@ static int lstm_gemm_f32(const float* A, const float* X, long sxb, float* C, lon
   g.M = M; g.N = Bn; g.Kc = K; g.B = nb;
   return ssv_launch_gemm_nn(g, st);
 }
-extern "C" size_t ssv_lstm_fwd_workspace(int Bn, int T, int F, int H, int layers) { (void)layers; return lstm_ws(Bn, T, F, H).total; }
+#define SSV_HIP(expr) do { hipError_t _he = (expr); if (_he != hipSuccess) { ssv_fail(0, "%s: %s", #expr, hipGetErrorString(_he)); return -(int)_he; } } while (0)
+// Wavefront (split-bf16) layout: h of every layer lives in a 2-frame ring, weights of layer l >= 1 are [W_ih | W_hh] side by side.
+struct LstmWave { size_t xt, xp, out, c, bias, ih0, hh0, comb, comb_stride, total; };
+static LstmWave lstm_wave_ws(int Bn, int T, int F, int H, int layers) {
+  LstmWave s;
+  s.xt = 0;
+  s.xp = s.xt + align256((size_t)T * F * Bn * sizeof(float));
+  s.out = s.xp + align256((size_t)T * 4 * H * Bn * sizeof(float));
+  s.c = s.out + align256((size_t)layers * 2 * H * Bn * sizeof(float));
+  s.bias = s.c + align256((size_t)layers * H * Bn * sizeof(float));
+  s.ih0 = s.bias + align256((size_t)layers * 8 * H * sizeof(float));
+  s.hh0 = s.ih0 + 2 * split_bytes(4 * H, F, 1);
+  s.comb = s.hh0 + 2 * split_bytes(4 * H, H, 1);
+  s.comb_stride = 2 * split_bytes(4 * H, 2 * H, 1);
+  s.total = s.comb + (size_t)(layers > 1 ? layers - 1 : 0) * s.comb_stride;
+  return s;
+}
+static bool lstm_wave_ok(int Bn, int H) { return Bn >= 64 && H >= 32 && H % 32 == 0; }
+extern "C" size_t ssv_lstm_fwd_workspace(int Bn, int T, int F, int H, int layers) {
+  return zmax(lstm_ws(Bn, T, F, H).total, lstm_wave_ws(Bn, T, F, H, layers).total);
+}
+// LSTM forward as a wavefront over (layer, frame): in step s layer l computes frame s - l, so the layers' recurrent products
+// (each too small to fill the chip: 672 workgroups of 24 K-chunks) run side by side in ONE launch, and a layer's input
+// projection rides along as the first K segment of the same product instead of a separate pass over all frames.
+// T + layers - 1 steps of two launches (layer 0, whose input projection W_ih x_t is precomputed for all frames, and layers
+// 1.. batched over grid.y) instead of layers * T sequential products.
+static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                         const float* const* b_hh, float* h_last, int Bn, int T, int F, int H, int layers, char* base, hipStream_t st) {
+  const LstmWave s = lstm_wave_ws(Bn, T, F, H, layers);
+  float* xt = (float*)(base + s.xt);
+  float* xp = (float*)(base + s.xp);
+  float* out = (float*)(base + s.out);
+  float* cbuf = (float*)(base + s.c);
+  float* bias = (float*)(base + s.bias);
+  const long HN = (long)H * Bn;
+  SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));    // [T][F][Bn]
+  for (int l = 0; l < layers; ++l) {                              // biases side by side: [layer][b_ih (4H) | b_hh (4H)]
+    SSV_HIP(hipMemcpyAsync(bias + (long)l * 8 * H, b_ih[l], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+    SSV_HIP(hipMemcpyAsync(bias + (long)l * 8 * H + 4 * H, b_hh[l], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  // weights, rows gate-interleaved (row 4u + gate) so that the product can finish the cell in its epilogue
+  unsigned short* ih0_hi = (unsigned short*)(base + s.ih0);
+  unsigned short* ih0_lo = (unsigned short*)(base + s.ih0 + split_bytes(4 * H, F, 1));
+  unsigned short* hh0_hi = (unsigned short*)(base + s.hh0);
+  unsigned short* hh0_lo = (unsigned short*)(base + s.hh0 + split_bytes(4 * H, H, 1));
+  SSV_TRY(ssv_launch_pack_split(w_ih[0], ih0_hi, ih0_lo, 4 * H, F, pad32(F), 1, F, 1, 1, H, st));
+  SSV_TRY(ssv_launch_pack_split(w_hh[0], hh0_hi, hh0_lo, 4 * H, H, H, 1, H, 1, 1, H, st));
+  const int hch = H / 32;
+  for (int l = 1; l < layers; ++l) {
+    unsigned short* hi = (unsigned short*)(base + s.comb + (size_t)(l - 1) * s.comb_stride);
+    unsigned short* lo = (unsigned short*)((char*)hi + split_bytes(4 * H, 2 * H, 1));
+    SSV_TRY(ssv_launch_pack_split(w_ih[l], hi, lo, 4 * H, H, H, 1, H, 1, 1, H, st, 2 * hch, 0));
+    SSV_TRY(ssv_launch_pack_split(w_hh[l], hi, lo, 4 * H, H, H, 1, H, 1, 1, H, st, 2 * hch, hch));
+  }
+  // layer 0's input projection for every frame at once (biases are left to the cell): xp[t] = W_ih x_t
+  {
+    GemmNNB g = nnb_zero();
+    g.Ahi = ih0_hi; g.Alo = ih0_lo; g.Kpad = pad32(F); g.Kc = F;
+    g.X = xt; g.sxb = (long)F * Bn; g.sxc = Bn; g.Lx = Bn;
+    g.C = xp; g.scb = (long)4 * H * Bn; g.scm = Bn;
+    g.M = 4 * H; g.N = Bn; g.B = T; g.perm_h = H;
+    SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+  }
+  GemmNNB g = nnb_zero();
+  g.sxc = Bn; g.Lx = Bn; g.scm = Bn; g.srm = Bn;
+  g.M = 4 * H; g.N = Bn; g.perm_h = H; g.epi = 1; g.cstate = cbuf;
+  g.lstm_out = out; g.lstm_D = 2; g.sbb = (long)8 * H;
+  g.X = out; g.C = out;                        // placeholders: the kernel derives X, X2 and C from (layer, frame)
+  for (int step = 0; step < T + layers - 1; ++step) {
+    g.lstm_s = step;
+    if (step < T) {                            // layer 0: gates = W_hh h_{t-1} + xp[t] + b
+      g.Ahi = hh0_hi; g.Alo = hh0_lo; g.Kpad = H; g.Kc = H; g.sab = 0;
+      g.xsplit = 0; g.lstm_lo = 0; g.B = 1;
+      g.R = xp + (long)step * 4 * H * Bn;
+      g.bias = bias; g.bias_b = bias + 4 * H;
+      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+    }
+    const int lo = step - T + 1 > 1 ? step - T + 1 : 1, hi = step < layers - 1 ? step : layers - 1;
+    if (lo <= hi) {                            // layers lo..hi: gates = [W_ih | W_hh] [h^{l-1}_t ; h^l_{t-1}] + b
+      g.Ahi = (unsigned short*)(base + s.comb + (size_t)(lo - 1) * s.comb_stride);
+      g.Alo = (unsigned short*)((char*)g.Ahi + split_bytes(4 * H, 2 * H, 1));
+      g.sab = (long)(s.comb_stride / sizeof(unsigned short));
+      g.Kpad = 2 * H; g.Kc = 2 * H;
+      g.xsplit = hch; g.lstm_lo = lo; g.B = hi - lo + 1;
+      g.R = nullptr;
+      g.bias = bias + (long)lo * 8 * H; g.bias_b = g.bias + 4 * H;
+      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+    }
+  }
+  (void)HN;
+  return ssv_launch_transpose_out(out + ((long)(layers - 1) * 2 + (T - 1) % 2) * H * Bn, h_last, H, Bn, st);
+}
+
 extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                             const float* const* b_hh, float* h_last, int Bn, int T, int F, int H, int layers,
                             void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w_ih && w_hh && b_ih && b_hh && h_last && Bn > 0 && T > 0 && F > 0 && H > 0 && layers > 0, SSV_BAD_SHAPE, "lstm_fwd: bad argument");
   SSV_CHECK(T <= 65535, SSV_UNSUPPORTED, "lstm_fwd: T=%d exceeds grid.y", T);
   const LstmWs s = lstm_ws(Bn, T, F, H);
-  SSV_CHECK(ws && ws_bytes >= s.total, SSV_BAD_SHAPE, "lstm_fwd: workspace too small (%zu < %zu)", ws_bytes, s.total);
+  SSV_CHECK(ws && ws_bytes >= ssv_lstm_fwd_workspace(Bn, T, F, H, layers), SSV_BAD_SHAPE, "lstm_fwd: workspace too small (%zu < %zu)", ws_bytes,
+            ssv_lstm_fwd_workspace(Bn, T, F, H, layers));
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
+  if (ssv_precision() == 1 && lstm_wave_ok(Bn, H) && !getenv("SSV_LSTM_SEQUENTIAL"))
+    return lstm_fwd_wave(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, base, st);
   float* xt = (float*)(base + s.xt);
   float* xp = (float*)(base + s.xp);
   float* seq[2] = {(float*)(base + s.seq0), (float*)(base + s.seq1)};

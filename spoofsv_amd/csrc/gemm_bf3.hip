@@ -44,7 +44,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
 // 64 lanes load as one A fragment (lane = kg*16 + m%16, 16 bytes each): the load covers 8 whole cache lines.  With the
 // plain [row][k] order the same fragment touched 16 lines and used half of each, doubling L2->L1 traffic for weights.
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
-                                                         int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h) {
+                                                         int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h,
+                                                         int nch_total, int ch_off) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int MB = (M + 15) >> 4, NCH = Kpad >> 5;
   const long n = (long)KT * MB * NCH * 512;
@@ -56,12 +57,16 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
   const int ms = perm_h ? (m & 3) * perm_h + (m >> 2) : m;       // LSTM: gate-interleaved output rows
   const float v = (m < M && k < K) ? w[(long)ms * sm + (long)k * sk + (long)j * sj] : 0.f;
   const __bf16 h = (__bf16)v;
-  hi[i] = h;
-  lo[i] = (__bf16)(v - (float)h);
+  const long d = ((((long)j * MB + mb) * nch_total + ch + ch_off) << 9) + (i & 511);
+  hi[d] = h;
+  lo[d] = (__bf16)(v - (float)h);
 }
-int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st) {
+int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st,
+                          int nch_total, int ch_off) {
   const long n = (long)KT * ((M + 15) / 16 * 16) * Kpad;
-  hipLaunchKernelGGL(pack_split_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, (__bf16*)hi, (__bf16*)lo, M, K, Kpad, KT, sm, sk, sj, perm_h);
+  if (nch_total <= 0) { nch_total = Kpad / 32; ch_off = 0; }
+  hipLaunchKernelGGL(pack_split_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, (__bf16*)hi, (__bf16*)lo, M, K, Kpad, KT, sm, sk, sj, perm_h,
+                     nch_total, ch_off);
   return ssv_check_launch("pack_split");
 }
 
@@ -125,8 +130,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   const int mt = bxx % mtiles, ntile = bxx / mtiles;
   const int m0 = mt * BM, n0 = ntile * BN;
   const float* __restrict__ Xb = p.X + (long)b * p.sxb;
+  // LSTM wavefront (see GemmNNB): layer / frame of this grid.y entry, the second K segment, the chunks to run
+  const float* __restrict__ X2b = nullptr;
+  int lstm_layer = 0, lstm_t = 0;
+  if constexpr (EPI == 1) {
+    if (p.lstm_D > 0) {
+      lstm_layer = p.lstm_lo + b;
+      lstm_t = p.lstm_s - lstm_layer;
+      const long HN = (long)p.perm_h * p.N;
+      Xb = p.lstm_out + ((long)max(lstm_layer - 1, 0) * p.lstm_D + lstm_t % p.lstm_D) * HN;
+      X2b = p.lstm_out + ((long)lstm_layer * p.lstm_D + (lstm_t + p.lstm_D - 1) % p.lstm_D) * HN - (long)p.xsplit * 32 * (long)p.sxc;
+    }
+  }
+  // chunks to run: all of K, except that an LSTM entry at its first frame has no h_{t-1} segment
+  const int nchunks_all = p.Kpad / 32;
+  const int nchunks = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? p.xsplit : nchunks_all;
   const int W = BN + span;
-  const int nchunks = p.Kpad / 32;
   const int kq = lane >> 4, nq = lane & 15;
 
   f32x4 acc[WM][NT];
@@ -147,14 +166,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int mb = (m0 + wave * WM * 16 + i * 16) >> 4;
-    arow[i] = (long)min(mb, MB - 1) * nchunks * 512 + lane * 8;     // blocks past M re-read the last one: never stored
+    arow[i] = (long)min(mb, MB - 1) * nchunks_all * 512 + lane * 8;     // blocks past M re-read the last one: never stored
   }
-  const long aplane = (long)MB * nchunks * 512;
+  const long aplane = (long)MB * nchunks_all * 512;
 
   auto loadA = [&](int set, int j, int ch) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-      const long off = j * aplane + arow[i] + ch * 512;
+      const long off = (long)b * p.sab + j * aplane + arow[i] + ch * 512;
       Ah_[set][j][i] = *reinterpret_cast<const uint4*>(p.Ahi + off);
       Al_[set][j][i] = *reinterpret_cast<const uint4*>(p.Alo + off);
     }
@@ -181,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     if (!ragged || ch + 1 < nchunks) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float* __restrict__ rowp = Xb + (long)(ch * 32 + i) * Lrow;     // uniform
+        const float* __restrict__ rowp = ((EPI == 1 && X2b && ch >= p.xsplit) ? X2b : Xb) + (long)(ch * 32 + i) * Lrow;     // uniform
 #pragma unroll
         for (int r = 0; r < NX; ++r) rx[r][i] = rowp[voff[r]];
       }
@@ -246,10 +265,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   // Prologue: chunk 0 staged, chunk 1 in flight.  Chunk c: MFMAs on image c & 1 (weight fragments of chunk c+1 re-loaded
   // tap by tap behind them), then chunk c+1 is split into the other image and the loads of chunk c+2 are issued.
   if constexpr (KT == 1) {
-    loadA(0, 0, 0);
-    prefetchX(0);
-    commitX(0);
-    if (nchunks > 1) { prefetchX(1); loadA(1, 0, 1); }
+    if (nchunks > 0) {
+      loadA(0, 0, 0);
+      prefetchX(0);
+      commitX(0);
+      if (nchunks > 1) { prefetchX(1); loadA(1, 0, 1); }
+    }
     __syncthreads();
     for (int ch = 0; ch < nchunks; ch += 2) {
       tap(0, 0, ch);
@@ -293,6 +314,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     // Fused LSTM cell (torch gate order i, f, g, o).  Rows were packed gate-interleaved, so the four accumulator rows a
     // lane holds for a 16-row tile (rows kq*4 .. kq*4+3) are the four gates of ONE hidden unit at column nq.
     const int H = p.perm_h;
+    float* __restrict__ cst = p.cstate;
+    const float* __restrict__ bia = p.bias ? p.bias + (long)b * p.sbb : nullptr;
+    const float* __restrict__ bib = p.bias_b ? p.bias_b + (long)b * p.sbb : nullptr;
+    bool first = p.first != 0;
+    if (p.lstm_D > 0) {
+      const long HN = (long)H * p.N;
+      cst += (long)lstm_layer * HN;
+      Cb = p.lstm_out + ((long)lstm_layer * p.lstm_D + lstm_t % p.lstm_D) * HN;
+      first = lstm_t == 0;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int row0 = m0 + wave * WM * 16 + i * 16 + kq * 4;       // = 4 * unit
@@ -300,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
       if (u >= H) continue;
       float add[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) add[r] = (p.bias ? p.bias[r * H + u] : 0.f) + (p.bias_b ? p.bias_b[r * H + u] : 0.f);
+      for (int r = 0; r < 4; ++r) add[r] = (bia ? bia[r * H + u] : 0.f) + (bib ? bib[r * H + u] : 0.f);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int gn = n0 + t * 16 + nq;
@@ -311,8 +342,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
         const float gi = 1.f / (1.f + expf(-gte[0])), gf = 1.f / (1.f + expf(-gte[1]));
         const float gg = tanhf(gte[2]), go = 1.f / (1.f + expf(-gte[3]));
         const long ci = (long)u * p.N + gn;
-        const float cn = (p.first ? 0.f : gf * p.cstate[ci]) + gi * gg;
-        p.cstate[ci] = cn;
+        const float cn = (first ? 0.f : gf * cst[ci]) + gi * gg;
+        cst[ci] = cn;
         Cb[(long)u * p.scm + gn] = go * tanhf(cn);
       }
     }
@@ -562,7 +593,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
     // k=1 products carry a third of the MFMAs per weight byte: 64-row tiles (twice the weight traffic per MAC) lose at every
     // conv shape measured (256 -> 256, L=650: 28 us on 64 x 112 tiles, 20 us on 128 x 64); only the single-"batch" LSTM
     // product, short of workgroups, still wants them
-    const int a_min = (KT == 1 && g.B > 1 && g.M > 64) ? 2 : 1;
+    const int a_min = (KT == 1 && g.B > 1 && !g.epi && g.M > 64) ? 2 : 1;
     for (int a = a_min; a <= 2; ++a)
       for (int c : nts) {
         const long tiles = (long)ssv_cdiv(g.M, 64 * a) * ssv_cdiv(g.N, 16 * c) * g.B;
@@ -591,7 +622,9 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nn_bf3: kernel_size %d", g.KT);
   SSV_CHECK(g.B <= 65535, SSV_UNSUPPORTED, "gemm_nn_bf3: batch %d exceeds grid.y", g.B);
   SSV_CHECK(g.sxn >= 1 && g.scn >= 1 && (g.scn == 1 || (!g.R && !g.epi)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad column strides");
-  SSV_CHECK(!g.epi || (g.KT == 1 && g.perm_h > 0 && g.M == 4 * g.perm_h && g.cstate && g.B == 1), SSV_BAD_SHAPE, "gemm_nn_bf3: bad LSTM epilogue request");
+  SSV_CHECK(!g.epi || (g.KT == 1 && g.perm_h > 0 && g.M == 4 * g.perm_h && g.cstate && (g.B == 1 || g.lstm_D > 0)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad LSTM epilogue request");
+  SSV_CHECK(g.lstm_D == 0 || (g.epi == 1 && g.lstm_out && g.lstm_D >= 2 && g.xsplit >= 0 && g.xsplit <= g.Kpad / 32 && g.Kc == g.Kpad && g.sxn == 1), SSV_BAD_SHAPE,
+            "gemm_nn_bf3: bad LSTM wavefront request");
   int smin = g.shift[0], smax = g.shift[0];
   for (int j = 1; j < g.KT; ++j) { smin = g.shift[j] < smin ? g.shift[j] : smin; smax = g.shift[j] > smax ? g.shift[j] : smax; }
   const int span = smax - smin;

@@ -63,11 +63,19 @@ struct GemmNNB {
   // the kernel adds R (the input projection) and the biases, updates cstate [H][N] in place and writes h to C [H][N].
   int perm_h, epi, first;
   float* cstate;
+  // LSTM wavefront (epi == 1 with lstm_D > 0): grid.y entry b is layer lstm_lo + b at frame t = lstm_s - layer.  The K axis
+  // has two segments: chunks [0, xsplit) read the lower layer's h_t, chunks [xsplit, Kpad/32) the layer's own h_{t-1}
+  // (skipped at t = 0).  All h live in lstm_out[layer][slot = frame % lstm_D][H][N]; the kernel derives X, X2 and C from
+  // (layer, t), and offsets the weight planes by b*sab, the biases by b*sbb and cstate by layer*H*N.
+  float* lstm_out; int lstm_s, lstm_lo, lstm_D, xsplit; long sab;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
 bool ssv_nt_bf3_fits(const GemmNT& g);          // operands addressable with the kernel's 32-bit element offsets
-int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st);
+// nch_total / ch_off: this source fills K chunks [ch_off, ch_off + Kpad/32) of planes that have nch_total chunks per row block
+// (two matrices side by side along K, e.g. [W_ih | W_hh]); 0, 0 = the plane holds this source only.
+int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st,
+                          int nch_total = 0, int ch_off = 0);
 int ssv_nt_bf3_tiles(int KT, int M, int Nc);
 int ssv_nt_bf3_target(int KT, int M, int Nc);  // workgroups to aim for when choosing the slab count   // output tiles of the weight-gradient kernel for this problem
 int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA (default)
