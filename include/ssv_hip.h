@@ -140,8 +140,13 @@ int ssv_attention_train_bwd(const float* dr, long dr_bs, const float* da_ext, co
  * q_last: (B,d) column t of Q (element stride q_cs between channels, batch stride q_bs);
  * a: (B,N,a_T) attention buffer, column `col` is written.  pma_in/pma_out int64 (B). */
 int ssv_attention_step(const float* k, long kv_bs, const float* q_last, long q_bs, long q_cs,
-                       const int64_t* pma_in, float* a, int a_T, int col, int64_t* pma_out,
+                       const int64_t* pma_in, float* a, int a_T, int col, const int* col_dev, int64_t* pma_out,
                        int B, int d, int N, ssv_stream_t stream);
+/* col_dev (DEVICE int*, may be NULL): when given, the frame index is *col_dev instead of `col` and q_last must point at
+ * column 0 of Q -- one captured hipGraph of a fixed-shape synthesis step can then be replayed for every frame.
+ * ssv_synth_advance closes such a step: mel_in[b][f][*col_dev + 1] = y[b][f][*col_dev] (both (B,F,T) dense; the frame just
+ * synthesised is the next input, synthesize.py:108-109), then *col_dev += 1. */
+int ssv_synth_advance(const float* y, float* mel_in, int* col_dev, int B, int F, int T, ssv_stream_t stream);
 /* r(b,c,t) = sum_n v(b,c,n) a(b,n,t) for t < T (a has row stride a_T). */
 int ssv_attention_apply(const float* v, long kv_bs, const float* a, int a_T, float* r, long r_bs,
                         int B, int d, int N, int T, ssv_stream_t stream);

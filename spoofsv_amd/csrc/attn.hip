@@ -141,10 +141,11 @@ int ssv_launch_softmax_cols_bwd(const float* a, float* da, const float* da_ext, 
 #define STEP_MAXN 1024
 __global__ __launch_bounds__(256) void attention_step_kernel(const float* __restrict__ k, long kv_bs, const float* __restrict__ q, long q_bs, long q_cs,
                                                              const int64_t* __restrict__ pma_in, float* __restrict__ a, int a_T, int col,
-                                                             int64_t* __restrict__ pma_out, int d, int N, float scale) {
+                                                             const int* __restrict__ col_dev, int64_t* __restrict__ pma_out, int d, int N, float scale) {
   __shared__ float logit[STEP_MAXN];
   __shared__ float red[4];
   __shared__ int redi[4];
+  if (col_dev) { col = col_dev[0]; q += col; }       // device-side frame counter: q is column 0 of Q, the step's frame is added here
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* kb = k + (long)b * kv_bs;
   const float* qb = q + (long)b * q_bs;
@@ -196,10 +197,27 @@ __global__ __launch_bounds__(256) void attention_step_kernel(const float* __rest
 }
 
 extern "C" int ssv_attention_step(const float* k, long kv_bs, const float* q_last, long q_bs, long q_cs, const int64_t* pma_in,
-                                  float* a, int a_T, int col, int64_t* pma_out, int B, int d, int N, ssv_stream_t stream) {
-  SSV_CHECK(B > 0 && d > 0 && N > 0 && col >= 0 && col < a_T, SSV_BAD_SHAPE, "attention_step: bad shape B=%d d=%d N=%d col=%d a_T=%d", B, d, N, col, a_T);
+                                  float* a, int a_T, int col, const int* col_dev, int64_t* pma_out, int B, int d, int N, ssv_stream_t stream) {
+  SSV_CHECK(B > 0 && d > 0 && N > 0 && (col_dev || (col >= 0 && col < a_T)), SSV_BAD_SHAPE, "attention_step: bad shape B=%d d=%d N=%d col=%d a_T=%d", B, d, N, col, a_T);
   SSV_CHECK(N <= STEP_MAXN, SSV_UNSUPPORTED, "attention_step: N=%d > %d", N, STEP_MAXN);
-  hipLaunchKernelGGL(attention_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, k, kv_bs, q_last, q_bs, q_cs, pma_in, a, a_T, col,
+  hipLaunchKernelGGL(attention_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, k, kv_bs, q_last, q_bs, q_cs, pma_in, a, a_T, col, col_dev,
                      pma_out, d, N, 1.f / sqrtf((float)d));
   return ssv_check_launch("attention_step");
+}
+
+// ---- synthesis loop bookkeeping (hipGraph replay of one fixed-shape step) ------------------------------------------
+// mel_in[b][f][col+1] = y[b][f][col] (the frame just synthesised becomes the next input, synthesize.py:108-109), then col += 1.
+__global__ __launch_bounds__(256) void synth_feed_kernel(const float* __restrict__ y, float* __restrict__ mel_in, const int* __restrict__ col_dev,
+                                                         int n, int T) {
+  const int i = blockIdx.x * 256 + threadIdx.x;            // (b, f) row
+  const int col = col_dev[0];
+  if (i < n && col + 1 < T) mel_in[(long)i * T + col + 1] = y[(long)i * T + col];
+}
+__global__ void synth_inc_kernel(int* col_dev) { col_dev[0] += 1; }
+extern "C" int ssv_synth_advance(const float* y, float* mel_in, int* col_dev, int B, int F, int T, ssv_stream_t stream) {
+  SSV_CHECK(y && mel_in && col_dev && B > 0 && F > 0 && T > 0, SSV_BAD_SHAPE, "synth_advance: bad argument");
+  hipLaunchKernelGGL(synth_feed_kernel, dim3(ssv_cdiv((long)B * F, 256)), dim3(256), 0, (hipStream_t)stream, y, mel_in, (const int*)col_dev, B * F, T);
+  SSV_TRY(ssv_check_launch("synth_feed"));
+  hipLaunchKernelGGL(synth_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, col_dev);
+  return ssv_check_launch("synth_inc");
 }

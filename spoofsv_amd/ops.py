@@ -323,8 +323,25 @@ def attention_step(kv, q, pma, a_buf, col):
     out = torch.empty((B,), dtype=torch.int64, device=q.device)
     q_last = ctypes.c_void_p(q.data_ptr() + 4 * (T - 1))
     _lib.call("ssv_attention_step", ctypes.c_void_p(kv.data_ptr()), kvbs, q_last, qbs, T, _p(pma), _p(a_buf),
-              a_buf.shape[2], col, _p(out), B, d, N, _stream())
+              a_buf.shape[2], col, None, _p(out), B, d, N, _stream())
     return out
+
+
+def attention_step_dev(kv, q, pma, a_buf, col_dev):
+    """attention_step with the frame index on the device (``col_dev``: int32 tensor of one element) and ``pma`` (int64,
+    (B,)) updated in place: the form a captured fixed-shape synthesis step uses (spoofsv_amd/synth.py)."""
+    kv, kvbs = _act3(kv, "K|V")
+    q, qbs = _act3(q, "Q")
+    B, d2, N = kv.shape
+    d, T = q.shape[1], q.shape[2]
+    _lib.call("ssv_attention_step", ctypes.c_void_p(kv.data_ptr()), kvbs, _p(q), qbs, T, _p(pma), _p(a_buf),
+              a_buf.shape[2], 0, _p(col_dev), _p(pma), B, d, N, _stream())
+
+
+def synth_advance(y, mel_in, col_dev):
+    """Feed the frame just synthesised back as the next input column and advance the device-side frame counter."""
+    B, F, T = y.shape
+    _lib.call("ssv_synth_advance", _p(y), _p(mel_in), _p(col_dev), B, F, T, _stream())
 
 
 def attention_apply(kv, a_buf, q, T):

@@ -21,5 +21,11 @@ for B, N in ((1, 43), (8, 43), (32, 186)):
         torch.cuda.synchronize(); t1 = time.perf_counter()
         lin = s(Y)
         torch.cuda.synchronize(); t2 = time.perf_counter()
-    print("B=%d N=%d: text2mel %d steps %.3f s (%.2f ms/step), ssrn %.1f ms -> %.0f mel frames/s" %
-          (B, N, frames, t1 - t0, (t1 - t0) / frames * 1e3, (t2 - t1) * 1e3, B * frames / (t2 - t0)), flush=True)
+        harness._free_run(m, text, spk, frames, 80, graph=True)   # capture
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        Yg, Ag = harness._free_run(m, text, spk, frames, 80, graph=True)
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+    same = bool(torch.equal(Yg, Y) and torch.equal(Ag, A))
+    print("B=%d N=%d: step-by-step %.3f s (%.2f ms/frame) | graph replay %.3f s (%.3f ms/frame), identical=%s | ssrn %.1f ms -> %.0f / %.0f mel frames/s" %
+          (B, N, t1 - t0, (t1 - t0) / frames * 1e3, t4 - t3, (t4 - t3) / frames * 1e3, same, (t2 - t1) * 1e3,
+           B * frames / (t2 - t0), B * frames / (t4 - t3 + t2 - t1)), flush=True)
