@@ -9,11 +9,15 @@
 // consecutive 16-byte slots, and because every k-group plane is a multiple of 256 bytes the four 16-lane groups of
 // ds_read_b128 hit disjoint banks (conflict-free for any row offset, hence for any dilation shift).
 //
-//   gemm_nn_bf3: Conv1d forward / data gradient.  Weights arrive pre-split in tap-major order [tap][row][k] (bf16 hi
-//     and lo planes written by pack_split_kernel), the input tile is split while it is staged (one fp32 global read
-//     per element; 8 channels of one column form a slot), taps address the same slots at column offsets.
+//   pack_split / pack_multi: weights -> bf16 hi / lo planes in MFMA fragment order (per call, or resident: one launch for
+//     all weights of a model after each optimizer step).
+//   gemm_nn_bf3 (4 waves) / gemm_nn_bf3w (8-16 waves, k=1 over long rows): Conv1d forward / data gradient, deconvolution
+//     halves, LSTM products (EPI = 1: cell update in the epilogue, wavefront over layers in grid.y).  Weight fragments go
+//     L2 -> registers; the input tile is split while it is staged (one fp32 global read per element; 8 channels of one
+//     column form a slot, two LDS images = one barrier per chunk), taps address the same slots at column offsets.
 //   gemm_nt_bf3: Conv1d weight gradient.  The reduction runs over time, so a dilation shift would be a misaligned
-//     shift along k; instead each tap gets its own staged copy of the input rows at its exact shift.
+//     shift along k; each tap gets its own staged copy of the input rows at its exact shift, one tap per step.
+//   All kernels re-number their workgroups so that every XCD walks a contiguous tile range (ssv_xcd_order).
 #include <stdio.h>
 #include <type_traits>
 #include <stdlib.h>
