@@ -81,3 +81,29 @@ def ge2e_loss(emb, w, b):
     pos = S[idx, :, idx]                                      # (N, M)
     per = -(pos - torch.log(torch.exp(S).sum(dim=2) + 1e-6))
     return per.sum(), per
+
+
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (train_speech_embedder.py:84-85): scale every gradient by
+    min(1, max_norm / (||g||_2 + 1e-6)) with the norm taken over all of them.  Returns (scaled grads, norm)."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return [g * coef for g in grads], total
+
+
+def ge2e_train_step(x, sd, w, b, N, M, num_layers=3, lr=0.01, clip_net=3.0, clip_loss=1.0):
+    """One iteration of GE2E/train_speech_embedder.py:70-86 (the batch permutation at :67-73 is undone at :78 and does not
+    enter the arithmetic): loss, gradients by autograd over this restatement, clip_grad_norm_(3.0) on the embedder and
+    (1.0) on (w, b), plain SGD.  Returns (loss, grads dict, (dw, db), new sd, (new w, new b))."""
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    wv = torch.tensor(float(w), requires_grad=True)
+    bv = torch.tensor(float(b), requires_grad=True)
+    emb = speech_embedder(x, p, num_layers)
+    loss, _ = ge2e_loss(emb.reshape(N, M, -1), wv, bv)
+    loss.backward()
+    keys = list(p.keys())
+    grads = {k: p[k].grad.clone() for k in keys}
+    gnet, _ = clip_grad_norm([grads[k] for k in keys], clip_net)
+    gloss, _ = clip_grad_norm([wv.grad, bv.grad], clip_loss)
+    new_sd = {k: (p[k].detach() - lr * g) for k, g in zip(keys, gnet)}
+    return loss.detach(), grads, (wv.grad.clone(), bv.grad.clone()), new_sd, (wv.detach() - lr * gloss[0], bv.detach() - lr * gloss[1])

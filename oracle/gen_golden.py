@@ -17,6 +17,7 @@ Fixtures (names follow SURVEY.md section 8c):
   gaw.npz            G5  guided_attention_mat(186,325) probes
   ge2e_embedder.npz  G6  SpeechEmbedder reduced dims
   ge2e_loss.npz      G7  GE2ELoss random case + the utils.py:89-96 known-answer case
+  ge2e_train.npz     G10 one GE2E training iteration (loss, gradients, clipped SGD step)
   init_pin.npz       G9  seed -> construct -> apply(init_weights): per-parameter checksums
   adam.npz           a13 three torch.optim.Adam steps with the config.json hyper-parameters
   adversarial_iter.npz G8 one G and one D iteration with the reference's melSyn + melDisc (critic dropout off)
@@ -278,6 +279,45 @@ def gen_ge2e(ref):
                         kat_emb=_np(kat), kat_cossim=_np(kc), kat_loss=_np(kl), kat_per=_np(kper))
 
 
+def gen_ge2e_train(ref):
+    """G10: one training iteration of GE2E/train_speech_embedder.py:70-86 with the reference's own SpeechEmbedder and
+    GE2ELoss at reduced dims (hidden 32, proj 16; N=4 speakers x M=3 utterances x 10 frames): loss, the gradient of every
+    parameter before clipping, and the parameters after clip_grad_norm_(3.0 / 1.0) + SGD(lr=0.01)."""
+    hp, net, U = _import_ge2e(ref)
+    full = (hp.model.hidden, hp.model.proj)
+    hp.model.hidden, hp.model.proj = 32, 16
+    torch.manual_seed(91)
+    m = net.SpeechEmbedder()
+    L = net.GE2ELoss(torch.device("cpu"))
+    with torch.no_grad():
+        for n, p in m.LSTM_stack.named_parameters():
+            if "bias" in n:
+                p.uniform_(-0.2, 0.2)
+    N, M, T = 4, 3, 10
+    x = torch.randn(N * M, T, hp.data.nmels)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    opt = torch.optim.SGD([{"params": m.parameters()}, {"params": L.parameters()}], lr=0.01)   # train_speech_embedder.py:54-57
+    m.train()
+    opt.zero_grad()
+    emb = m(x)
+    emb3 = torch.reshape(emb, (N, M, emb.size(1)))
+    loss = L(emb3)
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    gw, gb = L.w.grad.clone(), L.b.grad.clone()
+    n1 = torch.nn.utils.clip_grad_norm_(m.parameters(), 3.0)
+    n2 = torch.nn.utils.clip_grad_norm_(L.parameters(), 1.0)
+    opt.step()
+    out = dict(x=_np(x), dims=np.array([N, M, T, 32, 16], dtype=np.int64), loss=_np(loss.detach()), emb=_np(emb.detach()),
+               w0=np.float32(10.0), b0=np.float32(-5.0), dw=_np(gw), db=_np(gb), w1=_np(L.w.detach()), b1=_np(L.b.detach()),
+               norm_net=_np(n1), norm_loss=_np(n2))
+    out.update({"p0/" + k: _np(v) for k, v in sd0.items()})
+    out.update({"g/" + k: _np(v) for k, v in grads.items()})
+    out.update({"p1/" + k: _np(v.detach()) for k, v in m.state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, "ge2e_train.npz"), **out)
+    hp.model.hidden, hp.model.proj = full
+
+
 def gen_adversarial(TTS, ref):
     """G8: one generator iteration and one critic iteration of train/adversarial_wasserstein_gp.py:261-322, executed
     with the reference's own melSyn and melDisc modules and its loss expressions, at reduced dims.  The critic is put in
@@ -371,11 +411,15 @@ def gen_adam():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default=None, help="generate a single fixture group (e.g. ge2e_train) and leave the others as they are")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     sys.dont_write_bytecode = True
     sys.path.insert(0, args.ref)
     torch.set_num_threads(1)           # bit-stable reductions for the fixtures
+    if args.only == "ge2e_train":
+        gen_ge2e_train(args.ref)
+        return
     import models.TTSModel as TTS
     gen_highway(TTS)
     gen_melsyn_train(TTS)
@@ -386,6 +430,7 @@ def main():
     gen_adam()
     gen_adversarial(TTS, args.ref)
     gen_ge2e(args.ref)
+    gen_ge2e_train(args.ref)
     for f in sorted(os.listdir(OUT)):
         print("%-22s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))
 

@@ -164,3 +164,19 @@ def test_adversarial_iteration_golden_cpu():
     assert abs(float(gp) - float(g["d_gp"])) < 1e-5 * max(1.0, abs(float(g["d_gp"])))
     assert abs(float(loss_d) - float(g["d_loss"])) < 1e-6 * max(1.0, abs(float(g["d_loss"])))
     _critic_grads_agree(d, sub(g, "dgrad/"), 1e-4)
+
+
+def test_ge2e_training_iteration():
+    """G10: loss, every parameter gradient and the clipped SGD step of one GE2E training iteration (reference modules)."""
+    g = load("ge2e_train.npz")
+    N, M, T, H, P = [int(v) for v in g["dims"]]
+    sd = {k[3:]: t(v) for k, v in g.items() if k.startswith("p0/")}
+    loss, grads, (dw, db), new_sd, (w1, b1) = GO.ge2e_train_step(t(g["x"]), sd, float(g["w0"]), float(g["b0"]), N, M)
+    assert rel_err(loss, t(g["loss"])) < 1e-5
+    for k, v in grads.items():
+        assert rel_err(v, t(g["g/" + k])) < 2e-4, (k, rel_err(v, t(g["g/" + k])))
+    # dw, db are sums with heavy cancellation (|dw| ~ 5e-5 against per-embedding terms of order 1): absolute tolerance
+    assert abs(float(dw) - float(g["dw"])) < 1e-5 and abs(float(db) - float(g["db"])) < 1e-5
+    for k, v in new_sd.items():
+        assert rel_err(v, t(g["p1/" + k])) < 1e-5, k
+    assert abs(float(w1) - float(g["w1"])) < 1e-5 and abs(float(b1) - float(g["b1"])) < 1e-5
