@@ -219,6 +219,12 @@ size_t ssv_ge2e_loss_fwd_workspace(int N, int M, int D);
 int ssv_ge2e_loss_fwd(const float* emb, const float* w, const float* b, float* loss, float* per,
                       int N, int M, int D, void* ws, size_t ws_bytes, ssv_stream_t stream);
 
+/* Backward of the above (autograd of GE2ELoss.forward; GE2E/train_speech_embedder.py:82): dloss is the upstream gradient
+ * of the scalar loss (DEVICE float, NULL = 1).  demb (N,M,D), dw, db (DEVICE scalars). */
+size_t ssv_ge2e_loss_bwd_workspace(int N, int M, int D);
+int ssv_ge2e_loss_bwd(const float* emb, const float* w, const float* b, const float* dloss, float* demb, float* dw, float* db,
+                      int N, int M, int D, void* ws, size_t ws_bytes, ssv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,3 +133,145 @@ extern "C" int ssv_ge2e_loss_fwd(const float* emb, const float* w, const float* 
   hipLaunchKernelGGL(ge2e_total_kernel, dim3(1), dim3(256), 0, st, perbuf, loss, N * M);
   return ssv_check_launch("ge2e_total");
 }
+
+// ---- GE2E loss backward -------------------------------------------------------------------------------
+// L = sum_ji -(S_ji,j - log(sum_k exp S_ji,k + 1e-6)),  S = w cos + b,  cos_ji,k = <e_ji, c_k> / (|e_ji||c_k|) + 1e-6,
+// c_k = mean_m e_km, except k = j where the centroid leaves e_ji out (GE2E/utils.py:16-46).  With
+//   G_ji,k = exp(S_ji,k) / (sum_k' exp S_ji,k' + 1e-6) - [k = j]       (= dL/dS)
+// dw = sum G cos, db = sum G, and an embedding receives three kinds of terms: as the query of its own row (direct),
+// through the centroids of the other speakers' rows (1/M each), through the leave-one-out centroids of its own speaker.
+// The problem is tiny (880 x 88 x 256); the kernels are written for clarity and a fixed summation order.
+__device__ __forceinline__ float block_sum_256(float v, float* red4) {      // sum over a 256-thread block, all threads get it
+  v = ssv_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+#define GE2E_MAXN 1024
+// one workgroup per embedding (j, i)
+__global__ __launch_bounds__(256) void ge2e_bwd_rows_kernel(const float* __restrict__ emb, const float* __restrict__ csum, const float* __restrict__ wp,
+                                                            const float* __restrict__ bp, const float* __restrict__ dloss,
+                                                            float* __restrict__ Hc, float* __restrict__ C0, float* __restrict__ Vn, float* __restrict__ En,
+                                                            float* __restrict__ direct, float* __restrict__ dloo, float* __restrict__ part,
+                                                            int N, int M, int D) {
+  __shared__ float sS[GE2E_MAXN], sC[GE2E_MAXN], sV[GE2E_MAXN], sH[GE2E_MAXN];
+  __shared__ float red4[4];
+  const int ji = blockIdx.x, j = ji / M, tid = threadIdx.x;
+  const float* e = emb + (long)ji * D;
+  const float w = wp[0], b = bp[0], gs = dloss ? dloss[0] : 1.f;
+  const float invM = 1.f / (float)M, invM1 = 1.f / (float)(M - 1);
+  float t = 0.f;
+  for (int d = tid; d < D; d += 256) t += e[d] * e[d];
+  const float en = sqrtf(block_sum_256(t, red4));
+  for (int k = 0; k < N; ++k) {
+    const float* c = csum + (long)k * D;
+    float dot = 0.f, cn = 0.f;
+    for (int d = tid; d < D; d += 256) {
+      const float v = (k == j) ? (c[d] - e[d]) * invM1 : c[d] * invM;
+      dot += e[d] * v; cn += v * v;
+    }
+    dot = block_sum_256(dot, red4);
+    cn = block_sum_256(cn, red4);
+    if (tid == 0) {
+      const float vn = sqrtf(cn), c0 = dot / fmaxf(en * vn, 1e-8f);
+      sC[k] = c0; sV[k] = vn; sS[k] = w * (c0 + 1e-6f) + b;
+    }
+  }
+  __syncthreads();
+  float se = 0.f;
+  for (int k = tid; k < N; k += 256) se += expf(sS[k]);
+  se = block_sum_256(se, red4);
+  float pw = 0.f, pb = 0.f;
+  for (int k = tid; k < N; k += 256) {
+    const float G = expf(sS[k]) / (se + 1e-6f) - (k == j ? 1.f : 0.f);
+    pw += G * (sC[k] + 1e-6f); pb += G;
+    sH[k] = gs * w * G;
+    Hc[(long)ji * N + k] = sH[k]; C0[(long)ji * N + k] = sC[k]; Vn[(long)ji * N + k] = sV[k];
+  }
+  pw = block_sum_256(pw, red4);
+  pb = block_sum_256(pb, red4);
+  if (tid == 0) { part[2 * ji] = pw; part[2 * ji + 1] = pb; En[ji] = en; }
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    float acc = 0.f;
+    for (int k = 0; k < N; ++k) {
+      const float v = (k == j) ? (csum[(long)k * D + d] - e[d]) * invM1 : csum[(long)k * D + d] * invM;
+      const float den = fmaxf(en * sV[k], 1e-8f);
+      acc += sH[k] * (v / den - sC[k] * e[d] / (en * en));
+    }
+    direct[(long)ji * D + d] = acc;
+    const float vj = (csum[(long)j * D + d] - e[d]) * invM1, denj = fmaxf(en * sV[j], 1e-8f);
+    dloo[(long)ji * D + d] = sH[j] * (e[d] / denj - sC[j] * vj / fmaxf(sV[j] * sV[j], 1e-16f)) * invM1;
+  }
+}
+// one workgroup per speaker k: gradient that reaches the centroid c_k from the rows of the OTHER speakers
+__global__ __launch_bounds__(256) void ge2e_bwd_centroid_kernel(const float* __restrict__ emb, const float* __restrict__ csum, const float* __restrict__ Hc,
+                                                                const float* __restrict__ C0, const float* __restrict__ En, float* __restrict__ dcent,
+                                                                int N, int M, int D) {
+  __shared__ float red4[4];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float invM = 1.f / (float)M;
+  float t = 0.f;
+  for (int d = tid; d < D; d += 256) { const float v = csum[(long)k * D + d] * invM; t += v * v; }
+  const float vk = sqrtf(block_sum_256(t, red4));
+  for (int d = tid; d < D; d += 256) {
+    const float v = csum[(long)k * D + d] * invM;
+    float acc = 0.f;
+    for (int ji = 0; ji < N * M; ++ji) {
+      if (ji / M == k) continue;
+      const float h = Hc[(long)ji * N + k];
+      acc += h * (emb[(long)ji * D + d] / fmaxf(En[ji] * vk, 1e-8f) - C0[(long)ji * N + k] * v / fmaxf(vk * vk, 1e-16f));
+    }
+    dcent[(long)k * D + d] = acc * invM;
+  }
+}
+__global__ __launch_bounds__(256) void ge2e_bwd_finish_kernel(const float* __restrict__ direct, const float* __restrict__ dcent, const float* __restrict__ dloo,
+                                                              float* __restrict__ demb, int N, int M, int D) {
+  const int jm = blockIdx.x, j = jm / M;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int i = 0; i < M; ++i) s += dloo[((long)j * M + i) * D + d];
+    demb[(long)jm * D + d] = direct[(long)jm * D + d] + dcent[(long)j * D + d] + (s - dloo[(long)jm * D + d]);
+  }
+}
+__global__ __launch_bounds__(256) void ge2e_bwd_wb_kernel(const float* __restrict__ part, const float* __restrict__ dloss, float* __restrict__ dw, float* __restrict__ db, int n) {
+  __shared__ float red4[4];
+  float a = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { a += part[2 * i]; c += part[2 * i + 1]; }
+  a = block_sum_256(a, red4);
+  c = block_sum_256(c, red4);
+  const float gs = dloss ? dloss[0] : 1.f;
+  if (threadIdx.x == 0) { dw[0] = gs * a; db[0] = gs * c; }
+}
+extern "C" size_t ssv_ge2e_loss_bwd_workspace(int N, int M, int D) {
+  const size_t nm = (size_t)N * M;
+  return (3 * nm * N + nm + 2 * nm * D + 2 * (size_t)N * D + 2 * nm) * sizeof(float);
+}
+extern "C" int ssv_ge2e_loss_bwd(const float* emb, const float* w, const float* b, const float* dloss, float* demb, float* dw, float* db,
+                                 int N, int M, int D, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(emb && w && b && demb && dw && db && N > 0 && M > 1 && D > 0, SSV_BAD_SHAPE, "ge2e_loss_bwd: need N>0, M>1, D>0 (N=%d M=%d D=%d)", N, M, D);
+  SSV_CHECK(N <= GE2E_MAXN, SSV_UNSUPPORTED, "ge2e_loss_bwd: N=%d > %d speakers", N, GE2E_MAXN);
+  SSV_CHECK(ws && ws_bytes >= ssv_ge2e_loss_bwd_workspace(N, M, D), SSV_BAD_SHAPE, "ge2e_loss_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nm = (size_t)N * M;
+  float* Hc = (float*)ws;
+  float* C0 = Hc + nm * N;
+  float* Vn = C0 + nm * N;
+  float* En = Vn + nm * N;
+  float* direct = En + nm;
+  float* dloo = direct + nm * D;
+  float* dcent = dloo + nm * D;
+  float* csum = dcent + (size_t)N * D;
+  float* part = csum + (size_t)N * D;
+  hipLaunchKernelGGL(ge2e_centroid_kernel, dim3(ssv_cdiv((long)N * D, 256)), dim3(256), 0, st, emb, csum, N, M, D);
+  SSV_TRY(ssv_check_launch("ge2e_centroid"));
+  hipLaunchKernelGGL(ge2e_bwd_rows_kernel, dim3(N * M), dim3(256), 0, st, emb, (const float*)csum, w, b, dloss, Hc, C0, Vn, En, direct, dloo, part, N, M, D);
+  SSV_TRY(ssv_check_launch("ge2e_bwd_rows"));
+  hipLaunchKernelGGL(ge2e_bwd_centroid_kernel, dim3(N), dim3(256), 0, st, emb, (const float*)csum, (const float*)Hc, (const float*)C0, (const float*)En, dcent, N, M, D);
+  SSV_TRY(ssv_check_launch("ge2e_bwd_centroid"));
+  hipLaunchKernelGGL(ge2e_bwd_finish_kernel, dim3(N * M), dim3(256), 0, st, (const float*)direct, (const float*)dcent, (const float*)dloo, demb, N, M, D);
+  SSV_TRY(ssv_check_launch("ge2e_bwd_finish"));
+  hipLaunchKernelGGL(ge2e_bwd_wb_kernel, dim3(1), dim3(256), 0, st, (const float*)part, dloss, dw, db, N * M);
+  return ssv_check_launch("ge2e_bwd_wb");
+}

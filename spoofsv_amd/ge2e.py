@@ -62,6 +62,37 @@ class SpeechEmbedder(nn.Module):
         return e
 
 
+class _GE2ELossFn(torch.autograd.Function):
+    """GE2ELoss.forward (speech_embedder_net.py:43-49, utils.py:16-55) and its gradient w.r.t. embeddings, w, b."""
+
+    @staticmethod
+    def forward(ctx, emb, w, b):
+        e = _c(emb)
+        N, M, D = e.shape
+        w1, b1 = _c(w.reshape(1)), _c(b.reshape(1))
+        loss = torch.empty((1,), dtype=torch.float32, device=e.device)
+        per = torch.empty((N, M), dtype=torch.float32, device=e.device)
+        nb = _lib.query("ssv_ge2e_loss_fwd_workspace", N, M, D)
+        ws = _ws(nb, e.device)
+        _lib.call("ssv_ge2e_loss_fwd", _p(e), _p(w1), _p(b1), _p(loss), _p(per), N, M, D, _p(ws), nb, _stream())
+        ctx.save_for_backward(e, w1, b1)
+        ctx.mark_non_differentiable(per)
+        return loss[0], per
+
+    @staticmethod
+    def backward(ctx, dloss, _dper):
+        e, w1, b1 = ctx.saved_tensors
+        N, M, D = e.shape
+        demb = torch.empty_like(e)
+        dw = torch.empty((1,), dtype=torch.float32, device=e.device)
+        db = torch.empty((1,), dtype=torch.float32, device=e.device)
+        g = _c(dloss.reshape(1).float())
+        nb = _lib.query("ssv_ge2e_loss_bwd_workspace", N, M, D)
+        ws = _ws(nb, e.device)
+        _lib.call("ssv_ge2e_loss_bwd", _p(e), _p(w1), _p(b1), _p(g), _p(demb), _p(dw), _p(db), N, M, D, _p(ws), nb, _stream())
+        return demb, dw.reshape(()), db.reshape(())
+
+
 class GE2ELoss(nn.Module):
     def __init__(self, device):
         super().__init__()
@@ -69,15 +100,7 @@ class GE2ELoss(nn.Module):
         self.b = nn.Parameter(torch.tensor(-5.0).to(device), requires_grad=True)
         self.device = device
 
-    @torch.no_grad()
     def forward(self, embeddings, return_per_embedding=False):
         _dev(embeddings, "embeddings")
-        e = _c(embeddings)
-        N, M, D = e.shape
-        loss = torch.empty((1,), dtype=torch.float32, device=e.device)
-        per = torch.empty((N, M), dtype=torch.float32, device=e.device)
-        nb = _lib.query("ssv_ge2e_loss_fwd_workspace", N, M, D)
-        ws = _ws(nb, e.device)
-        _lib.call("ssv_ge2e_loss_fwd", _p(e), _p(_c(self.w.reshape(1))), _p(_c(self.b.reshape(1))), _p(loss), _p(per),
-                  N, M, D, _p(ws), nb, _stream())
-        return (loss[0], per) if return_per_embedding else loss[0]
+        loss, per = _GE2ELossFn.apply(embeddings.float(), self.w, self.b)
+        return (loss, per) if return_per_embedding else loss

@@ -227,12 +227,38 @@ def test_ge2e_loss_golden_and_known_answer():
     g = load("ge2e_loss.npz")
     L = GE2ELoss(DEV)
     loss = L(t(g["emb"], DEV))
-    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
     with torch.no_grad():
         L.w.fill_(1.0); L.b.fill_(0.0)
     kl, per = L(t(g["kat_emb"], DEV), return_per_embedding=True)
-    assert abs(float(kl) - 5.2501) < 1e-4                      # GE2E/utils.py:89-96
+    assert abs(float(kl.detach()) - 5.2501) < 1e-4                      # GE2E/utils.py:89-96
     assert rel_err(per, t(g["kat_per"])) < 1e-5
+
+
+def test_ge2e_loss_backward_golden_and_full_size_vs_oracle():
+    """Gradient of the GE2E loss w.r.t. embeddings, w and b: the reference's own autograd result (G7 fixture), then the
+    config-5 size (88 speakers x 10 utterances x 256) against autograd over the CPU oracle."""
+    from spoofsv_amd.ge2e import GE2ELoss
+    g = load("ge2e_loss.npz")
+    L = GE2ELoss(DEV)
+    e = t(g["emb"], DEV).requires_grad_(True)
+    L(e).backward()
+    assert rel_err(e.grad, t(g["demb"])) < 1e-4, rel_err(e.grad, t(g["demb"]))
+    assert abs(float(L.w.grad) - float(g["dw"])) < 1e-4 * max(1.0, abs(float(g["dw"])))
+    assert abs(float(L.b.grad) - float(g["db"])) < 1e-4 * max(1.0, abs(float(g["db"])))
+    torch.manual_seed(8)
+    emb = torch.randn(88, 10, 256)
+    emb = emb / emb.norm(dim=2, keepdim=True)
+    eo = emb.clone().requires_grad_(True)
+    wo, bo = torch.tensor(10.0, requires_grad=True), torch.tensor(-5.0, requires_grad=True)
+    lo, _ = GO.ge2e_loss(eo, wo, bo)
+    (0.5 * lo).backward()
+    L2 = GE2ELoss(DEV)
+    eg = emb.to(DEV).requires_grad_(True)
+    (0.5 * L2(eg)).backward()                                  # a non-unit upstream gradient
+    assert rel_err(eg.grad, eo.grad) < 1e-4, rel_err(eg.grad, eo.grad)
+    assert abs(float(L2.w.grad) - float(wo.grad)) < 1e-3 * (1 + abs(float(wo.grad)))
+    assert abs(float(L2.b.grad) - float(bo.grad)) < 1e-3 * (1 + abs(float(bo.grad)))
 
 
 def test_config2_synthesize_full_size_vs_oracle(precision):
