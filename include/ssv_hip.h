@@ -209,10 +209,27 @@ size_t ssv_lstm_fwd_workspace(int Bn, int T, int F, int H, int layers);
 int ssv_lstm_fwd(const float* x, const float* const* w_ih, const float* const* w_hh,
                  const float* const* b_ih, const float* const* b_hh, float* h_last,
                  int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream);
-/* e = normalize(h W^T + b): h (Bn,H), w (P,H), e (Bn,P). */
+/* e = normalize(h W^T + b): h (Bn,H), w (P,H), e (Bn,P).  norms (Bn, may be NULL): |h W^T + b| per row, kept for the backward. */
 size_t ssv_proj_l2norm_fwd_workspace(int Bn, int P);
-int ssv_proj_l2norm_fwd(const float* h, const float* w, const float* bias, float* e, int Bn, int H, int P,
+int ssv_proj_l2norm_fwd(const float* h, const float* w, const float* bias, float* e, float* norms, int Bn, int H, int P,
                         void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* Backward: de (Bn,P) -> dh (Bn,H), dw (P,H), dbias (P). */
+size_t ssv_proj_l2norm_bwd_workspace(int Bn, int P);
+int ssv_proj_l2norm_bwd(const float* de, const float* e, const float* norms, const float* h, const float* w,
+                        float* dh, float* dw, float* dbias, int Bn, int H, int P, void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* Training (GE2E/train_speech_embedder.py:77-83): the same LSTM forward, keeping every frame of h, c and
+ * the activated gates in `saved` (caller-owned, ssv_lstm_saved_bytes), and backpropagation through time from dh_last
+ * (Bn,H) to the gradients of all weights and biases (arrays of `layers` DEVICE pointers, torch layouts).  Split-bf16 mode,
+ * batch >= 8 and hidden % 32 == 0 only (SSV_UNSUPPORTED otherwise). */
+size_t ssv_lstm_saved_bytes(int Bn, int T, int F, int H, int layers);
+size_t ssv_lstm_train_fwd_workspace(int Bn, int T, int F, int H, int layers);
+int ssv_lstm_train_fwd(const float* x, const float* const* w_ih, const float* const* w_hh,
+                       const float* const* b_ih, const float* const* b_hh, float* h_last, void* saved,
+                       int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream);
+size_t ssv_lstm_bwd_workspace(int Bn, int T, int F, int H, int layers);
+int ssv_lstm_bwd(const float* dh_last, const void* saved, const float* const* w_ih, const float* const* w_hh,
+                 float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh,
+                 int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* Replaces GE2ELoss.forward, GE2E/speech_embedder_net.py:43-49 with GE2E/utils.py:16-55.
  * emb (N,M,D); w, b device scalars; loss[0] = total; per (N,M) per-embedding losses (may be NULL). */
 size_t ssv_ge2e_loss_fwd_workspace(int N, int M, int D);

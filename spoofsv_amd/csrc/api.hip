@@ -52,7 +52,10 @@ int ssv_launch_softmax_cols_bwd(const float*, float*, const float*, float, int, 
 int ssv_launch_lstm_in_transpose(const float*, float*, int, int, int, hipStream_t);
 int ssv_launch_lstm_cell(const float*, float*, float*, int, int, int, hipStream_t);
 int ssv_launch_transpose_out(const float*, float*, int, int, hipStream_t);
-int ssv_launch_l2norm_rows(const float*, float*, int, int, hipStream_t);
+int ssv_launch_l2norm_rows(const float*, float*, float*, int, int, hipStream_t);
+int ssv_launch_l2norm_bwd(const float*, const float*, const float*, float*, int, int, hipStream_t);
+int ssv_launch_colsum(const float*, float*, int, int, hipStream_t);
+int ssv_launch_lstm_cell_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, hipStream_t);
 
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
@@ -105,6 +108,7 @@ static GemmNNB nnb_zero() {
   g.sxn = g.scn = 1;
   g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
   g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0;
+  g.gates_out = nullptr;
   return g;
 }
 
@@ -524,13 +528,16 @@ extern "C" size_t ssv_lstm_fwd_workspace(int Bn, int T, int F, int H, int layers
 // projection rides along as the first K segment of the same product instead of a separate pass over all frames.
 // T + layers - 1 steps of two launches (layer 0, whose input projection W_ih x_t is precomputed for all frames, and layers
 // 1.. batched over grid.y) instead of layers * T sequential products.
+// Training (keep != null): every frame of h, c and the activated gates is kept in the caller's buffers (D = T instead of the 2-frame ring).
 static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
-                         const float* const* b_hh, float* h_last, int Bn, int T, int F, int H, int layers, char* base, hipStream_t st) {
+                         const float* const* b_hh, float* h_last, int Bn, int T, int F, int H, int layers, char* base, hipStream_t st,
+                         float* keep_xt = nullptr, float* keep_hs = nullptr, float* keep_cs = nullptr, float* keep_gates = nullptr) {
   const LstmWave s = lstm_wave_ws(Bn, T, F, H, layers);
-  float* xt = (float*)(base + s.xt);
+  const int D = keep_hs ? T : 2;
+  float* xt = keep_xt ? keep_xt : (float*)(base + s.xt);
   float* xp = (float*)(base + s.xp);
-  float* out = (float*)(base + s.out);
-  float* cbuf = (float*)(base + s.c);
+  float* out = keep_hs ? keep_hs : (float*)(base + s.out);
+  float* cbuf = keep_cs ? keep_cs : (float*)(base + s.c);
   float* bias = (float*)(base + s.bias);
   const long HN = (long)H * Bn;
   SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));    // [T][F][Bn]
@@ -564,7 +571,7 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   GemmNNB g = nnb_zero();
   g.sxc = Bn; g.Lx = Bn; g.scm = Bn; g.srm = Bn;
   g.M = 4 * H; g.N = Bn; g.perm_h = H; g.epi = 1; g.cstate = cbuf;
-  g.lstm_out = out; g.lstm_D = 2; g.sbb = (long)8 * H;
+  g.lstm_out = out; g.lstm_D = D; g.sbb = (long)8 * H; g.gates_out = keep_gates;
   g.X = out; g.C = out;                        // placeholders: the kernel derives X, X2 and C from (layer, frame)
   for (int step = 0; step < T + layers - 1; ++step) {
     g.lstm_s = step;
@@ -588,7 +595,7 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
     }
   }
   (void)HN;
-  return ssv_launch_transpose_out(out + ((long)(layers - 1) * 2 + (T - 1) % 2) * H * Bn, h_last, H, Bn, st);
+  return ssv_launch_transpose_out(out + ((long)(layers - 1) * D + (T - 1) % D) * H * Bn, h_last, H, Bn, st);
 }
 
 extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
@@ -668,7 +675,7 @@ extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const floa
 }
 
 extern "C" size_t ssv_proj_l2norm_fwd_workspace(int Bn, int P) { return align256((size_t)Bn * P * sizeof(float)); }
-extern "C" int ssv_proj_l2norm_fwd(const float* h, const float* w, const float* bias, float* e, int Bn, int H, int P,
+extern "C" int ssv_proj_l2norm_fwd(const float* h, const float* w, const float* bias, float* e, float* norms, int Bn, int H, int P,
                                    void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(h && w && e && Bn > 0 && H > 0 && P > 0, SSV_BAD_SHAPE, "proj_l2norm_fwd: bad argument");
   SSV_CHECK(ws && ws_bytes >= ssv_proj_l2norm_fwd_workspace(Bn, P), SSV_BAD_SHAPE, "proj_l2norm_fwd: workspace too small");
@@ -679,5 +686,162 @@ extern "C" int ssv_proj_l2norm_fwd(const float* h, const float* w, const float* 
   g.bias = bias;
   g.M = P; g.N = Bn; g.Kc = H; g.B = 1;
   SSV_TRY(ssv_launch_gemm_nn(g, (hipStream_t)stream));
-  return ssv_launch_l2norm_rows((const float*)ws, e, P, Bn, (hipStream_t)stream);
+  return ssv_launch_l2norm_rows((const float*)ws, e, norms, P, Bn, (hipStream_t)stream);
+}
+// Backward of the above: dy = (de - e <e,de>) / |y|;  dh = dy W,  dW = dy^T h,  dbias = column sums of dy.
+extern "C" size_t ssv_proj_l2norm_bwd_workspace(int Bn, int P) { return align256((size_t)Bn * P * sizeof(float)); }
+extern "C" int ssv_proj_l2norm_bwd(const float* de, const float* e, const float* norms, const float* h, const float* w, float* dh, float* dw,
+                                   float* dbias, int Bn, int H, int P, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(de && e && norms && h && w && dh && dw && dbias && Bn > 0 && H > 0 && P > 0, SSV_BAD_SHAPE, "proj_l2norm_bwd: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_proj_l2norm_bwd_workspace(Bn, P), SSV_BAD_SHAPE, "proj_l2norm_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* dy = (float*)ws;                      // (Bn, P)
+  SSV_TRY(ssv_launch_l2norm_bwd(de, e, norms, dy, P, Bn, st));
+  SSV_TRY(ssv_launch_colsum(dy, dbias, P, Bn, st));
+  GemmNN g = nn_zero();                        // dh (Bn,H): rows b, reduction over p
+  g.A = dy; g.sam = P; g.sac = 1; g.saj = 1;
+  g.X = w; g.sxc = H; g.Lx = H;
+  g.C = dh; g.scm = H;
+  g.M = Bn; g.N = H; g.Kc = P; g.B = 1;
+  SSV_TRY(ssv_launch_gemm_nn(g, st));
+  GemmNN q = nn_zero();                        // dW (P,H) = dy^T h: rows p, reduction over b
+  q.A = dy; q.sam = 1; q.sac = P; q.saj = 1;
+  q.X = h; q.sxc = H; q.Lx = H;
+  q.C = dw; q.scm = H;
+  q.M = P; q.N = H; q.Kc = Bn; q.B = 1;
+  return ssv_launch_gemm_nn(q, st);
+}
+
+// ---- LSTM training: forward that keeps every frame, and backpropagation through time ------------------------------------
+// saved (caller-owned, ssv_lstm_saved_bytes): xt [T][F][Bn] | hs [layers][T][H][Bn] | cs [layers][T][H][Bn] |
+// gates [layers][T][4H][Bn] (activated i, f, g, o; torch row order).
+struct LstmSaved { size_t xt, hs, cs, gates, total; };
+static LstmSaved lstm_saved(int Bn, int T, int F, int H, int layers) {
+  LstmSaved s;
+  s.xt = 0;
+  s.hs = s.xt + align256((size_t)T * F * Bn * sizeof(float));
+  s.cs = s.hs + align256((size_t)layers * T * H * Bn * sizeof(float));
+  s.gates = s.cs + align256((size_t)layers * T * H * Bn * sizeof(float));
+  s.total = s.gates + align256((size_t)layers * T * 4 * H * Bn * sizeof(float));
+  return s;
+}
+extern "C" size_t ssv_lstm_saved_bytes(int Bn, int T, int F, int H, int layers) { return lstm_saved(Bn, T, F, H, layers).total; }
+extern "C" size_t ssv_lstm_train_fwd_workspace(int Bn, int T, int F, int H, int layers) { return lstm_wave_ws(Bn, T, F, H, layers).total; }
+extern "C" int ssv_lstm_train_fwd(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                                  const float* const* b_hh, float* h_last, void* saved, int Bn, int T, int F, int H, int layers,
+                                  void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(x && w_ih && w_hh && b_ih && b_hh && h_last && saved && Bn > 0 && T > 0 && F > 0 && H > 0 && layers > 0, SSV_BAD_SHAPE, "lstm_train_fwd: bad argument");
+  SSV_CHECK(ssv_precision() == 1 && H % 32 == 0 && Bn >= 8, SSV_UNSUPPORTED, "lstm_train_fwd: needs the split-bf16 mode, batch >= 8 and hidden %% 32 == 0");
+  SSV_CHECK(ws && ws_bytes >= ssv_lstm_train_fwd_workspace(Bn, T, F, H, layers), SSV_BAD_SHAPE, "lstm_train_fwd: workspace too small");
+  const LstmSaved sv = lstm_saved(Bn, T, F, H, layers);
+  char* sb = (char*)saved;
+  return lstm_fwd_wave(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, (char*)ws, (hipStream_t)stream,
+                       (float*)(sb + sv.xt), (float*)(sb + sv.hs), (float*)(sb + sv.cs), (float*)(sb + sv.gates));
+}
+
+struct LstmBwdWs { size_t dgates, dxc, dx0, dcarry, dhtop, rs, wt0, wtc, wtc_stride, slabs, total; };
+static size_t lstm_dw_slab_bytes(int T, int H, int Fin) {
+  return align256((size_t)dw_splits(T, 4 * H, Fin, 1) * 4 * H * Fin * sizeof(float));
+}
+static LstmBwdWs lstm_bwd_ws(int Bn, int T, int F, int H, int layers) {
+  LstmBwdWs s;
+  s.dgates = 0;
+  s.dxc = s.dgates + align256((size_t)layers * T * 4 * H * Bn * sizeof(float));
+  s.dx0 = s.dxc + align256((size_t)(layers > 1 ? layers - 1 : 0) * T * 2 * H * Bn * sizeof(float));
+  s.dcarry = s.dx0 + align256((size_t)T * H * Bn * sizeof(float));
+  s.dhtop = s.dcarry + align256((size_t)layers * H * Bn * sizeof(float));
+  s.rs = s.dhtop + align256((size_t)H * Bn * sizeof(float));
+  s.wt0 = s.rs + align256((size_t)T * 4 * H * sizeof(float));
+  s.wtc = s.wt0 + 2 * split_bytes(H, 4 * H, 1);                    // W_hh[0]^T
+  s.wtc_stride = 2 * split_bytes(2 * H, 4 * H, 1);                 // [W_ih | W_hh]^T of a layer >= 1
+  s.slabs = s.wtc + (size_t)(layers > 1 ? layers - 1 : 0) * s.wtc_stride;
+  s.total = s.slabs + zmax(lstm_dw_slab_bytes(T, H, H), lstm_dw_slab_bytes(T, H, F));
+  return s;
+}
+extern "C" size_t ssv_lstm_bwd_workspace(int Bn, int T, int F, int H, int layers) { return lstm_bwd_ws(Bn, T, F, H, layers).total; }
+// dW (M x Nc) = sum over `items` frames of A_item (M x Bn) X_item^T (Nc x Bn): the conv weight-gradient kernel with time = batch
+static int lstm_weight_grad(const float* A, long sab, const float* X, long sxb, float* dw, int M, int Nc, int Bn, int items, void* slabs, hipStream_t st) {
+  GemmNT g = nt_zero();
+  const int Z = dw_splits(items, M, Nc, 1);
+  const long n = (long)M * Nc;
+  g.A = A; g.sab = sab; g.sam = Bn; g.La = Bn;
+  g.X = X; g.sxb = sxb; g.sxc = Bn; g.Lx = Bn;
+  if (Z == 1) { g.C = dw; g.scz = n; g.scm = Nc; g.scc = 1; g.scj = 0; }
+  else { g.C = (float*)slabs; g.scz = n; g.scm = Nc; g.scc = 1; g.scj = 0; }
+  g.M = M; g.Nc = Nc; g.KT = 1; g.B = items; g.Z = Z; g.bstep = Z;
+  SSV_CHECK(ssv_nt_bf3_fits(g), SSV_UNSUPPORTED, "lstm_bwd: sequence buffers exceed the weight-gradient kernel's 32-bit offsets");
+  SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
+  if (Z > 1) SSV_TRY(ssv_launch_reduce_slabs((const float*)slabs, dw, n, Z, n, st));
+  return 0;
+}
+extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float* const* w_ih, const float* const* w_hh,
+                            float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh,
+                            int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dh_last && saved && w_ih && w_hh && dw_ih && dw_hh && db_ih && db_hh && Bn > 0 && T > 0 && F > 0 && H > 0 && layers > 0, SSV_BAD_SHAPE, "lstm_bwd: bad argument");
+  SSV_CHECK(ssv_precision() == 1 && H % 32 == 0 && Bn >= 8, SSV_UNSUPPORTED, "lstm_bwd: needs the split-bf16 mode, batch >= 8 and hidden %% 32 == 0");
+  const LstmBwdWs s = lstm_bwd_ws(Bn, T, F, H, layers);
+  SSV_CHECK(ws && ws_bytes >= s.total, SSV_BAD_SHAPE, "lstm_bwd: workspace too small (%zu < %zu)", ws_bytes, s.total);
+  hipStream_t st = (hipStream_t)stream;
+  const LstmSaved sv = lstm_saved(Bn, T, F, H, layers);
+  const char* sb = (const char*)saved;
+  const float* xt = (const float*)(sb + sv.xt);
+  const float* hs = (const float*)(sb + sv.hs);
+  const float* cs = (const float*)(sb + sv.cs);
+  const float* gates = (const float*)(sb + sv.gates);
+  char* base = (char*)ws;
+  float* dgates = (float*)(base + s.dgates);
+  float* dxc = (float*)(base + s.dxc);
+  float* dx0 = (float*)(base + s.dx0);
+  float* dcarry = (float*)(base + s.dcarry);
+  float* dhtop = (float*)(base + s.dhtop);
+  float* rs = (float*)(base + s.rs);
+  const long HN = (long)H * Bn;
+  SSV_TRY(ssv_launch_transpose_out(dh_last, dhtop, Bn, H, st));               // (Bn, H) -> [H][Bn]
+  // transposed weights for the data-gradient products: rows = inputs of the layer, reduction over the 4H gate rows
+  unsigned short* w0_hi = (unsigned short*)(base + s.wt0);
+  unsigned short* w0_lo = (unsigned short*)(base + s.wt0 + split_bytes(H, 4 * H, 1));
+  SSV_TRY(ssv_launch_pack_split(w_hh[0], w0_hi, w0_lo, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));          // (m=q, k=r) = W_hh[r][q]
+  const size_t rows_h = (size_t)(H / 16) * (4 * H / 32) * 512;               // elements of the first H rows of a [2H x 4H] plane
+  for (int l = 1; l < layers; ++l) {
+    unsigned short* hi = (unsigned short*)(base + s.wtc + (size_t)(l - 1) * s.wtc_stride);
+    unsigned short* lo = (unsigned short*)((char*)hi + split_bytes(2 * H, 4 * H, 1));
+    SSV_TRY(ssv_launch_pack_split(w_ih[l], hi, lo, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));
+    SSV_TRY(ssv_launch_pack_split(w_hh[l], hi + rows_h, lo + rows_h, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));
+  }
+  GemmNNB g = nnb_zero();
+  g.Kpad = 4 * H; g.Kc = 4 * H; g.sxc = Bn; g.Lx = Bn; g.scm = Bn; g.N = Bn;
+  for (int step = T + layers - 2; step >= 0; --step) {
+    const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
+    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dx0, dxc, dhtop, dgates, dcarry, H, Bn, T, layers, step, lo, hi - lo + 1, st));
+    if (lo == 0 && step >= 1) {               // layer 0, frame t = step >= 1: dh_{t-1} = W_hh^T dgates_t (nothing to do for frame 0: x is data)
+      g.Ahi = w0_hi; g.Alo = w0_lo; g.sab = 0;
+      g.X = dgates + (long)step * 4 * HN; g.sxb = 0;
+      g.C = dx0 + (long)step * HN; g.scb = 0;
+      g.M = H; g.B = 1;
+      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+    }
+    const int l1 = lo > 1 ? lo : 1;
+    if (l1 <= hi) {                           // layers l1..hi at frames step - l: [dh^{l-1}_t ; dh^l_{t-1}] = [W_ih | W_hh]^T dgates^l_t
+      g.Ahi = (unsigned short*)(base + s.wtc + (size_t)(l1 - 1) * s.wtc_stride);
+      g.Alo = (unsigned short*)((char*)g.Ahi + split_bytes(2 * H, 4 * H, 1));
+      g.sab = (long)(s.wtc_stride / sizeof(unsigned short));
+      g.X = dgates + ((long)l1 * T + (step - l1)) * 4 * HN; g.sxb = (long)(T - 1) * 4 * HN;
+      g.C = dxc + ((long)(l1 - 1) * T + (step - l1)) * 2 * HN; g.scb = (long)(T - 1) * 2 * HN;
+      g.M = 2 * H; g.B = hi - l1 + 1;
+      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+    }
+  }
+  // parameter gradients: one reduction over all frames per matrix
+  for (int l = 0; l < layers; ++l) {
+    const float* dg = dgates + (long)l * T * 4 * HN;
+    const int Fin = l == 0 ? F : H;
+    const float* in = l == 0 ? xt : hs + (long)(l - 1) * T * HN;
+    SSV_TRY(lstm_weight_grad(dg, 4 * HN, in, (long)Fin * Bn, dw_ih[l], 4 * H, Fin, Bn, T, base + s.slabs, st));
+    if (T > 1) SSV_TRY(lstm_weight_grad(dg + 4 * HN, 4 * HN, hs + (long)l * T * HN, HN, dw_hh[l], 4 * H, H, Bn, T - 1, base + s.slabs, st));
+    else SSV_TRY(ssv_launch_fill(dw_hh[l], 0.f, (long)4 * H * H, st));
+    SSV_TRY(ssv_rowsum(dg, 4 * HN, rs, T, 4 * H, Bn, stream));              // rs[t][r] = sum_b dgates[l][t][r][b]
+    SSV_TRY(ssv_launch_reduce_slabs(rs, db_ih[l], 4 * H, T, 4 * H, st));
+    SSV_HIP(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
 }

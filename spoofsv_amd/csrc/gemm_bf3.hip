@@ -318,15 +318,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     // Fused LSTM cell (torch gate order i, f, g, o).  Rows were packed gate-interleaved, so the four accumulator rows a
     // lane holds for a 16-row tile (rows kq*4 .. kq*4+3) are the four gates of ONE hidden unit at column nq.
     const int H = p.perm_h;
-    float* __restrict__ cst = p.cstate;
+    float* cst = p.cstate;
     const float* __restrict__ bia = p.bias ? p.bias + (long)b * p.sbb : nullptr;
     const float* __restrict__ bib = p.bias_b ? p.bias_b + (long)b * p.sbb : nullptr;
     bool first = p.first != 0;
+    float* cnew = p.cstate;                       // where c_t goes (same place as c_{t-1} unless every frame is kept)
+    float* __restrict__ gsave = nullptr;
     if (p.lstm_D > 0) {
       const long HN = (long)H * p.N;
       cst += (long)lstm_layer * HN;
+      cnew = cst;
       Cb = p.lstm_out + ((long)lstm_layer * p.lstm_D + lstm_t % p.lstm_D) * HN;
       first = lstm_t == 0;
+      if (p.gates_out) {
+        cnew = p.cstate + ((long)lstm_layer * p.lstm_D + lstm_t) * HN;
+        cst = cnew - HN;                            // c_{t-1}: the previous frame of the same layer (not read at t = 0)
+        gsave = p.gates_out + ((long)lstm_layer * p.lstm_D + lstm_t) * 4 * HN;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
@@ -347,7 +355,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
         const float gg = tanhf(gte[2]), go = 1.f / (1.f + expf(-gte[3]));
         const long ci = (long)u * p.N + gn;
         const float cn = (first ? 0.f : gf * cst[ci]) + gi * gg;
-        cst[ci] = cn;
+        cnew[ci] = cn;
+        if (gsave) {
+          const long HN = (long)H * p.N;
+          gsave[ci] = gi; gsave[HN + ci] = gf; gsave[2 * HN + ci] = gg; gsave[3 * HN + ci] = go;
+        }
         Cb[(long)u * p.scm + gn] = go * tanhf(cn);
       }
     }

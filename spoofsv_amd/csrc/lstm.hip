@@ -49,7 +49,7 @@ int ssv_launch_transpose_out(const float* src, float* dst, int R, int Bn, hipStr
 }
 
 // y [P][Bn] -> e (Bn, P), each row divided by its L2 norm.  One wave per batch item.
-__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ y, float* __restrict__ e, int P, int Bn) {
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ y, float* __restrict__ e, float* __restrict__ norms, int P, int Bn) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= Bn) return;
   float s = 0.f;
@@ -57,10 +57,11 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   const float nrm = sqrtf(s);
+  if (norms && lane == 0) norms[b] = nrm;
   for (int p = lane; p < P; p += 64) e[(long)b * P + p] = y[(long)p * Bn + b] / nrm;
 }
-int ssv_launch_l2norm_rows(const float* y, float* e, int P, int Bn, hipStream_t st) {
-  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(ssv_cdiv(Bn, 4)), dim3(256), 0, st, y, e, P, Bn);
+int ssv_launch_l2norm_rows(const float* y, float* e, float* norms, int P, int Bn, hipStream_t st) {
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(ssv_cdiv(Bn, 4)), dim3(256), 0, st, y, e, norms, P, Bn);
   return ssv_check_launch("l2norm_rows");
 }
 
@@ -274,4 +275,69 @@ extern "C" int ssv_ge2e_loss_bwd(const float* emb, const float* w, const float* 
   SSV_TRY(ssv_check_launch("ge2e_bwd_finish"));
   hipLaunchKernelGGL(ge2e_bwd_wb_kernel, dim3(1), dim3(256), 0, st, (const float*)part, dloss, dw, db, N * M);
   return ssv_check_launch("ge2e_bwd_wb");
+}
+
+
+// ---- LSTM backward: cell ----------------------------------------------------------------------------------
+// Layer l = lo + blockIdx.y at frame t = s - l (reverse wavefront step s).  dh_t collects the gradient from the layer above
+// (rows [0, H) of its data-gradient product at the same frame), from the layer's own next frame (rows [H, 2H) of its product
+// at t + 1; layer 0's product has only those H rows) and, for the top layer's last frame, from the projection.  Writes the
+// pre-activation gate gradients dgates[l][t] in torch row order (gate*H + u) and carries dc_{t-1} = dc_t * f_t in dcarry[l].
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cs, const float* __restrict__ dx0,
+                                                            const float* __restrict__ dxc, const float* __restrict__ dh_top, float* __restrict__ dgates,
+                                                            float* __restrict__ dcarry, int H, int Bn, int T, int layers, int s, int lo) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long HN = (long)H * Bn;
+  if (i >= HN) return;
+  const int l = lo + blockIdx.y, t = s - l;
+  float dh = 0.f;
+  if (l + 1 < layers) dh += dxc[((long)l * T + t) * 2 * HN + i];                    // dxc is indexed by layer - 1
+  if (t + 1 < T) dh += (l == 0) ? dx0[(long)(t + 1) * HN + i] : dxc[((long)(l - 1) * T + t + 1) * 2 * HN + HN + i];
+  if (l == layers - 1 && t == T - 1) dh += dh_top[i];
+  const long gt = ((long)l * T + t) * 4 * HN;
+  const float gi = gates[gt + i], gf = gates[gt + HN + i], gg = gates[gt + 2 * HN + i], go = gates[gt + 3 * HN + i];
+  const float c = cs[((long)l * T + t) * HN + i];
+  const float cprev = t > 0 ? cs[((long)l * T + t - 1) * HN + i] : 0.f;
+  const float tc = tanhf(c);
+  const float dc = dh * go * (1.f - tc * tc) + (t + 1 < T ? dcarry[(long)l * HN + i] : 0.f);
+  dcarry[(long)l * HN + i] = dc * gf;
+  dgates[gt + i] = dc * gg * gi * (1.f - gi);
+  dgates[gt + HN + i] = dc * cprev * gf * (1.f - gf);
+  dgates[gt + 2 * HN + i] = dc * gi * (1.f - gg * gg);
+  dgates[gt + 3 * HN + i] = dh * tc * go * (1.f - go);
+}
+int ssv_launch_lstm_cell_bwd(const float* gates, const float* cs, const float* dx0, const float* dxc, const float* dh_top, float* dgates, float* dcarry,
+                             int H, int Bn, int T, int layers, int s, int lo, int nl, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ssv_cdiv((long)H * Bn, 256), nl), dim3(256), 0, st, gates, cs, dx0, dxc, dh_top, dgates, dcarry, H, Bn, T,
+                     layers, s, lo);
+  return ssv_check_launch("lstm_cell_bwd");
+}
+
+// ---- projection + L2 normalisation backward ---------------------------------------------------------------
+// e = y / |y|:  dy = (de - e <e, de>) / |y|.  One wave per batch row.
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ de, const float* __restrict__ e, const float* __restrict__ norms,
+                                                         float* __restrict__ dy, int P, int Bn) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= Bn) return;
+  float s = 0.f;
+  for (int p = lane; p < P; p += 64) s += e[(long)b * P + p] * de[(long)b * P + p];
+  s = ssv_wave_sum(s);
+  const float inv = 1.f / norms[b];
+  for (int p = lane; p < P; p += 64) dy[(long)b * P + p] = (de[(long)b * P + p] - e[(long)b * P + p] * s) * inv;
+}
+// out[p] = sum_b x[b][p]   (x (Bn, P) row-major), fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int P, int Bn) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  float s = 0.f;
+  for (int b = 0; b < Bn; ++b) s += x[(long)b * P + p];
+  out[p] = s;
+}
+int ssv_launch_l2norm_bwd(const float* de, const float* e, const float* norms, float* dy, int P, int Bn, hipStream_t st) {
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ssv_cdiv(Bn, 4)), dim3(256), 0, st, de, e, norms, dy, P, Bn);
+  return ssv_check_launch("l2norm_bwd");
+}
+int ssv_launch_colsum(const float* x, float* out, int P, int Bn, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(ssv_cdiv(P, 256)), dim3(256), 0, st, x, out, P, Bn);
+  return ssv_check_launch("colsum");
 }

@@ -68,6 +68,9 @@ struct GemmNNB {
   // (skipped at t = 0).  All h live in lstm_out[layer][slot = frame % lstm_D][H][N]; the kernel derives X, X2 and C from
   // (layer, t), and offsets the weight planes by b*sab, the biases by b*sbb and cstate by layer*H*N.
   float* lstm_out; int lstm_s, lstm_lo, lstm_D, xsplit; long sab;
+  // training (gates_out != null, lstm_D = number of frames): the activated gates i, f, g, o are saved as
+  // gates_out[layer][frame][gate*H + u][N] (torch row order) and cstate is [layer][frame][H][N] (c_{t-1} read, c_t written)
+  float* gates_out;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);

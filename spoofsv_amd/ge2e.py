@@ -2,8 +2,9 @@
 
 ``SpeechEmbedder().forward(x)``: (B, frames, n_mels) -> (B, proj) unit-norm d-vectors
 (speech_embedder_net.py:27-33); ``GE2ELoss(device).forward(emb)``: (N, M, D) -> scalar loss
-(:43-49 with GE2E/utils.py:16-55).  Forward only, as BASELINE.json's north_star asks; the LSTM
-stack, the projection and the loss run in libssv_hip.so.  State-dict keys equal the reference's
+(:43-49 with GE2E/utils.py:16-55).  The LSTM stack, the projection and the loss run in libssv_hip.so, forward (what
+BASELINE.json's north_star asks) and backward (one iteration of GE2E/train_speech_embedder.py:70-86
+with torch's own clip_grad_norm_ and SGD on top).  State-dict keys equal the reference's
 (``LSTM_stack.weight_ih_l0`` ... ``projection.bias``), so its checkpoints load unchanged.
 
 The reference reads its sizes from a module-global ``hparam`` loaded from config/config.yaml; here they
@@ -19,6 +20,76 @@ from . import _lib
 from .ops import _c, _dev, _p, _stream, _ws
 
 
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class _EmbedderFn(torch.autograd.Function):
+    """SpeechEmbedder.forward (speech_embedder_net.py:27-33) with its backward: LSTM stack -> last frame -> Linear -> x/|x|.
+    Inputs: train flag (keep every frame for the backward), x, projection weight, projection bias, then per layer
+    w_ih, w_hh, b_ih, b_hh."""
+
+    @staticmethod
+    def forward(ctx, train, x, pw, pb, *lstm):
+        layers = len(lstm) // 4
+        Bn, T, F = x.shape
+        H, P = lstm[1].shape[1], pw.shape[0]
+        w_ih, w_hh = [_c(lstm[4 * l]) for l in range(layers)], [_c(lstm[4 * l + 1]) for l in range(layers)]
+        b_ih, b_hh = [_c(lstm[4 * l + 2]) for l in range(layers)], [_c(lstm[4 * l + 3]) for l in range(layers)]
+        pw, pb = _c(pw), _c(pb)
+        h_last = torch.empty((Bn, H), dtype=torch.float32, device=x.device)
+        args = (_ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih), _ptr_array(b_hh))
+        if train:
+            saved = _ws(_lib.query("ssv_lstm_saved_bytes", Bn, T, F, H, layers), x.device)
+            nb = _lib.query("ssv_lstm_train_fwd_workspace", Bn, T, F, H, layers)
+            ws = _ws(nb, x.device)
+            _lib.call("ssv_lstm_train_fwd", _p(x), *args, _p(h_last), _p(saved), Bn, T, F, H, layers, _p(ws), nb, _stream())
+        else:
+            nb = _lib.query("ssv_lstm_fwd_workspace", Bn, T, F, H, layers)
+            ws = _ws(nb, x.device)
+            _lib.call("ssv_lstm_fwd", _p(x), *args, _p(h_last), Bn, T, F, H, layers, _p(ws), nb, _stream())
+        e = torch.empty((Bn, P), dtype=torch.float32, device=x.device)
+        norms = torch.empty((Bn,), dtype=torch.float32, device=x.device) if train else None
+        nb2 = _lib.query("ssv_proj_l2norm_fwd_workspace", Bn, P)
+        ws2 = _ws(nb2, x.device)
+        _lib.call("ssv_proj_l2norm_fwd", _p(h_last), _p(pw), _p(pb), _p(e), _p(norms), Bn, H, P, _p(ws2), nb2, _stream())
+        if train:
+            ctx.save_for_backward(saved, h_last, e, norms, pw, *w_ih, *w_hh)
+            ctx.dims = (Bn, T, F, H, P, layers)
+        return e
+
+    @staticmethod
+    def backward(ctx, de):
+        Bn, T, F, H, P, layers = ctx.dims
+        saved, h_last, e, norms, pw = ctx.saved_tensors[:5]
+        w_ih = list(ctx.saved_tensors[5:5 + layers])
+        w_hh = list(ctx.saved_tensors[5 + layers:5 + 2 * layers])
+        dev = e.device
+        de = _c(de)
+        dh = torch.empty((Bn, H), dtype=torch.float32, device=dev)
+        dpw = torch.empty_like(pw)
+        dpb = torch.empty((P,), dtype=torch.float32, device=dev)
+        nb = _lib.query("ssv_proj_l2norm_bwd_workspace", Bn, P)
+        ws = _ws(nb, dev)
+        _lib.call("ssv_proj_l2norm_bwd", _p(de), _p(e), _p(norms), _p(h_last), _p(pw), _p(dh), _p(dpw), _p(dpb), Bn, H, P,
+                  _p(ws), nb, _stream())
+        dw_ih = [torch.empty_like(w) for w in w_ih]
+        dw_hh = [torch.empty_like(w) for w in w_hh]
+        db_ih = [torch.empty((4 * H,), dtype=torch.float32, device=dev) for _ in range(layers)]
+        db_hh = [torch.empty((4 * H,), dtype=torch.float32, device=dev) for _ in range(layers)]
+        nb2 = _lib.query("ssv_lstm_bwd_workspace", Bn, T, F, H, layers)
+        ws2 = _ws(nb2, dev)
+        _lib.call("ssv_lstm_bwd", _p(dh), _p(saved), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(dw_ih), _ptr_array(dw_hh),
+                  _ptr_array(db_ih), _ptr_array(db_hh), Bn, T, F, H, layers, _p(ws2), nb2, _stream())
+        grads = []
+        for l in range(layers):
+            grads += [dw_ih[l], dw_hh[l], db_ih[l], db_hh[l]]
+        return (None, None, dpw, dpb) + tuple(grads)
+
+
 class SpeechEmbedder(nn.Module):
     def __init__(self, nmels=40, hidden=768, num_layer=3, proj=256):
         super().__init__()
@@ -31,35 +102,21 @@ class SpeechEmbedder(nn.Module):
         self.projection = nn.Linear(hidden, proj)
         self.dims = (nmels, hidden, num_layer, proj)
 
-    @torch.no_grad()
     def forward(self, x):
         _dev(x, "utterance batch")
         x = _c(x)
-        Bn, T, F = x.shape
         nmels, H, layers, P = self.dims
-        if F != nmels:
-            raise RuntimeError("SpeechEmbedder: input has %d mel bins, model expects %d" % (F, nmels))
+        if x.shape[2] != nmels:
+            raise RuntimeError("SpeechEmbedder: input has %d mel bins, model expects %d" % (x.shape[2], nmels))
         lstm = self.LSTM_stack
-        arrs = []
-        keep = []
-        for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
-            ptrs = (ctypes.c_void_p * layers)()
-            for l in range(layers):
-                t = _c(getattr(lstm, "%s_l%d" % (kind, l)))
-                keep.append(t)
-                ptrs[l] = t.data_ptr()
-            arrs.append(ptrs)
-        h_last = torch.empty((Bn, H), dtype=torch.float32, device=x.device)
-        nb = _lib.query("ssv_lstm_fwd_workspace", Bn, T, F, H, layers)
-        ws = _ws(nb, x.device)
-        _lib.call("ssv_lstm_fwd", _p(x), arrs[0], arrs[1], arrs[2], arrs[3], _p(h_last), Bn, T, F, H, layers,
-                  _p(ws), nb, _stream())
-        e = torch.empty((Bn, P), dtype=torch.float32, device=x.device)
-        nb2 = _lib.query("ssv_proj_l2norm_fwd_workspace", Bn, P)
-        ws2 = _ws(nb2, x.device)
-        _lib.call("ssv_proj_l2norm_fwd", _p(h_last), _p(_c(self.projection.weight)), _p(_c(self.projection.bias)),
-                  _p(e), Bn, H, P, _p(ws2), nb2, _stream())
-        return e
+        params = []
+        for l in range(layers):
+            params += [getattr(lstm, "%s_l%d" % (kind, l)) for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        if self.training and torch.is_grad_enabled():
+            # keeps every frame for backpropagation through time (ssv_lstm_saved_bytes: 5.8 GB at 880 x 120 frames)
+            return _EmbedderFn.apply(True, x, self.projection.weight, self.projection.bias, *params)
+        with torch.no_grad():       # d-vector extraction (GE2E/dvector_create.py:100): nothing is kept
+            return _EmbedderFn.apply(False, x, self.projection.weight, self.projection.bias, *params)
 
 
 class _GE2ELossFn(torch.autograd.Function):

@@ -206,7 +206,7 @@ def test_ge2e_embedder_golden():
     g = load("ge2e_embedder.npz")
     m = SpeechEmbedder(nmels=40, hidden=32, num_layer=3, proj=16)
     m.load_state_dict(sub(g, "sd/"))
-    m = m.to(DEV)
+    m = m.to(DEV).eval()
     e = m(t(g["x"], DEV))
     assert rel_err(e, t(g["e"])) < 1e-4, rel_err(e, t(g["e"]))
 
@@ -218,7 +218,7 @@ def test_ge2e_embedder_midsize_vs_oracle():
     x = torch.randn(37, 21, 40)
     with torch.no_grad():
         eo = GO.speech_embedder(x, m.state_dict())
-    eg = m.to(DEV)(x.to(DEV))
+    eg = m.to(DEV).eval()(x.to(DEV))
     assert rel_err(eg, eo) < 1e-4, rel_err(eg, eo)
 
 
@@ -259,6 +259,57 @@ def test_ge2e_loss_backward_golden_and_full_size_vs_oracle():
     assert rel_err(eg.grad, eo.grad) < 1e-4, rel_err(eg.grad, eo.grad)
     assert abs(float(L2.w.grad) - float(wo.grad)) < 1e-3 * (1 + abs(float(wo.grad)))
     assert abs(float(L2.b.grad) - float(bo.grad)) < 1e-3 * (1 + abs(float(bo.grad)))
+
+
+def test_ge2e_training_iteration_golden():
+    """G10: one iteration of GE2E/train_speech_embedder.py:70-86 -- HIP forward + backward, then torch's own clip_grad_norm_
+    and SGD as the reference uses them -- against the loss, gradients and updated parameters of the reference's modules."""
+    import spoofsv_amd
+    from spoofsv_amd.ge2e import GE2ELoss, SpeechEmbedder
+    spoofsv_amd.set_precision("bf16x3")                        # the training kernels exist in the split-bf16 mode only
+    g = load("ge2e_train.npz")
+    N, M, T, H, P = [int(v) for v in g["dims"]]
+    m = SpeechEmbedder(nmels=40, hidden=H, num_layer=3, proj=P)
+    m.load_state_dict(sub(g, "p0/"))
+    m = m.to(DEV).train()
+    L = GE2ELoss(DEV)
+    opt = torch.optim.SGD([{"params": m.parameters()}, {"params": L.parameters()}], lr=0.01)
+    opt.zero_grad()
+    emb = m(t(g["x"], DEV))
+    assert rel_err(emb, t(g["emb"])) < 1e-4
+    loss = L(emb.reshape(N, M, -1))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, t(g["g/" + k])) < 2e-3, (k, rel_err(p.grad, t(g["g/" + k])))
+    assert abs(float(L.w.grad) - float(g["dw"])) < 1e-4 and abs(float(L.b.grad) - float(g["db"])) < 1e-4
+    torch.nn.utils.clip_grad_norm_(m.parameters(), 3.0)
+    torch.nn.utils.clip_grad_norm_(L.parameters(), 1.0)
+    opt.step()
+    for k, v in m.state_dict().items():
+        assert rel_err(v, t(g["p1/" + k])) < 1e-4, (k, rel_err(v, t(g["p1/" + k])))
+
+
+def test_ge2e_backward_midsize_vs_oracle():
+    """LSTM backpropagation through time at a ragged mid size (37 utterances, 21 frames, hidden 96) against autograd over
+    the CPU oracle, with a random upstream gradient on the embeddings."""
+    import spoofsv_amd
+    from spoofsv_amd.ge2e import SpeechEmbedder
+    spoofsv_amd.set_precision("bf16x3")
+    torch.manual_seed(4)
+    m = SpeechEmbedder(nmels=40, hidden=96, num_layer=3, proj=64)
+    with torch.no_grad():
+        for n, p in m.LSTM_stack.named_parameters():
+            if "bias" in n:
+                p.uniform_(-0.2, 0.2)
+    x = torch.randn(37, 21, 40)
+    de = torch.randn(37, 64)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    GO.speech_embedder(x, sd).backward(de)
+    m = m.to(DEV)
+    m(x.to(DEV)).backward(de.to(DEV))
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, sd[k].grad) < 2e-3, (k, rel_err(p.grad, sd[k].grad))
 
 
 def test_config2_synthesize_full_size_vs_oracle(precision):
