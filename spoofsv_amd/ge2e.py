@@ -161,3 +161,18 @@ class GE2ELoss(nn.Module):
         _dev(embeddings, "embeddings")
         loss, per = _GE2ELossFn.apply(embeddings.float(), self.w, self.b)
         return (loss, per) if return_per_embedding else loss
+
+
+def train_iteration(embedder_net, ge2e_loss, optimizer, mel_db_batch, N, M):
+    """One iteration of GE2E/train_speech_embedder.py:70-86 (the batch permutation of :67-73 is undone at :78 before the
+    loss and does not enter the arithmetic, so it is omitted): forward, loss, backward on the HIP path, then torch's own
+    ``clip_grad_norm_`` (3.0 on the embedder, 1.0 on the loss parameters) and the optimizer step, as the reference does."""
+    optimizer.zero_grad()
+    x = mel_db_batch.reshape(N * M, mel_db_batch.size(-2), mel_db_batch.size(-1))
+    embeddings = embedder_net(x).reshape(N, M, -1)
+    loss = ge2e_loss(embeddings)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(embedder_net.parameters(), 3.0)
+    torch.nn.utils.clip_grad_norm_(ge2e_loss.parameters(), 1.0)
+    optimizer.step()
+    return loss.detach()
