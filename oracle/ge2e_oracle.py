@@ -49,22 +49,24 @@ def speech_embedder(x, sd, num_layers=3):
     return e / torch.norm(e, dim=1).unsqueeze(1)
 
 
-def ge2e_cossim(emb):
-    """get_centroids + get_cossim, utils.py:16-46.  emb: (N, M, D) -> (N, M, N).
+def ge2e_cossim(emb, centroids=None):
+    """get_centroids + get_cossim, utils.py:16-46.  emb: (N, M, D) -> (N, M, K).
 
-    cos[j,i,k] = cosine(e_ji, c_k) + 1e-6 with c_k the speaker mean (utils.py:16-25),
-    except k == j where the centroid leaves e_ji out (utils.py:27-34, :42-43).
+    cos[j,i,k] = cosine(e_ji, c_k) + 1e-6 with c_k the speaker mean (utils.py:16-25) -- or the given ``centroids`` (K, D),
+    as the verification test passes enrollment centroids (train_speech_embedder.py:156-159) -- except k == j, where
+    the centroid is the mean of speaker j's OTHER embeddings in ``emb`` (utils.py:27-34, :42-43), also in that case.
     F.cosine_similarity clamps the *product* of norms at eps=1e-8 in torch>=1.12 (each
     norm separately in older versions); the embeddings are unit vectors so it is inert.
     """
     N, M, _ = emb.shape
-    cent = emb.mean(dim=1)                                   # (N, D)
+    cent = emb.mean(dim=1) if centroids is None else centroids   # (K, D)
+    K = cent.shape[0]
     loo = (emb.sum(dim=1, keepdim=True) - emb) / (M - 1)     # (N, M, D)
-    cos = F.cosine_similarity(emb.unsqueeze(2), cent.view(1, 1, N, -1), dim=3)
+    cos = F.cosine_similarity(emb.unsqueeze(2), cent.view(1, 1, K, -1), dim=3)
     own = F.cosine_similarity(emb, loo, dim=2)               # (N, M)
-    idx = torch.arange(N)
+    idx = torch.arange(min(N, K))
     cos = cos.clone()
-    cos[idx, :, idx] = own
+    cos[idx, :, idx] = own[idx]
     return cos + 1e-6
 
 
@@ -107,3 +109,29 @@ def ge2e_train_step(x, sd, w, b, N, M, num_layers=3, lr=0.01, clip_net=3.0, clip
     gloss, _ = clip_grad_norm([wv.grad, bv.grad], clip_loss)
     new_sd = {k: (p[k].detach() - lr * g) for k, g in zip(keys, gnet)}
     return loss.detach(), grads, (wv.grad.clone(), bv.grad.clone()), new_sd, (wv.detach() - lr * gloss[0], bv.detach() - lr * gloss[1])
+
+
+def eer_sweep(sim_matrix, size_1, es1, spoof=True):
+    """The threshold sweep of train_speech_embedder.py:168-191 (spoof=True: ``test``) and :262-282 (spoof=False:
+    ``test_nospoof``), written as the reference writes it: thresholds 0.50, 0.51, ..., 0.99; the first threshold with
+    the smallest |FAR - FRR| wins.  sim_matrix: (N, V, N) verification x enrollment-centroid similarities; size_1 = M
+    utterances per speaker in the batch, es1 = 2 * enroll_num of them used for enrollment.
+    Returns dict(EER, thres, FAR, FRR[, gt_FRR, spoof_rate])."""
+    N = sim_matrix.shape[0]
+    diff, out = 1, dict(EER=0, thres=0, FAR=0, FRR=0)
+    for thres in [0.01 * i + 0.5 for i in range(50)]:
+        th = sim_matrix > thres
+        if spoof:
+            FAR = sum(th[i].float().sum() - th[i, :, i].float().sum() for i in range(N)) / (N - 1.0) / float(size_1 - es1) / N
+            FRR = sum(size_1 - es1 - th[i, :, i].float().sum() for i in range(N)) / float(size_1 - es1) / N
+            gtfrr = sum(size_1 // 2 - es1 // 2 - th[i, :(size_1 - es1) // 2, i].float().sum() for i in range(N)) / float(size_1 / 2 - es1 / 2) / N
+            spoof_rate = sum(th[i, -(size_1 - es1) // 2:, i].float().sum() for i in range(N)) / float(size_1 / 2 - es1 / 2) / N
+        else:
+            FAR = sum(th[i].float().sum() - th[i, :, i].float().sum() for i in range(N)) / (N - 1.0) / float(size_1 / 2 - es1 / 2) / N
+            FRR = sum(size_1 // 2 - es1 // 2 - th[i, :, i].float().sum() for i in range(N)) / float(size_1 / 2 - es1 / 2) / N
+        if diff > abs(FAR - FRR):
+            diff = abs(FAR - FRR)
+            out = dict(EER=float((FAR + FRR) / 2), thres=thres, FAR=float(FAR), FRR=float(FRR))
+            if spoof:
+                out.update(gt_FRR=float(gtfrr), spoof_rate=float(spoof_rate))
+    return out

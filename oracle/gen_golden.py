@@ -308,7 +308,15 @@ def gen_ge2e_train(ref):
     n1 = torch.nn.utils.clip_grad_norm_(m.parameters(), 3.0)
     n2 = torch.nn.utils.clip_grad_norm_(L.parameters(), 1.0)
     opt.step()
+    # verification-against-enrollment similarity as GE2E/train_speech_embedder.py:156-159 computes it (utils.get_cossim with
+    # centroids of ANOTHER set: the own-speaker column still uses the leave-one-out centroid of the verification set)
+    torch.manual_seed(92)
+    ver = torch.randn(4, 5, 8); ver = ver / ver.norm(dim=2, keepdim=True)
+    enr = torch.randn(4, 3, 8); enr = enr / enr.norm(dim=2, keepdim=True)
+    ev_cent = U.get_centroids(enr)
+    ev_sim = U.get_cossim(ver, ev_cent)
     out = dict(x=_np(x), dims=np.array([N, M, T, 32, 16], dtype=np.int64), loss=_np(loss.detach()), emb=_np(emb.detach()),
+               ev_ver=_np(ver), ev_enr=_np(enr), ev_cent=_np(ev_cent), ev_sim=_np(ev_sim),
                w0=np.float32(10.0), b0=np.float32(-5.0), dw=_np(gw), db=_np(gb), w1=_np(L.w.detach()), b1=_np(L.b.detach()),
                norm_net=_np(n1), norm_loss=_np(n2))
     out.update({"p0/" + k: _np(v) for k, v in sd0.items()})

@@ -332,3 +332,36 @@ def test_graph_synthesis_matches_step_by_step_loop():
     assert torch.equal(Y1, Y2) and torch.equal(A1, A2)
     assert torch.equal(A0.argmax(dim=1), A1.argmax(dim=1))
     assert rel_err(Y1, Y0) < 1e-3 and rel_err(A1, A0) < 1e-3, (rel_err(Y1, Y0), rel_err(A1, A0))
+
+
+@pytest.mark.gpu
+def test_ge2e_harness_trains_checkpoints_and_verifies(tmp_path):
+    """GE2E/train_speech_embedder.py end to end on synthetic preprocessed TI-SV data: train (HIP forward + backward),
+    checkpoint, then the mixture / no-spoof verification tests and the spoof-rate pass over the saved matrices."""
+    import numpy as np
+    import spoofsv_amd
+    from spoofsv_amd import ge2e_harness as GH
+    spoofsv_amd.set_precision("bf16x3")
+    rng = np.random.RandomState(3)
+    for split, nspk in (("train", 8), ("test", 4)):
+        d = tmp_path / split
+        d.mkdir()
+        for s in range(nspk):
+            base = rng.randn(1, 40, 1).astype(np.float32)           # a speaker-specific spectral offset
+            np.save(d / ("spk%02d.npy" % s), base + 0.3 * rng.randn(16, 40, 24).astype(np.float32))
+    cfg = GH.default_config()
+    cfg["data"].update(train_path=str(tmp_path / "train"), test_path=str(tmp_path / "test"))
+    cfg["model"].update(hidden=32, proj=16)
+    cfg["train"].update(N=4, M=4, epochs=3, log_interval=1, checkpoint_interval=2, checkpoint_dir=str(tmp_path / "ckpt"))
+    cfg["test"].update(N=4, M=12, epochs=1)
+    cfg["save_simmat_dir"] = str(tmp_path / "simmat")
+    torch.manual_seed(0)
+    net, hist = GH.train(cfg)
+    assert len(hist) == 6 and all(np.isfinite(hist))
+    files = sorted(os.listdir(tmp_path / "ckpt"))
+    assert any(f.startswith("ckpt_epoch_2") for f in files) and any(f.endswith(".model") for f in files)
+    model_path = str(tmp_path / "ckpt" / [f for f in files if f.endswith(".model")][0])
+    eer, spoof = GH.test(cfg, model_path, enroll_num=2)
+    thres = GH.test_nospoof(cfg, model_path, enroll_num=2, eval_num=2)
+    rate = GH.spoof_rate_at(cfg, thres, eval_num=2)
+    assert 0.0 <= eer <= 1.0 and 0.0 <= spoof <= 1.0 and 0.5 <= thres < 1.0 and 0.0 <= rate <= 1.0

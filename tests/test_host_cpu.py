@@ -110,3 +110,29 @@ def test_data_parallel_ranks_gloo_world2():
     for i, (a, b) in enumerate(zip(g0, g1)):             # gradients averaged: (1 + 2)/2 * (i+1)
         assert np.allclose(a, 1.5 * (i + 1)) and np.array_equal(a, b)
     assert l0 == l1 == [0.5, 5.0]
+
+
+def test_ge2e_eval_host_logic_matches_reference_loops():
+    """cossim_eval against the reference's own get_cossim output (fixture) and the one-shot EER sweep against the
+    oracle's literal restatement of the reference's threshold loops, both test variants."""
+    import numpy as np
+    import torch
+    from _golden import load, rel_err, t
+    from oracle import ge2e_oracle as GO
+    from spoofsv_amd import ge2e_harness as GH
+    g = load("ge2e_train.npz")
+    assert rel_err(GH.cossim_eval(t(g["ev_ver"]), t(g["ev_cent"])), t(g["ev_sim"])) < 1e-5
+    torch.manual_seed(6)
+    for trial in range(4):
+        N, size_1, enroll = 5, 16, 2
+        es1 = 2 * enroll
+        sim = 0.45 + 0.6 * torch.rand(N, size_1 - es1, N)
+        idx = torch.arange(N)
+        sim[idx, :, idx] += 0.15                                   # genuine trials score higher
+        a, b = GH.eer_sweep(sim, size_1, es1, spoof=True), GO.eer_sweep(sim, size_1, es1, spoof=True)
+        for k in b:
+            assert abs(a[k] - b[k]) < 1e-6, (trial, k, a[k], b[k])
+        sim2 = sim[:, :6]
+        a, b = GH.eer_sweep(sim2, size_1, es1, spoof=False), GO.eer_sweep(sim2, size_1, es1, spoof=False)
+        for k in b:
+            assert abs(a[k] - b[k]) < 1e-6, (trial, k, a[k], b[k])

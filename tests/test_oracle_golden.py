@@ -180,3 +180,6 @@ def test_ge2e_training_iteration():
     for k, v in new_sd.items():
         assert rel_err(v, t(g["p1/" + k])) < 1e-5, k
     assert abs(float(w1) - float(g["w1"])) < 1e-5 and abs(float(b1) - float(g["b1"])) < 1e-5
+    # verification-style similarity (enrollment centroids of another set), train_speech_embedder.py:156-159
+    assert rel_err(GO.ge2e_cossim(t(g["ev_ver"]), t(g["ev_cent"])), t(g["ev_sim"])) < 1e-5
+    assert rel_err(t(g["ev_enr"]).mean(dim=1), t(g["ev_cent"])) < 1e-6
