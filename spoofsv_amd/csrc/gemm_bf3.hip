@@ -639,7 +639,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(g.B <= 65535, SSV_UNSUPPORTED, "gemm_nn_bf3: batch %d exceeds grid.y", g.B);
   SSV_CHECK(g.sxn >= 1 && g.scn >= 1 && (g.scn == 1 || (!g.R && !g.epi)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad column strides");
   SSV_CHECK(!g.epi || (g.KT == 1 && g.perm_h > 0 && g.M == 4 * g.perm_h && g.cstate && (g.B == 1 || g.lstm_D > 0)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad LSTM epilogue request");
-  SSV_CHECK(g.lstm_D == 0 || (g.epi == 1 && g.lstm_out && g.lstm_D >= 2 && g.xsplit >= 0 && g.xsplit <= g.Kpad / 32 && g.Kc == g.Kpad && g.sxn == 1), SSV_BAD_SHAPE,
+  SSV_CHECK(g.lstm_D == 0 || (g.epi == 1 && g.lstm_out && g.lstm_D >= 1 && g.xsplit >= 0 && g.xsplit <= g.Kpad / 32 && g.Kc == g.Kpad && g.sxn == 1), SSV_BAD_SHAPE,
             "gemm_nn_bf3: bad LSTM wavefront request");
   int smin = g.shift[0], smax = g.shift[0];
   for (int j = 1; j < g.KT; ++j) { smin = g.shift[j] < smin ? g.shift[j] : smin; smax = g.shift[j] > smax ? g.shift[j] : smax; }

@@ -312,6 +312,29 @@ def test_ge2e_backward_midsize_vs_oracle():
         assert rel_err(p.grad, sd[k].grad) < 2e-3, (k, rel_err(p.grad, sd[k].grad))
 
 
+@pytest.mark.parametrize("layers,T", [(1, 5), (2, 1), (3, 2)])
+def test_ge2e_backward_edge_shapes_vs_oracle(layers, T):
+    """Backpropagation through time at the edges of the wavefront: a single layer, a single frame, fewer frames than layers."""
+    import spoofsv_amd
+    from spoofsv_amd.ge2e import SpeechEmbedder
+    spoofsv_amd.set_precision("bf16x3")
+    torch.manual_seed(10 * layers + T)
+    m = SpeechEmbedder(nmels=40, hidden=32, num_layer=layers, proj=16)
+    with torch.no_grad():
+        for n, p in m.LSTM_stack.named_parameters():
+            if "bias" in n:
+                p.uniform_(-0.2, 0.2)
+    x = torch.randn(9, T, 40)
+    de = torch.randn(9, 16)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    GO.speech_embedder(x, sd, num_layers=layers).backward(de)
+    m = m.to(DEV)
+    m(x.to(DEV)).backward(de.to(DEV))
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        assert (p.grad.cpu() - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-6, (k, float((p.grad.cpu() - ref).abs().max()), float(ref.abs().max()))
+
+
 def test_config2_synthesize_full_size_vs_oracle(precision):
     """BASELINE config 2: Text2Mel free-running synthesis of the first Harvard sentence + SSRN, full-size models with
     seeded random weights (no trained checkpoint exists offline), one speaker code; GPU vs the CPU oracle.
