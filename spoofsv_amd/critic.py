@@ -1,4 +1,6 @@
-"""WGAN-GP critics of the reference (``models/discriminator.py:6-80``), on stock PyTorch-ROCm ops.
+"""WGAN-GP critics of the reference (``models/discriminator.py:6-80``), on stock PyTorch-ROCm ops except for the
+convolutions, which run on the HIP conv kernels (``ops.conv1d_dd``: forward, data gradient and weight gradient are closed
+under differentiation, so the double backward of the gradient penalty needs nothing else).
 
 NOT part of the hand-written HIP hot path: SURVEY.md section 8(f) ranks the critics as the first "next" row.
 They need double backward for the gradient penalty (train/adversarial_wasserstein_gp.py:300-308), which the
@@ -10,6 +12,17 @@ active whenever the module is in training mode, as in the reference (which never
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import ops
+
+
+def _conv(conv, x):
+    """nn.Conv1d forward.  On a ROCm device the convolution itself runs on the HIP conv kernels through
+    ``ops.conv1d_dd`` (differentiable to any order, as the gradient penalty needs; MIOpen's fp32 1-D convolutions were 23 %
+    of a critic iteration); everything else in the critics stays a stock torch op."""
+    if x.is_cuda and conv.kernel_size[0] in (1, 3) and conv.stride[0] == 1:
+        return ops.conv1d_dd(x, conv.weight, conv.bias, conv.kernel_size[0], conv.dilation[0], False)
+    return conv(x)
 
 
 class _HighwayConvDropout(nn.Module):
@@ -25,7 +38,7 @@ class _HighwayConvDropout(nn.Module):
         self.dp = nn.Dropout(p=0.05)
 
     def forward(self, x):
-        h = self.conv(x)
+        h = _conv(self.conv, x)
         h1 = self.ln1(h[:, :self.dimension].permute(0, 2, 1)).permute(0, 2, 1)
         h2 = self.ln2(h[:, self.dimension:].permute(0, 2, 1)).permute(0, 2, 1)
         g = torch.sigmoid(h1)
@@ -56,13 +69,13 @@ class _Disc(nn.Module):
         self.pl3 = nn.AdaptiveAvgPool1d(output_size=1)
 
     def forward(self, inputs):
-        x = self.dp1(_ln(self.conv1(inputs), self.ln1))
+        x = self.dp1(_ln(_conv(self.conv1, inputs), self.ln1))
         x = self.hc(x)
-        x = _ln(self.pl1(self.conv2(x)), self.ln2)
+        x = _ln(self.pl1(_conv(self.conv2, x)), self.ln2)
         x = self.dp2(F.leaky_relu(x, 0.05))
-        x = _ln(self.pl2(self.conv3(x)), self.ln3)
-        x = _ln(self.conv4(F.leaky_relu(x, 0.05)), self.ln4)
-        return self.pl3(self.conv5(F.leaky_relu(x, 0.05)))      # no sigmoid: Wasserstein critic
+        x = _ln(self.pl2(_conv(self.conv3, x)), self.ln3)
+        x = _ln(_conv(self.conv4, F.leaky_relu(x, 0.05)), self.ln4)
+        return self.pl3(_conv(self.conv5, F.leaky_relu(x, 0.05)))      # no sigmoid: Wasserstein critic
 
 
 class melDisc(_Disc):

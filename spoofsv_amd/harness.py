@@ -168,7 +168,7 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
             mel_gt = sp["data_0"].to(dev)
             if train_step == "train_text2mel":
                 l1, bd, la, att = train.text2mel_step(model, opt, mel_gt, sp["data_1"].to(dev), sp["data_2"].to(dev), gaw)
-                terms = (float(l1), float(bd), float(la))
+                terms = (float(l1.detach()), float(bd.detach()), float(la.detach()))
             else:
                 l1, bd = train.ssrn_step(model, opt, mel_gt, sp["data_1"].to(dev))
                 terms = (float(l1), float(bd))

@@ -237,6 +237,82 @@ class Conv1dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+# ------------------------------------------------------------------------------------------- conv, any-order differentiable
+# The WGAN-GP critic needs the gradient of a gradient (train/adversarial_wasserstein_gp.py:300-308).  A convolution is
+# bilinear in (x, w), so its three kernels -- forward, data gradient, weight gradient -- are closed under differentiation:
+# each is an autograd Function whose backward is written with the other two, which makes the op differentiable to any
+# order on the HIP kernels alone.  The bias gradient is a plain torch sum (already differentiable).
+class ConvFwdDD(torch.autograd.Function):
+    """y = conv1d(x, w) (no bias), kernel 1 or 3, "same" or causal zero padding."""
+
+    @staticmethod
+    def forward(ctx, x, w, k, dilation, causal):
+        x, xbs = _act3(x, "conv input")
+        w = _c(w)
+        B, Cin, L = x.shape
+        y = torch.empty((B, w.shape[0], L), dtype=_F32, device=x.device)
+        _conv_fwd(x, xbs, w, None, None, y, w.shape[0] * L, k, dilation, causal)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (k, dilation, causal)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k, dilation, causal = ctx.cfg
+        dx = ConvBwdDataDD.apply(dy, w, x.shape[1], k, dilation, causal) if ctx.needs_input_grad[0] else None
+        dw = ConvBwdWeightDD.apply(dy, x, k, dilation, causal) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None
+
+
+class ConvBwdDataDD(torch.autograd.Function):
+    """dx = conv1d_transpose(dy, w): linear in dy and in w."""
+
+    @staticmethod
+    def forward(ctx, dy, w, Cin, k, dilation, causal):
+        dy, dybs = _act3(dy, "grad")
+        w = _c(w)
+        dx = _conv_bwd_data(dy, dybs, w, Cin, dy.shape[2], k, dilation, causal)
+        ctx.save_for_backward(dy, w)
+        ctx.cfg = (k, dilation, causal)
+        return dx
+
+    @staticmethod
+    def backward(ctx, ddx):
+        dy, w = ctx.saved_tensors
+        k, dilation, causal = ctx.cfg
+        g_dy = ConvFwdDD.apply(ddx, w, k, dilation, causal) if ctx.needs_input_grad[0] else None
+        g_w = ConvBwdWeightDD.apply(dy, ddx, k, dilation, causal) if ctx.needs_input_grad[1] else None
+        return g_dy, g_w, None, None, None, None
+
+
+class ConvBwdWeightDD(torch.autograd.Function):
+    """dw = sum_{b,t} dy x: linear in dy and in x."""
+
+    @staticmethod
+    def forward(ctx, dy, x, k, dilation, causal):
+        dy, dybs = _act3(dy, "grad")
+        x, xbs = _act3(x, "conv input")
+        dw = _conv_bwd_weight(dy, dybs, x, xbs, (dy.shape[1], x.shape[1], k), k, dilation, causal)
+        ctx.save_for_backward(dy, x)
+        ctx.cfg = (k, dilation, causal)
+        return dw
+
+    @staticmethod
+    def backward(ctx, ddw):
+        dy, x = ctx.saved_tensors
+        k, dilation, causal = ctx.cfg
+        g_dy = ConvFwdDD.apply(x, ddw, k, dilation, causal) if ctx.needs_input_grad[0] else None
+        g_x = ConvBwdDataDD.apply(dy, ddw, x.shape[1], k, dilation, causal) if ctx.needs_input_grad[1] else None
+        return g_dy, g_x, None, None, None
+
+
+def conv1d_dd(x, w, bias=None, k=1, dilation=1, causal=False):
+    """Conv1d (kernel 1 or 3) differentiable to any order on the HIP kernels; the bias is added with a torch op."""
+    y = ConvFwdDD.apply(x, w, k, dilation, bool(causal))
+    return y if bias is None else y + bias.view(1, -1, 1)
+
+
 # ------------------------------------------------------------------------------------------- embedding
 class TextEmbedFn(torch.autograd.Function):
     """textEmbedding.forward, models/TTSModel.py:25-35: one-hot + Linear == column gather + bias."""
