@@ -162,7 +162,7 @@ def adversarial_cycle_ms(kind, batch, dev, cycles=3):
     model.apply(train.init_weights); disc.apply(train.init_weights)
     model.to(dev).train(); disc.to(dev).train()
     og = train.FusedAdam(model.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
-    od = train.FusedAdam(disc.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True, resident=False)
+    od = train.FusedAdam(disc.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
     stepper = train.AdversarialGraphStep(kind, model, disc, og, od, data, gaw)
     def cycle():
         stepper.g_step()

@@ -286,7 +286,7 @@ def _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, sav
     fixed batch shapes, i.e. the synthetic source).  Same schedule, losses, logs and checkpoints as the eager loop."""
     a = cfg["ADAM"]
     opt_syn = train.FusedAdam(model.parameters(), a["ALPHA"], (a["BETA_1"], a["BETA_2"]), a["EPSILON"], capturable=True)
-    opt_disc = train.FusedAdam(disc.parameters(), a["ALPHA"], (a["BETA_1"], a["BETA_2"]), a["EPSILON"], capturable=True, resident=False)
+    opt_disc = train.FusedAdam(disc.parameters(), a["ALPHA"], (a["BETA_1"], a["BETA_2"]), a["EPSILON"], capturable=True)
     w_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
     w_disc = {k: v.detach().clone() for k, v in disc.state_dict().items()}
     kind = "text2mel" if train_step == "train_text2mel" else "ssrn"

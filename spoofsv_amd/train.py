@@ -60,7 +60,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._step_dev = None
         self._steps = 0
         self._resident = None
-        self.resident = resident           # False for models that do not run on the HIP conv path (the critics)
+        self.resident = resident           # False for models that never reach the HIP conv path
 
     def refresh_resident_weights(self):
         """(Re)write the resident pre-split planes of every conv weight this optimizer owns (one launch; see
