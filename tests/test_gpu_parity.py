@@ -312,6 +312,29 @@ def test_ge2e_backward_midsize_vs_oracle():
         assert rel_err(p.grad, sd[k].grad) < 2e-3, (k, rel_err(p.grad, sd[k].grad))
 
 
+@pytest.mark.parametrize("k,d", [(1, 1), (3, 1), (3, 3)])
+def test_conv1d_dd_second_order_vs_torch(k, d):
+    """ops.conv1d_dd (forward / data-gradient / weight-gradient Functions that differentiate into each other) against
+    torch's conv1d on the CPU: first-order gradients and the gradient of a gradient-penalty style functional."""
+    from spoofsv_amd import ops
+    torch.manual_seed(7 + k + d)
+    B, Cin, Cout, L = 3, 24, 40, 150
+    x0, w0, b0 = torch.randn(B, Cin, L), torch.randn(Cout, Cin, k) * 0.2, torch.randn(Cout) * 0.1
+
+    def penalty(conv, x, w, b):
+        y = torch.tanh(conv(x, w, b))
+        (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+        return ((gx.norm(p=2, dim=(1, 2)) - 1) ** 2).mean() + y.mean()
+
+    pad = d * (k - 1) // 2
+    xc, wc, bc = [v.clone().requires_grad_(True) for v in (x0, w0, b0)]
+    penalty(lambda x, w, b: torch.nn.functional.conv1d(x, w, b, padding=pad, dilation=d), xc, wc, bc).backward()
+    xg, wg, bg = [v.clone().to(DEV).requires_grad_(True) for v in (x0, w0, b0)]
+    penalty(lambda x, w, b: ops.conv1d_dd(x, w, b, k, d), xg, wg, bg).backward()
+    for a, r, n in ((xg.grad, xc.grad, "dx"), (wg.grad, wc.grad, "dw"), (bg.grad, bc.grad, "db")):
+        assert rel_err(a, r) < 2e-3, (n, rel_err(a, r))
+
+
 @pytest.mark.parametrize("layers,T", [(1, 5), (2, 1), (3, 2)])
 def test_ge2e_backward_edge_shapes_vs_oracle(layers, T):
     """Backpropagation through time at the edges of the wavefront: a single layer, a single frame, fewer frames than layers."""
