@@ -96,6 +96,45 @@ class BatchSource:
             yield self._cached(i) if (self.files and self.step == "train_ssrn") else self._synthetic(i)
 
 
+class Prefetcher:
+    """Iterate over a batch source with the host work (file reads / synthetic generation, padding) done one or two batches
+    ahead on a background thread into pinned memory, and the host-to-device copies issued without blocking: the role of the
+    reference's multi-worker DataLoader (train/ordinary.py:199-200), sized for one process per GPU.  Yields the same dicts,
+    already on ``device``, in the same order."""
+
+    def __init__(self, source, device, depth=2):
+        self.source, self.device, self.depth = source, device, depth
+
+    def __len__(self):
+        return len(self.source)
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        pin = torch.cuda.is_available() and self.device.type == "cuda"
+        stop = object()
+
+        def work():
+            try:
+                for sp in self.source:
+                    q.put({k: (v.pin_memory() if pin else v) for k, v in sp.items()})
+                q.put(stop)
+            except BaseException as e:          # surface loader errors in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        while True:
+            item = q.get()
+            if item is stop:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield {k: v.to(self.device, non_blocking=pin) for k, v in item.items()}
+        th.join()
+
+
 def _build(train_step, train_pattern, cfg, adversarial):
     if train_step == "train_text2mel":
         model = melSyn(vocab_len=len(cfg["VOCABULARY"]) - 1, condition=(train_pattern == "conditional"),
@@ -158,7 +197,7 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
         opt.load_state_dict(ck["optimizer_state_dict"])
         epoch, iteration, loss_val_log = ck["epoch"], ck["iteration"], ck["loss_val_log"]
     model.train()
-    src = BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir)
+    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir), dev)
     gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
     max_iter = cfg.get("MAX_ITERATIONS")
     history = []
@@ -220,7 +259,7 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
             logs[k] = ck[k]
     model.train()
     disc.train()
-    src = BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir)
+    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir), dev)
     gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
     max_iter = cfg.get("MAX_ITERATIONS")
     if cfg.get("CAPTURE_GRAPHS") and resume_checkpoints is None and not src.files:
@@ -294,7 +333,7 @@ def _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, sav
     def pick(sp):
         keys = ("data_0", "data_1", "data_2") if kind == "text2mel" else ("data_0", "data_1")
         return [sp[k].to(dev) for k in keys]
-    first = pick(next(iter(src)))
+    first = pick(next(iter(src.source)))          # shapes only; the prefetching iterator starts with the training loop
     stepper = train.AdversarialGraphStep(kind, model, disc, opt_syn, opt_disc, first, gaw, cfg["LAMBDA"])
     # capturing ran warm-up iterations: put weights and optimizer state back to the start of training
     model.load_state_dict(w_model)

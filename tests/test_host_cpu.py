@@ -136,3 +136,28 @@ def test_ge2e_eval_host_logic_matches_reference_loops():
         a, b = GH.eer_sweep(sim2, size_1, es1, spoof=False), GO.eer_sweep(sim2, size_1, es1, spoof=False)
         for k in b:
             assert abs(a[k] - b[k]) < 1e-6, (trial, k, a[k], b[k])
+
+
+def test_prefetcher_yields_the_same_batches_in_order():
+    import json
+    import torch
+    from spoofsv_amd import harness
+    cfg = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config.json")))
+    cfg["SYNTHETIC_BATCHES_PER_EPOCH"] = 5
+    cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"] = 20, 30
+    plain = list(harness.BatchSource(cfg, "train_text2mel", 3))
+    pre = list(harness.Prefetcher(harness.BatchSource(cfg, "train_text2mel", 3), torch.device("cpu")))
+    assert len(pre) == len(plain) == 5
+    for a, b in zip(pre, plain):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k])
+
+    class Broken:
+        def __len__(self): return 1
+        def __iter__(self):
+            yield {"data_0": torch.zeros(1)}
+            raise ValueError("loader failed")
+    import pytest
+    with pytest.raises(ValueError):
+        list(harness.Prefetcher(Broken(), torch.device("cpu")))
