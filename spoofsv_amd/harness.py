@@ -262,7 +262,7 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
     src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir), dev)
     gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
     max_iter = cfg.get("MAX_ITERATIONS")
-    if cfg.get("CAPTURE_GRAPHS") and resume_checkpoints is None and not src.files:
+    if cfg.get("CAPTURE_GRAPHS") and resume_checkpoints is None and not src.source.files:
         return _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter)
     while epoch < cfg["MAX_EPOCHS"]:
         for i, sp in enumerate(src):
