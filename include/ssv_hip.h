@@ -242,6 +242,35 @@ size_t ssv_ge2e_loss_bwd_workspace(int N, int M, int D);
 int ssv_ge2e_loss_bwd(const float* emb, const float* w, const float* b, const float* dloss, float* demb, float* dw, float* db,
                       int N, int M, int D, void* ws, size_t ws_bytes, ssv_stream_t stream);
 
+/* ---- Vocoder and spectrogram front end ------------------------------------------------
+ * Replaces the CPU tail of synthesis, synthesize.py:138-147 / generate_test_utterances.py:128-139
+ * (`librosa.core.griffinlim(S, n_iter=64, hop_length, win_length)`, `signal.lfilter([1], [1, -PREEMPH], y)`, peak
+ * normalisation) and the STFT front end of data/dataset.py:96-110, for a batch of equal-length utterances.
+ * The DFTs are ssv_conv1d_fwd calls (k = 1) with windowed Fourier bases built by the host; these entries are the
+ * steps between them.  Spectra are (B, 2F, T): rows [0,F) real, [F,2F) imaginary.  Frame matrices are (B, N, T):
+ * row c holds sample c of every frame.  N = n_fft = 2(F-1), centred frames (librosa center=True, reflect padding),
+ * so a T-frame spectrum is a waveform of hop*(T-1) samples.  inv_env: (N + hop*(T-1)) reciprocals of librosa's
+ * window_sumsquare envelope (1 where the envelope vanishes). */
+/* proj = mag * a / (|a| + 1e-16), a = reb - alpha*tprev (tprev NULL = 0): the Griffin-Lim phase update fused with S*angles. */
+int ssv_gl_project(const float* mag, const float* reb, const float* tprev, float alpha, float* proj,
+                   int B, int F, int T, ssv_stream_t stream);
+/* mag = |spec| */
+int ssv_complex_abs(const float* spec, float* mag, int B, int F, int T, ssv_stream_t stream);
+/* istft overlap-add + envelope + centre trim, then stft reflect padding + framing, in one pass: windowed inverse frames
+ * fr (B,N,T) -> analysis frames out (B,N,T) of the same waveform (out must not alias fr).  Needs hop*(T-1) > N/2. */
+int ssv_ola_frames(const float* fr, const float* inv_env, float* out, int B, int N, int T, int hop, ssv_stream_t stream);
+/* istft overlap-add + envelope + centre trim: fr (B,N,T) -> y (B, hop*(T-1)). */
+int ssv_ola_signal(const float* fr, const float* inv_env, float* y, int B, int N, int T, int hop, ssv_stream_t stream);
+/* stft framing: y (B,n) -> fr (B,N,T), T = 1 + n/hop, reflect padding by N/2 (n > N/2). */
+int ssv_frame_signal(const float* y, float* fr, int B, int n, int N, int T, int hop, ssv_stream_t stream);
+/* out[b] = max_i x[b][i];   y = (x / rowmax[b])^p * s   (synthesize.py:141-142,147; data/dataset.py:107-111). */
+int ssv_rowmax(const float* x, float* out, int B, long n, ssv_stream_t stream);
+int ssv_scale_pow(const float* x, const float* rowmax, float* y, float p, float s, int B, long n, ssv_stream_t stream);
+/* y[n] = x[n] + a*y[n-1] per row, recurrence in double (scipy.signal.lfilter([1], [1, -a], x), synthesize.py:145). */
+int ssv_deemphasis(const float* x, float* y, double a, int B, int n, ssv_stream_t stream);
+/* y[0] = x[0], y[n] = x[n] - a*x[n-1] per row (data/dataset.py:96); y must not alias x. */
+int ssv_preemphasis(const float* x, float* y, float a, int B, int n, ssv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

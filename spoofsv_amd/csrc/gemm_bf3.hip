@@ -594,7 +594,10 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
     // (SSRN's 513-channel layers: 150 -> 205 TFLOP/s); the k=3 layers are as fast or faster on the 4-wave kernel.
     // 128 x 192 tiles (8 waves) are the faster wide shape (513 -> 512 channels: 104 -> 87 us, 256 -> 512: 60 -> 49 us) except
     // when M leaves a nearly empty last row tile (M = 513), where the 16-wave 128 x 448 tile loses less (tools/sweep_wide.py)
-    if (KT == 1 && !e && !g.epi && !g.perm_h && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256)
+    // ... and only when the 128 x 192 tiling still gives every CU a workgroup: a single long utterance (the vocoder's DFT
+    // at B = 1: 1026 x 1300 x 1024) is 27-56 wide tiles, a fifth of the chip; the cost model below then picks small tiles.
+    if (KT == 1 && !e && !g.epi && !g.perm_h && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256 &&
+        (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 192) * g.B >= 256)
       return (g.M % 128 == 0) ? launch_nnbw<KT, 2, 6, 2>(g, st, smin, span) : launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
   }
   static const int nts[] = {7, 6, 4, 2};

@@ -372,8 +372,10 @@ def _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, sav
 
 
 def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=None, max_frames=None):
-    """synthesize.py:41-147 up to the linear spectrogram: Text2Mel free-running loop, then SSRN.  Returns the
-    list of (mel, lin, attention) numpy triples and stores them under SRC_ROOT_DIR/samples/<time>/."""
+    """synthesize.py:41-147: Text2Mel free-running loop, SSRN, then the vocoder tail (max-normalise, power, Griffin-Lim
+    with 64 iterations, de-emphasis, peak 0.75; spoofsv_amd.vocoder) written as S<k>_B1.wav like synthesize.py:147.
+    Returns the list of (mel, lin, attention) numpy triples and stores them under SRC_ROOT_DIR/samples/<time>/.
+    cfg["VOCODE"] = False skips the waveform; cfg["GRIFFIN_LIM_ITERS"] overrides the 64 of synthesize.py:144."""
     dev = _device()
     sample_dir = os.path.join(cfg["SRC_ROOT_DIR"], "samples", str(current_time))
     os.makedirs(sample_dir, exist_ok=True)
@@ -393,6 +395,10 @@ def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=No
             texts = [ln.strip() for ln in f if ln.strip()][:1]
     frames = max_frames or cfg["MAX_FRAME_NUM"]
     outs = []
+    voc = None
+    if cfg.get("VOCODE", True) and not cfg.get("LOG_FEATURE", False):
+        from .vocoder import Vocoder
+        voc = Vocoder(cfg["STFT"]["FFT_LENGTH"], cfg["STFT"]["HOP_LENGTH"], dev)
     with torch.no_grad():
         for k, text in enumerate(texts):
             ids = torch.tensor(text2id(text, cfg["VOCABULARY"]), dtype=torch.long, device=dev).view(1, 1, -1)
@@ -402,5 +408,10 @@ def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=No
             mel_np, lin_np, a_np = Y[0].cpu().numpy(), lin[0].cpu().numpy(), A[0].cpu().numpy()
             np.save(os.path.join(sample_dir, "S{}_mel.npy".format(k + 1)), mel_np)
             np.save(os.path.join(sample_dir, "S{}_lin.npy".format(k + 1)), lin_np)
+            if voc is not None:
+                from scipy.io import wavfile       # what librosa 0.7.0's output.write_wav calls (synthesize.py:147)
+                wav = voc.spectrogram2wav(lin.contiguous(), cfg, n_iter=cfg.get("GRIFFIN_LIM_ITERS", 64),
+                                          graph=cfg.get("SYNTH_GRAPH", False))
+                wavfile.write(os.path.join(sample_dir, "S{}_B1.wav".format(k + 1)), cfg["SAMPLING_RATE"], wav[0].cpu().numpy())
             outs.append((mel_np, lin_np, a_np))
     return outs

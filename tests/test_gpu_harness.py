@@ -119,6 +119,10 @@ def test_main_cli_synthesize(tmp_path):
     mel, lin, att = outs[0]
     assert mel.shape == (80, 12) and lin.shape == (65, 48) and att.shape == (43, 12)
     assert os.path.exists(os.path.join(str(tmp_path), "samples", "syn", "S1_lin.npy"))
+    from scipy.io import wavfile                    # vocoder tail, synthesize.py:138-147
+    sr, wav = wavfile.read(os.path.join(str(tmp_path), "samples", "syn", "S1_B1.wav"))
+    assert sr == cfg["SAMPLING_RATE"] and wav.dtype.kind == "f" and wav.shape == (32 * 47,)
+    assert abs(float(wav.max()) - 0.75) < 1e-5 and (wav == wav).all()
 
 
 def test_adversarial_graph_step_matches_eager_generator_iteration():
