@@ -271,6 +271,29 @@ int ssv_deemphasis(const float* x, float* y, double a, int B, int n, ssv_stream_
 /* y[0] = x[0], y[n] = x[n] - a*x[n-1] per row (data/dataset.py:96); y must not alias x. */
 int ssv_preemphasis(const float* x, float* y, float a, int B, int n, ssv_stream_t stream);
 
+/* ---- Second order, for the critics' gradient penalty ------------------------------------------
+ * train/adversarial_wasserstein_gp.py:300-308 differentiates the critic's input gradient
+ * (`autograd.grad(..., create_graph=True)` then `loss.backward()`), so the LayerNorm / highway-gate BACKWARD kernels need
+ * gradients of their own.  Critics only: at most 256 channels, no activation inside the LayerNorm.
+ * ssv_channel_ln_bwd2: for dx = ssv_channel_ln_act_bwd(act = 0)(gn; x) and an upstream v (same shape as dx), the
+ * gradients of <v, dx> w.r.t. gn (d_gn), x (d_x) and gamma (dgamma (C)); beta does not enter. */
+size_t ssv_channel_ln_bwd2_workspace(int B, int C, int L);
+int ssv_channel_ln_bwd2(const float* v, long v_bs, const float* gn, long gn_bs, const float* x, long x_bs, const float* stats,
+                        const float* gamma, float* d_gn, long dgn_bs, float* d_x, long dx_bs, float* dgamma,
+                        int B, int C, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* The highway gate alone (models/TTSModel_dropout.py:63-84 without the conv and the dropout, which the critics keep as
+ * separate differentiable ops): h (B,2C,L) dense, y = sigmoid(LN1(h[:C])) * LN2(h[C:]) + (1 - sigmoid(..)) * x;
+ * stats (B,4,L) saved for ssv_highway_gate_bwd. */
+int ssv_highway_gate_fwd(const float* h, const float* x, long x_bs, const float* g1, const float* b1, const float* g2, const float* b2,
+                         float* stats, float* y, long y_bs, int B, int C, int L, ssv_stream_t stream);
+/* For (dh, dxres) = ssv_highway_gate_bwd(gy; h, x) and upstreams vh (B,2C,L dense), vx: gradients of <vh, dh> + <vx, dxres>
+ * w.r.t. gy (d_gy), h (d_h, dense), x (d_x) and pgrads (4,C) = dgamma1, dbeta1, dgamma2, dbeta2. */
+size_t ssv_highway_gate_bwd2_workspace(int B, int C, int L);
+int ssv_highway_gate_bwd2(const float* vh, const float* vx, long vx_bs, const float* gy, long gy_bs, const float* h, const float* x, long x_bs,
+                          const float* stats, const float* g1, const float* b1, const float* g2, const float* b2,
+                          float* d_gy, long dgy_bs, float* d_h, float* d_x, long dx_bs, float* pgrads,
+                          int B, int C, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,11 +1,12 @@
-"""WGAN-GP critics of the reference (``models/discriminator.py:6-80``), on stock PyTorch-ROCm ops except for the
-convolutions, which run on the HIP conv kernels (``ops.conv1d_dd``: forward, data gradient and weight gradient are closed
-under differentiation, so the double backward of the gradient penalty needs nothing else).
+"""WGAN-GP critics of the reference (``models/discriminator.py:6-80``), SURVEY.md section 8(f) row 1.
 
-NOT part of the hand-written HIP hot path: SURVEY.md section 8(f) ranks the critics as the first "next" row.
-They need double backward for the gradient penalty (train/adversarial_wasserstein_gp.py:300-308), which the
-generator kernels do not need, and cost 0.7 % of the generator's FLOPs.  They exist here so that the
-reference's adversarial iteration can run end to end and hand its dL/dY to the HIP generator path.
+The critics need the gradient of a gradient (the penalty of train/adversarial_wasserstein_gp.py:300-308), which the
+generator kernels do not.  On a ROCm device their heavy operators run on HIP kernels that are differentiable twice:
+  * convolutions -- ``ops.conv1d_dd`` (forward, data gradient and weight gradient are closed under differentiation);
+  * LayerNorm over channels and the highway gate -- ``ops.channel_ln_dd`` / ``ops.highway_gate_dd``: the fused forward and
+    first-order backward kernels of the generator path plus hand-written second-order kernels (``ssv_channel_ln_bwd2``,
+    ``ssv_highway_gate_bwd2``).
+Dropout, leaky-ReLU and the average pools stay torch ops (one small launch each, differentiable as they are).
 Same sub-module names as the reference, so ``disc_state_dict`` checkpoints interchange.  Dropout (p=0.05) is
 active whenever the module is in training mode, as in the reference (which never calls ``disc.eval()``).
 """
@@ -39,6 +40,8 @@ class _HighwayConvDropout(nn.Module):
 
     def forward(self, x):
         h = _conv(self.conv, x)
+        if x.is_cuda:
+            return self.dp(ops.highway_gate_dd(h, x, self.ln1.weight, self.ln1.bias, self.ln2.weight, self.ln2.bias))
         h1 = _ln(h[:, :self.dimension], self.ln1)
         h2 = _ln(h[:, self.dimension:], self.ln2)
         g = torch.sigmoid(h1)
@@ -47,13 +50,11 @@ class _HighwayConvDropout(nn.Module):
 
 def _ln(x, ln):
     """nn.LayerNorm over the channel axis of a (B, C, T) tensor.  The reference permutes to (B, T, C) and back
-    (discriminator.py:24-27); on a ROCm device the same normalisation is written with reductions over dim 1, which spares
-    the two strided copies per call (24 % of a critic iteration) and stays differentiable to any order."""
+    (discriminator.py:24-27); on a ROCm device the tensor stays (B, C, T) and the fused HIP LayerNorm runs on it."""
     if x.is_cuda:
-        mu = x.mean(dim=1, keepdim=True)
-        d = x - mu
-        var = (d * d).mean(dim=1, keepdim=True)
-        return d * torch.rsqrt(var + ln.eps) * ln.weight.view(1, -1, 1) + ln.bias.view(1, -1, 1)
+        if ln.eps != 1e-5:
+            raise RuntimeError("spoofsv_amd.critic: the HIP LayerNorm is built for eps = 1e-5")
+        return ops.channel_ln_dd(x, ln.weight, ln.bias)
     return ln(x.permute(0, 2, 1)).permute(0, 2, 1)
 
 

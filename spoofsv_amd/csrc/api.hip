@@ -45,6 +45,9 @@ extern "C" const char* ssv_last_error(void) { return g_err; }
 int ssv_launch_ln_gate_fwd(const float*, long, const float*, long, const float*, const float*, const float*, const float*, float*, long, float*, int, int, int, hipStream_t);
 int ssv_launch_ln_gate_bwd(const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*, const float*, float*, float*, long, float*, float*, int, int, int, hipStream_t);
 int ssv_ln_gate_bwd_nblk(int B, int L);
+int ssv_launch_ln_bwd2(const float*, long, const float*, long, const float*, long, const float*, const float*, float*, long, float*, long, float*, float*, int, int, int, hipStream_t);
+int ssv_launch_ln_gate_bwd2(const float*, const float*, long, const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*,
+                            const float*, float*, long, float*, float*, long, float*, float*, int, int, int, hipStream_t);
 int ssv_launch_ln_act_fwd(const float*, long, const float*, const float*, float*, long, float*, int, int, int, int, hipStream_t);
 int ssv_launch_ln_act_bwd(const float*, long, const float*, long, const float*, const float*, const float*, float*, long, float*, float*, int, int, int, int, hipStream_t);
 int ssv_launch_softmax_cols(float*, int, int, int, hipStream_t);
@@ -272,6 +275,32 @@ extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w,
   SSV_CHECK(x && w && g1 && b1 && g2 && b2 && h && y, SSV_BAD_SHAPE, "highway_conv1d_fwd: null argument");
   SSV_TRY(ssv_conv1d_fwd(x, x_bs, w, w_packed, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
   return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
+}
+
+// ---- second order (gradient penalty through the critics) and the gate forward alone ------------------------------------
+extern "C" size_t ssv_channel_ln_bwd2_workspace(int B, int C, int L) { return align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * C * sizeof(float)); }
+extern "C" int ssv_channel_ln_bwd2(const float* v, long v_bs, const float* gn, long gn_bs, const float* x, long x_bs, const float* stats,
+                                   const float* gamma, float* d_gn, long dgn_bs, float* d_x, long dx_bs, float* dgamma,
+                                   int B, int C, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(v && gn && x && stats && gamma && d_gn && d_x && dgamma && B > 0 && B <= 65535 && C > 0 && L > 0, SSV_BAD_SHAPE, "channel_ln_bwd2: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_channel_ln_bwd2_workspace(B, C, L), SSV_BAD_SHAPE, "channel_ln_bwd2: workspace too small");
+  return ssv_launch_ln_bwd2(v, v_bs, gn, gn_bs, x, x_bs, stats, gamma, d_gn, dgn_bs, d_x, dx_bs, (float*)ws, dgamma, B, C, L, (hipStream_t)stream);
+}
+extern "C" int ssv_highway_gate_fwd(const float* h, const float* x, long x_bs, const float* g1, const float* b1, const float* g2, const float* b2,
+                                    float* stats, float* y, long y_bs, int B, int C, int L, ssv_stream_t stream) {
+  SSV_CHECK(h && x && g1 && b1 && g2 && b2 && y && B > 0 && B <= 65535 && C > 0 && L > 0, SSV_BAD_SHAPE, "highway_gate_fwd: bad argument");
+  return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
+}
+extern "C" size_t ssv_highway_gate_bwd2_workspace(int B, int C, int L) { return align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 4 * C * sizeof(float)); }
+extern "C" int ssv_highway_gate_bwd2(const float* vh, const float* vx, long vx_bs, const float* gy, long gy_bs, const float* h, const float* x, long x_bs,
+                                     const float* stats, const float* g1, const float* b1, const float* g2, const float* b2,
+                                     float* d_gy, long dgy_bs, float* d_h, float* d_x, long dx_bs, float* pgrads,
+                                     int B, int C, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(vh && vx && gy && h && x && stats && g1 && b1 && g2 && b2 && d_gy && d_h && d_x && pgrads && B > 0 && B <= 65535 && C > 0 && L > 0,
+            SSV_BAD_SHAPE, "highway_gate_bwd2: bad argument");
+  SSV_CHECK(ws && ws_bytes >= ssv_highway_gate_bwd2_workspace(B, C, L), SSV_BAD_SHAPE, "highway_gate_bwd2: workspace too small");
+  return ssv_launch_ln_gate_bwd2(vh, vx, vx_bs, gy, gy_bs, h, x, x_bs, stats, g1, b1, g2, b2, d_gy, dgy_bs, d_h, d_x, dx_bs, (float*)ws, pgrads,
+                                 B, C, L, (hipStream_t)stream);
 }
 
 // ---- highway gate alone (building block: lets a caller overlap the two conv gradients on different streams) ---------------

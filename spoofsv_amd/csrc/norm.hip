@@ -272,6 +272,179 @@ __global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second order: the WGAN-GP gradient penalty (train/adversarial_wasserstein_gp.py:300-308) differentiates the critic's
+// input gradient, i.e. it needs the gradient of the BACKWARD kernels above.  For a scalar s = <v, dX> with
+// dX = ln_act_bwd(act = none)(gn; x):   a = gamma*gn,  u = r (v - mean v - xh mean(v xh)),
+//   ds/dgn = gamma u,   ds/dgamma = sum_cols gn u,
+//   ds/dx  = -r xh s_col / C - r^2 (w - mean w - xh mean(w xh)),   w = v mean(a xh) + a mean(v xh),
+// with s_col = r (<v,a> - C mean v mean a - C mean(v xh) mean(a xh)) this column's share of s.  part: [block][C] = dgamma.
+template <int CPT, int G>
+__global__ __launch_bounds__(16 * G) void ln_bwd2_kernel(
+    const float* __restrict__ V, long v_bs, const float* __restrict__ GN, long gn_bs, const float* __restrict__ X, long x_bs,
+    const float* __restrict__ stats, const float* __restrict__ gam,
+    float* __restrict__ dGN, long dgn_bs, float* __restrict__ dX, long dx_bs, float* __restrict__ part, int C, int L) {
+  __shared__ float red[16 * G];
+  const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int t = bx * 16 + col, b = by;
+  const bool tv = t < L;
+  float mu = 0.f, r = 0.f;
+  if (tv) { mu = stats[(long)b * 2 * L + t]; r = stats[(long)b * 2 * L + L + t]; }
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = (unsigned)G * (unsigned)L;
+  const float* __restrict__ Vb = V + (long)b * v_bs;
+  const float* __restrict__ GNb = GN + (long)b * gn_bs;
+  const float* __restrict__ Xb = X + (long)b * x_bs;
+  float xh[CPT], v[CPT], gn[CPT];
+  float sv = 0.f, svx = 0.f, sa = 0.f, sax = 0.f, sva = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + G * i;
+    xh[i] = 0.f; v[i] = 0.f; gn[i] = 0.f;
+    if (tv && c < C) {
+      xh[i] = (Xb[o0 + i * ostep] - mu) * r;
+      v[i] = Vb[o0 + i * ostep];
+      gn[i] = GNb[o0 + i * ostep];
+      const float a = gn[i] * gam[c];
+      sv += v[i]; svx += v[i] * xh[i]; sa += a; sax += a * xh[i]; sva += v[i] * a;
+    }
+  }
+  const float inv = 1.f / (float)C;
+  const float m_v = group_sum<G>(sv, red, col, g) * inv, m_vx = group_sum<G>(svx, red, col, g) * inv;
+  const float m_a = group_sum<G>(sa, red, col, g) * inv, m_ax = group_sum<G>(sax, red, col, g) * inv;
+  const float m_va = group_sum<G>(sva, red, col, g) * inv;
+  const float s_c = r * (m_va - m_v * m_a - m_vx * m_ax);            // s_col / C
+  const float mw = m_v * m_ax + m_a * m_vx, mwx = 2.f * m_vx * m_ax;
+  float* pblk = part + ((long)by * gridDim.x + bx) * C;
+  float* __restrict__ dGNb = dGN + (long)b * dgn_bs;
+  float* __restrict__ dXb = dX + (long)b * dx_bs;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + G * i;
+    const bool ok = tv && c < C;
+    const float gg = c < C ? gam[c] : 0.f;
+    const float u = ok ? r * (v[i] - m_v - xh[i] * m_vx) : 0.f;
+    if (ok) {
+      const float w = v[i] * m_ax + gn[i] * gg * m_vx;
+      dGNb[o0 + i * ostep] = gg * u;
+      dXb[o0 + i * ostep] = -r * xh[i] * s_c - r * r * (w - mw - xh[i] * mwx);
+    }
+    const float p0 = col_sum(gn[i] * u);
+    if (col == 0 && c < C) pblk[c] = p0;
+  }
+}
+
+// s = <v1, dH1> + <v2, dH2> + <vx, dXres> for (dH, dXres) = ln_gate_bwd(gy; h, x).  With, per LayerNorm i, a_i = gamma_i gn_i
+// (gn2 = gy g, gn1 = gy (n2 - x) g', g = sigmoid(n1), g' = g(1-g), g'' = g'(1-2g)), u_i as above and t_i = gamma_i u_i:
+//   ds/dgy = t2 g + t1 (n2 - x) g' + vx (1 - g)
+//   e2 = ds/dn2 = t1 gy g',   ds/dx = -e2,   e1 = ds/dn1 = (t2 - vx) gy g' + t1 gy (n2 - x) g''
+//   ds/dh_i = LNbwd_i(e_i) + (second-order LayerNorm term of ln_bwd2 with v_i, a_i)
+//   ds/dgamma_i = sum_cols gn_i u_i + e_i xh_i,   ds/dbeta_i = sum_cols e_i.        part: [block][4][C] = dg1, db1, dg2, db2
+template <int CPT, int G>
+__global__ __launch_bounds__(16 * G) void ln_gate_bwd2_kernel(
+    const float* __restrict__ VH, const float* __restrict__ VX, long vx_bs, const float* __restrict__ GY, long gy_bs,
+    const float* __restrict__ H, const float* __restrict__ X, long x_bs, const float* __restrict__ stats,
+    const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
+    float* __restrict__ dGY, long dgy_bs, float* __restrict__ dH, float* __restrict__ dX, long dx_bs,
+    float* __restrict__ part, int C, int L) {
+  __shared__ float red[16 * G];
+  const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int t = bx * 16 + col, b = by;
+  const bool tv = t < L;
+  const unsigned o0 = (unsigned)g * (unsigned)L + (unsigned)t, ostep = (unsigned)G * (unsigned)L;
+  const long hb = (long)b * 2 * C * L, cl = (long)C * L;
+  const float* __restrict__ H1 = H + hb;
+  const float* __restrict__ H2 = H1 + cl;
+  const float* __restrict__ V1 = VH + hb;
+  const float* __restrict__ V2 = V1 + cl;
+  const float* __restrict__ VXb = VX + (long)b * vx_bs;
+  const float* __restrict__ GYb = GY + (long)b * gy_bs;
+  const float* __restrict__ Xb = X + (long)b * x_bs;
+  float mu1 = 0.f, r1 = 0.f, mu2 = 0.f, r2 = 0.f;
+  if (tv) {
+    const float* sb = stats + (long)b * 4 * L + t;
+    mu1 = sb[0]; r1 = sb[L]; mu2 = sb[2L * L]; r2 = sb[3L * L];
+  }
+  // kept across the phases: normalised inputs, upstream v, first-backward gn; and the element-wise factors of e1, e2
+  float xh1[CPT], xh2[CPT], v1[CPT], v2[CPT], gn1[CPT], gn2[CPT];
+  float gy[CPT], dq[CPT], gp[CPT], gpp[CPT], vx[CPT], sg[CPT];      // gy, n2 - x, g', g'', vx, g
+  float s[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + G * i;
+    xh1[i] = xh2[i] = v1[i] = v2[i] = gn1[i] = gn2[i] = gy[i] = dq[i] = gp[i] = gpp[i] = vx[i] = sg[i] = 0.f;
+    if (tv && c < C) {
+      const float gg1 = g1[c], gg2 = g2[c];
+      xh1[i] = (H1[o0 + i * ostep] - mu1) * r1;
+      xh2[i] = (H2[o0 + i * ostep] - mu2) * r2;
+      const float n1 = xh1[i] * gg1 + b1[c], n2 = xh2[i] * gg2 + b2[c];
+      sg[i] = sigmoidf_(n1);
+      gp[i] = sg[i] * (1.f - sg[i]);
+      gpp[i] = gp[i] * (1.f - 2.f * sg[i]);
+      gy[i] = GYb[o0 + i * ostep];
+      dq[i] = n2 - Xb[o0 + i * ostep];
+      vx[i] = VXb[o0 + i * ostep];
+      v1[i] = V1[o0 + i * ostep];
+      v2[i] = V2[o0 + i * ostep];
+      gn2[i] = gy[i] * sg[i];
+      gn1[i] = gy[i] * dq[i] * gp[i];
+      const float a1 = gn1[i] * gg1, a2 = gn2[i] * gg2;
+      s[0] += v1[i]; s[1] += v1[i] * xh1[i]; s[2] += a1; s[3] += a1 * xh1[i]; s[4] += v1[i] * a1;
+      s[5] += v2[i]; s[6] += v2[i] * xh2[i]; s[7] += a2; s[8] += a2 * xh2[i]; s[9] += v2[i] * a2;
+    }
+  }
+  const float inv = 1.f / (float)C;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) s[k] = group_sum<G>(s[k], red, col, g) * inv;
+  const float sc1 = r1 * (s[4] - s[0] * s[2] - s[1] * s[3]), sc2 = r2 * (s[9] - s[5] * s[7] - s[6] * s[8]);
+  const float mw1 = s[0] * s[3] + s[2] * s[1], mwx1 = 2.f * s[1] * s[3];
+  const float mw2 = s[5] * s[8] + s[7] * s[6], mwx2 = 2.f * s[6] * s[8];
+  float* pblk = part + ((long)by * gridDim.x + bx) * 4 * C;
+  float* __restrict__ dGYb = dGY + (long)b * dgy_bs;
+  float* __restrict__ dXb = dX + (long)b * dx_bs;
+  float e1[CPT], e2[CPT];
+  float sb1 = 0.f, sbx1 = 0.f, sb2 = 0.f, sbx2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + G * i;
+    const bool ok = tv && c < C;
+    const float gg1 = c < C ? g1[c] : 0.f, gg2 = c < C ? g2[c] : 0.f;
+    const float u1 = ok ? r1 * (v1[i] - s[0] - xh1[i] * s[1]) : 0.f;
+    const float u2 = ok ? r2 * (v2[i] - s[5] - xh2[i] * s[6]) : 0.f;
+    const float t1 = gg1 * u1, t2 = gg2 * u2;
+    e2[i] = t1 * gy[i] * gp[i];
+    e1[i] = (t2 - vx[i]) * gy[i] * gp[i] + t1 * gy[i] * dq[i] * gpp[i];
+    if (ok) {
+      dGYb[o0 + i * ostep] = t2 * sg[i] + t1 * dq[i] * gp[i] + vx[i] * (1.f - sg[i]);
+      dXb[o0 + i * ostep] = -e2[i];
+    }
+    const float bb1 = gg1 * e1[i], bb2 = gg2 * e2[i];
+    sb1 += bb1; sbx1 += bb1 * xh1[i]; sb2 += bb2; sbx2 += bb2 * xh2[i];
+    const float p0 = col_sum(gn1[i] * u1 + e1[i] * xh1[i]), p1 = col_sum(e1[i]);
+    const float p2 = col_sum(gn2[i] * u2 + e2[i] * xh2[i]), p3 = col_sum(e2[i]);
+    if (col == 0 && c < C) { pblk[c] = p0; pblk[C + c] = p1; pblk[2 * C + c] = p2; pblk[3 * C + c] = p3; }
+    // second-order LayerNorm terms, stored in v_i (no longer needed): -r xh s_col/C - r^2 (w - mean w - xh mean(w xh))
+    const float w1 = v1[i] * s[3] + gn1[i] * gg1 * s[1], w2 = v2[i] * s[8] + gn2[i] * gg2 * s[6];
+    v1[i] = -r1 * xh1[i] * sc1 - r1 * r1 * (w1 - mw1 - xh1[i] * mwx1);
+    v2[i] = -r2 * xh2[i] * sc2 - r2 * r2 * (w2 - mw2 - xh2[i] * mwx2);
+  }
+  const float mb1 = group_sum<G>(sb1, red, col, g) * inv, mbx1 = group_sum<G>(sbx1, red, col, g) * inv;
+  const float mb2 = group_sum<G>(sb2, red, col, g) * inv, mbx2 = group_sum<G>(sbx2, red, col, g) * inv;
+  float* __restrict__ dH1 = dH + hb;
+  float* __restrict__ dH2 = dH1 + cl;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + G * i;
+    if (tv && c < C) {
+      dH1[o0 + i * ostep] = r1 * (g1[c] * e1[i] - mb1 - xh1[i] * mbx1) + v1[i];
+      dH2[o0 + i * ostep] = r2 * (g2[c] * e2[i] - mb2 - xh2[i] * mbx2) + v2[i];
+    }
+  }
+}
+
 // Sum the per-workgroup partial rows part[blk][n] in two levels, in a fixed order (bitwise reproducible).
 // Level 1: workgroup (x, y) folds rows y, y+RED_ROWS, ... into row y IN PLACE (every element of row y is read
 // and written by the same thread, so no other workgroup touches it).  Level 2: out[i] = sum of rows 0..RED_ROWS-1.
@@ -401,4 +574,38 @@ int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs
 #undef CALL
   SSV_TRY(ssv_check_launch("ln_act_bwd"));
   return reduce_partials(part, pgrads, 3 * C, (int)(grid.x * grid.y), st);
+}
+
+// ---- second-order launchers (critics: at most 256 channels, 16 groups) ------------------------------------------------
+#define LN2_DISPATCH(C, CALL)                                                                   \
+  do {                                                                                          \
+    const int _cpt = ((C) + 15) / 16;                                                           \
+    if (_cpt <= 2) { CALL(2, 16); } else if (_cpt <= 4) { CALL(4, 16); } else if (_cpt <= 8) { CALL(8, 16); } \
+    else if (_cpt <= 16) { CALL(16, 16); }                                                      \
+    else return ssv_fail(SSV_UNSUPPORTED, "second-order LayerNorm over %d channels not supported (max 256)", (C)); \
+  } while (0)
+
+int ssv_launch_ln_bwd2(const float* V, long v_bs, const float* GN, long gn_bs, const float* X, long x_bs, const float* stats,
+                       const float* gam, float* dGN, long dgn_bs, float* dX, long dx_bs, float* part, float* dgamma,
+                       int B, int C, int L, hipStream_t st) {
+  dim3 grid(ssv_cdiv(L, 16), B);
+  if ((long)(C + 32) * (long)L >= (1L << 31)) return ssv_fail(SSV_UNSUPPORTED, "LayerNorm: one batch item exceeds 2^31 elements");
+#define CALL(N, G) hipLaunchKernelGGL((ln_bwd2_kernel<N, G>), grid, dim3(16 * G), 0, st, V, v_bs, GN, gn_bs, X, x_bs, stats, gam, dGN, dgn_bs, dX, dx_bs, part, C, L)
+  LN2_DISPATCH(C, CALL);
+#undef CALL
+  SSV_TRY(ssv_check_launch("ln_bwd2"));
+  return reduce_partials(part, dgamma, C, (int)(grid.x * grid.y), st);
+}
+
+int ssv_launch_ln_gate_bwd2(const float* VH, const float* VX, long vx_bs, const float* GY, long gy_bs, const float* H,
+                            const float* X, long x_bs, const float* stats, const float* g1, const float* b1, const float* g2,
+                            const float* b2, float* dGY, long dgy_bs, float* dH, float* dX, long dx_bs, float* part,
+                            float* pgrads /* [4][C] */, int B, int C, int L, hipStream_t st) {
+  dim3 grid(ssv_cdiv(L, 16), B);
+  if ((long)(2 * C + 32) * (long)L >= (1L << 31)) return ssv_fail(SSV_UNSUPPORTED, "LayerNorm: one batch item exceeds 2^31 elements");
+#define CALL(N, G) hipLaunchKernelGGL((ln_gate_bwd2_kernel<N, G>), grid, dim3(16 * G), 0, st, VH, VX, vx_bs, GY, gy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dGY, dgy_bs, dH, dX, dx_bs, part, C, L)
+  LN2_DISPATCH(C, CALL);
+#undef CALL
+  SSV_TRY(ssv_check_launch("ln_gate_bwd2"));
+  return reduce_partials(part, pgrads, 4 * C, (int)(grid.x * grid.y), st);
 }

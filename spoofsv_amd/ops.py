@@ -313,6 +313,147 @@ def conv1d_dd(x, w, bias=None, k=1, dilation=1, causal=False):
     return y if bias is None else y + bias.view(1, -1, 1)
 
 
+# ------------------------------------------------------------------------------------------- critics: LayerNorm / gate, twice differentiable
+# models/discriminator.py:24-41 (LayerNorm over channels between the critic's convs) and models/TTSModel_dropout.py:63-84
+# (the highway gate), for the WGAN-GP critics.  The gradient penalty (train/adversarial_wasserstein_gp.py:300-308) takes the
+# gradient of the critic's input gradient, so each op is a pair of Functions: the forward, whose backward is itself a
+# Function (the first-order HIP backward kernel) with a hand-written backward of its own (ssv_*_bwd2).  Dropout stays a
+# separate torch op between them (a mask product, differentiable as it is).
+def _none_or_zero(*gs):
+    for g in gs:
+        if g is not None:
+            raise RuntimeError("spoofsv_amd: gradients through the parameter-gradient outputs of a critic backward are not "
+                               "implemented (third-order use); only the input-gradient path of the gradient penalty is")
+
+
+class ChannelLnDD(torch.autograd.Function):
+    """y = LayerNorm over channels of a (B, C, T) tensor (no activation), any use up to second order."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        x, xbs = _act3(x, "LayerNorm input")
+        B, C, L = x.shape
+        gamma, beta = _c(gamma), _c(beta)
+        y = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        stats = torch.empty((B, 2, L), dtype=_F32, device=x.device)
+        nb = _lib.query("ssv_channel_ln_act_fwd_workspace", B, C, L)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_channel_ln_act_fwd", _p(x), xbs, _p(gamma), _p(beta), _p(y), C * L, _p(stats), B, C, L, 0, _p(ws), nb, _stream())
+        ctx.save_for_backward(x, gamma, beta, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        return ChannelLnBwdDD.apply(gy, x, gamma, beta, stats)
+
+
+class ChannelLnBwdDD(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, x, gamma, beta, stats):
+        x, xbs = _act3(x)
+        gy, gybs = _act3(gy, "grad")
+        B, C, L = x.shape
+        dx = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        pg = torch.empty((3, C), dtype=_F32, device=x.device)
+        nb = _lib.query("ssv_channel_ln_act_bwd_workspace", B, C, L)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_channel_ln_act_bwd", _p(gy), gybs, _p(x), xbs, _p(stats), _p(gamma), _p(beta), _p(dx), C * L, _p(pg),
+                  B, C, L, 0, _p(ws), nb, _stream())
+        ctx.save_for_backward(gy, x, gamma, stats)
+        ctx.set_materialize_grads(False)
+        return dx, pg[0], pg[1]
+
+    @staticmethod
+    def backward(ctx, v, v_dg, v_db):
+        _none_or_zero(v_dg, v_db)
+        gy, x, gamma, stats = ctx.saved_tensors
+        if v is None:
+            return None, None, None, None, None
+        x, xbs = _act3(x)
+        gy, gybs = _act3(gy)
+        v, vbs = _act3(v, "grad")
+        B, C, L = x.shape
+        d_gy = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        d_x = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        dgamma = torch.empty((C,), dtype=_F32, device=x.device)
+        nb = _lib.query("ssv_channel_ln_bwd2_workspace", B, C, L)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_channel_ln_bwd2", _p(v), vbs, _p(gy), gybs, _p(x), xbs, _p(stats), _p(gamma), _p(d_gy), C * L, _p(d_x), C * L,
+                  _p(dgamma), B, C, L, _p(ws), nb, _stream())
+        return d_gy, d_x, dgamma, None, None
+
+
+class HighwayGateDD(torch.autograd.Function):
+    """y = sigmoid(LN1(h[:, :C])) * LN2(h[:, C:]) + (1 - sigmoid(LN1(h[:, :C]))) * x, any use up to second order."""
+
+    @staticmethod
+    def forward(ctx, h, x, g1, b1, g2, b2):
+        x, xbs = _act3(x, "gate input")
+        B, C, L = x.shape
+        h = _dev(h).float().contiguous()
+        if tuple(h.shape) != (B, 2 * C, L):
+            raise RuntimeError("highway gate: h %s does not match x %s" % (tuple(h.shape), tuple(x.shape)))
+        g1, b1, g2, b2 = map(_c, (g1, b1, g2, b2))
+        y = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        stats = torch.empty((B, 4, L), dtype=_F32, device=x.device)
+        _lib.call("ssv_highway_gate_fwd", _p(h), _p(x), xbs, _p(g1), _p(b1), _p(g2), _p(b2), _p(stats), _p(y), C * L, B, C, L, _stream())
+        ctx.save_for_backward(h, x, g1, b1, g2, b2, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return HighwayGateBwdDD.apply(gy, *ctx.saved_tensors)
+
+
+class HighwayGateBwdDD(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, h, x, g1, b1, g2, b2, stats):
+        x, xbs = _act3(x)
+        gy, gybs = _act3(gy, "grad")
+        B, C, L = x.shape
+        dh = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
+        dx = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        pg = torch.empty((6, C), dtype=_F32, device=x.device)
+        nb = _lib.query("ssv_highway_gate_bwd_workspace", B, C, L)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_highway_gate_bwd", _p(gy), gybs, _p(x), xbs, _p(g1), _p(b1), _p(g2), _p(b2), _p(h), _p(stats), _p(dh), _p(dx),
+                  C * L, _p(pg), B, C, L, _p(ws), nb, _stream())
+        ctx.save_for_backward(gy, h, x, g1, b1, g2, b2, stats)
+        ctx.set_materialize_grads(False)
+        return dh, dx, pg[0], pg[1], pg[2], pg[3]
+
+    @staticmethod
+    def backward(ctx, vh, vx, *rest):
+        _none_or_zero(*rest)
+        gy, h, x, g1, b1, g2, b2, stats = ctx.saved_tensors
+        if vh is None and vx is None:
+            return (None,) * 8
+        x, xbs = _act3(x)
+        gy, gybs = _act3(gy)
+        B, C, L = x.shape
+        vh = torch.zeros_like(h) if vh is None else _dev(vh).float().contiguous()
+        vx = torch.zeros_like(x) if vx is None else vx
+        vx, vxbs = _act3(vx, "grad")
+        d_gy = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        d_h = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
+        d_x = torch.empty((B, C, L), dtype=_F32, device=x.device)
+        pg = torch.empty((4, C), dtype=_F32, device=x.device)
+        nb = _lib.query("ssv_highway_gate_bwd2_workspace", B, C, L)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_highway_gate_bwd2", _p(vh), _p(vx), vxbs, _p(gy), gybs, _p(h), _p(x), xbs, _p(stats), _p(g1), _p(b1), _p(g2), _p(b2),
+                  _p(d_gy), C * L, _p(d_h), _p(d_x), C * L, _p(pg), B, C, L, _p(ws), nb, _stream())
+        return d_gy, d_h, d_x, pg[0], pg[1], pg[2], pg[3], None
+
+
+def channel_ln_dd(x, gamma, beta):
+    return ChannelLnDD.apply(x, gamma, beta)
+
+
+def highway_gate_dd(h, x, g1, b1, g2, b2):
+    return HighwayGateDD.apply(h, x, g1, b1, g2, b2)
+
+
 # ------------------------------------------------------------------------------------------- embedding
 class TextEmbedFn(torch.autograd.Function):
     """textEmbedding.forward, models/TTSModel.py:25-35: one-hot + Linear == column gather + bias."""

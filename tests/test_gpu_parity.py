@@ -462,3 +462,94 @@ def test_pointwise_conv_layernorm_long_rows_vs_oracle():
     assert rel_err(yg, yo) < FWD_TOL, rel_err(yg, yo)
     for a, o in zip(gl, lv):
         assert rel_err(a.grad, o.grad) < BWD_TOL, rel_err(a.grad, o.grad)
+
+
+# ---- critics: twice-differentiable LayerNorm / highway gate ---------------------------------------------
+# Reference arithmetic: the torch expressions of models/discriminator.py:24-27 and models/TTSModel_dropout.py:63-84 in
+# float64 on the CPU, differentiated twice by autograd exactly as train/adversarial_wasserstein_gp.py:300-308 does.
+# Tolerance: 2e-4 of each tensor's largest entry (fp32 kernels, sums over up to 256 channels and 10^4 columns).
+def _ln64(x, g, b):
+    mu = x.mean(1, keepdim=True)
+    d = x - mu
+    return d * torch.rsqrt((d * d).mean(1, keepdim=True) + 1e-5) * g.view(1, -1, 1) + b.view(1, -1, 1)
+
+
+def _close(got, want, tol=2e-4):
+    want = want.float()
+    return float((got.cpu() - want).abs().max()) <= tol * max(1e-6, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,L", [(3, 128, 325), (2, 64, 41), (2, 16, 20), (2, 4, 7), (1, 8, 5), (2, 256, 33), (2, 33, 17)])
+def test_channel_ln_dd_matches_autograd_to_second_order(B, C, L):
+    from spoofsv_amd import ops
+    gen = torch.Generator().manual_seed(B * 1000 + C)
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
+    x, g, b, gy, v = mk(B, C, L), mk(C), mk(C), mk(B, C, L), mk(B, C, L)
+    ref = [t.clone().requires_grad_(True) for t in (x, g, b, gy)]
+    y = _ln64(ref[0], ref[1], ref[2])
+    gx, gg, gb = torch.autograd.grad(y, ref[:3], ref[3], create_graph=True)
+    d2 = torch.autograd.grad(gx, (ref[3], ref[0], ref[1]), v)
+    dev = [t.float().cuda().requires_grad_(True) for t in (x, g, b, gy)]
+    yd = ops.channel_ln_dd(dev[0], dev[1], dev[2])
+    gxd, ggd, gbd = torch.autograd.grad(yd, dev[:3], dev[3], create_graph=True)
+    d2d = torch.autograd.grad(gxd, (dev[3], dev[0], dev[1]), v.float().cuda(), allow_unused=True)
+    assert _close(yd.detach(), y.detach()) and _close(gxd.detach(), gx.detach()) and _close(ggd.detach(), gg.detach()) and _close(gbd.detach(), gb.detach())
+    for got, want in zip(d2d, d2):
+        assert _close(got, want)
+
+
+@pytest.mark.parametrize("B,C,L", [(3, 128, 325), (2, 16, 41), (2, 64, 7), (1, 256, 19), (2, 24, 33)])
+def test_highway_gate_dd_matches_autograd_to_second_order(B, C, L):
+    from spoofsv_amd import ops
+    gen = torch.Generator().manual_seed(B * 1000 + C + 7)
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
+    h, x, g1, b1, g2, b2, gy = mk(B, 2 * C, L), mk(B, C, L), mk(C), mk(C), mk(C), mk(C), mk(B, C, L)
+    vh, vx = mk(B, 2 * C, L), mk(B, C, L)
+
+    def run(ts, fn, vh_, vx_):
+        h_, x_, g1_, b1_, g2_, b2_, gy_ = ts
+        y = fn(h_, x_, g1_, b1_, g2_, b2_)
+        first = torch.autograd.grad(y, ts[:6], gy_, create_graph=True)
+        second = torch.autograd.grad(first[:2], ts, (vh_, vx_), allow_unused=True)
+        return y, first, second
+
+    def gate64(h_, x_, g1_, b1_, g2_, b2_):
+        s = torch.sigmoid(_ln64(h_[:, :C], g1_, b1_))
+        return s * _ln64(h_[:, C:], g2_, b2_) + (1 - s) * x_
+    ref = [t.clone().requires_grad_(True) for t in (h, x, g1, b1, g2, b2, gy)]
+    dev = [t.float().cuda().requires_grad_(True) for t in (h, x, g1, b1, g2, b2, gy)]
+    y, f, s2 = run(ref, gate64, vh, vx)
+    yd, fd, s2d = run(dev, ops.highway_gate_dd, vh.float().cuda(), vx.float().cuda())
+    assert _close(yd.detach(), y.detach())
+    for got, want in zip(fd, f):
+        assert _close(got.detach(), want.detach())
+    for got, want in zip(s2d, s2):
+        assert _close(got, want)
+
+
+def test_critic_gradient_penalty_matches_cpu_reference_path():
+    """The whole critic, penalty and all (train/adversarial_wasserstein_gp.py:296-312), on the HIP ops versus the same module
+    on the CPU, where critic.py runs the reference's permute -> nn.LayerNorm -> permute ops.  eval(): no dropout RNG."""
+    from spoofsv_amd.critic import linDisc
+    torch.manual_seed(5)
+    d = linDisc(65, 32).eval()
+    B, T = 3, 64
+    real, fake, eps = torch.rand(B, 65, T), torch.rand(B, 65, T), torch.rand(B, 1, 1)
+
+    def d_loss(disc, dev):
+        disc.zero_grad()
+        r, f, e = real.to(dev), fake.to(dev), eps.to(dev)
+        xhat = (e * r + (1 - e) * f).requires_grad_(True)
+        out = disc(xhat)
+        grad, = torch.autograd.grad(out, xhat, torch.ones_like(out), create_graph=True)
+        gp = ((grad.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean()
+        loss = disc(f).mean() - disc(r).mean() + 10.0 * gp
+        loss.backward()
+        return float(loss), {n: p.grad.detach().cpu().clone() for n, p in disc.named_parameters()}
+    want_loss, want = d_loss(d, "cpu")
+    got_loss, got = d_loss(d.cuda(), "cuda")
+    assert abs(got_loss - want_loss) <= 1e-4 * max(1.0, abs(want_loss))
+    for n in want:
+        if n in ("conv1.bias", "conv2.bias", "conv3.bias", "conv4.bias", "hc.conv.bias"):
+            continue      # a bias feeding a LayerNorm has an exactly-zero gradient; both sides hold rounding noise there
+        assert float((got[n] - want[n]).norm()) <= 2e-3 * max(1e-6, float(want[n].norm())), n
