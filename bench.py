@@ -144,7 +144,7 @@ class Trainer:
 
 def adversarial_cycle_ms(kind, batch, dev, cycles=3):
     """One full WGAN-GP cycle of the reference (1 generator + RATIO=5 critic iterations,
-    train/adversarial_wasserstein_gp.py:261-322): generator on the HIP path, critic on stock torch ops
+    train/adversarial_wasserstein_gp.py:261-322): generator on the HIP path, critic on the twice-differentiable HIP conv / LayerNorm / gate ops
     with gradient penalty, both iterations replayed from captured hipGraphs (train.AdversarialGraphStep).
     Returns ms per ITERATION averaged over the cycle."""
     from spoofsv_amd import train
@@ -235,7 +235,7 @@ def kernel_roofline(dev):
 
 def cpu_baseline():
     """The CPU oracle (oracle/tts_oracle.py: the stock torch-CPU op sequence the reference itself runs),
-    one Text2Mel and one SSRN train step on a bounded sample (B=4 and B=2 utterances of the same shape),
+    Text2Mel and SSRN train steps on a bounded sample (1 warm-up + 4 timed steps each at the workload's batch, ~10-20 s),
     all host threads torch gives us."""
     from oracle import tts_oracle as TO
     from spoofsv_amd import train
@@ -252,7 +252,7 @@ def cpu_baseline():
     torch.set_num_threads(cores)
     out = {"host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
     times = {}
-    for kind, b in (("text2mel", 4), ("ssrn", 2)):
+    for kind, b in (("text2mel", B_PER_GPU), ("ssrn", B_PER_GPU)):
         if kind == "text2mel":
             m = melSyn(34, True, 200, 128, 80, 256)
             mel, text, spk = train.synthetic_text2mel_batch(b, N_TEXT, T_MEL, seed=0)
@@ -277,13 +277,13 @@ def cpu_baseline():
             opt.step()
         one()
         t0 = time.time()
-        reps = 2
+        reps = 4
         for _ in range(reps):
             one()
         times[kind] = (time.time() - t0) / reps / (b * T_MEL)     # seconds per mel frame
     fps = 1.0 / (times["text2mel"] + times["ssrn"])
     out.update({"value": round(fps, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": "1 warm-up + 2 timed train steps each of Text2Mel (B=4) and SSRN (B=2), N=186, T=325, fp32, torch CPU ops",
+                "sample": "1 warm-up + 4 timed train steps each of Text2Mel and SSRN at the workload's own batch (B=%d), N=186, T=325, fp32, torch CPU ops" % B_PER_GPU,
                 "text2mel_fps": round(1.0 / times["text2mel"], 1), "ssrn_fps": round(1.0 / times["ssrn"], 1)})
     return out
 
@@ -385,7 +385,7 @@ def main():
             res["config"]["adversarial"] = {"text2mel_ms_per_iter": round(a1, 3), "ssrn_ms_per_iter": round(a2, 3),
                                             "text2mel_fps": round(args.batch * T_MEL / a1 * 1e3, 1), "ssrn_fps": round(args.batch * T_MEL / a2 * 1e3, 1),
                                             "combined_fps": round(args.batch * T_MEL / (a1 + a2) * 1e3, 1),
-                                            "note": "1 G : 5 D cycle average, critic on stock torch ops, both iterations replayed from hipGraphs"}
+                                            "note": "1 G : 5 D cycle average, critic convs / LayerNorms / highway gate on twice-differentiable HIP kernels (dropout, leaky-ReLU, pooling: torch), both iterations replayed from hipGraphs"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["config"]["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)

@@ -231,7 +231,8 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
 
 def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpoints=None, current_time=None):
     """WGAN-GP training, train/adversarial_wasserstein_gp.py:148-450: one generator iteration, then RATIO critic
-    iterations (:267); the generator runs on the HIP path in all of them (:278, :329), the critic on stock ops."""
+    iterations (:267); the generator runs on the HIP path in all of them (:278, :329), the critic on its twice-differentiable HIP ops
+    (spoofsv_amd/critic.py)."""
     dev = _device()
     save_dir = os.path.join(cfg["SRC_ROOT_DIR"], "checkpoints", train_pattern, "adversarial", str(current_time))
     model, disc = _build(train_step, train_pattern, cfg, True)

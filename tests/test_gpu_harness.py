@@ -86,7 +86,7 @@ def test_adversarial_train_captured_graphs(tmp_path):
 
 
 def test_generator_accepts_critic_gradient_like_oracle():
-    """dL/dY coming from a stock-op critic flows through the HIP generator exactly as through the oracle."""
+    """dL/dY coming from the critic flows through the HIP generator exactly as through the oracle."""
     from spoofsv_amd import train
     from spoofsv_amd.critic import linDisc
     from spoofsv_amd.tts import SSRN
@@ -188,7 +188,7 @@ def _critic_grads_agree(module, want, tol):
 
 
 def test_adversarial_iteration_golden_gpu():
-    """G8 on the GPU: HIP generator + stock-op critic reproduce the reference's G and D iterations (losses, weights)."""
+    """G8 on the GPU: HIP generator + HIP-op critic reproduce the reference's G and D iterations (losses, weights)."""
     from _golden import load, sub, t
     from spoofsv_amd import ops, train
     from spoofsv_amd.critic import melDisc
