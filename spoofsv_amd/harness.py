@@ -416,3 +416,61 @@ def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=No
                 wavfile.write(os.path.join(sample_dir, "S{}_B1.wav".format(k + 1)), cfg["SAMPLING_RATE"], wav[0].cpu().numpy())
             outs.append((mel_np, lin_np, a_np))
     return outs
+
+
+def generate_test_utterances(cfg, current_time, eval_utt_num=20, speakers=None, texts=None, max_frames=None):
+    """generate_test_utterances.py:56-139: for every speaker, synthesize the first ``eval_utt_num`` sentences of TTS_TEXTS as
+    ONE batch (texts zero-padded to a common length, :67-72; the speaker code repeated, :105) -- Text2Mel free run for
+    MAX_FRAME_NUM further steps (:108-116), SSRN (:120), then per utterance Griffin-Lim(64), de-emphasis, trim(30 dB), clip to
+    9 s, peak 0.75 and ``s<id>/s<id>_<nnn>.wav`` (:128-139).  Here the vocoder runs once per speaker on the whole batch
+    (spoofsv_amd.vocoder); only trim / clip / write stay per utterance on the host.  The Kaldi / GE2E / ASVspoof trial-list
+    bookkeeping of :141-260 is not reproduced.  ``speakers``: {name: (SPK_EMB_DIM,) array}; default: the .npy files of
+    SPK_EMB_DIR.  Returns {speaker: [wav paths]}."""
+    from scipy.io import wavfile
+    from .vocoder import Vocoder, trim_silence
+    dev = _device()
+    if texts is None:
+        with open(cfg["TTS_TEXTS"]) as f:
+            texts = [ln.strip() for ln in f if ln.strip()]
+    texts = texts[:eval_utt_num]
+    ids = [text2id(t, cfg["VOCABULARY"]) for t in texts]
+    width = max(len(i) for i in ids)
+    text_id = torch.tensor([list(i) + [0] * (width - len(i)) for i in ids], dtype=torch.long, device=dev).view(len(ids), 1, width)
+    m1 = melSyn(vocab_len=len(cfg["VOCABULARY"]) - 1, condition=True, spkemb_dim=cfg["SPK_EMB_DIM"], textemb_dim=cfg["TEXT_EMB_DIM"],
+                freq_bins=cfg["COARSE_MELSPEC"]["FREQ_BINS"], hidden_dim=cfg["HIDDEN_DIM"])
+    m2 = SSRN(freq_bins=cfg["COARSE_MELSPEC"]["FREQ_BINS"], output_bins=1 + cfg["STFT"]["FFT_LENGTH"] // 2, ssrn_dim=cfg["SSRN_DIM"])
+    for m, key in ((m1, "INFERENCE_TEXT2MEL_MODEL"), (m2, "INFERENCE_SSRN_MODEL")):
+        path = cfg.get(key)
+        if path and os.path.exists(path):
+            m.load_state_dict(torch.load(path, map_location="cpu")["model_state_dict"])
+        else:   # no trained checkpoint available offline: seeded random weights
+            torch.manual_seed(1234)
+            m.apply(train.init_weights)
+        m.to(dev).eval()
+    if speakers is None:
+        d = cfg["SPK_EMB_DIR"]
+        speakers = {f[:-4]: np.load(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.endswith(".npy")}
+    voc = Vocoder(cfg["STFT"]["FFT_LENGTH"], cfg["STFT"]["HOP_LENGTH"], dev)
+    save_dir = os.path.join(cfg["SRC_ROOT_DIR"], "test", str(current_time), "spoof_data")
+    frames = (max_frames or cfg["MAX_FRAME_NUM"]) + 1                   # first frame + MAX_FRAME_NUM further steps (:110-116)
+    sr, out = cfg["SAMPLING_RATE"], {}
+    with torch.no_grad():
+        for spk, emb in speakers.items():
+            e = torch.as_tensor(np.asarray(emb, dtype=np.float32), device=dev).view(1, -1, 1).expand(len(ids), -1, -1).contiguous()
+            Y, _ = _free_run(m1, text_id, e, frames, cfg["COARSE_MELSPEC"]["FREQ_BINS"], graph=cfg.get("SYNTH_GRAPH", False))
+            lin = m2(Y).contiguous()
+            wav = voc.spectrogram2wav(lin, cfg, n_iter=cfg.get("GRIFFIN_LIM_ITERS", 64), graph=cfg.get("SYNTH_GRAPH", False),
+                                      peak=None).cpu().numpy()
+            sdir = os.path.join(save_dir, "s" + spk[1:])
+            os.makedirs(sdir, exist_ok=True)
+            paths = []
+            for k in range(len(ids)):
+                y, _ = trim_silence(wav[k], 30)
+                y = y[:9 * sr]
+                if len(y):
+                    y = (y / np.max(y) * 0.75).astype(np.float32)
+                path = os.path.join(sdir, "s{}_{}.wav".format(spk[1:], str(k + 1).zfill(3)))
+                wavfile.write(path, sr, y)
+                paths.append(path)
+            out[spk] = paths
+    return out

@@ -72,6 +72,27 @@ def _slaney_mel(sr, n_fft, n_mels):
     return fb.astype(np.float32)
 
 
+def trim_silence(y, top_db=60.0, frame_length=2048, hop_length=512):
+    """Host logic: ``librosa.effects.trim(y, top_db)`` of librosa 0.7.0 for a mono numpy signal -- frame RMS (centred,
+    reflect-padded frames), dB relative to the loudest frame, keep from the first to one past the last frame above -top_db.
+    Returns (y[start:end], (start, end)).  Runs once per written utterance on ~10^5 samples; not a GPU candidate."""
+    y = np.asarray(y)
+    pad = frame_length // 2
+    yp = np.pad(y.astype(np.float64), pad, mode="reflect") if len(y) > pad else np.pad(y.astype(np.float64), pad, mode="constant")
+    n_frames = 1 + (len(yp) - frame_length) // hop_length
+    if n_frames <= 0:
+        return y[0:0], (0, 0)
+    csum = np.concatenate([[0.0], np.cumsum(yp * yp)])
+    idx = np.arange(n_frames) * hop_length
+    mse = (csum[idx + frame_length] - csum[idx]) / frame_length
+    db = 10.0 * np.log10(np.maximum(1e-10, mse)) - 10.0 * np.log10(max(1e-10, float(mse.max())))
+    nz = np.flatnonzero(db > -top_db)
+    if nz.size == 0:
+        return y[0:0], (0, 0)
+    start, end = int(nz[0]) * hop_length, min(len(y), (int(nz[-1]) + 1) * hop_length)
+    return y[start:end], (start, end)
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
@@ -219,9 +240,10 @@ class Vocoder:
         _lib.call("ssv_scale_pow", _p(x2d), _p(mx), _p(out), float(p), float(s), B, n, ops._stream())
         return out
 
-    def spectrogram2wav(self, lin, cfg, angles0=None, n_iter=64, graph=False):
+    def spectrogram2wav(self, lin, cfg, angles0=None, n_iter=64, graph=False, peak=0.75):
         """synthesize.py:138-147 (LOG_FEATURE false) for a batch: SSRN output (B, F, T) -> (B, hop*(T-1)) waveforms,
-        each max-normalised to 0.75 as the reference writes them."""
+        each max-normalised to ``peak`` = 0.75 as the reference writes them (``peak=None``: the de-emphasised signal as it
+        is, for callers that trim before normalising, generate_test_utterances.py:135-139)."""
         self._check_spec(lin, self.F)
         B, F, T = lin.shape
         p = cfg["NORM_POWER"]["RECONSTRUCTION"] / cfg["NORM_POWER"]["ANALYSIS"]
@@ -229,7 +251,7 @@ class Vocoder:
         y = (self.griffinlim_graph if graph else self.griffinlim)(spec, angles0, n_iter=n_iter)
         out = torch.empty_like(y)
         _lib.call("ssv_deemphasis", _p(y), _p(out), float(cfg["PREEMPH"]), B, y.shape[1], ops._stream())
-        return self._norm_pow(out, 1.0, 0.75)
+        return out if peak is None else self._norm_pow(out, 1.0, peak)
 
     def mel_basis(self, sr, n_mels):
         key = (int(sr), int(n_mels))

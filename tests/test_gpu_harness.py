@@ -125,6 +125,23 @@ def test_main_cli_synthesize(tmp_path):
     assert abs(float(wav.max()) - 0.75) < 1e-5 and (wav == wav).all()
 
 
+def test_generate_test_utterances_writes_every_speakers_batch(tmp_path):
+    """generate_test_utterances.py:56-139 on the HIP path: one batched free run + SSRN + vocoder per speaker."""
+    import numpy as np
+    from scipy.io import wavfile
+    from spoofsv_amd import harness
+    cfg = _cfg(tmp_path, MAX_FRAME_NUM=9, GRIFFIN_LIM_ITERS=4)
+    spk = {"p225": np.full(200, 0.05, np.float32), "p301": np.linspace(-0.1, 0.1, 200).astype(np.float32)}
+    texts = ["The birch canoe slid.", "Glue the sheet.", "It's easy to tell the depth of a well."]
+    out = harness.generate_test_utterances(cfg, "gen", eval_utt_num=3, speakers=spk, texts=texts)
+    assert sorted(out) == ["p225", "p301"] and all(len(v) == 3 for v in out.values())
+    assert out["p301"][2].endswith(os.path.join("test", "gen", "spoof_data", "s301", "s301_003.wav"))
+    for paths in out.values():
+        for p in paths:
+            sr, wav = wavfile.read(p)
+            assert sr == cfg["SAMPLING_RATE"] and 0 < len(wav) <= 32 * (4 * 10 - 1) and abs(float(wav.max()) - 0.75) < 1e-5
+
+
 def test_adversarial_graph_step_matches_eager_generator_iteration():
     """The captured G iteration equals the eager one (same weights, same batch, critic in eval so no dropout RNG)."""
     from spoofsv_amd import ops, train

@@ -79,3 +79,16 @@ def test_vocoder_refuses_cpu():
     from spoofsv_amd import vocoder as V
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         V.Vocoder(128, 32, device="cpu")
+
+
+def test_trim_silence_host_logic():
+    """librosa.effects.trim restated (generate_test_utterances.py:136): frame-RMS threshold relative to the loudest frame."""
+    from spoofsv_amd.vocoder import trim_silence
+    sr = 22050
+    tone = 0.5 * np.sin(2 * np.pi * 220 * np.arange(20000) / sr)
+    y = np.concatenate([np.zeros(5000), tone, 1e-4 * np.random.RandomState(0).randn(8000)])
+    t, (a, b) = trim_silence(y, 30)
+    assert a % 512 == 0 and 5000 - 1024 - 512 <= a <= 5000 and 25000 <= b <= 25000 + 1024 + 512 and len(t) == b - a
+    assert trim_silence(y, 120)[1] == (0, len(y))                  # nothing is 120 dB below the peak frame
+    assert trim_silence(tone, 30)[1] == (0, len(tone))
+    assert trim_silence(np.zeros(0), 30)[1] == (0, 0)
