@@ -96,3 +96,17 @@ class ResidentWeights:
         _lib.call("ssv_conv_pack_multi", ctypes.c_void_p(self._jobs.data_ptr()), self._njobs, self._nblocks, stream)
         for p in self.params:
             _REG[p.data_ptr()].version = p._version
+
+
+_FROZEN = {}         # id(module) -> ResidentWeights of an inference model
+
+
+def ensure(module, stream):
+    """Inference helper: keep the conv weights of ``module`` resident.  The first call builds the planes; later calls cost
+    one version check per weight and re-split (one launch) only if a weight was modified since (``load_state_dict``, init)."""
+    rw = _FROZEN.get(id(module))
+    if rw is None or [id(p) for p in rw.params] != [id(p) for p in module.parameters() if eligible(p)]:
+        rw = _FROZEN[id(module)] = ResidentWeights(list(module.parameters()))
+    if any(lookup(p) is None for p in rw.params):
+        rw.refresh(stream)
+    return rw

@@ -4,7 +4,7 @@ steps, each re-encoding the whole prefix as the reference does, then SSRN.  Repo
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from spoofsv_amd import harness, train
+from spoofsv_amd import harness, ops, resident, train
 from spoofsv_amd.tts import melSyn, SSRN
 dev = "cuda:0"
 torch.manual_seed(1234)
@@ -19,6 +19,7 @@ for B, N in ((1, 43), (8, 43), (32, 186)):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         Y, A = harness._free_run(m, text, spk, frames, 80)
         torch.cuda.synchronize(); t1 = time.perf_counter()
+        resident.ensure(s, ops._stream())
         lin = s(Y)
         torch.cuda.synchronize(); t2 = time.perf_counter()
         harness._free_run(m, text, spk, frames, 80, graph=True)   # capture
@@ -43,6 +44,7 @@ with torch.no_grad():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         Y, A = harness._free_run(m, text, spk, frames, 80, graph=True)
         torch.cuda.synchronize(); t1 = time.perf_counter()
+        resident.ensure(s, ops._stream())
         lin = s(Y).contiguous()
         torch.cuda.synchronize(); t2 = time.perf_counter()
         wav = voc.spectrogram2wav(lin, cfg, peak=None)
