@@ -399,6 +399,7 @@ def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=No
     outs = []
     voc = None
     if cfg.get("VOCODE", True) and not cfg.get("LOG_FEATURE", False):
+        from scipy.io import wavfile               # what librosa 0.7.0's output.write_wav calls (synthesize.py:147)
         from .vocoder import Vocoder
         voc = Vocoder(cfg["STFT"]["FFT_LENGTH"], cfg["STFT"]["HOP_LENGTH"], dev)
     with torch.no_grad():
@@ -412,7 +413,6 @@ def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=No
             np.save(os.path.join(sample_dir, "S{}_mel.npy".format(k + 1)), mel_np)
             np.save(os.path.join(sample_dir, "S{}_lin.npy".format(k + 1)), lin_np)
             if voc is not None:
-                from scipy.io import wavfile       # what librosa 0.7.0's output.write_wav calls (synthesize.py:147)
                 wav = voc.spectrogram2wav(lin.contiguous(), cfg, n_iter=cfg.get("GRIFFIN_LIM_ITERS", 64),
                                           graph=cfg.get("SYNTH_GRAPH", False))
                 wavfile.write(os.path.join(sample_dir, "S{}_B1.wav".format(k + 1)), cfg["SAMPLING_RATE"], wav[0].cpu().numpy())

@@ -319,7 +319,7 @@ def conv1d_dd(x, w, bias=None, k=1, dilation=1, causal=False):
 # gradient of the critic's input gradient, so each op is a pair of Functions: the forward, whose backward is itself a
 # Function (the first-order HIP backward kernel) with a hand-written backward of its own (ssv_*_bwd2).  Dropout stays a
 # separate torch op between them (a mask product, differentiable as it is).
-def _none_or_zero(*gs):
+def _no_third_order(*gs):
     for g in gs:
         if g is not None:
             raise RuntimeError("spoofsv_amd: gradients through the parameter-gradient outputs of a critic backward are not "
@@ -366,7 +366,7 @@ class ChannelLnBwdDD(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v, v_dg, v_db):
-        _none_or_zero(v_dg, v_db)
+        _no_third_order(v_dg, v_db)
         gy, x, gamma, stats = ctx.saved_tensors
         if v is None:
             return None, None, None, None, None
@@ -425,7 +425,7 @@ class HighwayGateBwdDD(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, vh, vx, *rest):
-        _none_or_zero(*rest)
+        _no_third_order(*rest)
         gy, h, x, g1, b1, g2, b2, stats = ctx.saved_tensors
         if vh is None and vx is None:
             return (None,) * 8

@@ -11,7 +11,6 @@ What each piece replaces in the reference:
   DataParallelRanks      nn.DataParallel (train/ordinary.py:165-173) -> one rank per GPU, RCCL all-reduce
 """
 import ctypes
-import math
 
 import numpy as np
 import torch

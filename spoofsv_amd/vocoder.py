@@ -125,7 +125,8 @@ class Vocoder:
 
     def _dft(self, w, x, out=None):
         B, _, T = x.shape
-        assert w.is_contiguous() and x.is_contiguous() and x.shape[1] == w.shape[1]
+        if not (w.is_contiguous() and x.is_contiguous() and x.shape[1] == w.shape[1]):
+            raise RuntimeError("spoofsv_amd.vocoder: transform input %s does not match the basis %s" % (tuple(x.shape), tuple(w.shape)))
         y = out if out is not None else torch.empty((B, w.shape[0], T), dtype=_F32, device=x.device)
         ops._conv_fwd(x, x.shape[1] * T, w, None, None, y, w.shape[0] * T, 1, 1, 0)
         return y
