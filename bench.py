@@ -189,32 +189,55 @@ def kernel_roofline(dev):
     Algorithmic FLOPs per launch = 2*B*L*(2C)*C*k."""
     import ctypes
     from spoofsv_amd import _lib, resident
-    B, C, L, k = 32, 256, 325, 3
-    nset = 20
-    xs = [torch.randn(B, C, L, device=dev) for _ in range(nset)]
-    ys = [torch.empty(B, 2 * C, L, device=dev) for _ in range(nset)]
-    w = torch.randn(2 * C, C, k, device=dev) * 0.05
-    bias = torch.randn(2 * C, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
-    rw = resident.ResidentWeights([w])
-    rw.refresh(st)
-    wp = resident.lookup(w)
-    nb = _lib.query("ssv_conv1d_fwd_workspace", C, 2 * C, k)
-    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    run = lambda i: _lib.call("ssv_conv1d_fwd", P(xs[i]), C * L, P(w), wp, P(bias), None, P(ys[i]), 2 * C * L, B, C, 2 * C, L, k, 1, 1,
-                              P(ws), nb, st)
-    for i in range(nset):
-        run(i)
-    reps = 3 * nset
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(reps):
-        run(i % nset)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    resident.invalidate([w])
+
+    def time_conv_fwd(B, C, L, k, nset):
+        """ms per launch of the forward conv C -> 2C, cold operands, resident weights."""
+        xs = [torch.randn(B, C, L, device=dev) for _ in range(nset)]
+        ys = [torch.empty(B, 2 * C, L, device=dev) for _ in range(nset)]
+        w = torch.randn(2 * C, C, k, device=dev) * 0.05
+        bias = torch.randn(2 * C, device=dev)
+        rw = resident.ResidentWeights([w])
+        rw.refresh(st)
+        wp = resident.lookup(w)
+        nb = _lib.query("ssv_conv1d_fwd_workspace", C, 2 * C, k)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        run = lambda i: _lib.call("ssv_conv1d_fwd", P(xs[i]), C * L, P(w), wp, P(bias), None, P(ys[i]), 2 * C * L, B, C, 2 * C, L, k, 1, 1,
+                                  P(ws), nb, st)
+        for i in range(nset):
+            run(i)
+        reps = 3 * nset
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            run(i % nset)
+        e1.record()
+        torch.cuda.synchronize()
+        resident.invalidate([w])
+        return e0.elapsed_time(e1) / reps
+
+    def time_conv_dw(B, C, L, k, nset):
+        """ms per call of the weight gradient of the same conv (gemm_nt_bf3_kernel + its slab reduction), cold operands."""
+        xs = [torch.randn(B, C, L, device=dev) for _ in range(nset)]
+        dys = [torch.randn(B, 2 * C, L, device=dev) for _ in range(nset)]
+        dw = torch.empty(2 * C, C, k, device=dev)
+        nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, C, 2 * C, k)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        run = lambda i: _lib.call("ssv_conv1d_bwd_weight", P(dys[i]), 2 * C * L, P(xs[i]), C * L, P(dw), B, C, 2 * C, L, k, 1, 1, P(ws), nb, st)
+        for i in range(nset):
+            run(i)
+        reps = 3 * nset
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            run(i % nset)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    B, C, L, k = 32, 256, 325, 3
+    ms = time_conv_fwd(B, C, L, k, 20)
     flops = 2.0 * B * L * (2 * C) * C * k
     bytes_alg = 4.0 * (B * C * L + B * 2 * C * L + 2 * C * C * k + 2 * C)
     ach = flops / (ms * 1e-3) / 1e12
@@ -223,6 +246,16 @@ def kernel_roofline(dev):
     # split-bf16 mode executes 3 bf16 MFMAs per algorithmic fp32 product: the roof for ALGORITHMIC flops is peak/3
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
     name = "gemm_nn_bf3_kernel<3,1,7,0> (split-bf16 MFMA, 3 bf16 MFMAs per fp32 product)" if split else "gemm_nn_kernel<KT=3> (fp32 MFMA)"
+    # the same measurement for the step's most expensive single launch (SSRN highwayConv C=512, L=1300: 130.9 GFLOP)
+    # and for the weight gradient of the headline shape (kernel + slab reduction), so the line shows the range, not one point
+    others = []
+    for label, fn, (b_, c_, l_) in (("Conv1d fwd C=512->1024 L=1300 (gemm_nn_bf3_kernel<3,2,7,0>)", time_conv_fwd, (32, 512, 1300)),
+                                     ("Conv1d weight gradient C=256->512 L=325 (gemm_nt_bf3_kernel<3,2,4> + reduce_slabs_perm)", time_conv_dw, (32, 256, 325)),
+                                     ("Conv1d weight gradient C=512->1024 L=1300 (gemm_nt_bf3_kernel<3,2,4> + reduce_slabs_perm)", time_conv_dw, (32, 512, 1300))):
+        m_ = fn(b_, c_, l_, k, 4 if l_ > 1000 else 20)
+        f_ = 2.0 * b_ * l_ * (2 * c_) * c_ * k
+        a_ = f_ / (m_ * 1e-3) / 1e12
+        others.append({"kernel": label, "us_per_launch": round(m_ * 1e3, 2), "achieved": round(a_, 2), "frac": round(a_ / peak, 4)})
     return {"bound": "mfma", "kernel": name + ", dilated Conv1d fwd B=32 C=256->512 L=325",
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "peak_note": "bf16 dense 2500 TFLOP/s / 3" if split else "fp32-input MFMA dense",
@@ -230,7 +263,8 @@ def kernel_roofline(dev):
             "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4),
             # PMC: FETCH_SIZE + WRITE_SIZE per launch of this kernel instantiation, separate rocprofv3 --pmc passes (not collected live)
             "traffic": (12900.7 + 20839.0) * 1024 if split else (45959.9 + 20878.8) * 1024,
-            "traffic_source": "profiles/round1_bench_kernel_stats_v5_final.txt" if split else "profiles/round1_bench_kernel_stats_v1_fp32.txt"}
+            "traffic_source": "profiles/round1_bench_kernel_stats_v5_final.txt" if split else "profiles/round1_bench_kernel_stats_v1_fp32.txt",
+            "others": others}
 
 
 def cpu_baseline():
