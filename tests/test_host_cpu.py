@@ -161,3 +161,75 @@ def test_prefetcher_yields_the_same_batches_in_order():
     import pytest
     with pytest.raises(ValueError):
         list(harness.Prefetcher(Broken(), torch.device("cpu")))
+
+
+class _CpuEmbedder(torch.nn.Module):
+    """Stand-in for SpeechEmbedder on the CPU (same structure: LSTM -> last frame -> Linear -> L2 normalise)."""
+
+    def __init__(self):
+        super().__init__()
+        self.LSTM_stack = torch.nn.LSTM(6, 8, num_layers=2, batch_first=True)
+        self.projection = torch.nn.Linear(8, 5)
+
+    def forward(self, x):
+        h, _ = self.LSTM_stack(x.float())
+        e = self.projection(h[:, -1])
+        return e / torch.norm(e, dim=1, keepdim=True)
+
+
+class _CpuGE2ELoss(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor(10.0))
+        self.b = torch.nn.Parameter(torch.tensor(-5.0))
+
+    def forward(self, emb):
+        from oracle import ge2e_oracle as GO
+        out = GO.ge2e_loss(emb, self.w, self.b)
+        return out[0] if isinstance(out, tuple) else out
+
+
+def _ge2e_setup():
+    torch.manual_seed(77)
+    net, crit = _CpuEmbedder(), _CpuGE2ELoss()
+    x = torch.randn(4, 3, 7, 6)            # N = 4 speakers, M = 3 utterances, 7 frames, 6 mels
+    return net, crit, x
+
+
+def _ge2e_worker(rank, world, port, q):
+    from spoofsv_amd import ge2e
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net, crit, x = _ge2e_setup()
+    opt = torch.optim.SGD([{"params": net.parameters()}, {"params": crit.parameters()}], lr=0.01)
+    n_local = x.shape[0] // world
+    loss = ge2e.sharded_train_iteration(net, crit, opt, x[rank * n_local:(rank + 1) * n_local], n_local, 3)
+    q.put((rank, float(loss), [p.detach().numpy().copy() for p in list(net.parameters()) + list(crit.parameters())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ge2e_sharded_iteration_equals_single_process_gloo_world2():
+    """speakers split over 2 ranks, one all-gather of the embeddings, SUM all-reduce of the embedder
+    gradients -> the same loss and the same post-step weights as train_iteration on the whole batch."""
+    from spoofsv_amd import ge2e
+    net, crit, x = _ge2e_setup()
+    opt = torch.optim.SGD([{"params": net.parameters()}, {"params": crit.parameters()}], lr=0.01)
+    want_loss = float(ge2e.train_iteration(net, crit, opt, x, 4, 3))
+    want = [p.detach().numpy().copy() for p in list(net.parameters()) + list(crit.parameters())]
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ge2e_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, loss, weights in res:
+        assert abs(loss - want_loss) <= 1e-5 * abs(want_loss)
+        for a, b in zip(weights, want):
+            assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
