@@ -270,6 +270,11 @@ int ssv_scale_pow(const float* x, const float* rowmax, float* y, float p, float 
 int ssv_deemphasis(const float* x, float* y, double a, int B, int n, ssv_stream_t stream);
 /* y[0] = x[0], y[n] = x[n] - a*x[n-1] per row (data/dataset.py:96); y must not alias x. */
 int ssv_preemphasis(const float* x, float* y, float a, int B, int n, ssv_stream_t stream);
+/* LOG_FEATURE spectrograms (config.json:26-28).  y = exp(a*x + b): dB de-normalisation, 10^(dB/20) and the reconstruction
+ * power of synthesize.py:133-135,142 folded into one pass.  y = clip((20 log10(max(1e-5, x)) - ref_db + max_db) / max_db,
+ * 1e-8, 1): data/dataset.py:101-105. */
+int ssv_exp_affine(const float* x, float* y, float a, float b, long n, ssv_stream_t stream);
+int ssv_log_norm(const float* x, float* y, float ref_db, float max_db, long n, ssv_stream_t stream);
 
 /* ---- Second order, for the critics' gradient penalty ------------------------------------------
  * train/adversarial_wasserstein_gp.py:300-308 differentiates the critic's input gradient

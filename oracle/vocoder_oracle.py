@@ -133,25 +133,34 @@ def deemphasis(x, a=0.97):
     return _signal.lfilter([1], [1, -a], x)
 
 
-def spectrogram2wav(lin, angles0, cfg):
-    """synthesize.py:138-147 for one utterance (LOG_FEATURE false): lin (F, T) SSRN output -> waveform."""
+def spectrogram2wav(lin, angles0, cfg, n_iter=64):
+    """synthesize.py:129-147 for one utterance: lin (F, T) SSRN output -> waveform."""
     lin = np.asarray(lin, dtype=np.float64)
-    spec = (lin / np.max(lin)) ** (cfg["NORM_POWER"]["RECONSTRUCTION"] / cfg["NORM_POWER"]["ANALYSIS"])
-    y = griffinlim(spec, angles0, n_iter=64, hop=cfg["STFT"]["HOP_LENGTH"])
+    if cfg.get("LOG_FEATURE", False):                      # :133-135
+        lin = np.power(10, 0.05 * (lin * cfg["MAX_DB"] - cfg["MAX_DB"] + cfg["REF_DB"]))
+    else:                                                  # :140-141
+        lin = lin / np.max(lin)
+    spec = lin ** (cfg["NORM_POWER"]["RECONSTRUCTION"] / cfg["NORM_POWER"]["ANALYSIS"])
+    y = griffinlim(spec, angles0, n_iter=n_iter, hop=cfg["STFT"]["HOP_LENGTH"])
     y = deemphasis(y, cfg["PREEMPH"])
-    return y / np.max(y) * 0.75
+    return y if cfg.get("LOG_FEATURE", False) else y / np.max(y) * 0.75      # :147
 
 
 def wav2spectrogram(speech, sr, cfg):
-    """data/dataset.py:96-118 for one (already loaded and trimmed) utterance, LOG_FEATURE false.
+    """data/dataset.py:96-118 for one (already loaded and trimmed) utterance.
     Returns (reduced mel (80, T//4), linear (513, 4*(T//4)))."""
     n_fft, hop = cfg["STFT"]["FFT_LENGTH"], cfg["STFT"]["HOP_LENGTH"]
     r = cfg["COARSE_MELSPEC"]["REDUCTION"]
     speech = preemphasis(speech, cfg["PREEMPH"])
     lin = np.abs(stft(speech, n_fft, hop))
     mel = np.dot(mel_filterbank(sr, n_fft, cfg["COARSE_MELSPEC"]["FREQ_BINS"]).astype(np.float64), lin)
-    p = cfg["NORM_POWER"]["ANALYSIS"]
-    lin_n = (lin / np.max(lin)) ** p
-    mel_n = (mel / np.max(mel)) ** p
+    if cfg.get("LOG_FEATURE", False):                      # :101-105
+        mel_db, lin_db = 20 * np.log10(np.maximum(1e-5, mel)), 20 * np.log10(np.maximum(1e-5, lin))
+        mel_n = np.clip((mel_db - cfg["REF_DB"] + cfg["MAX_DB"]) / cfg["MAX_DB"], 1e-8, 1)
+        lin_n = np.clip((lin_db - cfg["REF_DB"] + cfg["MAX_DB"]) / cfg["MAX_DB"], 1e-8, 1)
+    else:                                                  # :107-111
+        p = cfg["NORM_POWER"]["ANALYSIS"]
+        lin_n = (lin / np.max(lin)) ** p
+        mel_n = (mel / np.max(mel)) ** p
     rt = mel.shape[1] // r
     return mel_n[:, [r * k for k in range(rt)]], lin_n[:, :r * rt]

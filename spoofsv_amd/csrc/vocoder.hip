@@ -135,6 +135,18 @@ __global__ __launch_bounds__(256) void preemphasis_kernel(const float* __restric
   y[o] = i ? x[o] - a * x[o - 1] : x[o];
 }
 
+// LOG_FEATURE spectrograms.  exp_affine: y = exp(a*x + b) -- the dB de-normalisation, 10^(dB/20) and the reconstruction
+// power of synthesize.py:133-135,142 in one pass.  log_norm: y = clip((20 log10(max(1e-5, x)) - ref_db + max_db) / max_db,
+// 1e-8, 1), data/dataset.py:101-105.
+__global__ __launch_bounds__(256) void exp_affine_kernel(const float* __restrict__ x, float* __restrict__ y, float a, float b, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = expf(a * x[i] + b);
+}
+__global__ __launch_bounds__(256) void log_norm_kernel(const float* __restrict__ x, float* __restrict__ y, float ref_db, float max_db, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = fminf(fmaxf((20.f * log10f(fmaxf(1e-5f, x[i])) - ref_db + max_db) / max_db, 1e-8f), 1.f);
+}
+
 // ---- C ABI ---------------------------------------------------------------------------------------------------------
 static bool frames_ok(int B, int N, int T, int hop) {
   return B > 0 && B <= 65535 && N >= 2 && N <= 65535 && N % 2 == 0 && hop > 0 && hop <= N && T >= 2 &&
@@ -199,4 +211,16 @@ extern "C" int ssv_preemphasis(const float* x, float* y, float a, int B, int n, 
   SSV_CHECK(x && y && x != y && B > 0 && B <= 65535 && n > 0, SSV_BAD_SHAPE, "preemphasis: bad argument B=%d n=%d", B, n);
   hipLaunchKernelGGL(preemphasis_kernel, dim3(ssv_cdiv(n, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, a, n);
   return ssv_check_launch("preemphasis");
+}
+
+extern "C" int ssv_exp_affine(const float* x, float* y, float a, float b, long n, ssv_stream_t stream) {
+  SSV_CHECK(x && y && n > 0 && n < (1L << 39), SSV_BAD_SHAPE, "exp_affine: bad argument n=%ld", n);
+  hipLaunchKernelGGL(exp_affine_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, a, b, n);
+  return ssv_check_launch("exp_affine");
+}
+
+extern "C" int ssv_log_norm(const float* x, float* y, float ref_db, float max_db, long n, ssv_stream_t stream) {
+  SSV_CHECK(x && y && n > 0 && n < (1L << 39) && max_db > 0.f, SSV_BAD_SHAPE, "log_norm: bad argument n=%ld max_db=%g", n, (double)max_db);
+  hipLaunchKernelGGL(log_norm_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, ref_db, max_db, n);
+  return ssv_check_launch("log_norm");
 }

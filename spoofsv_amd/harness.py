@@ -398,7 +398,7 @@ def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=No
     frames = max_frames or cfg["MAX_FRAME_NUM"]
     outs = []
     voc = None
-    if cfg.get("VOCODE", True) and not cfg.get("LOG_FEATURE", False):
+    if cfg.get("VOCODE", True):
         from scipy.io import wavfile               # what librosa 0.7.0's output.write_wav calls (synthesize.py:147)
         from .vocoder import Vocoder
         voc = Vocoder(cfg["STFT"]["FFT_LENGTH"], cfg["STFT"]["HOP_LENGTH"], dev)

@@ -242,17 +242,26 @@ class Vocoder:
         return out
 
     def spectrogram2wav(self, lin, cfg, angles0=None, n_iter=64, graph=False, peak=0.75):
-        """synthesize.py:138-147 (LOG_FEATURE false) for a batch: SSRN output (B, F, T) -> (B, hop*(T-1)) waveforms,
+        """synthesize.py:129-147 for a batch (both settings of LOG_FEATURE): SSRN output (B, F, T) -> (B, hop*(T-1)) waveforms,
         each max-normalised to ``peak`` = 0.75 as the reference writes them (``peak=None``: the de-emphasised signal as it
         is, for callers that trim before normalising, generate_test_utterances.py:135-139)."""
         self._check_spec(lin, self.F)
         B, F, T = lin.shape
         p = cfg["NORM_POWER"]["RECONSTRUCTION"] / cfg["NORM_POWER"]["ANALYSIS"]
-        spec = self._norm_pow(lin.view(B, F * T), p, 1.0).view(B, F, T)
+        log = bool(cfg.get("LOG_FEATURE", False))
+        if log:      # synthesize.py:133-135: dB = x*MAX_DB - MAX_DB + REF_DB, amplitude 10^(dB/20); then the power of :142
+            k = np.log(10.0) * 0.05 * p
+            spec = torch.empty_like(lin)
+            _lib.call("ssv_exp_affine", _p(lin), _p(spec), float(k * cfg["MAX_DB"]), float(k * (cfg["REF_DB"] - cfg["MAX_DB"])),
+                      B * F * T, ops._stream())
+        else:
+            spec = self._norm_pow(lin.view(B, F * T), p, 1.0).view(B, F, T)
         y = (self.griffinlim_graph if graph else self.griffinlim)(spec, angles0, n_iter=n_iter)
         out = torch.empty_like(y)
         _lib.call("ssv_deemphasis", _p(y), _p(out), float(cfg["PREEMPH"]), B, y.shape[1], ops._stream())
-        return out if peak is None else self._norm_pow(out, 1.0, peak)
+        if log or peak is None:      # synthesize.py:147 writes the LOG_FEATURE signal as it is
+            return out
+        return self._norm_pow(out, 1.0, peak)
 
     def mel_basis(self, sr, n_mels):
         key = (int(sr), int(n_mels))
@@ -262,7 +271,7 @@ class Vocoder:
         return w
 
     def wav2spectrogram(self, speech, sr, cfg):
-        """data/dataset.py:96-118 (LOG_FEATURE false) for one loaded, trimmed utterance (n,) on the device:
+        """data/dataset.py:96-118 (both settings of LOG_FEATURE) for one loaded, trimmed utterance (n,) on the device:
         returns (reduced mel (n_mels, T//r), linear (F, r*(T//r))) normalised spectrograms."""
         if not (speech.is_cuda and speech.dim() == 1):
             raise RuntimeError("spoofsv_amd.vocoder: speech must be a 1-D ROCm tensor")
@@ -273,9 +282,15 @@ class Vocoder:
         lin = self.magnitude(self.stft(pre))                               # (1, F, T)
         T = lin.shape[2]
         mel = self._dft(self.mel_basis(sr, cfg["COARSE_MELSPEC"]["FREQ_BINS"]), lin)
-        p = cfg["NORM_POWER"]["ANALYSIS"]
-        lin_n = self._norm_pow(lin.view(1, -1), p, 1.0).view(self.F, T)
-        mel_n = self._norm_pow(mel.view(1, -1), p, 1.0).view(-1, T)
+        if cfg.get("LOG_FEATURE", False):      # data/dataset.py:101-105
+            lin_n, mel_n = torch.empty_like(lin), torch.empty_like(mel)
+            for src, dst in ((lin, lin_n), (mel, mel_n)):
+                _lib.call("ssv_log_norm", _p(src), _p(dst), float(cfg["REF_DB"]), float(cfg["MAX_DB"]), src.numel(), ops._stream())
+            lin_n, mel_n = lin_n.view(self.F, T), mel_n.view(-1, T)
+        else:
+            p = cfg["NORM_POWER"]["ANALYSIS"]
+            lin_n = self._norm_pow(lin.view(1, -1), p, 1.0).view(self.F, T)
+            mel_n = self._norm_pow(mel.view(1, -1), p, 1.0).view(-1, T)
         r = cfg["COARSE_MELSPEC"]["REDUCTION"]
         rt = T // r
         return mel_n[:, 0:r * rt:r].contiguous(), lin_n[:, :r * rt].contiguous()

@@ -119,6 +119,23 @@ def test_spectrogram2wav_matches_reference_call_sequence(voc):
     assert np.allclose(got.max(1), 0.75, atol=1e-6)
 
 
+def test_log_feature_spectrograms_both_directions(voc):
+    """LOG_FEATURE = true (config.json:26-28): synthesize.py:133-135,147 and data/dataset.py:101-105."""
+    cfg = dict(CFG, LOG_FEATURE=True)
+    rng = np.random.RandomState(19)
+    B, T = 2, 20
+    lin = (0.5 + 0.5 * rng.rand(B, 513, T)).astype(np.float32)
+    a0 = vo.random_angles((B, 513, T), rng)
+    want = np.stack([vo.spectrogram2wav(lin[b], a0[b], cfg, n_iter=4) for b in range(B)])
+    got = voc.spectrogram2wav(_dev(lin), cfg, _pack(a0), n_iter=4).cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
+    y = _wave(rng, 1, 256 * 30 + 100)[0]
+    mel, ln = voc.wav2spectrogram(_dev(y), cfg["SAMPLING_RATE"], cfg)
+    mr, lr = vo.wav2spectrogram(y, cfg["SAMPLING_RATE"], cfg)
+    # the log of magnitudes near the 1e-5 floor magnifies the transform's 1e-6 error: absolute tolerance on the [0, 1] scale
+    assert np.abs(mel.cpu().numpy() - mr).max() <= 2e-4 and np.abs(ln.cpu().numpy() - lr).max() <= 2e-3
+
+
 def test_deemphasis_long_rows_match_scipy(voc):
     from spoofsv_amd import _lib, ops
     from spoofsv_amd.vocoder import _p
