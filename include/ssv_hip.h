@@ -299,6 +299,31 @@ int ssv_highway_gate_bwd2(const float* vh, const float* vx, long vx_bs, const fl
                           float* d_gy, long dgy_bs, float* d_h, float* d_x, long dx_bs, float* pgrads,
                           int B, int C, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
 
+/* ---- Column-incremental synthesis ------------------------------------------------------
+ * The reference's free-running loop (synthesize.py:103-109, models/TTSModel.py:275-300) re-encodes the whole prefix at
+ * every step.  The audio encoder and decoder are causal, so only column t of every layer is new at step t; these entries
+ * compute that column.  Step activations are (B, C) matrices, channels contiguous; the input history of a causal k = 3
+ * convolution is (B, Tmax, C); the frame counter is a DEVICE int so a captured step can be replayed for every frame.
+ * ssv_column_matvec: out[b][m] = bias[m] + bias_b[b][m] + sum_{j,c} w[m][j][c] x_j[b][c] with w TAP-MAJOR, (M, k, C) =
+ * nn.Conv1d's (M, C, k) weight with its last two axes swapped (the weights are frozen during synthesis: permute once; for
+ * k = 1 the layouts coincide).  C a multiple of 4, buffers 16-byte aligned.  k = 1: x_0 = cur.  k = 3 (causal, `dilation`): x_2 = cur (frame t = *t_dev), x_1 = hist[t-d], x_0 = hist[t-2d]
+ * (zero before frame 0); cur is also stored as column t of hist.  bias, bias_b, and (k = 1) hist / t_dev may be NULL. */
+int ssv_column_matvec(const float* w, const float* bias, const float* bias_b, long bb_bs, const float* cur, long cur_bs,
+                      float* hist, long hist_bs, int Tmax, const int* t_dev, int dilation, float* out, long out_bs,
+                      int B, int C, int M, int k, ssv_stream_t stream);
+/* LayerNorm over channels (+ activation, as ssv_channel_ln_act_fwd) and the highway gate (as ssv_highway_gate_fwd, h (B,2C)
+ * dense) on one column per batch item. */
+int ssv_column_ln_act(const float* x, long x_bs, const float* gamma, const float* beta, float* y, long y_bs, int B, int C, int act,
+                      ssv_stream_t stream);
+int ssv_column_gate(const float* h, const float* x, long x_bs, const float* g1, const float* b1, const float* g2, const float* b2,
+                    float* y, long y_bs, int B, int C, ssv_stream_t stream);
+/* One new attention frame, models/TTSModel.py:281-295: kv (B,2d,N) = K | V; q (B,d); pma (B) int64 is read and replaced by
+ * the arg-max of the new column; column *t_dev of a (B,N,a_T) is written; rq (B,2d) = [V a ; q]. */
+int ssv_attention_column(const float* kv, long kv_bs, const float* q, int64_t* pma, float* a, int a_T, const int* t_dev,
+                         float* rq, int B, int d, int N, ssv_stream_t stream);
+/* End of a step: Y[:, :, t] = y_cur (B,F), mel_cur = y_cur (the next step's input frame, synthesize.py:108-109), t += 1. */
+int ssv_synth_column_advance(const float* y_cur, float* Y, float* mel_cur, int* t_dev, int B, int F, int T, ssv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

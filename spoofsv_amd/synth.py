@@ -11,8 +11,9 @@ values in the columns already synthesised.  One fixed-shape step
 is captured once per (batch, text length, frames) and replayed ``frames`` times; K, V come from one eager text-encoder
 call.  Same kernels per column as ``melSyn.forward`` in eval mode; the only difference from the step-by-step loop is
 that very short prefixes (B*T < 128) run on the exact-fp32 GEMM kernels there and on the split-bf16 ones here (1e-5).
-Measured (tools/bench_synth.py): 0.99 -> 0.67 ms per frame at batch 1, 0.98 -> 0.75 at batch 8, no gain at batch 32 --
-each step still computes all ``frames`` columns; a per-layer ring buffer (one column per step) is the next step.
+Measured (tools/bench_synth.py): 0.92 -> 0.57 ms per frame at batch 1, 0.90 -> 0.65 at batch 8, no gain at batch 32 --
+each step still computes all ``frames`` columns.  ``IncrementalSynthesizer`` below computes one column per step instead
+(0.19 / 0.25 / 0.30 ms per frame at batch 1 / 8 / 32).
 """
 import torch
 
@@ -84,4 +85,154 @@ def free_run(model, text_id, spk_emb, frames):
     g = _CACHE.get(key)
     if g is None:
         g = _CACHE[key] = GraphSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device)
+    return g.run(text_id, spk_emb)
+
+
+# ------------------------------------------------------------------------------------------------ column-incremental synthesis
+class IncrementalSynthesizer:
+    """The same loop with one NEW column per step instead of the whole prefix (include/ssv_hip.h, "Column-incremental
+    synthesis").  The audio encoder and decoder are causal and LayerNorm acts per column, so the values of every layer at
+    frames < t are final; step t computes column t only: 1x1 convs and causal k=3 convs as ``ssv_column_matvec`` (the k=3
+    ones read frames t-d, t-2d from their (B, Tmax, C) input history), LayerNorm / highway gate on a length-1 sequence with
+    the fused kernels of the full path, ``ssv_attention_column`` for the new attention frame.  ~55 launches per step, each a
+    few microseconds, captured once per (batch, text length, frames) and replayed; work per step no longer grows with t.
+
+    Values differ from the prefix loop only by fp32 summation order (plain fp32 dot products here, split-bf16 GEMMs there).
+    """
+
+    def __init__(self, model, batch, text_len, frames, device):
+        if model.training:
+            raise RuntimeError("IncrementalSynthesizer needs the model in eval mode")
+        import ctypes
+        from . import _lib
+        self._lib, self._vp = _lib, ctypes.c_void_p
+        self.model, self.B, self.N, self.T, self.dev = model, batch, text_len, frames, device
+        enc, dec = model.audio_encoder, model.audio_decoder
+        self.d, self.F = model.hidden_dim, dec.conv5.out_channels
+        B, d, F = batch, self.d, self.F
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+        self.kv = z(B, 2 * d, text_len)
+        self.mel_cur = z(B, F)
+        self.Y = z(B, F, frames)
+        self.A = z(B, text_len, frames)
+        self.pma = torch.zeros((B,), dtype=torch.int64, device=device)
+        self.t = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.s1, self.s2 = z(B, d), z(B, d)                         # fc1(spk), fc2(spk): models/TTSModel.py:174,179
+        self.enc_hw = [enc.hci1.hc1, enc.hci1.hc2, enc.hci1.hc3, enc.hci1.hc4, enc.hci2.hc1, enc.hci2.hc2, enc.hci2.hc3, enc.hci2.hc4,
+                       enc.hc1, enc.hc2]
+        self.dec_hw = [dec.hci.hc1, dec.hci.hc2, dec.hci.hc3, dec.hci.hc4, dec.hc1, dec.hc2]
+        for hc in self.enc_hw + self.dec_hw:
+            if not (hc.causal and hc.kernel_size == 3 and hc.dimension == d):
+                raise RuntimeError("IncrementalSynthesizer: unexpected highwayConv configuration")
+        self.hist = [z(B, frames, d) for _ in self.enc_hw + self.dec_hw]
+        self.pre, self.a, self.b = z(B, 2 * d), z(B, d), z(B, d)              # gate pre-activations / two ping-pong columns
+        self.pre1 = z(B, max(d, F))                                            # 1x1 conv outputs before their LayerNorm
+        self.rq = z(B, 2 * d)
+        self.y_cur = z(B, F)
+        self._wt = {}
+        self.graph = None
+
+    # ---- one-column operators on fixed buffers -------------------------------------------------------------------
+    def _p(self, t):
+        return self._vp(t.data_ptr())
+
+    def _tap_major(self, conv):
+        """(M, k, C) copy of a k = 3 conv weight (made once: the weights are frozen in eval mode); k = 1 weights as they are."""
+        w = conv.weight
+        if w.shape[2] == 1:
+            return w
+        key = id(conv)
+        ent = self._wt.get(key)
+        if ent is None or ent[1] != w._version or ent[2] != w.data_ptr():
+            ent = self._wt[key] = (w.detach().permute(0, 2, 1).contiguous(), w._version, w.data_ptr())
+        return ent[0]
+
+    def _mv(self, conv, cur, out, hist=None, dilation=1, bias_b=None):
+        M, C, k = conv.weight.shape
+        w = self._tap_major(conv)
+        self._lib.call("ssv_column_matvec", self._p(w), self._p(conv.bias), None if bias_b is None else self._p(bias_b), M,
+                       self._p(cur), cur.stride(0), None if hist is None else self._p(hist), 0 if hist is None else hist.stride(0),
+                       self.T, self._p(self.t), dilation, self._p(out), out.stride(0), self.B, C, M, k, ops._stream())
+
+    def _ln(self, x, ln, y, act):
+        C = ln.weight.shape[0]
+        self._lib.call("ssv_column_ln_act", self._p(x), x.stride(0), self._p(ln.weight), self._p(ln.bias), self._p(y), y.stride(0),
+                       self.B, C, act, ops._stream())
+
+    def _cla(self, conv, ln, cur, out, act=0, bias_b=None):
+        self._mv(conv, cur, self.pre1, bias_b=bias_b)
+        self._ln(self.pre1, ln, out, act)
+
+    def _highway(self, hc, hist, cur, out):
+        d = self.d
+        self._mv(hc.conv, cur, self.pre, hist=hist, dilation=hc.dilation)
+        self._lib.call("ssv_column_gate", self._p(self.pre), self._p(cur), cur.stride(0), self._p(hc.ln1.weight), self._p(hc.ln1.bias),
+                       self._p(hc.ln2.weight), self._p(hc.ln2.bias), self._p(out), out.stride(0), self.B, d, ops._stream())
+
+    def _step(self):
+        enc, dec, d = self.model.audio_encoder, self.model.audio_decoder, self.d
+        a, b = self.a, self.b
+        cond = enc.condition
+        self._cla(enc.conv1, enc.ln1, self.mel_cur, a, act=1, bias_b=self.s1 if cond else None)
+        self._cla(enc.conv2, enc.ln2, a, b, act=1)
+        self._cla(enc.conv3, enc.ln3, b, a, bias_b=self.s2 if cond else None)
+        cur, nxt, h = a, b, 0
+        for hc in self.enc_hw:
+            self._highway(hc, self.hist[h], cur, nxt)
+            cur, nxt, h = nxt, cur, h + 1
+        self._lib.call("ssv_attention_column", self._p(self.kv), self.kv.stride(0), self._p(cur), self._p(self.pma), self._p(self.A), self.T,
+                       self._p(self.t), self._p(self.rq), self.B, d, self.N, ops._stream())
+        self._cla(dec.conv1, dec.ln1, self.rq, a)
+        cur, nxt = a, b
+        for hc in self.dec_hw:
+            self._highway(hc, self.hist[h], cur, nxt)
+            cur, nxt, h = nxt, cur, h + 1
+        self._cla(dec.conv2, dec.ln2, cur, nxt, act=1)
+        self._cla(dec.conv3, dec.ln3, nxt, cur, act=1)
+        self._cla(dec.conv4, dec.ln4, cur, nxt, act=1)
+        self._cla(dec.conv5, dec.ln5, nxt, self.y_cur, act=2)
+        self._lib.call("ssv_synth_column_advance", self._p(self.y_cur), self._p(self.Y), self._p(self.mel_cur), self._p(self.t),
+                       self.B, self.F, self.T, ops._stream())
+
+    def _capture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self._step()
+
+    @torch.no_grad()
+    def run(self, text_id, spk_emb):
+        B, N, T = self.B, self.N, self.T
+        if tuple(text_id.shape) != (B, 1, N):
+            raise RuntimeError("IncrementalSynthesizer was built for text ids of shape %s, got %s" % ((B, 1, N), tuple(text_id.shape)))
+        enc = self.model.audio_encoder
+        self.kv.copy_(self.model.text_encoder.encode(text_id))
+        if enc.condition:
+            spk = spk_emb.to(self.dev).float()
+            self.s1.copy_(ops.conv1d(spk, enc.fc1.weight.unsqueeze(-1), enc.fc1.bias).reshape(B, self.d))
+            self.s2.copy_(ops.conv1d(spk, enc.fc2.weight.unsqueeze(-1), enc.fc2.bias).reshape(B, self.d))
+        if self.graph is None:
+            self._capture()
+        self.mel_cur.zero_(); self.pma.zero_(); self.t.zero_(); self.A.zero_(); self.Y.zero_()
+        for h in self.hist:
+            h.zero_()
+        for _ in range(T):
+            self.graph.replay()
+        return self.Y.clone(), self.A.clone()
+
+
+_ICACHE = {}
+
+
+def free_run_incremental(model, text_id, spk_emb, frames):
+    """Drop-in for the step-by-step loop on the column-incremental path (cached per model / batch / text length / frames)."""
+    key = (id(model), text_id.shape[0], text_id.shape[2], frames)
+    g = _ICACHE.get(key)
+    if g is None:
+        g = _ICACHE[key] = IncrementalSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device)
     return g.run(text_id, spk_emb)

@@ -130,7 +130,7 @@ def test_generate_test_utterances_writes_every_speakers_batch(tmp_path):
     import numpy as np
     from scipy.io import wavfile
     from spoofsv_amd import harness
-    cfg = _cfg(tmp_path, MAX_FRAME_NUM=9, GRIFFIN_LIM_ITERS=4)
+    cfg = _cfg(tmp_path, MAX_FRAME_NUM=9, GRIFFIN_LIM_ITERS=4, SYNTH_INCREMENTAL=True)
     spk = {"p225": np.full(200, 0.05, np.float32), "p301": np.linspace(-0.1, 0.1, 200).astype(np.float32)}
     texts = ["The birch canoe slid.", "Glue the sheet.", "It's easy to tell the depth of a well."]
     out = harness.generate_test_utterances(cfg, "gen", eval_utt_num=3, speakers=spk, texts=texts)

@@ -91,6 +91,74 @@ def test_melsyn_eval_loop_golden_indices_exact():
     assert rel_err(A, t(g["A"])) < 1e-4
 
 
+def test_incremental_synthesis_golden_indices_exact():
+    """G3 through the column-incremental path (spoofsv_amd/synth.py): same golden Y, A and the exact pma sequence.  The
+    golden pma sequence has steps + 1 entries; the arg-max of attention frame t IS pma after step t."""
+    from spoofsv_amd import synth
+    from spoofsv_amd.tts import melSyn
+    g = load("melsyn_eval.npz")
+    hidden, temb, B, N = [int(v) for v in g["dims"]]
+    m = _load_module_sd(melSyn(34, True, 200, textemb_dim=temb, freq_bins=80, hidden_dim=hidden), sub(g, "sd/"))
+    m.eval()
+    frames = int(g["steps"]) + 1
+    Y, A = synth.free_run_incremental(m, t(g["text"], DEV), t(g["spk"], DEV), frames)
+    assert torch.equal(A.argmax(1).t().cpu(), t(g["pma"]))       # bit-exact attention indices, every frame
+    assert rel_err(Y, t(g["Y"])) < 1e-4
+    assert rel_err(A, t(g["A"])) < 1e-4
+    Y2, A2 = synth.free_run_incremental(m, t(g["text"], DEV), t(g["spk"], DEV), frames)      # replay of the cached graph: same result
+    assert torch.equal(Y2, Y) and torch.equal(A2, A)
+
+
+def test_column_step_kernels_match_full_sequence_ops():
+    """The one-column kernels against the full-sequence operators they stand for (same weights, same inputs)."""
+    import ctypes
+    from spoofsv_amd import _lib, ops
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    st = ops._stream()
+    torch.manual_seed(3)
+    B, C, T = 5, 64, 40
+    x = torch.randn(B, C, T, device=DEV)
+    # causal k = 3 convolution, dilation 9: column t from a (B, T, C) history
+    w = torch.randn(2 * C, C, 3, device=DEV) * 0.1
+    bias = torch.randn(2 * C, device=DEV)
+    want = ops.conv1d(x, w, bias, 3, 9, True)
+    hist = torch.zeros(B, T, C, device=DEV)
+    xt = x.permute(0, 2, 1).contiguous()
+    wt = w.permute(0, 2, 1).contiguous()
+    tdev = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = torch.empty(B, 2 * C, device=DEV)
+    for tt in range(T):
+        tdev.fill_(tt)
+        _lib.call("ssv_column_matvec", P(wt), P(bias), None, 0, P(xt[:, tt]), xt.stride(0), P(hist), hist.stride(0), T, P(tdev), 9,
+                  P(out), 2 * C, B, C, 2 * C, 3, st)
+        assert rel_err(out, want[:, :, tt]) < 1e-4, tt
+    assert torch.equal(hist, xt)                                   # the by-product: every column was filed in the history
+    # 1x1 convolution with a per-item bias term
+    w1 = torch.randn(48, C, 1, device=DEV) * 0.1
+    sb = torch.randn(B, 48, device=DEV)
+    out1 = torch.empty(B, 48, device=DEV)
+    _lib.call("ssv_column_matvec", P(w1), None, P(sb), 48, P(xt[:, 7]), xt.stride(0), None, 0, T, None, 1, P(out1), 48, B, C, 48, 1, st)
+    assert rel_err(out1, torch.einsum("mc,bc->bm", w1[:, :, 0], x[:, :, 7]) + sb) < 1e-4
+    # LayerNorm + activation and the highway gate on one column
+    g1, b1, g2, b2 = (torch.randn(C, device=DEV) for _ in range(4))
+    for act in (0, 1, 2):
+        y = torch.empty(B, C, device=DEV)
+        _lib.call("ssv_column_ln_act", P(xt[:, 3]), xt.stride(0), P(g1), P(b1), P(y), C, B, C, act, st)
+        ref = torch.nn.functional.layer_norm(x[:, :, 3], (C,), g1, b1, 1e-5)
+        ref = torch.relu(ref) if act == 1 else torch.sigmoid(ref) if act == 2 else ref
+        assert rel_err(y, ref) < 1e-5
+    h = torch.randn(B, 2 * C, device=DEV)
+    y = torch.empty(B, C, device=DEV)
+    _lib.call("ssv_column_gate", P(h), P(xt[:, 3]), xt.stride(0), P(g1), P(b1), P(g2), P(b2), P(y), C, B, C, st)
+    n1 = torch.nn.functional.layer_norm(h[:, :C], (C,), g1, b1, 1e-5)
+    n2 = torch.nn.functional.layer_norm(h[:, C:], (C,), g2, b2, 1e-5)
+    sg = torch.sigmoid(n1)
+    assert rel_err(y, sg * n2 + (1 - sg) * x[:, :, 3]) < 1e-5
+    # unsupported shapes fail loudly
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        _lib.call("ssv_column_matvec", P(w1), None, None, 0, P(xt[:, 7]), xt.stride(0), None, 0, T, None, 1, P(out1), 48, B, 62, 48, 1, st)
+
+
 def test_ssrn_small_golden():
     from spoofsv_amd import ops
     from spoofsv_amd.tts import SSRN
@@ -409,6 +477,14 @@ def test_config2_synthesize_full_size_vs_oracle(precision):
     assert first_bad is None or first_bad >= limit, (first_bad, limit, float(margins.min()))
     if first_bad is None:
         assert rel_err(Y, Yo) < 1e-3 and rel_err(lin, lin_o) < 1e-3, (rel_err(Y, Yo), rel_err(lin, lin_o))
+    # the same run on the column-incremental path (one new column per step, spoofsv_amd/synth.py)
+    from spoofsv_amd import synth
+    Yi, Ai = synth.free_run_incremental(m1, idg, spg, steps + 1)
+    pma_i = Ai.argmax(1).t().cpu()                                  # frame t's arg-max is pma after step t
+    first_bad = next((i for i in range(steps + 1) if not torch.equal(pma_i[i], pma_o[i])), None)
+    assert first_bad is None or first_bad >= limit, (first_bad, limit, float(margins.min()))
+    if first_bad is None:
+        assert rel_err(Yi, Yo) < 1e-3 and rel_err(m2(Yi), lin_o) < 1e-3, (rel_err(Yi, Yo),)
 
 
 @pytest.mark.parametrize("B,C,L,k,d,causal", [
