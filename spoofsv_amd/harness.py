@@ -160,8 +160,8 @@ def _free_run(model, text_id, spk_emb, frames, freq_bins, graph=False, increment
     a replayed hipGraph of one fixed-shape step (spoofsv_amd/synth.py; config key SYNTH_GRAPH): 1.5x faster at batch 1,
     same values up to the arithmetic mode of the first few frames (short prefixes run the exact-fp32 kernels step by step)."""
     resident.ensure(model, ops._stream())       # frozen weights: split once, not once per conv call (~30 launches per step)
-    if incremental:       # config key SYNTH_INCREMENTAL: one new column per step (spoofsv_amd/synth.py, IncrementalSynthesizer)
-        from . import synth
+    if incremental:       # config key SYNTH_INCREMENTAL (default on in synthesize / generate_test_utterances): one new column
+        from . import synth       # per step instead of the whole prefix (spoofsv_amd/synth.py, IncrementalSynthesizer)
         return synth.free_run_incremental(model, text_id, spk_emb, frames)
     if graph:
         from . import synth
@@ -410,7 +410,7 @@ def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=No
             ids = torch.tensor(text2id(text, cfg["VOCABULARY"]), dtype=torch.long, device=dev).view(1, 1, -1)
             spk = (spk_emb if spk_emb is not None else torch.full((1, cfg["SPK_EMB_DIM"], 1), 0.06)).to(dev).float()
             Y, A = _free_run(m1, ids, spk, frames, cfg["COARSE_MELSPEC"]["FREQ_BINS"], graph=cfg.get("SYNTH_GRAPH", False),
-                             incremental=cfg.get("SYNTH_INCREMENTAL", False))
+                             incremental=cfg.get("SYNTH_INCREMENTAL", True))
             resident.ensure(m2, ops._stream())
             lin = m2(Y)
             mel_np, lin_np, a_np = Y[0].cpu().numpy(), lin[0].cpu().numpy(), A[0].cpu().numpy()
@@ -464,7 +464,7 @@ def generate_test_utterances(cfg, current_time, eval_utt_num=20, speakers=None, 
         for spk, emb in speakers.items():
             e = torch.as_tensor(np.asarray(emb, dtype=np.float32), device=dev).view(1, -1, 1).expand(len(ids), -1, -1).contiguous()
             Y, _ = _free_run(m1, text_id, e, frames, cfg["COARSE_MELSPEC"]["FREQ_BINS"], graph=cfg.get("SYNTH_GRAPH", False),
-                             incremental=cfg.get("SYNTH_INCREMENTAL", False))
+                             incremental=cfg.get("SYNTH_INCREMENTAL", True))
             resident.ensure(m2, ops._stream())
             lin = m2(Y).contiguous()
             wav = voc.spectrogram2wav(lin, cfg, n_iter=cfg.get("GRIFFIN_LIM_ITERS", 64), graph=cfg.get("SYNTH_GRAPH", False),
