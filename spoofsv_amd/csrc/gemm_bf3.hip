@@ -839,6 +839,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       const uint4* Xl = lds[q_] + X_SLOTS;
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) {
+        if (s2 > 0 && ct0[0] + 32 * s2 >= p.La) continue;                  // ragged last chunk: this k-step lies past the row end (A is zero there)
         const int kg = s2 * 4 + kq;
 #pragma unroll
         for (int q = 0; q < NTC; ++q) {
