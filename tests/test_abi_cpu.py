@@ -71,6 +71,19 @@ def test_bad_arguments_fail_before_the_device():
     assert rc == -1 and b"workspace" in L.ssv_last_error()
     with pytest.raises(RuntimeError):
         _lib.call("ssv_ge2e_loss_fwd", one, one, one, one, null, 4, 1, 8, one, 1 << 20, null)   # M must be > 1
+    # the later additions check their arguments on the host as well (vocoder, second order, column-incremental synthesis)
+    rc = L.ssv_ola_frames(one, one, one, 1, 1024, 2, 256, null)                                 # hop*(T-1) <= N/2
+    assert rc == -1 and b"ola_frames" in L.ssv_last_error()
+    rc = L.ssv_frame_signal(one, one, 1, 100, 1024, 1, 256, null)                               # n <= N/2: no reflect padding
+    assert rc == -1
+    rc = L.ssv_channel_ln_bwd2(one, 0, one, 0, one, 0, one, one, one, 0, one, 0, one, 1, 8, 4, one, 0, null)
+    assert rc == -1 and b"workspace" in L.ssv_last_error()
+    rc = L.ssv_column_matvec(one, null, null, 0, one, 64, null, 0, 0, null, 1, one, 64, 2, 62, 8, 1, null)   # C not a multiple of 4
+    assert rc == -2 and b"multiple of 4" in L.ssv_last_error()
+    rc = L.ssv_column_matvec(one, null, null, 0, one, 64, null, 0, 0, null, 1, one, 64, 2, 64, 8, 3, null)   # k = 3 without a history
+    assert rc == -1 and b"history" in L.ssv_last_error()
+    rc = L.ssv_column_ln_act(one, 0, one, one, one, 0, 2, 5000, 0, null)
+    assert rc == -2
 
 
 def test_ops_fail_loudly_on_cpu_tensors():
