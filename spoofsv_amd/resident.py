@@ -106,6 +106,12 @@ def ensure(module, stream):
     one version check per weight and re-split (one launch) only if a weight was modified since (``load_state_dict``, init)."""
     rw = _FROZEN.get(id(module))
     if rw is None or [id(p) for p in rw.params] != [id(p) for p in module.parameters() if eligible(p)]:
+        while len(_FROZEN) >= 8:                 # a handful of inference models at most; older plane sets are dropped
+            old = _FROZEN.pop(next(iter(_FROZEN)))
+            for p in old.params:
+                e = _REG.get(p.data_ptr())
+                if e is not None and e.param is p:
+                    _REG.pop(p.data_ptr())
         rw = _FROZEN[id(module)] = ResidentWeights(list(module.parameters()))
     if any(lookup(p) is None for p in rw.params):
         rw.refresh(stream)

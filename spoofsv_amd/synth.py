@@ -76,15 +76,26 @@ class GraphSynthesizer:
         return self.Y.clone(), self.A.clone()
 
 
-_CACHE = {}
+_CACHE = {}            # small FIFO caches: a synthesizer owns frame-sized buffers and a captured graph
+_CACHE_MAX = 4
+
+
+def _remember(cache, key, make):
+    g = cache.get(key)
+    if g is None:
+        while len(cache) >= _CACHE_MAX:
+            cache.pop(next(iter(cache)))
+        g = cache[key] = make()
+    return g
 
 
 def free_run(model, text_id, spk_emb, frames):
     """Drop-in for the step-by-step loop: cached GraphSynthesizer per (model, batch, text length, frames)."""
     key = (id(model), text_id.shape[0], text_id.shape[2], frames)
-    g = _CACHE.get(key)
-    if g is None:
-        g = _CACHE[key] = GraphSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device)
+    g = _remember(_CACHE, key, lambda: GraphSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device))
+    if g.model is not model:                  # an id() can be reused after the first model is gone
+        _CACHE.pop(key)
+        g = _remember(_CACHE, key, lambda: GraphSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device))
     return g.run(text_id, spk_emb)
 
 
@@ -232,7 +243,9 @@ _ICACHE = {}
 def free_run_incremental(model, text_id, spk_emb, frames):
     """Drop-in for the step-by-step loop on the column-incremental path (cached per model / batch / text length / frames)."""
     key = (id(model), text_id.shape[0], text_id.shape[2], frames)
-    g = _ICACHE.get(key)
-    if g is None:
-        g = _ICACHE[key] = IncrementalSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device)
+    make = lambda: IncrementalSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device)
+    g = _remember(_ICACHE, key, make)
+    if g.model is not model:
+        _ICACHE.pop(key)
+        g = _remember(_ICACHE, key, make)
     return g.run(text_id, spk_emb)
