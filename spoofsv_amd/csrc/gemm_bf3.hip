@@ -607,6 +607,10 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
     int a = 0, c = 0;
     if (sscanf(e, "%d,%d", &a, &c) == 2 && (a == 1 || a == 2)) for (int x : nts) if (x == c) { wm = a; nt = c; forced = true; }
   }
+  // LSTM wavefront with two or more layers in one launch (the steady state of the GE2E embedder: 2 x 3072 x 880 x 1536): the
+  // cost model below picks 64 x 112 tiles; measured over the 122 steps of config 5, 128 x 64 tiles are 6 % faster
+  // (13.8 -> 13.0 ms; 128 x 96: 13.5, 128 x 112: 14.2, 64 x 96: 14.8) as long as they still give every CU two workgroups.
+  if (!forced && g.epi && g.lstm_D > 0 && g.B >= 2 && (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 64) * g.B >= 512) { wm = 2; nt = 4; forced = true; }
   if (!forced) {
     double best = 1e30;
     // k=1 products carry a third of the MFMAs per weight byte: 64-row tiles (twice the weight traffic per MAC) lose at every
