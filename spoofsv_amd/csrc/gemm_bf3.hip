@@ -21,6 +21,8 @@
 #include <stdio.h>
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
 #include "ssv_common.h"
 #ifndef SSV_ABL
 #define SSV_ABL 0      // tuning builds only: 1 = weight-gradient kernel without its MFMAs
@@ -611,6 +613,18 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   // cost model below picks 64 x 112 tiles; measured over the 122 steps of config 5, 128 x 64 tiles are 6 % faster
   // (13.8 -> 13.0 ms; 128 x 96: 13.5, 128 x 112: 14.2, 64 x 96: 14.8) as long as they still give every CU two workgroups.
   if (!forced && g.epi && g.lstm_D > 0 && g.B >= 2 && (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 64) * g.B >= 512) { wm = 2; nt = 4; forced = true; }
+  if (!forced) {
+    // tuning aid (tools/sweep_step_tiles.py): SSV_NNB_FORCE="kt:M:N=a,c;kt:M:N=a,c;..." forces the tile of one problem shape
+    // inside a whole training step, where a tile's effect on its neighbours shows (isolated timings miss it)
+    if (const char* e = getenv("SSV_NNB_FORCE")) {
+      char key[48];
+      snprintf(key, sizeof key, "%d:%d:%d=", KT, g.M, g.N);
+      const char* hit = strstr(e, key);
+      int a = 0, c = 0;
+      if (hit && (hit == e || hit[-1] == ';') && sscanf(hit + strlen(key), "%d,%d", &a, &c) == 2 && (a == 1 || a == 2))
+        for (int x : nts) if (x == c) { wm = a; nt = c; forced = true; }
+    }
+  }
   if (!forced) {
     double best = 1e30;
     // k=1 products carry a third of the MFMAs per weight byte: 64-row tiles (twice the weight traffic per MAC) lose at every
