@@ -482,3 +482,30 @@ def generate_test_utterances(cfg, current_time, eval_utt_num=20, speakers=None, 
                 paths.append(path)
             out[spk] = paths
     return out
+
+
+def extract_features(wav_paths, cfg, spec_dir):
+    """data/dataset.py:94-123 for a list of wav files: read, trim leading/trailing silence (22 dB), then pre-emphasis, |STFT|,
+    mel projection, normalisation and time reduction on the GPU (spoofsv_amd.vocoder.Vocoder.wav2spectrogram), and the
+    reference's cache files ``<spec_dir>/<pXXX>/<pXXX_NNN>_{mel,lin}.npy`` (:85-91,120-123) that ``BatchSource`` reads.
+    File decoding is ``scipy.io.wavfile`` (PCM or float wav at its native rate, as ``librosa.load(sr=None)`` returns it;
+    resampling, metagen.py:29-62, is not reproduced).  Returns the list of (mel, lin) shapes written."""
+    from scipy.io import wavfile
+    from .vocoder import Vocoder, trim_silence
+    dev = _device()
+    voc = Vocoder(cfg["STFT"]["FFT_LENGTH"], cfg["STFT"]["HOP_LENGTH"], dev)
+    shapes = []
+    for path in wav_paths:
+        sr, y = wavfile.read(path)
+        if y.ndim > 1:
+            y = y.mean(axis=1)                                   # librosa.load(mono=True)
+        if y.dtype.kind in "iu":
+            y = y.astype(np.float32) / float(1 << (8 * y.dtype.itemsize - 1))
+        y, _ = trim_silence(y.astype(np.float32), 22)
+        mel, lin = voc.wav2spectrogram(torch.from_numpy(np.ascontiguousarray(y)).to(dev), sr, cfg)
+        key = path[-17:-4]                                       # 'pXXX/pXXX_NNN', data/dataset.py:85
+        os.makedirs(os.path.join(spec_dir, os.path.dirname(key)), exist_ok=True)
+        np.save(os.path.join(spec_dir, key + "_mel.npy"), mel.cpu().numpy())
+        np.save(os.path.join(spec_dir, key + "_lin.npy"), lin.cpu().numpy())
+        shapes.append((tuple(mel.shape), tuple(lin.shape)))
+    return shapes

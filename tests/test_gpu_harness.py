@@ -125,6 +125,38 @@ def test_main_cli_synthesize(tmp_path):
     assert abs(float(wav.max()) - 0.75) < 1e-5 and (wav == wav).all()
 
 
+def test_extract_features_writes_the_reference_cache_layout(tmp_path):
+    """data/dataset.py:94-123 with the spectrogram front end on the GPU: wav -> <spec_dir>/pXXX/pXXX_NNN_{mel,lin}.npy, values as
+    the numpy oracle computes them, and BatchSource picks the cache up for SSRN training."""
+    import json as _json
+    import numpy as np
+    from scipy.io import wavfile
+    from oracle import vocoder_oracle as vo
+    from spoofsv_amd import harness
+    from spoofsv_amd.vocoder import trim_silence
+    cfg = _json.load(open(os.path.join(ROOT, "config.json")))
+    rng = np.random.RandomState(5)
+    sr = cfg["SAMPLING_RATE"]
+    tone = (0.3 * np.sin(2 * np.pi * 330 * np.arange(sr) / sr) * np.hanning(sr) + 0.01 * rng.randn(sr)).astype(np.float32)
+    wav = np.concatenate([np.zeros(3000, np.float32), tone, np.zeros(2000, np.float32)])
+    wdir = os.path.join(str(tmp_path), "wav22", "p225")
+    os.makedirs(wdir)
+    path = os.path.join(wdir, "p225_001.wav")
+    wavfile.write(path, sr, (wav * 32767).astype(np.int16))
+    spec_dir = os.path.join(str(tmp_path), "spec") + os.sep
+    shapes = harness.extract_features([path], cfg, spec_dir)
+    mel = np.load(os.path.join(spec_dir, "p225", "p225_001_mel.npy"))
+    lin = np.load(os.path.join(spec_dir, "p225", "p225_001_lin.npy"))
+    assert shapes == [(mel.shape, lin.shape)] and mel.shape[0] == 80 and lin.shape == (513, 4 * mel.shape[1])
+    y = (wav * 32767).astype(np.int16).astype(np.float32) / 32768.0
+    y, _ = trim_silence(y, 22)
+    mr, lr = vo.wav2spectrogram(y, sr, cfg)
+    assert np.abs(mel - mr).max() <= 5e-5 and np.abs(lin - lr).max() <= 5e-5
+    src = harness.BatchSource(dict(cfg, BATCH_SIZE=2), "train_ssrn", 2, spec_dir)
+    batch = next(iter(src))
+    assert tuple(batch["data_0"].shape) == (2, 80, mel.shape[1]) and tuple(batch["data_1"].shape) == (2, 513, 4 * mel.shape[1])
+
+
 def test_generate_test_utterances_writes_every_speakers_batch(tmp_path):
     """generate_test_utterances.py:56-139 on the HIP path: one batched free run + SSRN + vocoder per speaker."""
     import numpy as np
