@@ -44,14 +44,84 @@ def text2id(text, vocabulary):
     return [table[ch] for ch in text if ch in table]
 
 
+class CorpusSource:
+    """The reference's ``VCTKDataset`` + ``DataLoader(shuffle=True, collate_fn=collate_pad_*)`` (data/dataset.py:13-258,
+    train/ordinary.py:199-200) over a corpus laid out as the reference expects: ``DATA_ROOT_DIR/data_path/ordinary/
+    {wav,txt}.path.{train,validate}`` (one path per line; a wav path ends in ``pXXX/pXXX_NNN.wav``), one-line transcripts,
+    ``SPK_EMB_DIR/pXXX.npy`` speaker codes.  Spectrograms come from the ``.npy`` cache of data/dataset.py:85-91; files that
+    are not cached yet are extracted once, up front, on the GPU (``extract_features``).  Batches are zero-padded to their own
+    longest item, as the collate functions do ('P' = id 0 pads the text)."""
+
+    def __init__(self, cfg, step, pattern, mode, batch_size, spec_dir=None, seed=0, rank=0, world=1, stage=None):
+        self.cfg, self.step, self.mode, self.B = cfg, step, mode, batch_size
+        self.seed, self.rank, self.world, self.epoch = seed, rank, world, 0
+        root = cfg["DATA_ROOT_DIR"]
+        if pattern == "ubm-finetune":
+            base, tag = os.path.join(root, "data_path", "ubm-finetune"), ".%s.%s" % (stage or "ubm", mode)
+        else:
+            base, tag = os.path.join(root, "data_path", "ordinary"), "." + mode
+        with open(os.path.join(base, "wav.path" + tag)) as f:
+            self.wavlist = [ln.strip() for ln in f if ln.strip()]
+        with open(os.path.join(base, "txt.path" + tag)) as f:
+            self.txtlist = [ln.strip() for ln in f if ln.strip()]
+        if len(self.wavlist) != len(self.txtlist):
+            raise RuntimeError("corpus lists differ in length: %d wav paths, %d transcripts" % (len(self.wavlist), len(self.txtlist)))
+        self.cache = spec_dir or (os.path.join(cfg["SRC_ROOT_DIR"], "spec_cache") + os.sep)
+        missing = [w for w in self.wavlist if not os.path.exists(self.cache + w[-17:-4] + "_mel.npy")]
+        if missing:
+            extract_features(missing, cfg, self.cache)
+
+    def __len__(self):
+        per = self.B * self.world
+        return (len(self.wavlist) + per - 1) // per
+
+    def _item(self, idx):
+        key = self.wavlist[idx][-17:-4]
+        out = {"data_0": torch.from_numpy(np.load(self.cache + key + "_mel.npy")).float()}
+        if self.step == "train_ssrn":
+            out["data_1"] = torch.from_numpy(np.load(self.cache + key + "_lin.npy")).float()
+            return out
+        with open(self.txtlist[idx]) as f:
+            text = f.readline().strip()
+        out["data_1"] = torch.tensor(text2id(text, self.cfg["VOCABULARY"]), dtype=torch.long).view(1, -1)
+        spk = np.load(os.path.join(self.cfg["SPK_EMB_DIR"], self.wavlist[idx][-12:-8] + ".npy"))
+        out["data_2"] = torch.from_numpy(np.asarray(spk, dtype=np.float32)).view(-1, 1)
+        if self.step == "synthesize" and self.mode != "validate":
+            out["data_3"] = torch.from_numpy(np.load(self.cache + key + "_lin.npy")).float()
+        return out
+
+    @staticmethod
+    def _pad_stack(items, key):
+        width = max(it[key].shape[-1] for it in items)
+        return torch.stack([torch.nn.functional.pad(it[key], (0, width - it[key].shape[-1])) for it in items], 0)
+
+    def __iter__(self):
+        n = len(self.wavlist)
+        order = np.arange(n)
+        if self.mode == "train":                                    # DataLoader(shuffle=True): a fresh permutation per epoch
+            order = np.random.RandomState(self.seed + self.epoch).permutation(n)
+        self.epoch += 1
+        per = self.B * self.world
+        for i in range(len(self)):
+            idx = order[i * per + self.rank * self.B:i * per + (self.rank + 1) * self.B]
+            if len(idx) == 0:
+                continue
+            items = [self._item(int(k)) for k in idx]
+            yield {key: (torch.stack([it[key] for it in items], 0) if key == "data_2" else self._pad_stack(items, key)) for key in items[0]}
+
+
 class BatchSource:
     """Yields the dicts the reference's collate functions produce: data_0 mel (B,80,T), data_1 text (B,1,N)
     int64 or lin (B,513,4T), data_2 spk (B,200,1), data_3 lin (synthesis)."""
 
-    def __init__(self, cfg, step, batch_size, spec_dir=None, seed=0, rank=0, world=1):
+    def __init__(self, cfg, step, batch_size, spec_dir=None, seed=0, rank=0, world=1, pattern="conditional", mode="train"):
         self.cfg, self.step, self.B = cfg, step, batch_size
         self.rank, self.world, self.seed = rank, world, seed
         self.files = []
+        self.corpus = None
+        lists = os.path.join(cfg.get("DATA_ROOT_DIR", ""), "data_path", "ubm-finetune" if pattern == "ubm-finetune" else "ordinary")
+        if os.path.isdir(lists):          # a corpus in the reference's layout: real batches (CorpusSource)
+            self.corpus = CorpusSource(cfg, step, pattern, mode, batch_size, spec_dir, seed, rank, world)
         if spec_dir and os.path.isdir(spec_dir):
             self.files = sorted(glob.glob(os.path.join(spec_dir, "p*", "*_mel.npy")))
         self.n_synth = int(cfg.get("SYNTHETIC_BATCHES_PER_EPOCH", 8))
@@ -60,6 +130,8 @@ class BatchSource:
         self.bins = 1 + cfg["STFT"]["FFT_LENGTH"] // 2
 
     def __len__(self):
+        if self.corpus is not None:
+            return len(self.corpus)
         if self.files:
             return max(1, len(self.files) // (self.B * self.world))
         return self.n_synth
@@ -92,6 +164,9 @@ class BatchSource:
         raise RuntimeError("cached text2mel batches need the corpus transcripts; use synthetic batches")
 
     def __iter__(self):
+        if self.corpus is not None:
+            yield from self.corpus
+            return
         for i in range(len(self)):
             yield self._cached(i) if (self.files and self.step == "train_ssrn") else self._synthetic(i)
 
@@ -201,7 +276,7 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
         opt.load_state_dict(ck["optimizer_state_dict"])
         epoch, iteration, loss_val_log = ck["epoch"], ck["iteration"], ck["loss_val_log"]
     model.train()
-    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir), dev)
+    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir, pattern=train_pattern), dev)
     gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
     max_iter = cfg.get("MAX_ITERATIONS")
     history = []
@@ -214,7 +289,7 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
                 terms = (float(l1.detach()), float(bd.detach()), float(la.detach()))
             else:
                 l1, bd = train.ssrn_step(model, opt, mel_gt, sp["data_1"].to(dev))
-                terms = (float(l1), float(bd))
+                terms = (float(l1.detach()), float(bd.detach()))
             history.append(sum(terms))
             print("Iteration {}/{} for epoch {}, loss: {} {} global iteration {}".format(
                 i + 1, len(src), epoch + 1, " ".join(str(t) for t in terms), sum(terms), iteration + 1))
@@ -264,10 +339,10 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
             logs[k] = ck[k]
     model.train()
     disc.train()
-    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir), dev)
+    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir, pattern=train_pattern), dev)
     gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
     max_iter = cfg.get("MAX_ITERATIONS")
-    if cfg.get("CAPTURE_GRAPHS") and resume_checkpoints is None and not src.source.files:
+    if cfg.get("CAPTURE_GRAPHS") and resume_checkpoints is None and not src.source.files and src.source.corpus is None:
         return _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter)
     while epoch < cfg["MAX_EPOCHS"]:
         for i, sp in enumerate(src):

@@ -157,6 +157,21 @@ def test_extract_features_writes_the_reference_cache_layout(tmp_path):
     assert tuple(batch["data_0"].shape) == (2, 80, mel.shape[1]) and tuple(batch["data_1"].shape) == (2, 513, 4 * mel.shape[1])
 
 
+def test_training_from_a_corpus_in_the_reference_layout(tmp_path):
+    """wav files + path lists + transcripts + speaker codes (data/dataset.py:37-51): features are extracted once on the GPU into
+    the reference's cache layout, then ordinary_train runs on real, variable-length batches for both models."""
+    from test_host_cpu import _make_corpus
+    from spoofsv_amd import harness
+    cfg, _ = _make_corpus(str(tmp_path), n_items=5, with_cache=False, wav=True)
+    cfg.update(BATCH_SIZE=2, HIDDEN_DIM=32, TEXT_EMB_DIM=16, SSRN_DIM=32, VAL_EVERY_ITER=100, MAX_ITERATIONS=4)
+    spec = os.path.join(str(tmp_path), "spec") + os.sep
+    model, hist = harness.ordinary_train("train_text2mel", "conditional", cfg, spec_dir=spec, current_time="c")
+    assert len(hist) == 4 and all(h == h for h in hist)
+    assert len([f for _, _, fs in os.walk(spec) for f in fs if f.endswith("_mel.npy")]) == 5      # every file cached once
+    model, hist = harness.ordinary_train("train_ssrn", "conditional", cfg, spec_dir=spec, current_time="c")
+    assert len(hist) == 4 and all(h == h for h in hist)
+
+
 def test_generate_test_utterances_writes_every_speakers_batch(tmp_path):
     """generate_test_utterances.py:56-139 on the HIP path: one batched free run + SSRN + vocoder per speaker."""
     import numpy as np

@@ -233,3 +233,68 @@ def test_ge2e_sharded_iteration_equals_single_process_gloo_world2():
         assert abs(loss - want_loss) <= 1e-5 * abs(want_loss)
         for a, b in zip(weights, want):
             assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def _make_corpus(tmp, n_items=5, with_cache=True, wav=False):
+    """A corpus in the reference's layout (data/dataset.py:37-51,84-91): path lists, one-line transcripts, speaker codes."""
+    import json as _json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = _json.load(open(os.path.join(root, "config.json")))
+    data = os.path.join(tmp, "corpus") + os.sep
+    cfg.update(DATA_ROOT_DIR=data, SPK_EMB_DIR=os.path.join(tmp, "spk_emb") + os.sep, SRC_ROOT_DIR=os.path.join(tmp, "runs") + os.sep)
+    os.makedirs(os.path.join(data, "data_path", "ordinary"))
+    os.makedirs(cfg["SPK_EMB_DIR"])
+    spec = os.path.join(tmp, "spec") + os.sep
+    rng = np.random.RandomState(0)
+    wavs, txts = [], []
+    for i in range(n_items):
+        spk = "p%d" % (225 + i % 2)
+        wdir, tdir = os.path.join(data, "wav22", spk), os.path.join(data, "txt", spk)
+        os.makedirs(wdir, exist_ok=True); os.makedirs(tdir, exist_ok=True)
+        name = "%s_%03d" % (spk, i + 1)
+        wavs.append(os.path.join(wdir, name + ".wav"))
+        txts.append(os.path.join(tdir, name + ".txt"))
+        open(txts[-1], "w").write(["Please call Stella.", "Ask her to bring these things!", "Six spoons", "of fresh \"snow\" peas", "Bob."][i % 5] + "\n")
+        np.save(os.path.join(cfg["SPK_EMB_DIR"], spk + ".npy"), rng.rand(200).astype(np.float32))
+        if wav:
+            from scipy.io import wavfile
+            n = 22050 // 2 + 3000 * i
+            y = 0.3 * np.sin(2 * np.pi * (200 + 40 * i) * np.arange(n) / 22050) * np.hanning(n)
+            wavfile.write(wavs[-1], 22050, (y * 32767).astype(np.int16))
+        if with_cache:
+            T = 7 + 3 * i
+            os.makedirs(os.path.join(spec, spk), exist_ok=True)
+            np.save(spec + wavs[-1][-17:-4] + "_mel.npy", rng.rand(80, T).astype(np.float32))
+            np.save(spec + wavs[-1][-17:-4] + "_lin.npy", rng.rand(513, 4 * T).astype(np.float32))
+    for mode in ("train", "validate"):
+        open(os.path.join(data, "data_path", "ordinary", "wav.path." + mode), "w").write("\n".join(wavs) + "\n")
+        open(os.path.join(data, "data_path", "ordinary", "txt.path." + mode), "w").write("\n".join(txts) + "\n")
+    return cfg, spec
+
+
+def test_corpus_source_collates_like_the_reference(tmp_path):
+    """data/dataset.py:175-258: text ids (lower-case, 'E' appended, unknown characters dropped, '"' folded), zero padding to the
+    batch's longest item, speaker codes (B, 200, 1); one permutation per epoch; ranks take disjoint slices."""
+    from spoofsv_amd import harness
+    cfg, spec = _make_corpus(str(tmp_path))
+    src = harness.BatchSource(cfg, "train_text2mel", 2, spec, pattern="conditional", mode="validate")      # validate: file order
+    batches = list(src)
+    assert len(src) == 3 and len(batches) == 3
+    b0 = batches[0]
+    assert tuple(b0["data_0"].shape) == (2, 80, 10) and b0["data_1"].dtype == torch.int64 and tuple(b0["data_2"].shape) == (2, 200, 1)
+    vocab = cfg["VOCABULARY"]
+    want0 = [vocab.index(ch) for ch in "please call stella.e".replace("e", "e")[:-1]] + [1]
+    assert b0["data_1"][0, 0, :len(want0)].tolist() == want0 and b0["data_1"].shape[-1] == len("ask her to bring these things") + 1
+    assert torch.all(b0["data_1"][0, 0, len(want0):] == 0)                    # 'P' padding
+    assert torch.all(b0["data_0"][0, :, 7:] == 0) and not torch.all(b0["data_0"][1, :, 7:] == 0)
+    assert tuple(batches[2]["data_0"].shape) == (1, 80, 19)                   # last, partial batch (drop_last is False)
+    quote = harness.text2id('of fresh "snow" peas', vocab)
+    assert quote.count(len(vocab) - 2) == 2                                    # '"' shares the id of "'"
+    ssrn = list(harness.BatchSource(cfg, "train_ssrn", 2, spec, mode="validate"))
+    assert tuple(ssrn[1]["data_0"].shape) == (2, 80, 16) and tuple(ssrn[1]["data_1"].shape) == (2, 513, 64)
+    tr = harness.BatchSource(cfg, "train_ssrn", 5, spec, mode="train")
+    e1, e2 = next(iter(tr))["data_0"], next(iter(tr))["data_0"]
+    assert e1.shape[0] == 5 and not torch.equal(e1, e2)                       # reshuffled every epoch
+    r0 = list(harness.BatchSource(cfg, "train_ssrn", 2, spec, mode="validate", rank=0, world=2))
+    r1 = list(harness.BatchSource(cfg, "train_ssrn", 2, spec, mode="validate", rank=1, world=2))
+    assert len(r0) == 2 and r0[0]["data_0"].shape[-1] == 10 and r1[0]["data_0"].shape[-1] == 16
