@@ -257,6 +257,35 @@ def _save(path, payload):
     torch.save(payload, path)
 
 
+def validate(loader, trainloader, gaw, cfg, model, train_step="train_text2mel"):
+    """train/ordinary.py:46-128: mean loss over the validation loader and the loss of one training batch, the model in eval mode.
+    Text2Mel is validated by FREE-RUNNING synthesis of as many frames as the ground truth has (:61-65), then the three training
+    losses against it; SSRN by one forward pass (:80-85).  The free run goes through ``_free_run`` (column-incremental)."""
+    dev = _device()
+    F = cfg["COARSE_MELSPEC"]["FREQ_BINS"]
+
+    def one(sp, tag):
+        mel_gt = sp["data_0"].to(dev)
+        if train_step == "train_text2mel":
+            Y, A = _free_run(model, sp["data_1"].to(dev), sp["data_2"].to(dev), mel_gt.shape[-1], F,
+                             incremental=cfg.get("SYNTH_INCREMENTAL", True))
+            terms = train.text2mel_losses(Y, A, mel_gt, gaw)
+        else:
+            terms = ops.spec_losses(model(mel_gt), sp["data_1"].to(dev))
+        terms = [float(t) for t in terms]
+        print("{} set loss: {} {}".format(tag, " ".join(str(t) for t in terms), sum(terms)))
+        return sum(terms)
+    with torch.no_grad():
+        total, n = 0.0, 0
+        for sp in loader:
+            total, n = total + one(sp, "val"), n + 1
+        last = float("nan")
+        for sp in trainloader:
+            last = one(sp, "train")
+            break
+    return total / max(n, 1), last
+
+
 def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpoints=None, current_time=None):
     """Non-adversarial training, train/ordinary.py:130-293."""
     dev = _device()
@@ -277,6 +306,9 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
         epoch, iteration, loss_val_log = ck["epoch"], ck["iteration"], ck["loss_val_log"]
     model.train()
     src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir, pattern=train_pattern), dev)
+    val_src = BatchSource(cfg, train_step, 8, spec_dir, seed=7919, pattern=train_pattern, mode="validate")     # batch 8, :200
+    if val_src.corpus is None:
+        val_src.n_synth = int(cfg.get("SYNTHETIC_VALIDATION_BATCHES", 1))
     gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
     max_iter = cfg.get("MAX_ITERATIONS")
     history = []
@@ -294,7 +326,12 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
             print("Iteration {}/{} for epoch {}, loss: {} {} global iteration {}".format(
                 i + 1, len(src), epoch + 1, " ".join(str(t) for t in terms), sum(terms), iteration + 1))
             if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
-                loss_val_log.append(history[-1])
+                model.eval()                                       # train/ordinary.py:264-267
+                loss_val, loss_val_train = validate(val_src, src.source, gaw, cfg, model, train_step)
+                model.train()
+                loss_val_log.append(loss_val)
+                print("Validation loss of No.{} validation: {} on validation set. {} on train set.".format(
+                    iteration // cfg["VAL_EVERY_ITER"], loss_val, loss_val_train))
                 payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
                            "optimizer_state_dict": opt.state_dict(), "loss_val_log": loss_val_log}
                 _save(os.path.join(save_dir, "{}_iteration_{}.tar.pth".format(train_step[6:], iteration + 1)), payload)

@@ -163,11 +163,14 @@ def test_training_from_a_corpus_in_the_reference_layout(tmp_path):
     from test_host_cpu import _make_corpus
     from spoofsv_amd import harness
     cfg, _ = _make_corpus(str(tmp_path), n_items=5, with_cache=False, wav=True)
-    cfg.update(BATCH_SIZE=2, HIDDEN_DIM=32, TEXT_EMB_DIM=16, SSRN_DIM=32, VAL_EVERY_ITER=100, MAX_ITERATIONS=4)
+    cfg.update(BATCH_SIZE=2, HIDDEN_DIM=32, TEXT_EMB_DIM=16, SSRN_DIM=32, VAL_EVERY_ITER=2, MAX_ITERATIONS=4)
     spec = os.path.join(str(tmp_path), "spec") + os.sep
     model, hist = harness.ordinary_train("train_text2mel", "conditional", cfg, spec_dir=spec, current_time="c")
     assert len(hist) == 4 and all(h == h for h in hist)
     assert len([f for _, _, fs in os.walk(spec) for f in fs if f.endswith("_mel.npy")]) == 5      # every file cached once
+    ck = os.path.join(cfg["SRC_ROOT_DIR"], "checkpoints", "conditional", "not_adversarial", "c")
+    val = torch.load(os.path.join(ck, "text2mel_iteration_3.tar.pth"), map_location="cpu")["loss_val_log"]
+    assert len(val) == 1 and val[0] == val[0] and os.path.exists(os.path.join(ck, "text2mel_best_model.tar.pth"))   # free-running validation ran
     model, hist = harness.ordinary_train("train_ssrn", "conditional", cfg, spec_dir=spec, current_time="c")
     assert len(hist) == 4 and all(h == h for h in hist)
 
