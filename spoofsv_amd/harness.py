@@ -379,8 +379,11 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
     src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir, pattern=train_pattern), dev)
     gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
     max_iter = cfg.get("MAX_ITERATIONS")
+    val_src = BatchSource(cfg, train_step, 8, spec_dir, seed=7919, pattern=train_pattern, mode="validate")
+    if val_src.corpus is None:
+        val_src.n_synth = int(cfg.get("SYNTHETIC_VALIDATION_BATCHES", 1))
     if cfg.get("CAPTURE_GRAPHS") and resume_checkpoints is None and not src.source.files and src.source.corpus is None:
-        return _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter)
+        return _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter, val_src)
     while epoch < cfg["MAX_EPOCHS"]:
         for i, sp in enumerate(src):
             t0 = time.time()
@@ -424,10 +427,18 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
                 logs["wd_log"].append(-float(loss_D))
                 print("training D  DISC:{}, WD:{}".format(float(loss_D) + float(loss_gp), -float(loss_D)))
             if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
+                model.eval()                                       # train/adversarial_wasserstein_gp.py:392-395
+                loss_val, loss_val_train = validate(val_src, src.source, gaw, cfg, model, train_step)
+                model.train()
+                logs["loss_val_log"].append(loss_val)
+                print("Validation loss of No.{} validation: {} on validation set. {} on train set.".format(
+                    iteration // cfg["VAL_EVERY_ITER"], loss_val, loss_val_train))
                 payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
                            "disc_state_dict": disc.state_dict(), "opt_state_dict_syn": opt_syn.state_dict(),
                            "opt_state_dict_disc": opt_disc.state_dict()}
                 payload.update(logs)
+                if logs["loss_val_log"].index(min(logs["loss_val_log"])) == len(logs["loss_val_log"]) - 1:      # :398-416
+                    _save(os.path.join(save_dir, "{}_best_model.tar.pth".format(train_step[6:])), payload)
                 _save(os.path.join(save_dir, "{}_iteration_{}.tar.pth".format(train_step[6:], iteration + 1)), payload)
             iteration += 1
             print("Time elapsed {}s.".format(time.time() - t0))
@@ -437,7 +448,7 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
     return model, disc, logs
 
 
-def _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter):
+def _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter, val_src):
     """adversarial_train with both iteration kinds replayed from hipGraphs (optional config key CAPTURE_GRAPHS; needs
     fixed batch shapes, i.e. the synthetic source).  Same schedule, losses, logs and checkpoints as the eager loop."""
     a = cfg["ADAM"]
@@ -475,10 +486,18 @@ def _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, sav
                 logs["wd_log"].append(-ld)
                 print("training D  DISC:{}, WD:{}".format(ld + gp, -ld))
             if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
+                model.eval()                                       # train/adversarial_wasserstein_gp.py:392-395
+                loss_val, loss_val_train = validate(val_src, src.source, gaw, cfg, model, train_step)
+                model.train()
+                logs["loss_val_log"].append(loss_val)
+                print("Validation loss of No.{} validation: {} on validation set. {} on train set.".format(
+                    iteration // cfg["VAL_EVERY_ITER"], loss_val, loss_val_train))
                 payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
                            "disc_state_dict": disc.state_dict(), "opt_state_dict_syn": opt_syn.state_dict(),
                            "opt_state_dict_disc": opt_disc.state_dict()}
                 payload.update(logs)
+                if logs["loss_val_log"].index(min(logs["loss_val_log"])) == len(logs["loss_val_log"]) - 1:      # :398-416
+                    _save(os.path.join(save_dir, "{}_best_model.tar.pth".format(train_step[6:])), payload)
                 _save(os.path.join(save_dir, "{}_iteration_{}.tar.pth".format(train_step[6:], iteration + 1)), payload)
             iteration += 1
             print("Time elapsed {}s.".format(time.time() - t0))
