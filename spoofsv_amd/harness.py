@@ -86,7 +86,7 @@ class CorpusSource:
         out["data_1"] = torch.tensor(text2id(text, self.cfg["VOCABULARY"]), dtype=torch.long).view(1, -1)
         spk = np.load(os.path.join(self.cfg["SPK_EMB_DIR"], self.wavlist[idx][-12:-8] + ".npy"))
         out["data_2"] = torch.from_numpy(np.asarray(spk, dtype=np.float32)).view(-1, 1)
-        if self.step == "synthesize" and self.mode != "validate":
+        if self.step == "synthesize" and self.mode != "validate":      # data/dataset.py:131-132
             out["data_3"] = torch.from_numpy(np.load(self.cache + key + "_lin.npy")).float()
         return out
 
@@ -526,9 +526,6 @@ def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=No
             torch.manual_seed(1234)
             m.apply(train.init_weights)
         m.to(dev).eval()
-    if texts is None:
-        with open(cfg["TTS_TEXTS"]) as f:
-            texts = [ln.strip() for ln in f if ln.strip()][:1]
     frames = max_frames or cfg["MAX_FRAME_NUM"]
     outs = []
     voc = None
@@ -536,6 +533,32 @@ def synthesize(pattern, cfg, spec_dir, current_time=None, texts=None, spk_emb=No
         from scipy.io import wavfile               # what librosa 0.7.0's output.write_wav calls (synthesize.py:147)
         from .vocoder import Vocoder
         voc = Vocoder(cfg["STFT"]["FFT_LENGTH"], cfg["STFT"]["HOP_LENGTH"], dev)
+    syn_list = os.path.join(cfg.get("DATA_ROOT_DIR", ""), "data_path", "ordinary", "wav.path.synthesize")
+    if texts is None and os.path.exists(syn_list):
+        # synthesize.py:62,90-147 proper: the 'synthesize' split of the corpus in batches of 8 -- free run for as many frames as
+        # the ground truth has, both models' losses against it, then the whole batch through the vocoder (S<k>_B<i>.wav)
+        gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
+        loader = CorpusSource(cfg, "synthesize", pattern, "synthesize", 8, spec_dir)
+        with torch.no_grad():
+            for i, sp in enumerate(loader):
+                mel_gt, lin_gt = sp["data_0"].to(dev), sp["data_3"].to(dev)
+                Y, A = _free_run(m1, sp["data_1"].to(dev), sp["data_2"].to(dev), mel_gt.shape[-1], cfg["COARSE_MELSPEC"]["FREQ_BINS"],
+                                 graph=cfg.get("SYNTH_GRAPH", False), incremental=cfg.get("SYNTH_INCREMENTAL", True))
+                t2m = [float(t) for t in train.text2mel_losses(Y, A, mel_gt, gaw)]
+                print("syn set text2mel loss: {} {}".format(" ".join(str(t) for t in t2m), sum(t2m)))
+                resident.ensure(m2, ops._stream())
+                lin = m2(Y).contiguous()
+                ss = [float(t) for t in ops.spec_losses(lin, lin_gt)]
+                print("syn set ssrn loss: {} {}".format(" ".join(str(t) for t in ss), sum(ss)))
+                wav = voc.spectrogram2wav(lin, cfg, n_iter=cfg.get("GRIFFIN_LIM_ITERS", 64)).cpu().numpy() if voc is not None else None
+                for k in range(lin.shape[0]):
+                    if wav is not None:
+                        wavfile.write(os.path.join(sample_dir, "S{}_B{}.wav".format(k + 1, i + 1)), cfg["SAMPLING_RATE"], wav[k])
+                    outs.append((Y[k].cpu().numpy(), lin[k].cpu().numpy(), A[k].cpu().numpy()))
+        return outs
+    if texts is None:
+        with open(cfg["TTS_TEXTS"]) as f:
+            texts = [ln.strip() for ln in f if ln.strip()][:1]
     with torch.no_grad():
         for k, text in enumerate(texts):
             ids = torch.tensor(text2id(text, cfg["VOCABULARY"]), dtype=torch.long, device=dev).view(1, 1, -1)

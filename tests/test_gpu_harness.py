@@ -173,6 +173,11 @@ def test_training_from_a_corpus_in_the_reference_layout(tmp_path):
     assert len(val) == 1 and val[0] == val[0] and os.path.exists(os.path.join(ck, "text2mel_best_model.tar.pth"))   # free-running validation ran
     model, hist = harness.ordinary_train("train_ssrn", "conditional", cfg, spec_dir=spec, current_time="c")
     assert len(hist) == 4 and all(h == h for h in hist)
+    # synthesize.py proper: the 'synthesize' split in batches of 8, losses against the ground truth, every item vocoded
+    outs = harness.synthesize("conditional", dict(cfg, GRIFFIN_LIM_ITERS=4), spec, current_time="s")
+    assert len(outs) == 5 and outs[0][0].shape[0] == 80 and outs[0][1].shape == (513, 4 * outs[0][0].shape[1])
+    assert sorted(f for f in os.listdir(os.path.join(cfg["SRC_ROOT_DIR"], "samples", "s")) if f.endswith(".wav")) == \
+        ["S%d_B1.wav" % (k + 1) for k in range(5)]
 
 
 def test_generate_test_utterances_writes_every_speakers_batch(tmp_path):

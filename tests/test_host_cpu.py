@@ -266,7 +266,7 @@ def _make_corpus(tmp, n_items=5, with_cache=True, wav=False):
             os.makedirs(os.path.join(spec, spk), exist_ok=True)
             np.save(spec + wavs[-1][-17:-4] + "_mel.npy", rng.rand(80, T).astype(np.float32))
             np.save(spec + wavs[-1][-17:-4] + "_lin.npy", rng.rand(513, 4 * T).astype(np.float32))
-    for mode in ("train", "validate"):
+    for mode in ("train", "validate", "synthesize"):
         open(os.path.join(data, "data_path", "ordinary", "wav.path." + mode), "w").write("\n".join(wavs) + "\n")
         open(os.path.join(data, "data_path", "ordinary", "txt.path." + mode), "w").write("\n".join(txts) + "\n")
     return cfg, spec
