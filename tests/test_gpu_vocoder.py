@@ -54,6 +54,25 @@ def test_stft_istft_match_oracle(voc, T):
     assert np.abs(voc.istft(S).cpu().numpy() - y).max() <= 2e-5 * np.abs(y).max()    # exact reconstruction
 
 
+def test_full_size_batch_round_trip_and_consistency(voc):
+    """Synthesis size (T = 1300 frames, 8 utterances: the DFT convs take the wide-workgroup tiles here, unlike the small cases):
+    ISTFT(STFT(y)) = y, one item against the oracle, and a Griffin-Lim run from the TRUE phases stays at the fixed point."""
+    rng = np.random.RandomState(23)
+    B, T = 8, 1300
+    n = 256 * (T - 1)
+    y = (rng.randn(B, n) * 0.1).astype(np.float32)
+    S = voc.stft(_dev(y))
+    assert tuple(S.shape) == (B, 1026, T)
+    back = voc.istft(S).cpu().numpy()
+    assert np.abs(back - y).max() <= 2e-5 * np.abs(y).max()
+    ref = vo.stft(y[3])
+    assert np.abs(S[3].cpu().numpy() - np.concatenate([ref.real, ref.imag], 0)).max() <= 2e-5 * np.abs(ref).max()
+    mag = voc.magnitude(S)
+    ang = S / torch.cat([mag, mag], 1).clamp_min(1e-12)               # the consistent phases: Griffin-Lim must not move off them
+    w = voc.griffinlim(mag, ang.contiguous(), 3).cpu().numpy()
+    assert np.abs(w - y).max() <= 1e-3 * np.abs(y).max()
+
+
 def test_small_transform_sizes(voc):
     from spoofsv_amd.vocoder import Vocoder
     v = Vocoder(128, 32)
