@@ -629,6 +629,34 @@ def test_highway_gate_dd_matches_autograd_to_second_order(B, C, L):
         assert _close(got, want)
 
 
+def test_critic_gradient_penalty_full_size_lin_critic():
+    """linDisc at its real size (513 bins x 1300 frames, DISC_DIM 128): critic loss with gradient penalty, HIP ops vs the CPU
+    reference path.  Tolerance 3e-3 in the relative L2 norm per parameter (sums over 1300 columns in fp32)."""
+    from spoofsv_amd.critic import linDisc
+    torch.manual_seed(9)
+    d = linDisc(513, 128).eval()
+    B, T = 2, 1300
+    real, fake, eps = torch.rand(B, 513, T), torch.rand(B, 513, T), torch.rand(B, 1, 1)
+
+    def d_loss(disc, dev):
+        disc.zero_grad()
+        r, f, e = real.to(dev), fake.to(dev), eps.to(dev)
+        xhat = (e * r + (1 - e) * f).requires_grad_(True)
+        out = disc(xhat)
+        grad, = torch.autograd.grad(out, xhat, torch.ones_like(out), create_graph=True)
+        gp = ((grad.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean()
+        loss = disc(f).mean() - disc(r).mean() + 10.0 * gp
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.detach().cpu().clone() for n, p in disc.named_parameters()}
+    want_loss, want = d_loss(d, "cpu")
+    got_loss, got = d_loss(d.cuda(), "cuda")
+    assert abs(got_loss - want_loss) <= 2e-4 * max(1.0, abs(want_loss))
+    for n in want:
+        if n in ("conv1.bias", "conv2.bias", "conv3.bias", "conv4.bias", "hc.conv.bias"):
+            continue      # exactly-zero gradients (a bias in front of a LayerNorm): rounding noise on both sides
+        assert float((got[n] - want[n]).norm()) <= 3e-3 * max(1e-6, float(want[n].norm())), n
+
+
 def test_critic_gradient_penalty_matches_cpu_reference_path():
     """The whole critic, penalty and all (train/adversarial_wasserstein_gp.py:296-312), on the HIP ops versus the same module
     on the CPU, where critic.py runs the reference's permute -> nn.LayerNorm -> permute ops.  eval(): no dropout RNG."""
