@@ -441,3 +441,79 @@ def test_ge2e_harness_trains_checkpoints_and_verifies(tmp_path):
     thres = GH.test_nospoof(cfg, model_path, enroll_num=2, eval_num=2)
     rate = GH.spoof_rate_at(cfg, thres, eval_num=2)
     assert 0.0 <= eer <= 1.0 and 0.0 <= spoof <= 1.0 and 0.5 <= thres < 1.0 and 0.0 <= rate <= 1.0
+
+
+def _t2m_grads(m, mel, text, spk, gaw, ddp=None):
+    from spoofsv_amd import train
+    for p in m.parameters():
+        p.grad = None
+    pred, att = m(train.shift_right(mel), text, spk)
+    l1, bd, la = train.text2mel_losses(pred, att, mel, gaw)
+    (l1 + bd + la).backward()
+    if ddp is not None:
+        ddp.all_reduce_grads()
+    torch.cuda.synchronize()
+    return [p.grad.detach().cpu().numpy() for p in m.parameters()]
+
+
+def _ddp_gpu_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from spoofsv_amd import train
+    from spoofsv_amd.tts import melSyn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = "cuda:0"                                       # rehearsal: both ranks share the one GPU of the test box
+    torch.manual_seed(100 + rank)                        # replicas start different; broadcast_parameters must fix that
+    m = melSyn(34, True, 200, textemb_dim=16, freq_bins=80, hidden_dim=32)
+    m.apply(train.init_weights)
+    m = m.to(dev).train()
+    ddp = train.DataParallelRanks(list(m.parameters()))
+    ddp.broadcast_parameters(0)
+    opt = train.FusedAdam(m.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    mel, text, spk = train.synthetic_text2mel_batch(4, N=20, T=33, seed=3, device=dev)
+    gaw = train.guided_attention_mat(20, 33, device=dev)
+    sl = slice(2 * rank, 2 * rank + 2)                  # each rank takes its half of the global batch
+    grads = _t2m_grads(m, mel[sl], text[sl], spk[sl], gaw, ddp)
+    for _ in range(2):                                   # and two full optimizer steps: replicas must stay identical
+        train.text2mel_step(m, opt, mel[sl], text[sl], spk[sl], gaw, ddp=ddp)
+    torch.cuda.synchronize()
+    q.put((rank, grads, [p.detach().cpu().numpy() for p in m.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_equals_single_process_on_the_global_batch():
+    """One process per rank: utterances sharded by rank, gradients averaged by the flat-bucket all-reduce.  Two ranks
+    with half the batch each must produce the gradient one process computes on the whole batch (every loss is a mean over the
+    batch), and their replicas must stay bit-identical through optimizer steps.  gloo here because the test box has one GPU; the
+    driver's multi-GPU runs use RCCL through the same code path."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    from spoofsv_amd import train
+    from spoofsv_amd.tts import melSyn
+    dev = "cuda:0"
+    torch.manual_seed(100)                               # = rank 0's seed
+    m = melSyn(34, True, 200, textemb_dim=16, freq_bins=80, hidden_dim=32)
+    m.apply(train.init_weights)
+    m = m.to(dev).train()
+    mel, text, spk = train.synthetic_text2mel_batch(4, N=20, T=33, seed=3, device=dev)
+    gaw = train.guided_attention_mat(20, 33, device=dev)
+    want = _t2m_grads(m, mel, text, spk, gaw)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b)                      # replicas bit-identical after two steps
+    scale = max(float(np.abs(w).max()) for w in want)
+    for g0, g1, w in zip(res[0][1], res[1][1], want):
+        assert np.array_equal(g0, g1)
+        # split-bf16 products over a different batch partition: agreement to a few 1e-4 of the gradient's own size
+        assert float(np.abs(g0 - w).max()) <= 2e-5 * scale + 5e-4 * float(np.abs(w).max())
