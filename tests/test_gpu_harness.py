@@ -517,3 +517,56 @@ def test_two_rank_data_parallel_step_equals_single_process_on_the_global_batch()
         assert np.array_equal(g0, g1)
         # split-bf16 products over a different batch partition: agreement to a few 1e-4 of the gradient's own size
         assert float(np.abs(g0 - w).max()) <= 2e-5 * scale + 5e-4 * float(np.abs(w).max())
+
+
+def _ge2e_setup_gpu():
+    from spoofsv_amd.ge2e import GE2ELoss, SpeechEmbedder
+    torch.manual_seed(55)
+    net = SpeechEmbedder(nmels=40, hidden=32, num_layer=3, proj=16).to("cuda:0").train()
+    crit = GE2ELoss("cuda:0")
+    x = torch.randn(4, 4, 20, 40, device="cuda:0")                       # N = 4 speakers x M = 4 utterances x 20 frames x 40 mels
+    return net, crit, x
+
+
+def _ge2e_gpu_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from spoofsv_amd import ge2e
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net, crit, x = _ge2e_setup_gpu()
+    opt = torch.optim.SGD([{"params": net.parameters()}, {"params": crit.parameters()}], lr=0.01)
+    n_local = x.shape[0] // world
+    loss = ge2e.sharded_train_iteration(net, crit, opt, x[rank * n_local:(rank + 1) * n_local], n_local, 4)
+    torch.cuda.synchronize()
+    q.put((rank, float(loss), [p.detach().cpu().numpy() for p in list(net.parameters()) + list(crit.parameters())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ge2e_speaker_sharded_iteration_on_the_hip_path():
+    """SURVEY 8e, GE2E row, on the HIP embedder: speakers split over two ranks, one all-gather of the embeddings, summed embedder
+    gradients -> the loss and the post-step weights of the single-process iteration on the whole batch."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    from spoofsv_amd import ge2e
+    net, crit, x = _ge2e_setup_gpu()
+    opt = torch.optim.SGD([{"params": net.parameters()}, {"params": crit.parameters()}], lr=0.01)
+    before = [p.detach().cpu().numpy().copy() for p in list(net.parameters()) + list(crit.parameters())]
+    want_loss = float(ge2e.train_iteration(net, crit, opt, x, 4, 4))
+    want = [p.detach().cpu().numpy() for p in list(net.parameters()) + list(crit.parameters())]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ge2e_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, loss, weights in res:
+        assert abs(loss - want_loss) <= 1e-4 * abs(want_loss)
+        for a, b, b0 in zip(weights, want, before):
+            step = float(np.abs(b - b0).max())                          # compare the UPDATE (SGD: lr * clipped gradient)
+            assert float(np.abs(a - b).max()) <= 2e-3 * step + 1e-7
