@@ -217,6 +217,12 @@ static int dw_splits(int B, int M, int Nc, int k) {
   const int tiles = ssv_nt_bf3_tiles(k == 3 ? 3 : 1, M, Nc);
   int z = ssv_cdiv(ssv_nt_bf3_target(k == 3 ? 3 : 1, M, Nc), tiles);
   if (const char* e = getenv("SSV_NT_Z")) { const int v = atoi(e); if (v > 0) z = v; }
+  if (const char* e = getenv("SSV_NT_FORCE")) {      // "M:Nc:k=Z;..." -- one shape's slab count inside a whole step (tools/sweep_step_tiles.py)
+    char key[48];
+    snprintf(key, sizeof key, "%d:%d:%d=", M, Nc, k);
+    const char* hit = strstr(e, key);
+    if (hit && (hit == e || hit[-1] == ';')) { const int v = atoi(hit + strlen(key)); if (v > 0) z = v; }
+  }
   if (z > B) z = B;
   if (z < 1) z = 1;
   return z;
