@@ -570,3 +570,22 @@ def test_ge2e_speaker_sharded_iteration_on_the_hip_path():
         for a, b, b0 in zip(weights, want, before):
             step = float(np.abs(b - b0).max())                          # compare the UPDATE (SGD: lr * clipped gradient)
             assert float(np.abs(a - b).max()) <= 2e-3 * step + 1e-7
+
+
+def test_integration_md_binding_snippet_runs_as_written():
+    """INTEGRATION.md section 2 is executable documentation: the ctypes stub, pasted into a reference-style module, must give the
+    same output as this repo's own highwayConv (same weights)."""
+    import re
+    from spoofsv_amd.tts import highwayConv as mine_cls
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch.*?)```", text, flags=re.S).group(1)
+    code = code.replace('ctypes.CDLL("spoofsv_amd/libssv_hip.so")', 'ctypes.CDLL(%r)' % os.path.join(ROOT, "spoofsv_amd", "libssv_hip.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    torch.manual_seed(12)
+    mine = mine_cls(32, 3, 9, causal=True).to("cuda:0").eval()
+    doc = ns["highwayConv"]()                                   # the documented class: a torch.nn.Module with a re-routed forward
+    doc.conv, doc.ln1, doc.ln2, doc.causal = mine.conv, mine.ln1, mine.ln2, True
+    x = torch.randn(3, 32, 70, device="cuda:0")
+    with torch.no_grad():
+        assert torch.equal(doc(x), mine(x))
