@@ -373,6 +373,15 @@ extern "C" int ssv_attention_train_fwd(const float* k, const float* v, long kv_b
   return ssv_attention_apply(v, kv_bs, a, T, r, r_bs, B, d, N, T, stream);
 }
 extern "C" size_t ssv_attention_train_bwd_workspace(int B, int d, int N, int T) { (void)d; return align256((size_t)B * N * T * sizeof(float)); }
+// Per-batch-item products reduced over time (attention dV, dK): the split-bf16 weight-gradient kernel with one slab per batch
+// item and no slab sum (21 -> ~100 TFLOP/s at d = 256, N = 186, T = 325; the fp32 kernel's 128 x 96 tiles leave the chip idle).
+static int nt_per_batch(GemmNT& g, int T, hipStream_t st) {
+  g.KT = 1;
+  g.scj = 1;
+  if (ssv_precision() == 1 && (long)g.B * T >= 256 && ssv_nt_bf3_fits(g)) return ssv_launch_gemm_nt_bf3(g, st);
+  return ssv_launch_gemm_nt(g, st);
+}
+
 extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float* da_ext, const float* dq_add, long dq_add_bs,
                                        const float* k, const float* v, long kv_bs, const float* q, long q_bs, const float* a,
                                        float* dk, float* dv, long dkv_bs, float* dq, long dq_bs, int B, int d, int N, int T,
@@ -395,7 +404,7 @@ extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float*
     g.X = a; g.sxb = (long)N * T; g.sxc = T; g.Lx = T;
     g.C = dv; g.scz = dkv_bs; g.scm = N; g.scc = 1;
     g.M = d; g.Nc = N; g.B = B; g.Z = B; g.bstep = B;
-    SSV_TRY(ssv_launch_gemm_nt(g, st));
+    SSV_TRY(nt_per_batch(g, T, st));
   }
   SSV_TRY(ssv_launch_softmax_cols_bwd(a, dA, da_ext, 1.f / sqrtf((float)d), B, N, T, st));   // dA now holds dScores
   {  // dk(b,c,n) = sum_t q(b,c,t) ds(b,n,t)
@@ -404,7 +413,7 @@ extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float*
     g.X = dA; g.sxb = (long)N * T; g.sxc = T; g.Lx = T;
     g.C = dk; g.scz = dkv_bs; g.scm = N; g.scc = 1;
     g.M = d; g.Nc = N; g.B = B; g.Z = B; g.bstep = B;
-    SSV_TRY(ssv_launch_gemm_nt(g, st));
+    SSV_TRY(nt_per_batch(g, T, st));
   }
   {  // dq(b,c,t) = sum_n k(b,c,n) ds(b,n,t) + dq_add
     GemmNN g = nn_zero();
