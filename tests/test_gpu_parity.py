@@ -159,6 +159,17 @@ def test_column_step_kernels_match_full_sequence_ops():
                   P(out), 2 * C, B, C, 2 * C, 3, st)
         assert rel_err(out, want[:, :, tt]) < 1e-4, tt
     assert torch.equal(hist, xt)                                   # the by-product: every column was filed in the history
+    # K = k*C = 1536 > 768: the part of a weight row beyond the prefetched 24 float4 per lane
+    Cw = 512
+    xw = torch.randn(B, 6, Cw, device=DEV)
+    ww = torch.randn(24, Cw, 3, device=DEV) * 0.05
+    histw = xw.clone()
+    tdev.fill_(5)
+    outw = torch.empty(B, 24, device=DEV)
+    _lib.call("ssv_column_matvec", P(ww.permute(0, 2, 1).contiguous()), None, None, 0, P(xw[:, 5]), xw.stride(0), P(histw), histw.stride(0), 6,
+              P(tdev), 2, P(outw), 24, B, Cw, 24, 3, st)
+    wantw = sum(torch.einsum("mc,bc->bm", ww[:, :, j], xw[:, 5 - 2 * (2 - j)]) for j in range(3))
+    assert rel_err(outw, wantw) < 1e-4
     # 1x1 convolution with a per-item bias term
     w1 = torch.randn(48, C, 1, device=DEV) * 0.1
     sb = torch.randn(B, 48, device=DEV)
