@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adversarial", action="store_true", help="skip the extra WGAN-GP cycle timing")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 timing of the same step")
+    ap.add_argument("--no-ge2e", action="store_true", help="skip the GE2E (config 5) figures on the line")
     ap.add_argument("--ge2e", action="store_true", help="measure BASELINE config 5 (GE2E speaker embedder) instead and print its JSON line")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
@@ -49,136 +51,96 @@ def parse():
 
 
 class Trainer:
-    """Holds model + optimizer + static batch; runs fwd+bwd (+Adam) eagerly or from a captured graph."""
+    """Model + optimizer + static batch behind ``train.TrainStep``: forward, losses, backward, Adam -- one hipGraph on a
+    single GPU; with N > 1 the backward runs in the segments of ``tts.ddp_plan`` (separate hipGraphs) and every gradient
+    bucket's RCCL all-reduce is launched between the replays, overlapping the remaining backward."""
 
     def __init__(self, kind, batch, dev, rank, world, use_graph):
         from spoofsv_amd import train
         from spoofsv_amd.tts import SSRN, melSyn
-        self.kind, self.world, self.train = kind, world, train
+        self.kind, self.world = kind, world
         torch.manual_seed(1234)
+        gaw = None
         if kind == "text2mel":
             self.model = melSyn(34, True, 200, textemb_dim=128, freq_bins=80, hidden_dim=256)
-            self.batch = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=rank, device=dev)
-            self.gaw = train.guided_attention_mat(186, 325, device=dev)
+            data = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=rank, device=dev)
+            gaw = train.guided_attention_mat(186, 325, device=dev)
         else:
             self.model = SSRN(80, 513, 256)
-            self.batch = train.synthetic_ssrn_batch(batch, T_MEL, seed=rank, device=dev)
+            data = train.synthetic_ssrn_batch(batch, T_MEL, seed=rank, device=dev)
         self.model.apply(train.init_weights)
         self.model.to(dev).train()
-        self.params = [p for p in self.model.parameters()]
-        self.opt = train.FusedAdam(self.params, 2e-4, (0.5, 0.9), 1e-6, capturable=True)
-        self.ddp = train.DataParallelRanks(self.params) if world > 1 else None
-        if self.ddp:
+        self.opt = train.FusedAdam(self.model.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+        self.ddp = None
+        if world > 1 or os.environ.get("SSV_FORCE_SEGMENTED") == "1":      # the second form: rehearse the N > 1 launch structure on one GPU
+            self.ddp = train.DataParallelRanks(model=self.model)
             self.ddp.broadcast_parameters(0)
-        self.graph = None
-        self.use_graph = use_graph
-        self.losses = None
-
-    def _fwd_bwd(self):
-        t = self.train
-        self.opt.zero_grad(set_to_none=True)
-        if self.kind == "text2mel":
-            mel, text, spk = self.batch
-            pred, att = self.model(t.shift_right(mel), text, spk)
-            l1, bd, la = t.text2mel_losses(pred, att, mel, self.gaw)
-            loss = l1 + bd + la
-        else:
-            mel, lin = self.batch
-            l1, bd = t.ops.spec_losses(self.model(mel), lin)
-            loss = l1 + bd
-        loss.backward()
-        self.losses = loss
-
-    def _whole(self):
-        self._fwd_bwd()
-        if self.ddp:
-            self.ddp.all_reduce_grads()
-        self.opt.step()
+        self.opt.refresh_resident_weights()
+        self.stepper = train.TrainStep(kind, self.model, self.opt, list(data), gaw, self.ddp, graph=use_graph)
 
     def prepare(self):
-        """Warm the allocator on a side stream and capture the step.  Single GPU: forward, backward and
-        Adam in ONE graph.  Multi GPU: forward+backward is captured, the gradient all-reduce and Adam
-        are launched eagerly after the replay (RCCL collectives stay outside the capture)."""
-        if not self.use_graph:
-            return
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                self._whole()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            if self.ddp:
-                self._fwd_bwd()
-                self.graph_grads = [p.grad for p in self.params]      # the tensors every replay writes
-            else:
-                self._whole()
+        self.stepper.prepare()
 
     def step(self):
-        self.step_begin()
-        self.step_end()
+        self.stepper()
 
-    # Two halves, so that with N > 1 the gradient all-reduce of one model overlaps the other model's compute:
-    #   begin = forward + backward (+ start of the asynchronous all-reduce);  end = wait + Adam.
-    def step_begin(self):
-        self._pending = None
-        if self.ddp is None:
-            if self.graph is None:
-                self._whole()
-            else:
-                self.graph.replay()
-            return
-        if self.graph is None:
-            self._fwd_bwd()
-            self._pending = self.ddp.all_reduce_grads_begin()
-        else:
-            self.graph.replay()
-            self._pending = self.ddp.all_reduce_grads_begin(self.graph_grads)
-
-    def step_end(self):
-        if self.ddp is not None:
-            self.ddp.all_reduce_grads_end(self._pending)
-            self.opt.step()
+    @property
+    def loss(self):
+        return float(sum(self.stepper.out))
 
 
-def adversarial_cycle_ms(kind, batch, dev, cycles=3):
+def adversarial_cycle_ms(kind, batch, dev, world=1, cycles=3):
     """One full WGAN-GP cycle of the reference (1 generator + RATIO=5 critic iterations,
     train/adversarial_wasserstein_gp.py:261-322): generator on the HIP path, critic on the twice-differentiable HIP conv / LayerNorm / gate ops
-    with gradient penalty, both iterations replayed from captured hipGraphs (train.AdversarialGraphStep).
-    Returns ms per ITERATION averaged over the cycle."""
+    with gradient penalty, both iterations replayed from captured hipGraphs (train.AdversarialGraphStep); with N > 1 data
+    parallel (BASELINE config 4): global adaptive weight, bucketed generator all-reduce between the backward segments, one packed
+    critic all-reduce.  Returns ms per ITERATION averaged over the cycle (max over ranks)."""
     from spoofsv_amd import train
     from spoofsv_amd.critic import linDisc, melDisc
     from spoofsv_amd.tts import SSRN, melSyn
+    rank = dist.get_rank() if world > 1 else 0
     torch.manual_seed(1234)
     gaw = None
     if kind == "text2mel":
         model, disc = melSyn(34, True, 200, 128, 80, 256), melDisc(80, 128)
-        data = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=0, device=dev)
+        data = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=rank, device=dev)
         gaw = train.guided_attention_mat(186, 325, device=dev)
     else:
         model, disc = SSRN(80, 513, 256), linDisc(513, 128)
-        data = train.synthetic_ssrn_batch(batch, T_MEL, seed=0, device=dev)
+        data = train.synthetic_ssrn_batch(batch, T_MEL, seed=rank, device=dev)
     model.apply(train.init_weights); disc.apply(train.init_weights)
     model.to(dev).train(); disc.to(dev).train()
     og = train.FusedAdam(model.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
     od = train.FusedAdam(disc.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
-    stepper = train.AdversarialGraphStep(kind, model, disc, og, od, data, gaw)
+    ddp_syn = ddp_disc = None
+    if world > 1:
+        ddp_syn, ddp_disc = train.DataParallelRanks(model=model), train.DataParallelRanks(list(disc.parameters()))
+        ddp_syn.broadcast_parameters(0); ddp_disc.broadcast_parameters(0)
+        torch.cuda.manual_seed(1234 + rank)                   # dropout masks: independent draws per rank, as per sample in one big batch
+    stepper = train.AdversarialGraphStep(kind, model, disc, og, od, data, gaw, 10.0, ddp_syn, ddp_disc)
     def cycle():
         stepper.g_step()
         for _ in range(5):
             stepper.d_step()
     cycle()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(cycles):
         cycle()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
     out = stepper.g_step()
     if not all(float(v) == float(v) for v in out):
         raise SystemExit("non-finite loss in the adversarial cycle")
-    return (time.perf_counter() - t0) / (6 * cycles) * 1e3
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[0])
+    return dt / (6 * cycles) * 1e3
 
 
 def kernel_roofline(dev):
@@ -262,13 +224,27 @@ def kernel_roofline(dev):
             "peak_note": "bf16 dense 2500 TFLOP/s / 3" if split else "fp32-input MFMA dense",
             "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
             "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4),
-            # PMC: FETCH_SIZE + WRITE_SIZE per launch of this kernel instantiation, separate rocprofv3 --pmc passes (not collected live)
-            # gfx950 correction (MI355X_MICROARCH.md, FETCH_SIZE): 16-byte-per-lane loads are tallied at half their bytes -- here only the
-            # pre-split weight fragments (2 planes x 512 x 768 bf16 = 1.5 MiB fetched once from HBM), so +768 KiB; the input tile
-            # loads are 4-byte-per-lane and counted in full
-            "traffic": (12900.7 + 768.0 + 20839.0) * 1024 if split else (45959.9 + 20878.8) * 1024,
-            "traffic_source": "profiles/round1_bench_kernel_stats_v5_final.txt (PMC passes; kernel times of the final tree: ..._v6_final.txt)" if split else "profiles/round1_bench_kernel_stats_v1_fp32.txt",
+            **pmc_traffic(split),
             "others": others}
+
+
+def pmc_traffic(split):
+    """``roofline.traffic``: HBM bytes per launch of the headline kernel from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate
+    rocprofv3 --pmc passes, gfx950 corrections of MI355X_MICROARCH.md applied).  Counters cannot be collected by the run that
+    prints the line, so the figure is read from ``profiles/traffic.json``, which records the sha256 of the kernel sources it was
+    measured on; if the sources have changed since, the figure is withheld (null) instead of going stale silently."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path))["bf16x3" if split else "fp32"]
+    except Exception as e:
+        return {"traffic": None, "traffic_source": "no PMC record (%s)" % type(e).__name__}
+    h = hashlib.sha256()
+    for f in rec["sources"]:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    if h.hexdigest()[:16] != rec["sources_sha16"]:
+        return {"traffic": None, "traffic_source": "stale: %s changed since the PMC pass %s" % (", ".join(rec["sources"]), rec["profile"])}
+    return {"traffic": rec["traffic_bytes"], "traffic_source": "%s (sources sha %s); %s" % (rec["profile"], rec["sources_sha16"], rec["note"])}
 
 
 def cpu_baseline():
@@ -380,16 +356,18 @@ def ge2e_config5():
         lo, _ = GO.ge2e_loss(GO.speech_embedder(x[:40], sd).view(4, 10, 256), torch.tensor(10.0), torch.tensor(-5.0))
     err = float((e[:44].cpu() - eo).abs().max() / eo.abs().max())
     flops = 880 * 120 * 2 * (4 * 768 * (40 + 768) + 2 * 4 * 768 * (768 + 768)) + 880 * 2 * 768 * 256
-    print(json.dumps({"metric": "GE2E utterances/s (LSTM fwd + projection + loss)", "value": round(880 / dt, 1), "ms": round(dt * 1e3, 2),
-                      "tflops": round(flops / dt / 1e12, 1), "loss": round(float(loss), 4), "rel_err_vs_cpu_oracle": err,
-                      "train_iteration": {"ms": round(dtt * 1e3, 2), "utterances_per_s": round(880 / dtt, 1), "tflops": round(3 * flops / dtt / 1e12, 1),
-                                          "loss_after": round(float(tl.detach()), 4)},
-                      "cpu_baseline": {"value": round(44 / tc, 1), "unit": "utterances/s", "cores": cores, "sample": "44 utterances x 120 frames"}}))
+    return {"metric": "GE2E utterances/s (LSTM fwd + projection + loss)", "value": round(880 / dt, 1), "ms": round(dt * 1e3, 2),
+            "tflops": round(flops / dt / 1e12, 1), "loss": round(float(loss), 4), "rel_err_vs_cpu_oracle": err,
+            "train_iteration": {"ms": round(dtt * 1e3, 2), "utterances_per_s": round(880 / dtt, 1), "tflops": round(3 * flops / dtt / 1e12, 1),
+                                "loss_after": round(float(tl.detach()), 4)},
+            "cpu_baseline": {"value": round(44 / tc, 1), "unit": "utterances/s", "cores": cores, "sample": "44 utterances x 120 frames"}}
+
 
 def main():
     args = parse()
     if args.ge2e:
-        return ge2e_config5()
+        print(json.dumps(ge2e_config5()))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -413,82 +391,91 @@ def main():
     import spoofsv_amd
     spoofsv_amd.set_precision(args.precision)
     use_bf3_mode = args.precision == "bf16x3"
-    t2m = Trainer("text2mel", args.batch, dev, rank, world, use_graph)
-    ssr = Trainer("ssrn", args.batch, dev, rank, world, use_graph)
-    t2m.prepare()
-    ssr.prepare()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Leave each model's gradient all-reduce in flight while the other model computes (RCCL runs collectives on its own
-    # stream).  Only with the RCCL backend: gloo's CUDA path synchronises with the host and the overlap backfires.
-    pipeline = world > 1 and os.environ.get("SSV_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("SSV_DDP_PIPELINE", "1") != "0"
-
-    def both():
-        # one "step" of the benchmark: a Text2Mel iteration and an SSRN iteration (independent models)
-        if pipeline:
-            t2m.step_begin()
-            ssr.step_begin()
-            t2m.step_end()
-            ssr.step_end()
-        else:
-            t2m.step()
-            ssr.step()
-
-    for _ in range(args.warmup):
-        both()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        both()
-    barrier()
-    dt = time.perf_counter() - t0
-    # per-model split (same number of steps, timed separately, not part of `value`)
-    split = {}
-    for name, tr in (("text2mel", t2m), ("ssrn", ssr)):
+    def timed(trainers, steps, warmup):
+        """ms per step of one iteration of EVERY trainer in ``trainers``: barrier + synchronize on both sides, max over ranks."""
+        for _ in range(warmup):
+            for tr in trainers:
+                tr.step()
         barrier()
-        s0 = time.perf_counter()
-        for _ in range(args.steps):
-            tr.step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for tr in trainers:
+                tr.step()
         barrier()
-        split[name] = (time.perf_counter() - s0) / args.steps
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax[0])
-    frames = args.batch * T_MEL * world * args.steps
-    loss_t2m, loss_ssrn = float(t2m.losses.detach()), float(ssr.losses.detach())
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax[0])
+        return dt / steps
+
+    t2m = Trainer("text2mel", args.batch, dev, rank, world, use_graph)
+    ssr = Trainer("ssrn", args.batch, dev, rank, world, use_graph)
+    t2m.prepare()
+    ssr.prepare()
+    # one "step" of the benchmark: a Text2Mel iteration and an SSRN iteration (independent models), back to back
+    per_step = timed([t2m, ssr], args.steps, args.warmup)
+    split = {"text2mel": timed([t2m], args.steps, 0), "ssrn": timed([ssr], args.steps, 0)}      # per model, not part of `value`
+    frames_per_step = args.batch * T_MEL * world
+    loss_t2m, loss_ssrn = t2m.loss, ssr.loss
     if not (loss_t2m == loss_t2m and loss_ssrn == loss_ssrn):
         raise SystemExit("non-finite loss in the benchmark step")
-
+    ddp_note = "none"
+    if world > 1:
+        ddp_note = ("gradient arena, backward in %d+%d segments (hipGraphs), one RCCL all-reduce per bucket launched between the replays"
+                    % (t2m.ddp.n_buckets, ssr.ddp.n_buckets))
+    res = {"metric": "mel-frames/sec (Text2Mel+SSRN train)", "value": round(frames_per_step / per_step, 1), "unit": "mel-frames/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (conv GEMMs: split-bf16 hi+lo operands, fp32 accumulate)" if use_bf3_mode else "f32", "data": "synthetic",
+           "config": {"workload": "train_text2mel + train_ssrn (train/ordinary.py step: fwd, l1+bin-div+guided-att losses, bwd, Adam), "
+                                  "batch %d utterances/GPU, N=186, T=325, 80 mel -> 513x1300 linear, hidden 256, random-init" % args.batch,
+                      "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                      "launch": "hipGraph replay" if use_graph else "eager", "ddp": ddp_note,
+                      "text2mel_ms": round(split["text2mel"] * 1e3, 3), "ssrn_ms": round(split["ssrn"] * 1e3, 3),
+                      "text2mel_fps": round(frames_per_step / split["text2mel"], 1),
+                      "ssrn_fps": round(frames_per_step / split["ssrn"], 1),
+                      "final_loss_text2mel": round(loss_t2m, 5), "final_loss_ssrn": round(loss_ssrn, 5)}}
+    cfg = res["config"]          # scalars only: the driver's parser keeps flat keys
+    del t2m, ssr
+    torch.cuda.empty_cache()
+    if not args.no_adversarial:
+        # BASELINE config 3 (--adversarial; config 4 when N > 1): reported beside the headline, never inside `value`
+        a1 = adversarial_cycle_ms("text2mel", args.batch, dev, world)
+        a2 = adversarial_cycle_ms("ssrn", args.batch, dev, world)
+        cfg.update({"adversarial_text2mel_ms": round(a1, 3), "adversarial_ssrn_ms": round(a2, 3),
+                    "adversarial_text2mel_fps": round(frames_per_step / a1 * 1e3, 1), "adversarial_ssrn_fps": round(frames_per_step / a2 * 1e3, 1),
+                    "adversarial_combined_fps": round(frames_per_step / (a1 + a2) * 1e3, 1),
+                    "adversarial_note": "ms per iteration averaged over 1 G : 5 D cycles (RATIO=5), WGAN-GP critics on twice-differentiable HIP kernels, "
+                                        "hipGraph replay" + ("; data parallel: global adaptive weight, bucketed generator all-reduce, packed critic all-reduce" if world > 1 else "")})
+        torch.cuda.empty_cache()
+    if world == 1 and use_bf3_mode and not args.no_fp32:
+        # the same step in the exact-fp32 arithmetic mode (v_mfma_f32_16x16x4_f32), so the cost of strict precision is on record
+        spoofsv_amd.set_precision("fp32")
+        f1, f2 = Trainer("text2mel", args.batch, dev, rank, world, use_graph), Trainer("ssrn", args.batch, dev, rank, world, use_graph)
+        f1.prepare(); f2.prepare()
+        fp = timed([f1, f2], 5, 1)
+        cfg.update({"fp32_exact_ms_per_step": round(fp * 1e3, 3), "fp32_exact_value": round(frames_per_step / fp, 1)})
+        del f1, f2
+        spoofsv_amd.set_precision(args.precision)
+        torch.cuda.empty_cache()
     if rank == 0:
-        res = {"metric": "mel-frames/sec (Text2Mel+SSRN train)", "value": round(frames / dt, 1), "unit": "mel-frames/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (conv GEMMs: split-bf16 hi+lo operands, fp32 accumulate)" if use_bf3_mode else "f32", "data": "synthetic",
-               "config": {"workload": "train_text2mel + train_ssrn (train/ordinary.py step: fwd, l1+bin-div+guided-att losses, bwd, Adam), "
-                                      "batch %d utterances/GPU, N=186, T=325, 80 mel -> 513x1300 linear, hidden 256, random-init" % args.batch,
-                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                          "launch": "hipGraph replay" if use_graph else "eager",
-                          "ddp": ("flat-bucket RCCL all-reduce, pipelined under the other model's step" if pipeline else
-                                  ("flat-bucket all-reduce" if world > 1 else "none")),
-                          "text2mel_ms": round(split["text2mel"] * 1e3, 3), "ssrn_ms": round(split["ssrn"] * 1e3, 3),
-                          "text2mel_fps": round(args.batch * T_MEL * world / split["text2mel"], 1),
-                          "ssrn_fps": round(args.batch * T_MEL * world / split["ssrn"], 1),
-                          "final_loss": [round(loss_t2m, 5), round(loss_ssrn, 5)]}}
         res["roofline"] = kernel_roofline(dev)
-        if world == 1 and not args.no_adversarial:
-            # BASELINE config 3 (--adversarial): reported beside the headline, never inside `value`
-            a1, a2 = adversarial_cycle_ms("text2mel", args.batch, dev), adversarial_cycle_ms("ssrn", args.batch, dev)
-            res["config"]["adversarial"] = {"text2mel_ms_per_iter": round(a1, 3), "ssrn_ms_per_iter": round(a2, 3),
-                                            "text2mel_fps": round(args.batch * T_MEL / a1 * 1e3, 1), "ssrn_fps": round(args.batch * T_MEL / a2 * 1e3, 1),
-                                            "combined_fps": round(args.batch * T_MEL / (a1 + a2) * 1e3, 1),
-                                            "note": "1 G : 5 D cycle average, critic convs / LayerNorms / highway gate on twice-differentiable HIP kernels (dropout, leaky-ReLU, pooling: torch), both iterations replayed from hipGraphs"}
+        if world == 1 and not args.no_ge2e:
+            # BASELINE config 5 on the same line (flat scalars); `python bench.py --ge2e` prints the full record
+            g = ge2e_config5()
+            cfg.update({"ge2e_utt_per_s": g["value"], "ge2e_ms": g["ms"], "ge2e_tflops": g["tflops"], "ge2e_rel_err_vs_oracle": g["rel_err_vs_cpu_oracle"],
+                        "ge2e_train_iteration_ms": g["train_iteration"]["ms"], "ge2e_cpu_utt_per_s": g["cpu_baseline"]["value"],
+                        "ge2e_cpu_cores": g["cpu_baseline"]["cores"]})
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-            res["config"]["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+            cfg["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

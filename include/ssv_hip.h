@@ -36,6 +36,9 @@ const char* ssv_last_error(void); /* thread-local, valid until the next failing 
  * operand as bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate; ~1e-5 relative; default; env
  * SSV_PRECISION=fp32 selects 0 at load).  Returns the previous mode.  Process-wide. */
 int ssv_set_precision(int mode);
+/* Tuning knobs (SSV_NNB_TILE, SSV_NT_Z, SSV_LN_GROUPS, ... -- tile / slab overrides used by tools/sweep_*.py) are read
+ * from the environment once, at first use; a tuning script that changes them inside one process calls this to re-read. */
+void ssv_reload_tuning(void);
 
 /* ---- Conv1d (stride 1, kernel 1 or 3, dilated, "same" or causal zero padding) -------------------
  * Replaces nn.Conv1d as used at models/TTSModel.py:59,78 (highway), :115-117, :154-158, :203-214,

@@ -21,6 +21,7 @@ Fixtures (names follow SURVEY.md section 8c):
   init_pin.npz       G9  seed -> construct -> apply(init_weights): per-parameter checksums
   adam.npz           a13 three torch.optim.Adam steps with the config.json hyper-parameters
   adversarial_iter.npz G8 one G and one D iteration with the reference's melSyn + melDisc (critic dropout off)
+  critic_dropout.npz G11 melDisc / linDisc critic iteration in TRAINING mode (dropout active, as the reference runs them)
 """
 import argparse
 import hashlib
@@ -383,6 +384,46 @@ def gen_adversarial(TTS, ref):
     np.savez_compressed(os.path.join(OUT, "adversarial_iter.npz"), **out)
 
 
+def gen_critic_dropout(ref):
+    """G11: the critic side of one D iteration (train/adversarial_wasserstein_gp.py:300-316) with the reference's own
+    melDisc and linDisc IN TRAINING MODE -- the reference never calls disc.eval(), so dropout (p = 0.05, three sites per
+    critic call, three calls per iteration) is always active.  Dropout draws from the CPU generator: the seed set right
+    before the iteration is stored, and a restatement that issues its dropouts at the same sites in the same order
+    reproduces the masks.  Stored: inputs, parameters, the two losses, every critic gradient, and the first call's output."""
+    import importlib
+    D = importlib.import_module("models.discriminator")
+    out = {}
+    for tag, ctor, (B, Fb, T) in (("mel", lambda: D.melDisc(freq_bins=80, disc_dim=16), (3, 80, 24)),
+                                  ("lin", lambda: D.linDisc(freq_bins=65, disc_dim=16), (2, 65, 64))):
+        torch.manual_seed(41)
+        d = ctor()
+        d.apply(init_weights)
+        randomize_ln(d, torch.Generator().manual_seed(5))
+        d.train()
+        g = torch.Generator().manual_seed(19)
+        gt, pred = torch.rand(B, Fb, T, generator=g), torch.rand(B, Fb, T, generator=g)
+        coeff_b = torch.rand(B, generator=g)
+        out.update(_sd_np(d.state_dict(), tag + "/sd/"))
+        out.update({tag + "/gt": _np(gt), tag + "/pred": _np(pred), tag + "/coeff": _np(coeff_b)})
+        seed = 1000 + len(tag)
+        torch.manual_seed(seed)
+        coeff = torch.stack(T * [torch.stack(Fb * [coeff_b], dim=1)], dim=2)
+        mid = coeff * gt.detach() + (1 - coeff) * pred.detach()
+        mid.requires_grad = True
+        out_mid = d(mid)
+        grads = torch.autograd.grad(outputs=out_mid, inputs=mid, grad_outputs=torch.ones(out_mid.size()), retain_graph=True, create_graph=True)[0]
+        gp = torch.mean(10 * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
+        gp.backward()
+        disc_gt = d(gt.detach())
+        disc_syn = d(pred.detach())
+        loss_D = torch.mean(disc_syn - disc_gt)
+        loss_D.backward()
+        out.update(_grads_np(d, tag + "/grad/"))
+        out.update({tag + "/seed": np.array(seed), tag + "/out_mid": _np(out_mid), tag + "/gp": _np(gp), tag + "/loss_d": _np(loss_D),
+                    tag + "/dmid": _np(grads)})
+    np.savez_compressed(os.path.join(OUT, "critic_dropout.npz"), **out)
+
+
 def gen_init_pin(TTS):
     out = {}
     for tag, ctor in (("t2m", lambda: TTS.melSyn(vocab_len=34, condition=True, spkemb_dim=200, textemb_dim=128,
@@ -428,6 +469,9 @@ def main():
     if args.only == "ge2e_train":
         gen_ge2e_train(args.ref)
         return
+    if args.only == "critic_dropout":
+        gen_critic_dropout(args.ref)
+        return
     import models.TTSModel as TTS
     gen_highway(TTS)
     gen_melsyn_train(TTS)
@@ -437,6 +481,7 @@ def main():
     gen_init_pin(TTS)
     gen_adam()
     gen_adversarial(TTS, args.ref)
+    gen_critic_dropout(args.ref)
     gen_ge2e(args.ref)
     gen_ge2e_train(args.ref)
     for f in sorted(os.listdir(OUT)):

@@ -7,23 +7,48 @@ generator kernels do not.  On a ROCm device their heavy operators run on HIP ker
     first-order backward kernels of the generator path plus hand-written second-order kernels (``ssv_channel_ln_bwd2``,
     ``ssv_highway_gate_bwd2``).
 Dropout, leaky-ReLU and the average pools stay torch ops (one small launch each, differentiable as they are).
+There is no CPU branch: a CPU tensor raises (the stock-op restatement used as the parity arm is oracle/critic_oracle.py).
 Same sub-module names as the reference, so ``disc_state_dict`` checkpoints interchange.  Dropout (p=0.05) is
 active whenever the module is in training mode, as in the reference (which never calls ``disc.eval()``).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
 
+_P_DROP = 0.05
+_MASKS = None          # test hook: a list of pre-scaled keep masks consumed in call order instead of drawing from the RNG
+
+
+@contextlib.contextmanager
+def injected_dropout_masks(masks):
+    """Within the block every dropout of the critics multiplies by the next tensor of ``masks`` (already scaled by
+    1/(1-p), i.e. exactly what ``nn.Dropout`` multiplies by) instead of drawing one.  The reference never puts its critics
+    in eval mode, so parity with dropout ACTIVE needs the same masks on both sides (tests, oracle/critic_oracle.py)."""
+    global _MASKS
+    prev, _MASKS = _MASKS, list(masks)
+    try:
+        yield
+    finally:
+        _MASKS = prev
+
+
+def _dropout(x, training):
+    if _MASKS is not None:
+        return x * _MASKS.pop(0)
+    return F.dropout(x, _P_DROP, training)
+
 
 def _conv(conv, x):
-    """nn.Conv1d forward.  On a ROCm device the convolution itself runs on the HIP conv kernels through
-    ``ops.conv1d_dd`` (differentiable to any order, as the gradient penalty needs; MIOpen's fp32 1-D convolutions were 23 %
-    of a critic iteration); everything else in the critics stays a stock torch op."""
-    if x.is_cuda and conv.kernel_size[0] in (1, 3) and conv.stride[0] == 1:
-        return ops.conv1d_dd(x, conv.weight, conv.bias, conv.kernel_size[0], conv.dilation[0], False)
-    return conv(x)
+    """nn.Conv1d forward on the HIP conv kernels through ``ops.conv1d_dd`` (differentiable to any order, as the gradient
+    penalty needs; MIOpen's fp32 1-D convolutions were 23 % of a critic iteration)."""
+    ops._dev(x, "critic input")
+    if conv.kernel_size[0] not in (1, 3) or conv.stride[0] != 1:
+        raise RuntimeError("spoofsv_amd.critic: only stride-1 convolutions of kernel size 1 or 3 exist on the HIP path")
+    return ops.conv1d_dd(x, conv.weight, conv.bias, conv.kernel_size[0], conv.dilation[0], False)
 
 
 class _HighwayConvDropout(nn.Module):
@@ -36,26 +61,19 @@ class _HighwayConvDropout(nn.Module):
         self.conv = nn.Conv1d(dimension, 2 * dimension, kernel_size, padding=pad, dilation=dilation)
         self.ln1 = nn.LayerNorm(dimension)
         self.ln2 = nn.LayerNorm(dimension)
-        self.dp = nn.Dropout(p=0.05)
+        self.dp = nn.Dropout(p=_P_DROP)
 
     def forward(self, x):
         h = _conv(self.conv, x)
-        if x.is_cuda:
-            return self.dp(ops.highway_gate_dd(h, x, self.ln1.weight, self.ln1.bias, self.ln2.weight, self.ln2.bias))
-        h1 = _ln(h[:, :self.dimension], self.ln1)
-        h2 = _ln(h[:, self.dimension:], self.ln2)
-        g = torch.sigmoid(h1)
-        return self.dp(g * h2 + (1 - g) * x)
+        return _dropout(ops.highway_gate_dd(h, x, self.ln1.weight, self.ln1.bias, self.ln2.weight, self.ln2.bias), self.training)
 
 
 def _ln(x, ln):
     """nn.LayerNorm over the channel axis of a (B, C, T) tensor.  The reference permutes to (B, T, C) and back
-    (discriminator.py:24-27); on a ROCm device the tensor stays (B, C, T) and the fused HIP LayerNorm runs on it."""
-    if x.is_cuda:
-        if ln.eps != 1e-5:
-            raise RuntimeError("spoofsv_amd.critic: the HIP LayerNorm is built for eps = 1e-5")
-        return ops.channel_ln_dd(x, ln.weight, ln.bias)
-    return ln(x.permute(0, 2, 1)).permute(0, 2, 1)
+    (discriminator.py:24-27); here the tensor stays (B, C, T) and the fused HIP LayerNorm runs on it."""
+    if ln.eps != 1e-5:
+        raise RuntimeError("spoofsv_amd.critic: the HIP LayerNorm is built for eps = 1e-5")
+    return ops.channel_ln_dd(x, ln.weight, ln.bias)
 
 
 class _Disc(nn.Module):
@@ -63,12 +81,12 @@ class _Disc(nn.Module):
         super().__init__()
         self.conv1 = nn.Conv1d(freq_bins, disc_dim, 1)
         self.ln1 = nn.LayerNorm(disc_dim)
-        self.dp1 = nn.Dropout(p=0.05)
+        self.dp1 = nn.Dropout(p=_P_DROP)
         self.hc = _HighwayConvDropout(disc_dim, 3, 1)
         self.conv2 = nn.Conv1d(disc_dim, 64, 1)
         self.pl1 = nn.AvgPool1d(kernel_size=pool1)
         self.ln2 = nn.LayerNorm(64)
-        self.dp2 = nn.Dropout(p=0.05)
+        self.dp2 = nn.Dropout(p=_P_DROP)
         self.conv3 = nn.Conv1d(64, 16, 1)
         self.pl2 = nn.AvgPool1d(kernel_size=pool2)
         self.ln3 = nn.LayerNorm(16)
@@ -78,10 +96,10 @@ class _Disc(nn.Module):
         self.pl3 = nn.AdaptiveAvgPool1d(output_size=1)
 
     def forward(self, inputs):
-        x = self.dp1(_ln(_conv(self.conv1, inputs), self.ln1))
+        x = _dropout(_ln(_conv(self.conv1, inputs), self.ln1), self.training)
         x = self.hc(x)
         x = _ln(self.pl1(_conv(self.conv2, x)), self.ln2)
-        x = self.dp2(F.leaky_relu(x, 0.05))
+        x = _dropout(F.leaky_relu(x, 0.05), self.training)
         x = _ln(self.pl2(_conv(self.conv3, x)), self.ln3)
         x = _ln(_conv(self.conv4, F.leaky_relu(x, 0.05)), self.ln4)
         return self.pl3(_conv(self.conv5, F.leaky_relu(x, 0.05)))      # no sigmoid: Wasserstein critic

@@ -32,6 +32,24 @@ int ssv_precision() {
   }
   return g_precision;
 }
+static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_Z", "SSV_NT_FORCE", "SSV_LSTM_SEQUENTIAL", "SSV_NNB_WIDE", "SSV_NNB_TILE",
+                                                       "SSV_NNB_FORCE", "SSV_NT_PLAN", "SSV_NN_TILE", "SSV_LN_GROUPS"};
+static char g_knob_val[SSV_T_COUNT][512];
+static const char* g_knob[SSV_T_COUNT];
+static int g_knobs_loaded = 0;
+static void load_knobs() {
+  for (int i = 0; i < SSV_T_COUNT; ++i) {
+    const char* e = getenv(g_knob_names[i]);
+    if (e) { strncpy(g_knob_val[i], e, sizeof g_knob_val[i] - 1); g_knob_val[i][sizeof g_knob_val[i] - 1] = 0; g_knob[i] = g_knob_val[i]; }
+    else g_knob[i] = nullptr;
+  }
+  __atomic_store_n(&g_knobs_loaded, 1, __ATOMIC_RELEASE);
+}
+const char* ssv_tuning(int knob) {
+  if (!__atomic_load_n(&g_knobs_loaded, __ATOMIC_ACQUIRE)) load_knobs();
+  return g_knob[knob];
+}
+extern "C" void ssv_reload_tuning(void) { load_knobs(); }
 extern "C" int ssv_set_precision(int mode) {
   const int prev = ssv_precision();
   g_precision = mode ? 1 : 0;
@@ -216,8 +234,8 @@ extern "C" int ssv_conv_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int 
 static int dw_splits(int B, int M, int Nc, int k) {
   const int tiles = ssv_nt_bf3_tiles(k == 3 ? 3 : 1, M, Nc);
   int z = ssv_cdiv(ssv_nt_bf3_target(k == 3 ? 3 : 1, M, Nc), tiles);
-  if (const char* e = getenv("SSV_NT_Z")) { const int v = atoi(e); if (v > 0) z = v; }
-  if (const char* e = getenv("SSV_NT_FORCE")) {      // "M:Nc:k=Z;..." -- one shape's slab count inside a whole step (tools/sweep_step_tiles.py)
+  if (const char* e = ssv_tuning(SSV_T_NT_Z)) { const int v = atoi(e); if (v > 0) z = v; }
+  if (const char* e = ssv_tuning(SSV_T_NT_FORCE)) {      // "M:Nc:k=Z;..." -- one shape's slab count inside a whole step (tools/sweep_step_tiles.py)
     char key[48];
     snprintf(key, sizeof key, "%d:%d:%d=", M, Nc, k);
     const char* hit = strstr(e, key);
@@ -652,7 +670,7 @@ extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const floa
             ssv_lstm_fwd_workspace(Bn, T, F, H, layers));
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
-  if (ssv_precision() == 1 && lstm_wave_ok(Bn, H) && !getenv("SSV_LSTM_SEQUENTIAL"))
+  if (ssv_precision() == 1 && lstm_wave_ok(Bn, H) && !ssv_tuning(SSV_T_LSTM_SEQUENTIAL))
     return lstm_fwd_wave(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, base, st);
   float* xt = (float*)(base + s.xt);
   float* xp = (float*)(base + s.xp);

@@ -586,7 +586,7 @@ template <int KT>
 static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   {
     int wm = 0, nt = 0, nwn = 0;
-    const char* e = getenv("SSV_NNB_WIDE");
+    const char* e = ssv_tuning(SSV_T_NNB_WIDE);
     if (e && g.sxn == 1 && g.scn == 1 && sscanf(e, "%d,%d,%d", &wm, &nt, &nwn) == 3) {
 #define SSV_W(A_, C_, D_) if (wm == A_ && nt == C_ && nwn == D_) return launch_nnbw<KT, A_, C_, D_>(g, st, smin, span)
       SSV_W(2, 7, 3); SSV_W(1, 7, 3); SSV_W(2, 7, 2); SSV_W(2, 6, 2); SSV_W(1, 6, 2); SSV_W(2, 4, 4); SSV_W(2, 7, 4);
@@ -605,7 +605,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   static const int nts[] = {7, 6, 4, 2};
   int wm = 2, nt = 7;
   bool forced = false;
-  if (const char* e = getenv("SSV_NNB_TILE")) {
+  if (const char* e = ssv_tuning(SSV_T_NNB_TILE)) {
     int a = 0, c = 0;
     if (sscanf(e, "%d,%d", &a, &c) == 2 && (a == 1 || a == 2)) for (int x : nts) if (x == c) { wm = a; nt = c; forced = true; }
   }
@@ -616,7 +616,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   if (!forced) {
     // tuning aid (tools/sweep_step_tiles.py): SSV_NNB_FORCE="kt:M:N=a,c;kt:M:N=a,c;..." forces the tile of one problem shape
     // inside a whole training step, where a tile's effect on its neighbours shows (isolated timings miss it)
-    if (const char* e = getenv("SSV_NNB_FORCE")) {
+    if (const char* e = ssv_tuning(SSV_T_NNB_FORCE)) {
       char key[48];
       snprintf(key, sizeof key, "%d:%d:%d=", KT, g.M, g.N);
       const char* hit = strstr(e, key);
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 // so smaller tiles with fewer slabs win when the output is small.  SSV_NT_PLAN="wm,ntc" forces a tile (tuning aid).
 void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
   int a = 0, c = 0;
-  if (const char* e = getenv("SSV_NT_PLAN")) {
+  if (const char* e = ssv_tuning(SSV_T_NT_PLAN)) {
     if (sscanf(e, "%d,%d", &a, &c) == 2 && (a == 1 || a == 2) && (c == 2 || c == 4 || c == 6)) {
       if (KT == 3 && c == 6) c = 4;
       *wm = a; *ntc = c;

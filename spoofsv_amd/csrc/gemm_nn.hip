@@ -193,7 +193,7 @@ static int launch_cfg(const GemmNN& g, hipStream_t st, int smin, int span) {
 // staging/barrier overhead that grows with the tile perimeter.  SSV_NN_TILE="WM,NT" overrides (tuning knob).
 static void pick_tile(const GemmNN& g, int* wm_out, int* nt_out) {
   static const int nts[] = {8, 7, 6, 4, 2};
-  if (const char* e = getenv("SSV_NN_TILE")) {
+  if (const char* e = ssv_tuning(SSV_T_NN_TILE)) {
     int wm = 0, nt = 0;
     if (sscanf(e, "%d,%d", &wm, &nt) == 2 && (wm == 1 || wm == 2)) {
       for (int c : nts) if (c == nt) { *wm_out = wm; *nt_out = nt; return; }

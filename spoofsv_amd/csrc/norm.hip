@@ -515,7 +515,7 @@ static int reduce_partials(float* part, float* out, int n, int nblk, hipStream_t
 // the 513-channel backward is fastest on 64 groups (113 -> 92 us at L = 1300), its forward on 16.
 // SSV_LN_GROUPS forces G (tuning aid).
 static int ln_groups(int C, bool bwd) {
-  if (const char* e = getenv("SSV_LN_GROUPS")) { const int g = atoi(e); if (g == 16 || g == 32 || g == 64) return g; }
+  if (const char* e = ssv_tuning(SSV_T_LN_GROUPS)) { const int g = atoi(e); if (g == 16 || g == 32 || g == 64) return g; }
   if (C > 512) return bwd ? 64 : 16;
   return C > 256 ? 32 : 16;
 }

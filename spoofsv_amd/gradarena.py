@@ -1,0 +1,135 @@
+"""Flat gradient arena: every parameter gradient of one model lives in ONE fp32 buffer, bucket after bucket.
+
+Why: the data-parallel exchange (the reference's nn.DataParallel reduce, train/ordinary.py:165-173) all-reduces
+a few large flat messages over RCCL/xGMI.  Packing 214 gradient tensors into a flat bucket after backward costs a copy of
+the whole gradient and delays the first collective to the end of backward.  Here the backward kernels WRITE their parameter
+gradients straight into the arena (``ops`` asks ``view`` / ``block`` for the destination instead of allocating), autograd
+adopts those views as ``p.grad``, and a bucket -- a contiguous arena range ordered by when its gradients become final --
+can be handed to the collective as soon as the backward segment that produces it has been enqueued.
+
+A *plan* is ``[(bucket name, [group, ...]), ...]`` with ``group`` a list of parameters laid out adjacently in that order:
+the LayerNorm / bias gradients of one fused operator come out of the kernel as one ``(rows, C)`` block, so their slots must
+be neighbours (``block``).  Group starts are 16-byte aligned (the Adam kernel's vector path).
+"""
+import weakref
+
+import torch
+
+_SLOTS = {}      # parameter data_ptr -> (arena weakref, offset, numel, shape)
+
+
+def _entry(t):
+    e = _SLOTS.get(t.data_ptr())
+    if e is None or e[2] != t.numel():          # same storage start and size (nn.Linear weights arrive with a trailing unit axis)
+        return None
+    arena = e[0]()
+    if arena is None:
+        _SLOTS.pop(t.data_ptr(), None)
+        return None
+    return arena, e[1], e[2]
+
+
+def view(w):
+    """The arena slot of parameter ``w`` (looked up by address and shape) as a tensor of ``w``'s shape, or None."""
+    e = _entry(w)
+    if e is None:
+        return None
+    arena, off, n = e
+    return arena.flat[off:off + n].view(w.shape)
+
+
+def block(params, rows, cols):
+    """One ``(rows, cols)`` view covering the slots of ``params`` when they are adjacent in this order and fill it exactly,
+    else None."""
+    first = _entry(params[0])
+    if first is None:
+        return None
+    arena, off0, _ = first
+    off = off0
+    for p in params:
+        e = _entry(p)
+        if e is None or e[0] is not arena or e[1] != off:
+            return None
+        off += e[2]
+    if off - off0 != rows * cols:
+        return None
+    return arena.flat[off0:off].view(rows, cols)
+
+
+def grad_like(w):
+    v = view(w)
+    return v if v is not None else torch.empty_like(w)
+
+
+def grad_block(params, rows, cols, device):
+    v = block(params, rows, cols)
+    return v if v is not None else torch.empty((rows, cols), dtype=torch.float32, device=device)
+
+
+class GradArena:
+    def __init__(self, plan, device=None, align=4):
+        self.names, self.ranges, self.slots = [], [], {}
+        self.params = []
+        off = 0
+        seen = set()
+        for name, groups in plan:
+            start = off
+            for g in groups:
+                off = (off + align - 1) // align * align
+                for p in g:
+                    if id(p) in seen:
+                        raise RuntimeError("GradArena: parameter listed twice in the plan")
+                    seen.add(id(p))
+                    if p.dtype != torch.float32 or not p.is_contiguous():
+                        raise RuntimeError("GradArena needs dense float32 parameters")
+                    self.slots[id(p)] = (off, p.numel())
+                    self.params.append(p)
+                    off += p.numel()
+            off = (off + 63) // 64 * 64            # buckets start on 256-byte boundaries
+            self.names.append(name)
+            self.ranges.append((start, off))
+        dev = device if device is not None else self.params[0].device
+        self.flat = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
+        ref = weakref.ref(self)
+        for p in self.params:
+            o, n = self.slots[id(p)]
+            _SLOTS[p.data_ptr()] = (ref, o, n, tuple(p.shape))
+
+    def release(self):
+        for p in self.params:
+            e = _SLOTS.get(p.data_ptr())
+            if e is not None and e[0]() is self:
+                _SLOTS.pop(p.data_ptr())
+
+    def bucket(self, i):
+        a, b = self.ranges[i]
+        return self.flat[a:b]
+
+    def bucket_of(self, p):
+        off = self.slots[id(p)][0]
+        for i, (a, b) in enumerate(self.ranges):
+            if a <= off < b:
+                return i
+        raise KeyError("parameter is not in the arena")
+
+    def slot(self, p):
+        o, n = self.slots[id(p)]
+        return self.flat[o:o + n].view(p.shape)
+
+    @torch.no_grad()
+    def adopt(self, params=None):
+        """Make every ``p.grad`` the arena slot: gradients an operator produced elsewhere are copied in (one small copy each
+        -- the fused operators of ``ops`` never take this path), missing gradients become zero slots."""
+        moved = 0
+        for p in (self.params if params is None else params):
+            o, n = self.slots[id(p)]
+            dst = self.flat[o:o + n].view(p.shape)
+            g = p.grad
+            if g is None:
+                dst.zero_()
+                p.grad = dst
+            elif g.data_ptr() != dst.data_ptr():
+                dst.copy_(g)
+                p.grad = dst
+                moved += 1
+        return moved

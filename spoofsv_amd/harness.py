@@ -36,6 +36,58 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _distributed(cfg):
+    """-> (rank, world).  One process per GPU replaces the reference's in-process nn.DataParallel
+    (``MULTI_GPU``, train/ordinary.py:165-173, train/adversarial_wasserstein_gp.py:183-196): launched under ``torchrun`` /
+    ``python -m torch.distributed.run`` (RANK / WORLD_SIZE / LOCAL_RANK in the environment) the trainers build the process
+    group HERE, before the first GPU call, bind the rank's GPU, shard the batches by rank and average gradients over
+    RCCL.  ``MULTI_GPU: true`` in a single process with several GPUs visible is refused: silently training on one GPU (or
+    N unsynchronised replicas) is not what the flag asks for.  ``APPLY_DROPOUT`` selects the reference's dropout generator
+    (models/TTSModel_dropout.py), which is outside this path: refused loudly rather than ignored."""
+    import torch.distributed as dist
+    if cfg.get("APPLY_DROPOUT"):
+        raise RuntimeError("spoofsv_amd: APPLY_DROPOUT=true selects models/TTSModel_dropout.py, which this hot path does not "
+                           "implement (SURVEY.md section 2, row 5); set it to false")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("SSV_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(ndev, 1))
+        return rank, world
+    if cfg.get("MULTI_GPU") and torch.cuda.device_count() > 1:
+        raise RuntimeError("spoofsv_amd: MULTI_GPU=true needs one process per GPU: launch with `python -m torch.distributed.run "
+                           "--nproc-per-node <gpus> --master-addr 127.0.0.1 main.py ...` (set MULTI_GPU=false to train on one GPU)")
+    return 0, 1
+
+
+def _rank0_print(rank):
+    import builtins
+    return builtins.print if rank == 0 else (lambda *a, **k: None)
+
+
+def _pad_to_global(sp, world):
+    """the collate functions pad a batch to ITS longest item (data/dataset.py:215-224); with the global batch
+    sharded over ranks every rank pads to the longest item of the GLOBAL batch, so the mean-type losses keep the
+    denominators a single process would use.  One all-reduce(max) of two integers; a no-op for fixed-shape batches."""
+    import torch.distributed as dist
+    if world == 1:
+        return sp
+    dims = torch.tensor([sp["data_0"].shape[-1], sp["data_1"].shape[-1]], dtype=torch.int64, device=sp["data_0"].device)
+    dist.all_reduce(dims, op=dist.ReduceOp.MAX)
+    T, N = int(dims[0]), int(dims[1])
+    out = dict(sp)
+    pad = lambda t, n: torch.nn.functional.pad(t, (0, n - t.shape[-1])) if t.shape[-1] < n else t
+    out["data_0"] = pad(sp["data_0"], T)
+    out["data_1"] = pad(sp["data_1"], N)
+    if "data_3" in sp:
+        out["data_3"] = pad(sp["data_3"], 4 * T)
+    return out
+
+
 def text2id(text, vocabulary):
     """data/dataset.py:175-185: lower-case, map through VOCABULARY (the double quote folds into the single
     quote), append 'E'."""
@@ -287,7 +339,9 @@ def validate(loader, trainloader, gaw, cfg, model, train_step="train_text2mel"):
 
 
 def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpoints=None, current_time=None):
-    """Non-adversarial training, train/ordinary.py:130-293."""
+    """Non-adversarial training, train/ordinary.py:130-293.  Under torchrun: data parallel, one rank per GPU (``_distributed``)."""
+    rank, world = _distributed(cfg)
+    print = _rank0_print(rank)                               # the reference prints from its one process: rank 0 here
     dev = _device()
     save_dir = os.path.join(cfg["SRC_ROOT_DIR"], "checkpoints", train_pattern, "not_adversarial", str(current_time))
     model, _ = _build(train_step, train_pattern, cfg, False)
@@ -305,7 +359,13 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
         opt.load_state_dict(ck["optimizer_state_dict"])
         epoch, iteration, loss_val_log = ck["epoch"], ck["iteration"], ck["loss_val_log"]
     model.train()
-    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir, pattern=train_pattern), dev)
+    ddp = None
+    if world > 1:
+        ddp = train.DataParallelRanks(model=model)           # gradient arena + bucketed all-reduce overlapped with backward
+        if resume_checkpoints is None:
+            ddp.broadcast_parameters(0)                      # what DataParallel's replicate does, once instead of per iteration
+            opt.refresh_resident_weights()
+    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir, rank=rank, world=world, pattern=train_pattern), dev)
     val_src = BatchSource(cfg, train_step, 8, spec_dir, seed=7919, pattern=train_pattern, mode="validate")     # batch 8, :200
     if val_src.corpus is None:
         val_src.n_synth = int(cfg.get("SYNTHETIC_VALIDATION_BATCHES", 1))
@@ -315,17 +375,20 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
     while epoch < cfg["MAX_EPOCHS"]:
         for i, sp in enumerate(src):
             t0 = time.time()
+            sp = _pad_to_global(sp, world)
             mel_gt = sp["data_0"].to(dev)
             if train_step == "train_text2mel":
-                l1, bd, la, att = train.text2mel_step(model, opt, mel_gt, sp["data_1"].to(dev), sp["data_2"].to(dev), gaw)
-                terms = (float(l1.detach()), float(bd.detach()), float(la.detach()))
+                l1, bd, la, att = train.text2mel_step(model, opt, mel_gt, sp["data_1"].to(dev), sp["data_2"].to(dev), gaw, ddp=ddp)
+                terms = (l1, bd, la)
             else:
-                l1, bd = train.ssrn_step(model, opt, mel_gt, sp["data_1"].to(dev))
-                terms = (float(l1.detach()), float(bd.detach()))
+                terms = train.ssrn_step(model, opt, mel_gt, sp["data_1"].to(dev), ddp=ddp)
+            if ddp is not None:
+                terms = ddp.all_reduce_mean(*terms)          # the log shows the global-batch loss, as the reference's gathered outputs do
+            terms = tuple(float(t.detach()) for t in terms)
             history.append(sum(terms))
             print("Iteration {}/{} for epoch {}, loss: {} {} global iteration {}".format(
                 i + 1, len(src), epoch + 1, " ".join(str(t) for t in terms), sum(terms), iteration + 1))
-            if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
+            if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0 and rank == 0:      # replicas are identical: rank 0 validates and saves
                 model.eval()                                       # train/ordinary.py:264-267
                 loss_val, loss_val_train = validate(val_src, src.source, gaw, cfg, model, train_step)
                 model.train()
@@ -348,42 +411,47 @@ def ordinary_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpo
 def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_checkpoints=None, current_time=None):
     """WGAN-GP training, train/adversarial_wasserstein_gp.py:148-450: one generator iteration, then RATIO critic
     iterations (:267); the generator runs on the HIP path in all of them (:278, :329), the critic on its twice-differentiable HIP ops
-    (spoofsv_amd/critic.py)."""
+    (spoofsv_amd/critic.py).  Under torchrun: data parallel, one rank per GPU (``_distributed``; the reference's MULTI_GPU
+    branch :183-196) -- both iteration kinds then run through ``train.AdversarialGraphStep`` with the gradient all-reduces
+    overlapped with backward; so does a single rank with the optional config key CAPTURE_GRAPHS (hipGraph replay, needs
+    fixed batch shapes)."""
+    rank, world = _distributed(cfg)
+    print = _rank0_print(rank)
     dev = _device()
     save_dir = os.path.join(cfg["SRC_ROOT_DIR"], "checkpoints", train_pattern, "adversarial", str(current_time))
     model, disc = _build(train_step, train_pattern, cfg, True)
     epoch = iteration = 0
     logs = {"wd_log": [], "loss_train_log_syn": [], "loss_train_log_syn_onlyfromD": [], "loss_train_log_disc": [], "loss_val_log": []}
+    stepped = world > 1 or bool(cfg.get("CAPTURE_GRAPHS"))
+    ck = None
     if resume_checkpoints is None:
         model.apply(train.init_weights)
         disc.apply(train.init_weights)
-        model.to(dev)
-        disc.to(dev)
-        opt_syn = _adam(model.parameters(), cfg)
-        opt_disc = _adam(disc.parameters(), cfg, fused=False)
     else:
         ck = torch.load(resume_checkpoints, map_location="cpu")
         epoch, iteration = ck["epoch"], ck["iteration"]
         model.load_state_dict(ck["model_state_dict"])
         disc.load_state_dict(ck["disc_state_dict"])
-        model.to(dev)
-        disc.to(dev)
-        opt_syn = _adam(model.parameters(), cfg)
-        opt_disc = _adam(disc.parameters(), cfg, fused=False)
-        opt_syn.load_state_dict(ck["opt_state_dict_syn"])
-        opt_disc.load_state_dict(ck["opt_state_dict_disc"])
         for k in logs:
             logs[k] = ck[k]
+    model.to(dev)
+    disc.to(dev)
     model.train()
     disc.train()
-    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir, pattern=train_pattern), dev)
+    src = Prefetcher(BatchSource(cfg, train_step, cfg["BATCH_SIZE"], spec_dir, rank=rank, world=world, pattern=train_pattern), dev)
     gaw = train.guided_attention_mat(cfg["MAX_TEXT_LEN"], cfg["MAX_FRAME_NUM"], device=dev)
     max_iter = cfg.get("MAX_ITERATIONS")
     val_src = BatchSource(cfg, train_step, 8, spec_dir, seed=7919, pattern=train_pattern, mode="validate")
     if val_src.corpus is None:
         val_src.n_synth = int(cfg.get("SYNTHETIC_VALIDATION_BATCHES", 1))
-    if cfg.get("CAPTURE_GRAPHS") and resume_checkpoints is None and not src.source.files and src.source.corpus is None:
-        return _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter, val_src)
+    if stepped:
+        return _adversarial_train_stepped(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter, val_src, ck,
+                                          epoch, iteration, rank, world)
+    opt_syn = _adam(model.parameters(), cfg)
+    opt_disc = _adam(disc.parameters(), cfg, fused=False)
+    if ck is not None:
+        opt_syn.load_state_dict(ck["opt_state_dict_syn"])
+        opt_disc.load_state_dict(ck["opt_state_dict_disc"])
     while epoch < cfg["MAX_EPOCHS"]:
         for i, sp in enumerate(src):
             t0 = time.time()
@@ -427,19 +495,8 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
                 logs["wd_log"].append(-float(loss_D))
                 print("training D  DISC:{}, WD:{}".format(float(loss_D) + float(loss_gp), -float(loss_D)))
             if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
-                model.eval()                                       # train/adversarial_wasserstein_gp.py:392-395
-                loss_val, loss_val_train = validate(val_src, src.source, gaw, cfg, model, train_step)
-                model.train()
-                logs["loss_val_log"].append(loss_val)
-                print("Validation loss of No.{} validation: {} on validation set. {} on train set.".format(
-                    iteration // cfg["VAL_EVERY_ITER"], loss_val, loss_val_train))
-                payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
-                           "disc_state_dict": disc.state_dict(), "opt_state_dict_syn": opt_syn.state_dict(),
-                           "opt_state_dict_disc": opt_disc.state_dict()}
-                payload.update(logs)
-                if logs["loss_val_log"].index(min(logs["loss_val_log"])) == len(logs["loss_val_log"]) - 1:      # :398-416
-                    _save(os.path.join(save_dir, "{}_best_model.tar.pth".format(train_step[6:])), payload)
-                _save(os.path.join(save_dir, "{}_iteration_{}.tar.pth".format(train_step[6:], iteration + 1)), payload)
+                _adversarial_validate_and_save(train_step, cfg, model, disc, opt_syn, opt_disc, val_src, src.source, gaw, logs, save_dir,
+                                               epoch, iteration, print)
             iteration += 1
             print("Time elapsed {}s.".format(time.time() - t0))
             if max_iter is not None and iteration >= max_iter:
@@ -448,29 +505,83 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
     return model, disc, logs
 
 
-def _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter, val_src):
-    """adversarial_train with both iteration kinds replayed from hipGraphs (optional config key CAPTURE_GRAPHS; needs
-    fixed batch shapes, i.e. the synthetic source).  Same schedule, losses, logs and checkpoints as the eager loop."""
+def _adversarial_validate_and_save(train_step, cfg, model, disc, opt_syn, opt_disc, val_src, train_src, gaw, logs, save_dir, epoch, iteration, print):
+    """train/adversarial_wasserstein_gp.py:392-437: validation pass, then the iteration checkpoint and, when the validation loss
+    is the best so far, the best-model checkpoint (reference key names)."""
+    model.eval()
+    loss_val, loss_val_train = validate(val_src, train_src, gaw, cfg, model, train_step)
+    model.train()
+    logs["loss_val_log"].append(loss_val)
+    print("Validation loss of No.{} validation: {} on validation set. {} on train set.".format(
+        iteration // cfg["VAL_EVERY_ITER"], loss_val, loss_val_train))
+    payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
+               "disc_state_dict": disc.state_dict(), "opt_state_dict_syn": opt_syn.state_dict(),
+               "opt_state_dict_disc": opt_disc.state_dict()}
+    payload.update(logs)
+    if logs["loss_val_log"].index(min(logs["loss_val_log"])) == len(logs["loss_val_log"]) - 1:      # :398-416
+        _save(os.path.join(save_dir, "{}_best_model.tar.pth".format(train_step[6:])), payload)
+    _save(os.path.join(save_dir, "{}_iteration_{}.tar.pth".format(train_step[6:], iteration + 1)), payload)
+
+
+def _restore_adam(opt, saved):
+    """Put a FusedAdam whose state tensors are baked into captured hipGraphs back to ``saved`` (a torch-style optimizer state
+    dict, or None = a fresh optimizer) by writing INTO the existing tensors."""
+    params = [p for g in opt.param_groups for p in g["params"]]
+    step = 0
+    for i, p in enumerate(params):
+        st = opt.state.get(p)
+        if not st:
+            continue
+        if saved is None:
+            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+        else:
+            sv = saved["state"][i]
+            st["exp_avg"].copy_(sv["exp_avg"]); st["exp_avg_sq"].copy_(sv["exp_avg_sq"])
+            step = int(sv["step"])
+    opt._steps = step
+    if opt._step_dev is not None:
+        opt._step_dev.fill_(step)
+
+
+def _adversarial_train_stepped(train_step, cfg, dev, model, disc, src, gaw, save_dir, logs, max_iter, val_src, ck, epoch, iteration,
+                               rank, world):
+    """adversarial_train on ``train.AdversarialGraphStep``: both iteration kinds replayed from hipGraphs when the batch shapes
+    are fixed (config key CAPTURE_GRAPHS with the synthetic source), run phase by phase otherwise; data parallel when
+    ``world`` > 1.  Same schedule, losses, logs and checkpoints as the eager loop."""
+    print = _rank0_print(rank)
     a = cfg["ADAM"]
     opt_syn = train.FusedAdam(model.parameters(), a["ALPHA"], (a["BETA_1"], a["BETA_2"]), a["EPSILON"], capturable=True)
     opt_disc = train.FusedAdam(disc.parameters(), a["ALPHA"], (a["BETA_1"], a["BETA_2"]), a["EPSILON"], capturable=True)
+    ddp_syn = ddp_disc = None
+    if world > 1:
+        ddp_syn = train.DataParallelRanks(model=model)
+        ddp_disc = train.DataParallelRanks(list(disc.parameters()))
+        if ck is None:
+            ddp_syn.broadcast_parameters(0)
+            ddp_disc.broadcast_parameters(0)
+    graph = bool(cfg.get("CAPTURE_GRAPHS")) and not src.source.files and src.source.corpus is None
     w_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
     w_disc = {k: v.detach().clone() for k, v in disc.state_dict().items()}
     kind = "text2mel" if train_step == "train_text2mel" else "ssrn"
 
     def pick(sp):
+        sp = _pad_to_global(sp, world)
         keys = ("data_0", "data_1", "data_2") if kind == "text2mel" else ("data_0", "data_1")
         return [sp[k].to(dev) for k in keys]
     first = pick(next(iter(src.source)))          # shapes only; the prefetching iterator starts with the training loop
-    stepper = train.AdversarialGraphStep(kind, model, disc, opt_syn, opt_disc, first, gaw, cfg["LAMBDA"])
-    # capturing ran warm-up iterations: put weights and optimizer state back to the start of training
+    stepper = train.AdversarialGraphStep(kind, model, disc, opt_syn, opt_disc, first, gaw, cfg["LAMBDA"], ddp_syn, ddp_disc, graph=graph,
+                                         coeff_seed=cfg.get("SEED", 0))
+    # capturing ran warm-up iterations: put weights and optimizer state back to the start of training (or to the checkpoint),
+    # writing into the tensors the graphs hold, and re-split the resident weight planes the captured convolutions read
     model.load_state_dict(w_model)
     disc.load_state_dict(w_disc)
-    for opt in (opt_syn, opt_disc):
-        for st in opt.state.values():
-            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
-        opt._step_dev.zero_()
-    epoch = iteration = 0
+    _restore_adam(opt_syn, ck["opt_state_dict_syn"] if ck is not None else None)
+    _restore_adam(opt_disc, ck["opt_state_dict_disc"] if ck is not None else None)
+    if ck is not None and not opt_syn.state:      # nothing ran yet (eager phases): plain load
+        opt_syn.load_state_dict(ck["opt_state_dict_syn"])
+        opt_disc.load_state_dict(ck["opt_state_dict_disc"])
+    opt_syn.refresh_resident_weights()
+    opt_disc.refresh_resident_weights()
     while epoch < cfg["MAX_EPOCHS"]:
         for sp in src:
             t0 = time.time()
@@ -485,20 +596,9 @@ def _adversarial_train_captured(train_step, cfg, dev, model, disc, src, gaw, sav
                 logs["loss_train_log_disc"].append(ld + gp)
                 logs["wd_log"].append(-ld)
                 print("training D  DISC:{}, WD:{}".format(ld + gp, -ld))
-            if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0:
-                model.eval()                                       # train/adversarial_wasserstein_gp.py:392-395
-                loss_val, loss_val_train = validate(val_src, src.source, gaw, cfg, model, train_step)
-                model.train()
-                logs["loss_val_log"].append(loss_val)
-                print("Validation loss of No.{} validation: {} on validation set. {} on train set.".format(
-                    iteration // cfg["VAL_EVERY_ITER"], loss_val, loss_val_train))
-                payload = {"epoch": epoch + 1, "iteration": iteration + 1, "model_state_dict": model.state_dict(),
-                           "disc_state_dict": disc.state_dict(), "opt_state_dict_syn": opt_syn.state_dict(),
-                           "opt_state_dict_disc": opt_disc.state_dict()}
-                payload.update(logs)
-                if logs["loss_val_log"].index(min(logs["loss_val_log"])) == len(logs["loss_val_log"]) - 1:      # :398-416
-                    _save(os.path.join(save_dir, "{}_best_model.tar.pth".format(train_step[6:])), payload)
-                _save(os.path.join(save_dir, "{}_iteration_{}.tar.pth".format(train_step[6:], iteration + 1)), payload)
+            if iteration % cfg["VAL_EVERY_ITER"] == 0 and iteration > 0 and rank == 0:      # replicas are identical: rank 0 validates and saves
+                _adversarial_validate_and_save(train_step, cfg, model, disc, opt_syn, opt_disc, val_src, src.source, gaw, logs, save_dir,
+                                               epoch, iteration, print)
             iteration += 1
             print("Time elapsed {}s.".format(time.time() - t0))
             if max_iter is not None and iteration >= max_iter:

@@ -12,7 +12,7 @@ import ctypes
 
 import torch
 
-from . import _lib, resident
+from . import _lib, gradarena, resident
 
 _F32 = torch.float32
 
@@ -87,6 +87,7 @@ class HighwayConvFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(x, w, g1, b1, g2, b2, h, stats)
             ctx.cfg = (k, dilation, int(causal))
+            ctx.bias_ref = bias           # only its address is used (gradient-arena lookup); not needed by the kernels
         return y
 
     @staticmethod
@@ -97,8 +98,10 @@ class HighwayConvFn(torch.autograd.Function):
         dy, dybs = _act3(dy, "highwayConv grad")
         B, C, L = x.shape
         dx = torch.empty((B, C, L), dtype=_F32, device=x.device)
-        dw = torch.empty_like(w)
-        pg = torch.empty((6, C), dtype=_F32, device=x.device)
+        # parameter gradients go straight into the data-parallel gradient arena when the model has one (gradarena.py)
+        dw = gradarena.grad_like(w)
+        bias = ctx.bias_ref
+        pg = gradarena.grad_block((g1, b1, g2, b2, bias), 6, C, x.device) if bias is not None else torch.empty((6, C), dtype=_F32, device=x.device)
         nb = _lib.query("ssv_highway_conv1d_bwd_workspace", B, C, L, k)
         ws = _ws(nb, x.device)
         _lib.call("ssv_highway_conv1d_bwd", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
@@ -126,10 +129,10 @@ def _conv_bwd_data(dy, dybs, w, Cin, L, k=1, dilation=1, causal=0):
     return dx
 
 
-def _conv_bwd_weight(dy, dybs, x, xbs, wshape, k=1, dilation=1, causal=0):
+def _conv_bwd_weight(dy, dybs, x, xbs, wshape, k=1, dilation=1, causal=0, out=None):
     B, Cin, L = x.shape
     Cout = wshape[0]
-    dw = torch.empty(wshape, dtype=_F32, device=x.device)
+    dw = out if out is not None else torch.empty(wshape, dtype=_F32, device=x.device)
     nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, Cin, Cout, k)
     ws = _ws(nb, x.device)
     _lib.call("ssv_conv1d_bwd_weight", _p(dy), dybs, _p(x), xbs, _p(dw), B, Cin, Cout, L, k, dilation, int(causal),
@@ -137,9 +140,10 @@ def _conv_bwd_weight(dy, dybs, x, xbs, wshape, k=1, dilation=1, causal=0):
     return dw
 
 
-def _sum_over_batch(rows, B, n):
+def _sum_over_batch(rows, B, n, out=None):
     """rows: (B, n) dense -> (n,) summed in batch order."""
-    out = torch.empty((n,), dtype=_F32, device=rows.device)
+    if out is None:
+        out = torch.empty((n,), dtype=_F32, device=rows.device)
     _lib.call("ssv_sum_slabs", _p(rows), _p(out), n, B, n, _stream())
     return out
 
@@ -175,6 +179,7 @@ class PointwiseConvLnActFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(x, w, gamma, beta, pre, stats)
             ctx.act = act
+            ctx.bias_ref = bias
             ctx.has_s = s is not None
             ctx.need_dx = ctx.needs_input_grad[0]
         return y
@@ -187,13 +192,13 @@ class PointwiseConvLnActFn(torch.autograd.Function):
         B, Cin, L = x.shape
         Cout = w.shape[0]
         dpre = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
-        pg = torch.empty((3, Cout), dtype=_F32, device=x.device)
+        pg = gradarena.grad_block((gamma, beta, ctx.bias_ref), 3, Cout, x.device)
         nb = _lib.query("ssv_channel_ln_act_bwd_workspace", B, Cout, L)
         ws = _ws(nb, x.device)
         _lib.call("ssv_channel_ln_act_bwd", _p(dy), dybs, _p(pre), Cout * L, _p(stats), _p(gamma), _p(beta),
                   _p(dpre), Cout * L, _p(pg), B, Cout, L, ctx.act, _p(ws), nb, _stream())
         dx = _conv_bwd_data(dpre, Cout * L, w, Cin, L) if ctx.need_dx else None
-        dw = _conv_bwd_weight(dpre, Cout * L, x, xbs, tuple(w.shape))
+        dw = _conv_bwd_weight(dpre, Cout * L, x, xbs, tuple(w.shape), out=gradarena.view(w))
         ds = None
         if ctx.has_s:
             ds = torch.empty((B, Cout, 1), dtype=_F32, device=x.device)
@@ -217,6 +222,7 @@ class Conv1dFn(torch.autograd.Function):
         if _needs_grad(ctx):
             ctx.save_for_backward(x, w)
             ctx.cfg = (k, dilation, int(causal), ctx.needs_input_grad[0], bias is not None)
+            ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -228,12 +234,12 @@ class Conv1dFn(torch.autograd.Function):
         B, Cin, L = x.shape
         Cout = w.shape[0]
         dx = _conv_bwd_data(dy, dybs, w, Cin, L, k, dilation, causal) if need_dx else None
-        dw = _conv_bwd_weight(dy, dybs, x, xbs, tuple(w.shape), k, dilation, causal)
+        dw = _conv_bwd_weight(dy, dybs, x, xbs, tuple(w.shape), k, dilation, causal, out=gradarena.view(w))
         db = None
         if has_bias:
             rows = torch.empty((B, Cout), dtype=_F32, device=x.device)
             _lib.call("ssv_rowsum", _p(dy), dybs, _p(rows), B, Cout, L, _stream())
-            db = _sum_over_batch(rows, B, Cout)
+            db = _sum_over_batch(rows, B, Cout, out=gradarena.view(ctx.bias_ref))
         return dx, dw, db, None, None, None
 
 
@@ -470,6 +476,7 @@ class TextEmbedFn(torch.autograd.Function):
         if _needs_grad(ctx):
             ctx.save_for_backward(ids)
             ctx.dims = (B, N, E, V)
+            ctx.refs = (w, bias)
         return y
 
     @staticmethod
@@ -477,8 +484,8 @@ class TextEmbedFn(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         B, N, E, V = ctx.dims
         dy = _c(dy)
-        dw = torch.empty((E, V), dtype=_F32, device=dy.device)
-        db = torch.empty((E,), dtype=_F32, device=dy.device)
+        dw = gradarena.grad_like(ctx.refs[0])
+        db = gradarena.grad_like(ctx.refs[1])
         _lib.call("ssv_text_embed_bwd", _p(ids), _p(dy), _p(dw), _p(db), B, N, E, V, _stream())
         return None, dw, db
 
@@ -592,6 +599,7 @@ class DeconvK2S2Fn(torch.autograd.Function):
         _lib.call("ssv_deconv1d_k2s2_fwd", _p(x), xbs, _p(w), _p(bias), _p(y), Cout * 2 * L, B, Cin, Cout, L, _p(ws), nb, _stream())
         if _needs_grad(ctx):
             ctx.save_for_backward(x, w)
+            ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -602,8 +610,8 @@ class DeconvK2S2Fn(torch.autograd.Function):
         B, Cin, L = x.shape
         Cout = w.shape[1]
         dx = torch.empty((B, Cin, L), dtype=_F32, device=x.device)
-        dw = torch.empty_like(w)
-        db = torch.empty((Cout,), dtype=_F32, device=x.device)
+        dw = gradarena.grad_like(w)
+        db = gradarena.grad_like(ctx.bias_ref)
         nb = _lib.query("ssv_deconv1d_k2s2_bwd_workspace", B, Cin, Cout)
         ws = _ws(nb, x.device)
         _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, _p(x), xbs, _p(w), _p(dx), Cin * L, _p(dw), _p(db),

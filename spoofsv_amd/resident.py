@@ -23,7 +23,7 @@ _REG = {}            # weight data_ptr -> _Entry
 
 
 class _Entry:
-    __slots__ = ("param", "planes", "version", "shape", "ptr")
+    __slots__ = ("param", "planes", "version", "shape", "ptr", "owner")
 
 
 def lookup(w):
@@ -85,6 +85,7 @@ class ResidentWeights:
         for p, t in zip(self.params, self._planes):
             e = _Entry()
             e.param, e.planes, e.version, e.shape, e.ptr = p, t, -1, tuple(p.shape), ctypes.c_void_p(t.data_ptr())
+            e.owner = self
             _REG[p.data_ptr()] = e
         self._key = key
 
@@ -95,7 +96,9 @@ class ResidentWeights:
         self._build()
         _lib.call("ssv_conv_pack_multi", ctypes.c_void_p(self._jobs.data_ptr()), self._njobs, self._nblocks, stream)
         for p in self.params:
-            _REG[p.data_ptr()].version = p._version
+            e = _REG.get(p.data_ptr())
+            if e is not None and e.owner is self:
+                e.version = p._version
 
 
 _FROZEN = {}         # id(module) -> ResidentWeights of an inference model
@@ -104,8 +107,26 @@ _FROZEN = {}         # id(module) -> ResidentWeights of an inference model
 def ensure(module, stream):
     """Inference helper: keep the conv weights of ``module`` resident.  The first call builds the planes; later calls cost
     one version check per weight and re-split (one launch) only if a weight was modified since (``load_state_dict``, init)."""
+    # A weight has ONE set of planes.  When the module's weights already belong to a training optimizer's ResidentWeights
+    # (FusedAdam re-splits those after every update -- inside the captured hipGraph when the step is replayed from one),
+    # use and, if stale, refresh THOSE: a second set registered here would be written once and then go stale behind the
+    # version check, because FusedAdam updates weights through raw pointers.
+    mine = [p for p in module.parameters() if eligible(p)]
+    owners = []
+    for p in mine:
+        e = _REG.get(p.data_ptr())
+        if e is None or e.param is not p or e.owner is None:
+            owners = None
+            break
+        if not any(o is e.owner for o in owners):
+            owners.append(e.owner)
+    if owners and not any(o is _FROZEN.get(id(module)) for o in owners):
+        if any(lookup(p) is None for p in mine):
+            for o in owners:
+                o.refresh(stream)
+        return owners[0]
     rw = _FROZEN.get(id(module))
-    if rw is None or [id(p) for p in rw.params] != [id(p) for p in module.parameters() if eligible(p)]:
+    if rw is None or [id(p) for p in rw.params] != [id(p) for p in mine]:
         while len(_FROZEN) >= 8:                 # a handful of inference models at most; older plane sets are dropped
             old = _FROZEN.pop(next(iter(_FROZEN)))
             for p in old.params:

@@ -148,15 +148,23 @@ class IncrementalSynthesizer:
         return self._vp(t.data_ptr())
 
     def _tap_major(self, conv):
-        """(M, k, C) copy of a k = 3 conv weight (made once: the weights are frozen in eval mode); k = 1 weights as they are."""
+        """(M, k, C) copy of a k = 3 conv weight in a buffer that lives as long as the synthesizer (the captured step holds its
+        address); k = 1 weights are read in place.  ``_repack`` rewrites the copies at the start of every ``run``."""
         w = conv.weight
         if w.shape[2] == 1:
             return w
-        key = id(conv)
-        ent = self._wt.get(key)
-        if ent is None or ent[1] != w._version or ent[2] != w.data_ptr():
-            ent = self._wt[key] = (w.detach().permute(0, 2, 1).contiguous(), w._version, w.data_ptr())
+        ent = self._wt.get(id(conv))
+        if ent is None:
+            ent = self._wt[id(conv)] = (torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=torch.float32, device=w.device), conv)
+            ent[0].copy_(w.detach().permute(0, 2, 1))
         return ent[0]
+
+    def _repack(self):
+        """Bring the tap-major copies up to date with the live weights (one strided copy per k = 3 layer, 16 per run against
+        ~50 launches per frame).  The synthesizer is cached per model and the validation pass of the trainers calls it on the
+        model that is being trained; FusedAdam updates weights through raw pointers, so no version counter would tell."""
+        for buf, conv in self._wt.values():
+            buf.copy_(conv.weight.detach().permute(0, 2, 1))
 
     def _mv(self, conv, cur, out, hist=None, dilation=1, bias_b=None):
         M, C, k = conv.weight.shape
@@ -229,6 +237,8 @@ class IncrementalSynthesizer:
             self.s2.copy_(ops.conv1d(spk, enc.fc2.weight.unsqueeze(-1), enc.fc2.bias).reshape(B, self.d))
         if self.graph is None:
             self._capture()
+        else:
+            self._repack()
         self.mel_cur.zero_(); self.pma.zero_(); self.t.zero_(); self.A.zero_(); self.Y.zero_()
         for h in self.hist:
             h.zero_()

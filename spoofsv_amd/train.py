@@ -50,11 +50,21 @@ class FusedAdam(torch.optim.Optimizer):
     captured hipGraph of the whole training step replays correctly.
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False, resident=True):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False, resident=True,
+                 weight_decay=0, amsgrad=False, maximize=False):
+        if weight_decay != 0 or amsgrad or maximize:
+            raise ValueError("FusedAdam implements plain Adam as the reference uses it (train/ordinary.py:182): "
+                             "weight_decay, amsgrad and maximize are not supported")
+        # the full set of torch.optim.Adam defaults, so that a saved state dict loads into torch.optim.Adam (the reference's
+        # -R resume, train/ordinary.py:188-197) and steps there
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         self.capturable = capturable
         self._table = None
-        self._host_table = None
+        self._host_tables = None
+        self._host_flip = 0
+        self._copied = None
         self._key = None
         self._step_dev = None
         self._steps = 0
@@ -93,18 +103,32 @@ class FusedAdam(torch.optim.Optimizer):
         assert ctypes.sizeof(_lib.AdamChunk) == 40
         # Pinned staging buffer + async copy, both allocated once (sized for every parameter): refilling
         # them is legal while a hipGraph is being captured (the copy becomes a memcpy node).
-        if self._host_table is None:
+        # Two pinned tables used alternately, and an event after each copy: a rebuild (gradient addresses can move between
+        # eager iterations) must not overwrite a pinned table whose asynchronous copy has not executed yet.
+        if self._host_tables is None:
             cap = sum((p.numel() + _CHUNK - 1) // _CHUNK for g in self.param_groups for p in g["params"])
-            self._host_table = torch.empty((cap, 5), dtype=torch.int64).pin_memory()
+            self._host_tables = [torch.empty((cap, 5), dtype=torch.int64).pin_memory() for _ in range(2)]
+            self._copied = [None, None]
             self._table = torch.empty((cap, 5), dtype=torch.int64, device=plist[0].device)
-        self._host_table[:len(rows)].copy_(torch.from_numpy(arr))
-        self._table.copy_(self._host_table, non_blocking=True)
+        self._host_flip ^= 1
+        host, ev = self._host_tables[self._host_flip], self._copied[self._host_flip]
+        capturing = torch.cuda.is_current_stream_capturing()
+        if ev is not None and not capturing:
+            ev.synchronize()
+        host[:len(rows)].copy_(torch.from_numpy(arr))
+        self._table.copy_(host, non_blocking=True)
+        if not capturing:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._copied[self._host_flip] = ev
         self._nchunks = len(rows)
         self._key = key
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        if len(self.param_groups) != 1:
+            raise RuntimeError("FusedAdam keeps one device-side step counter: use one parameter group")
         for group in self.param_groups:
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:
@@ -173,56 +197,51 @@ def shift_right(mel_gt):
     return torch.cat((torch.zeros_like(mel_gt[:, :, :1]), mel_gt[:, :, :-1]), dim=-1)
 
 
-# --------------------------------------------------------------------------------------------- steps
-def text2mel_losses(pred, att, mel_gt, gaw):
-    """(l1, bin_div, att) of train/ordinary.py:230-236 on the HIP loss kernels."""
-    l1, bd = ops.spec_losses(pred, mel_gt)
-    return l1, bd, ops.guided_att_loss(att, gaw)
-
-
-def text2mel_step(model, optimizer, mel_gt, text_id, spk_emb, gaw, ddp=None):
-    """One non-adversarial Text2Mel iteration (train/ordinary.py:221-238).  Returns the loss terms."""
-    optimizer.zero_grad(set_to_none=True)
-    pred, att = model(shift_right(mel_gt), text_id, spk_emb)
-    l1, bd, la = text2mel_losses(pred, att, mel_gt, gaw)
-    loss = l1 + bd + la
-    loss.backward()
-    if ddp is not None:
-        ddp.all_reduce_grads()
-    optimizer.step()
-    return l1, bd, la, att
-
-
-def ssrn_step(model, optimizer, mel_gt, lin_gt, ddp=None):
-    """One non-adversarial SSRN iteration (train/ordinary.py:240-254)."""
-    optimizer.zero_grad(set_to_none=True)
-    pred = model(mel_gt)
-    l1, bd = ops.spec_losses(pred, lin_gt)
-    (l1 + bd).backward()
-    if ddp is not None:
-        ddp.all_reduce_grads()
-    optimizer.step()
-    return l1, bd
-
-
 # --------------------------------------------------------------------------------------------- DDP
 class DataParallelRanks:
-    """One process per GPU; utterances are sharded by rank and gradients are averaged with ONE flat
-    all-reduce per bucket over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in the CPU tests).
+    """One process per GPU; utterances are sharded by rank and gradients are averaged with flat all-reduces over RCCL/xGMI
+    (backend "nccl" on ROCm; "gloo" in the CPU tests).
 
-    The reference's nn.DataParallel (train/ordinary.py:165-173) re-broadcasts all parameters every
-    iteration and reduces gradients to GPU 0; here replicas stay in sync because every rank applies the
-    same averaged gradient, so the only traffic is the gradient all-reduce (96.3 MB for Text2Mel).
-    Gradients are packed into a few large flat buckets because xGMI is point-to-point: large messages
-    keep each link busy, per-tensor all-reduces (214 tensors) would be launch/latency bound.
+    The reference's nn.DataParallel (train/ordinary.py:165-173) re-broadcasts all parameters every iteration and reduces
+    gradients to GPU 0; here replicas stay in sync because every rank applies the same averaged gradient, so the only
+    traffic is the gradient all-reduce (96.3 MB for Text2Mel).  xGMI is point-to-point: a few large messages keep the links
+    busy, per-tensor all-reduces (214 tensors) would be latency bound.
+
+    Two modes:
+      * ``DataParallelRanks(model=m)`` -- gradient ARENA (gradarena.py): the backward kernels write parameter gradients
+        straight into one flat buffer laid out bucket by bucket in the order backward finishes them (``tts.ddp_plan``).
+        ``start_bucket(i)`` hands bucket i to an asynchronous all-reduce as soon as the backward segment producing it has
+        been enqueued, so the exchange overlaps the rest of backward (``SegmentedBackward``); no packing copy.
+      * ``DataParallelRanks(params)`` -- any parameter list (the critics, 0.5-0.7 MB): gradients are packed into persistent
+        flat buckets after backward, all-reduced, and ``p.grad`` re-pointed at the averaged slices.
+    Gradients are SUMMED over ranks: callers seed backward with ``grad_scale`` (= 1/world) so the sum is the global-batch
+    mean (exact for power-of-two worlds); the legacy ``all_reduce_grads`` scales after the sum instead.
     """
 
-    def __init__(self, params, bucket_mb=64, group=None):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params=None, bucket_mb=64, group=None, model=None, segmented=True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.grad_scale = 1.0 / self.world
         self.bucket_elems = max(1, int(bucket_mb * 1024 * 1024 // 4))
         self._flat = None
+        self._works = []
+        self.arena = None
+        self.cut_names = []
+        if model is not None:
+            from . import gradarena, tts
+            plan, cuts = tts.ddp_plan(model)
+            if not segmented:
+                plan, cuts = [("all", [g for _, gs in plan for g in gs])], []
+            self.arena = gradarena.GradArena(plan)
+            self.cut_names = cuts
+            self.params = list(self.arena.params)
+            self.bucket_params = [[p for g in gs for p in g] for _, gs in plan]
+        else:
+            self.params = [p for p in params if p.requires_grad]
+
+    @property
+    def n_buckets(self):
+        return len(self.arena.ranges) if self.arena is not None else 1
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank `src`'s weights (what DataParallel's replicate does)."""
@@ -233,6 +252,27 @@ class DataParallelRanks:
                 dist.broadcast(p.data, src, group=self.group)
         _resident.invalidate(self.params)      # p.data writes do not bump the version the resident planes are checked against
 
+    # ---- arena mode -------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def adopt_bucket(self, i):
+        """End of backward segment ``i`` (device work: belongs inside the captured phase): every gradient of bucket ``i``
+        must live in the arena.  The fused operators wrote them there; anything else is copied in."""
+        self.arena.adopt(self.bucket_params[i])
+
+    @torch.no_grad()
+    def start_bucket(self, i):
+        """Backward has produced every gradient of bucket ``i`` (enqueued on the current stream): start the bucket's
+        all-reduce (asynchronous: RCCL runs it on its own stream behind an event on the current one)."""
+        if self.world > 1:
+            self._works.append(dist.all_reduce(self.arena.bucket(i), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Make the current stream wait for every collective started since the last ``finish``."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    # ---- packed mode ------------------------------------------------------------------------------------------------
     def _buckets(self, grads):
         buckets, cur, n = [], [], 0
         for p, g in zip(self.params, grads):
@@ -248,43 +288,67 @@ class DataParallelRanks:
         return buckets
 
     @torch.no_grad()
-    def all_reduce_grads_begin(self, grads=None):
-        """Start averaging gradients over ranks and return a handle for ``all_reduce_grads_end``.  ``grads`` defaults
-        to each parameter's ``.grad`` (pass the tensors a captured hipGraph writes when replaying one).  Gradients are
-        packed into persistent flat buckets (one ``cat`` kernel each) and every bucket is all-reduced asynchronously:
-        packing bucket i+1 overlaps the collective of bucket i, and whatever the caller enqueues before calling
-        ``..._end`` (e.g. the other model's step) overlaps the collectives on RCCL's own stream."""
-        if self.world == 1:
-            return None
-        if grads is None:
-            grads = [p.grad for p in self.params]
+    def pack(self, extra=()):
+        """Pack every ``p.grad`` (and the scalars ``extra``, e.g. losses to be averaged for the log) into the persistent flat
+        buckets; returns the handle for ``exchange`` / ``unpack``."""
+        grads = [p.grad for p in self.params]
         buckets = self._buckets(grads)
-        if self._flat is None or len(self._flat) != len(buckets):
-            self._flat = [torch.empty(sum(g.numel() for _, g in b), dtype=b[0][1].dtype, device=b[0][1].device) for b in buckets]
-        works = []
-        for flat, bucket in zip(self._flat, buckets):
-            torch.cat([g.reshape(-1) for _, g in bucket], out=flat)
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        return buckets, works
+        tail = [e.detach().reshape(1).float() for e in extra]
+        sizes = [sum(g.numel() for _, g in b) for b in buckets]
+        if tail:
+            if not buckets:
+                buckets, sizes = [[]], [0]
+            sizes[-1] += len(tail)
+        if self._flat is None or [f.numel() for f in self._flat] != sizes:
+            dev = (grads[0] if grads and grads[0] is not None else tail[0]).device
+            self._flat = [torch.empty(n, dtype=torch.float32, device=dev) for n in sizes]
+        for j, (flat, bucket) in enumerate(zip(self._flat, buckets)):
+            parts = [g.reshape(-1) for _, g in bucket] + (tail if j == len(buckets) - 1 else [])
+            torch.cat(parts, out=flat)
+        return buckets, len(tail)
+
+    def exchange(self):
+        """All-reduce (sum) the packed buckets; asynchronous, ``finish`` waits."""
+        if self.world > 1:
+            for flat in self._flat:
+                self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     @torch.no_grad()
-    def all_reduce_grads_end(self, handle):
-        """Wait for the collectives, scale by 1/world and re-point every ``p.grad`` at its averaged slice of the
-        bucket -- no copy back, and the optimizer's pointer table stays stable from step to step."""
-        if handle is None:
-            return
-        buckets, works = handle
-        for flat, bucket, w in zip(self._flat, buckets, works):
-            w.wait()
-            flat.mul_(1.0 / self.world)
+    def unpack(self, handle, scale=None):
+        """Re-point every ``p.grad`` at its slice of the (now reduced) bucket -- no copy back, and the optimizer's pointer
+        table stays stable from step to step.  Returns the reduced ``extra`` scalars."""
+        buckets, ntail = handle
+        for flat, bucket in zip(self._flat, buckets):
+            if scale is not None:
+                flat.mul_(scale)
             off = 0
             for p, g in bucket:
                 n = g.numel()
                 p.grad = flat[off:off + n].view_as(g)
                 off += n
+        last = self._flat[-1]
+        return [last[last.numel() - ntail + j] for j in range(ntail)]
 
+    # ---- legacy one-shot API (gradients NOT pre-scaled) ----------------------------------------------------------------
+    @torch.no_grad()
     def all_reduce_grads(self, grads=None):
-        self.all_reduce_grads_end(self.all_reduce_grads_begin(grads))
+        """Average gradients over ranks after a complete backward."""
+        if self.world == 1:
+            return
+        if self.arena is not None:
+            for i in range(self.n_buckets):
+                self.adopt_bucket(i)
+                self.start_bucket(i)
+            self.finish()
+            self.arena.flat.mul_(1.0 / self.world)
+            return
+        if grads is not None:
+            for p, g in zip(self.params, grads):
+                p.grad = g
+        h = self.pack()
+        self.exchange()
+        self.finish()
+        self.unpack(h, 1.0 / self.world)
 
     @torch.no_grad()
     def all_reduce_mean(self, *scalars):
@@ -297,42 +361,311 @@ class DataParallelRanks:
         v /= self.world
         return tuple(v[i] for i in range(len(scalars)))
 
+    @torch.no_grad()
+    def all_reduce_mean_(self, vec):
+        """In-place variant on a persistent device vector (the form used between captured hipGraphs)."""
+        if self.world > 1:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
+            vec.mul_(1.0 / self.world)
+        return vec
+
+
+class _cuts_installed:
+    """Install a ``Cuts`` as the model's ``_cut`` hook for the duration of ONE forward call only: a forward run outside a
+    segmented step must record an uncut tape."""
+
+    def __init__(self, model, cuts):
+        self.model, self.cuts = model, cuts
+
+    def __enter__(self):
+        self.prev = getattr(self.model, "_cut", None)
+        if self.prev is not None and self.cuts.names:
+            self.model._cut = self.cuts
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            self.model._cut = self.prev
+        return False
+
+
+class Cuts:
+    """The ``_cut`` hook of ``tts.melSyn`` / ``tts.SSRN`` for a segmented backward: at every named cut the activation is
+    detached (so a ``backward`` call stops there) and the pair (tensor on the tape, detached leaf) is remembered."""
+
+    def __init__(self, names):
+        self.names = list(names)
+        self.rec = {}
+
+    def reset(self):
+        self.rec = {}
+
+    def __call__(self, name, x):
+        if name not in self.names or not x.requires_grad:
+            return x
+        leaf = x.detach().requires_grad_(True)
+        self.rec[name] = (x, leaf)
+        return leaf
+
+
+def backward_segments(cuts, roots, side_roots=None, ddp=None):
+    """The backward pass as a list of closures, one per segment.  Segment 0 differentiates ``roots`` (``[(tensor, grad)]``,
+    grad None = 1) down to the nearest cuts; segment i continues from cut ``cuts.names[i-1]`` with the gradient that arrived
+    at its leaf, plus the ``side_roots[name]`` that join the tape there (the attention loss of Text2Mel).  Every parameter
+    of gradient bucket i (tts.ddp_plan) is final once segment i has run."""
+    side_roots = side_roots or {}
+
+    def run(pairs):
+        ts = [t for t, _ in pairs]
+        gs = [g for _, g in pairs]
+        torch.autograd.backward(ts, gs)
+
+    arena = ddp is not None and ddp.arena is not None
+
+    def seg0():
+        run([(t, g if g is not None else torch.ones_like(t)) for t, g in roots])
+        if arena:
+            ddp.adopt_bucket(0)
+    segs = [seg0]
+    for i, name in enumerate(cuts.names):
+        def seg(name=name, i=i):
+            x, leaf = cuts.rec[name]
+            pairs = [(x, leaf.grad)] + [(t, g if g is not None else torch.ones_like(t)) for t, g in side_roots.get(name, [])]
+            run(pairs)
+            leaf.grad = None
+            if arena:
+                ddp.adopt_bucket(i + 1)
+        segs.append(seg)
+    return segs
+
+
+class PhasedStep:
+    """A training iteration as a list of phases ``(kind, fn)``: ``"graph"`` phases are device work only (kernel launches
+    through libssv_hip / torch) and are captured into hipGraphs -- consecutive ones into one graph, all graphs sharing one
+    memory pool because activations recorded in an earlier phase are consumed by later ones -- while ``"eager"`` phases
+    (RCCL collectives, which stay outside captures) are called between the replays.  ``graph=False`` runs everything
+    eagerly, same order."""
+
+    def __init__(self, phases, graph=True, warmup=2):
+        self.phases = phases
+        self.use_graph = graph
+        self.plan = None
+        self.warmup = warmup
+
+    def _eager(self):
+        for _, fn in self.phases:
+            fn()
+
+    def prepare(self):
+        if not self.use_graph or self.plan is not None:
+            return self
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self.warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        plan, i = [], 0
+        while i < len(self.phases):
+            kind, fn = self.phases[i]
+            if kind == "eager":
+                fn()
+                plan.append(fn)
+                i += 1
+                continue
+            j = i
+            while j < len(self.phases) and self.phases[j][0] == "graph":
+                j += 1
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                for _, f in self.phases[i:j]:
+                    f()
+            plan.append(g.replay)
+            self._graphs = getattr(self, "_graphs", []) + [g]
+            i = j
+        self.plan = plan
+        return self
+
+    def run(self):
+        if self.plan is None:
+            self._eager()
+        else:
+            for f in self.plan:
+                f()
+
+
+# --------------------------------------------------------------------------------------------- steps
+def text2mel_losses(pred, att, mel_gt, gaw):
+    """(l1, bin_div, att) of train/ordinary.py:230-236 on the HIP loss kernels."""
+    l1, bd = ops.spec_losses(pred, mel_gt)
+    return l1, bd, ops.guided_att_loss(att, gaw)
+
+
+class TrainStep:
+    """One non-adversarial optimizer iteration (train/ordinary.py:221-254) of ``kind`` "text2mel" (batch = mel, text, spk) or
+    "ssrn" (batch = mel, lin): forward, the reference's losses, backward, Adam.
+
+    Single rank: one phase (one hipGraph when ``graph``).  With a ``DataParallelRanks(model=...)``: backward runs in the
+    segments of ``tts.ddp_plan`` and every gradient bucket's all-reduce is started right after its segment, overlapping the
+    remaining segments; Adam follows the last collective.  ``out`` holds the iteration's loss terms (device scalars)."""
+
+    def __init__(self, kind, model, opt, batch=None, gaw=None, ddp=None, graph=False):
+        self.kind, self.model, self.opt, self.gaw, self.ddp = kind, model, opt, gaw, ddp
+        self.static = [b.clone() for b in batch] if (graph and batch is not None) else None
+        self.batch = self.static if self.static is not None else batch
+        self.out = self.att = None
+        seg = ddp is not None and ddp.arena is not None
+        self.cuts = Cuts(ddp.cut_names if seg else [])
+        self._segs = None
+        nseg = len(self.cuts.names) + 1
+        phases = [("graph", self._forward_seg0)]
+        if seg:
+            for i in range(nseg):
+                if i > 0:
+                    phases.append(("graph", lambda i=i: self._segs[i]()))
+                last = i == nseg - 1
+                phases.append(("eager", (lambda i=i: (ddp.start_bucket(i), ddp.finish())) if last else (lambda i=i: ddp.start_bucket(i))))
+        elif ddp is not None:
+            phases.append(("eager", ddp.all_reduce_grads))
+        phases.append(("graph", self._adam))
+        self.stepper = PhasedStep(phases, graph=graph)
+
+    def _forward_seg0(self):
+        self.opt.zero_grad(set_to_none=True)
+        self.cuts.reset()
+        scale = self.ddp.grad_scale if (self.ddp is not None and self.ddp.arena is not None) else 1.0
+        seed = lambda t: (t, torch.full_like(t, scale))
+        if self.kind == "text2mel":
+            mel, text, spk = self.batch
+            with _cuts_installed(self.model, self.cuts):
+                pred, att = self.model(shift_right(mel), text, spk)
+            l1, bd, la = text2mel_losses(pred, att, mel, self.gaw)
+            self.out, self.att = (l1.detach(), bd.detach(), la.detach()), att.detach()
+            if "dec_in" in self.cuts.rec:
+                segs = backward_segments(self.cuts, [seed(l1 + bd)], {"dec_in": [seed(la)]}, self.ddp)
+            else:
+                segs = backward_segments(self.cuts, [seed(l1 + bd + la)], None, self.ddp)
+        else:
+            mel, lin = self.batch
+            with _cuts_installed(self.model, self.cuts):
+                pred = self.model(mel)
+            l1, bd = ops.spec_losses(pred, lin)
+            self.out = (l1.detach(), bd.detach())
+            segs = backward_segments(self.cuts, [seed(l1 + bd)], None, self.ddp)
+        self._segs = segs
+        segs[0]()
+
+    def _adam(self):
+        self.opt.step()
+
+    def prepare(self):
+        self.stepper.prepare()
+        return self
+
+    def __call__(self, *batch):
+        """Run one iteration; with a batch argument, on that batch (copied into the static buffers of a captured step)."""
+        if batch:
+            if self.static is not None:
+                for dst, src in zip(self.static, batch):
+                    dst.copy_(src, non_blocking=True)
+            else:
+                self.batch = list(batch)
+        self.stepper.run()
+        return self.out
+
+
+def text2mel_step(model, optimizer, mel_gt, text_id, spk_emb, gaw, ddp=None):
+    """One non-adversarial Text2Mel iteration (train/ordinary.py:221-238), eagerly.  Returns the loss terms."""
+    st = TrainStep("text2mel", model, optimizer, [mel_gt, text_id, spk_emb], gaw, ddp, graph=False)
+    l1, bd, la = st()
+    return l1, bd, la, st.att
+
+
+def ssrn_step(model, optimizer, mel_gt, lin_gt, ddp=None):
+    """One non-adversarial SSRN iteration (train/ordinary.py:240-254), eagerly."""
+    return TrainStep("ssrn", model, optimizer, [mel_gt, lin_gt], None, ddp, graph=False)()
+
 
 # --------------------------------------------------------------------------------------------- WGAN-GP
 class AdversarialGraphStep:
     """The generator iteration and the critic iteration of the reference's WGAN-GP trainer
-    (train/adversarial_wasserstein_gp.py:261-322), each captured ONCE as a hipGraph over static input buffers and
+    (train/adversarial_wasserstein_gp.py:261-322), each captured ONCE as hipGraph(s) over static input buffers and
     replayed per iteration -- the eager form is host-bound (hundreds of small critic kernels, three critic forwards and a
     double backward per D iteration, Python autograd glue), not GPU-bound.
 
     Differences to the eager reference that make capture possible, none changing the mathematics:
       * the adaptive weight of the critic term, (l1+bd+att).item()/|disc|.item() (:290, :338), is formed on the device
         from detached tensors instead of through two host round trips;
-      * the interpolation coefficients of the gradient penalty (:300) come from the device RNG instead of the CPU RNG;
+      * the interpolation coefficients of the gradient penalty (:300) are drawn on the host like the reference's
+        ``torch.rand(B)``, from a generator of their own, and copied into a static buffer before the replay;
       * D iterations run the generator forward without recording a tape (the reference records one and discards it:
         only ``pred.detach()`` is used, :311-313).
+
+    Data parallel (``ddp_syn`` = DataParallelRanks(model=generator), ``ddp_disc`` = DataParallelRanks(critic parameters);
+    BASELINE config 4, the reference's MULTI_GPU branch :183-196): every rank holds its shard of the global batch.
+      * G iteration: forward graph -> all-reduce(mean) of (l1, bd, att, disc) so the adaptive weight is the GLOBAL-batch value
+        -> backward in the segments of ``tts.ddp_plan``, each gradient bucket's all-reduce overlapping the next segment
+        -> generator Adam.
+      * D iteration: one graph up to the critic gradients (packed with the two loss scalars into one flat bucket) -> one
+        all-reduce -> critic Adam.  The penalty coefficients are drawn for the GLOBAL batch from the shared generator and
+        sliced by rank, so the iteration does not depend on how the batch is sharded.
     ``kind``: "text2mel" (batch = mel, text, spk) or "ssrn" (batch = mel, lin).  Optimizers must be FusedAdam(capturable=True).
     """
 
-    def __init__(self, kind, model, disc, opt_syn, opt_disc, batch, gaw=None, lam=10.0):
+    def __init__(self, kind, model, disc, opt_syn, opt_disc, batch, gaw=None, lam=10.0, ddp_syn=None, ddp_disc=None, graph=True,
+                 coeff_seed=0):
         self.kind, self.model, self.disc, self.opt_syn, self.opt_disc = kind, model, disc, opt_syn, opt_disc
         self.static = [b.clone() for b in batch]
         self.gaw, self.lam = gaw, float(lam)
+        self.ddp_syn, self.ddp_disc = ddp_syn, ddp_disc
+        self.world = ddp_syn.world if ddp_syn is not None else 1
+        self.rank = dist.get_rank(ddp_syn.group) if (ddp_syn is not None and dist.is_initialized()) else 0
         self.g_out = self.d_out = None
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                self._g_iter()
-                self._d_iter()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self.g_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_graph):
-            self.g_out = self._g_iter()
-        self.d_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.d_graph):
-            self.d_out = self._d_iter()
+        dev = self.static[0].device
+        B = self.static[0].shape[0]
+        self.coeff = torch.zeros((B, 1, 1), device=dev)
+        self._coeff_gen = torch.Generator().manual_seed(int(coeff_seed))
+        self.scalars = torch.zeros(4, device=dev)                      # (l1, bd, att, disc), averaged over ranks on G iterations
+        seg = ddp_syn is not None and ddp_syn.arena is not None
+        self.cuts = Cuts(ddp_syn.cut_names if seg else [])
+        self._segs = None
+        # ---- generator iteration
+        if ddp_syn is None:
+            g_phases = [("graph", self._g_forward), ("graph", self._g_backward0), ("graph", self.opt_syn.step)]
+        else:
+            g_phases = [("graph", self._g_forward), ("eager", lambda: ddp_syn.all_reduce_mean_(self.scalars)), ("graph", self._g_backward0)]
+            if seg:
+                nseg = len(self.cuts.names) + 1
+                for i in range(nseg):
+                    if i > 0:
+                        g_phases.append(("graph", lambda i=i: self._segs[i]()))
+                    last = i == nseg - 1
+                    g_phases.append(("eager", (lambda i=i: (ddp_syn.start_bucket(i), ddp_syn.finish())) if last else (lambda i=i: ddp_syn.start_bucket(i))))
+            else:
+                g_phases.append(("eager", self._g_exchange_packed))
+            g_phases.append(("graph", self.opt_syn.step))
+        # ---- critic iteration
+        if ddp_disc is None:
+            d_phases = [("graph", self._d_compute), ("graph", self.opt_disc.step)]
+        else:
+            d_phases = [("graph", self._d_compute), ("graph", self._d_pack), ("eager", lambda: (ddp_disc.exchange(), ddp_disc.finish())),
+                        ("graph", self._d_unpack_step)]
+        self.g_stepper = PhasedStep(g_phases, graph=graph)
+        self.d_stepper = PhasedStep(d_phases, graph=graph)
+        if graph:
+            # warm up both kinds alternately (as the training loop runs them), then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self.g_stepper._eager()
+                    self.d_stepper._eager()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.g_stepper.warmup = self.d_stepper.warmup = 0
+            self.g_stepper.prepare()
+            self.d_stepper.prepare()
 
     def _forward(self):
         if self.kind == "text2mel":
@@ -342,54 +675,94 @@ class AdversarialGraphStep:
         mel, lin = self.static
         return self.model(mel), None, lin
 
-    def _g_iter(self):
+    # ---- G
+    def _g_forward(self):
         self.opt_syn.zero_grad(set_to_none=True)
         self.opt_disc.zero_grad(set_to_none=True)
-        pred, att, gt = self._forward()
+        self.cuts.reset()
+        with _cuts_installed(self.model, self.cuts):
+            pred, att, gt = self._forward()
         l1, bd = ops.spec_losses(pred, gt)
-        base = l1 + bd
-        la = None
-        if att is not None:
-            la = ops.guided_att_loss(att, self.gaw)
-            base = base + la
+        la = ops.guided_att_loss(att, self.gaw) if att is not None else None
         ld = torch.mean(-self.disc(pred))
-        loss = base + (base.detach() / ld.detach().abs()) * ld
-        loss.backward()
-        self.opt_syn.step()
-        return tuple(t.detach() for t in (l1, bd, la if la is not None else l1 * 0, ld, loss))
+        self._g_terms = (l1, bd, la, ld)
+        torch.stack([l1.detach(), bd.detach(), la.detach() if la is not None else l1.detach() * 0, ld.detach()], out=self.scalars)
 
-    def _d_iter(self):
+    def _g_backward0(self):
+        l1, bd, la, ld = self._g_terms
+        g = self.scalars                                             # global-batch means when data parallel
+        base_g = g[0] + g[1] + g[2]
+        weight = (base_g / g[3].abs()).detach()
+        scale = self.ddp_syn.grad_scale if self.ddp_syn is not None else 1.0
+        seed = lambda t: (t, torch.full_like(t, scale))
+        top = l1 + bd + weight * ld
+        if "dec_in" in self.cuts.rec:
+            segs = backward_segments(self.cuts, [seed(top)], {"dec_in": [seed(la)]}, self.ddp_syn)
+        else:
+            segs = backward_segments(self.cuts, [seed(top + la if la is not None else top)], None, self.ddp_syn)
+        self._segs = segs
+        segs[0]()
+        total = base_g + weight * g[3]
+        self.g_out = (g[0], g[1], g[2], g[3], total)
+        self._g_terms = None
+
+    def _g_exchange_packed(self):
+        h = self.ddp_syn.pack()
+        self.ddp_syn.exchange()
+        self.ddp_syn.finish()
+        self.ddp_syn.unpack(h)
+
+    # ---- D
+    def _d_compute(self):
         self.opt_syn.zero_grad(set_to_none=True)
         self.opt_disc.zero_grad(set_to_none=True)
         with torch.no_grad():
             pred, _, gt = self._forward()
-        B, C, T = gt.shape
-        coeff = torch.rand(B, 1, 1, device=gt.device)
-        mid = (coeff * gt + (1 - coeff) * pred).requires_grad_(True)
+        B = gt.shape[0]
+        scale = self.ddp_disc.grad_scale if self.ddp_disc is not None else 1.0
+        mid = (self.coeff * gt + (1 - self.coeff) * pred).requires_grad_(True)
         out = self.disc(mid)
         grads = torch.autograd.grad(outputs=out, inputs=mid, grad_outputs=torch.ones_like(out), retain_graph=True, create_graph=True)[0]
         loss_gp = torch.mean(self.lam * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
-        loss_gp.backward()
+        loss_gp.backward(torch.full_like(loss_gp, scale))
         # disc(pred) and disc(gt) as ONE critic call on the concatenated batch: the critic has no cross-sample operation
         # (LayerNorm is per column, dropout per element), so mean(disc(pred) - disc(gt)) is unchanged and the iteration runs
         # a third fewer (small, launch-bound) critic kernels
         both = self.disc(torch.cat((pred, gt), dim=0))
         loss_d = torch.mean(both[:B] - both[B:])
-        loss_d.backward()
+        loss_d.backward(torch.full_like(loss_d, scale))
+        self.d_out = (loss_d.detach(), loss_gp.detach())
+
+    def _d_pack(self):
+        ld, gp = self.d_out
+        s = self.ddp_disc.grad_scale
+        self._d_handle = self.ddp_disc.pack(extra=(ld * s, gp * s))
+
+    def _d_unpack_step(self):
+        self.d_out = tuple(self.ddp_disc.unpack(self._d_handle))
         self.opt_disc.step()
-        return loss_d.detach(), loss_gp.detach()
 
     def load(self, batch):
-        """Copy a new batch (same shapes) into the static buffers the graphs read."""
+        """Copy a new batch (same shapes) into the static buffers the graphs read; without graphs the batch is simply used
+        (shapes may change from iteration to iteration)."""
+        if self.g_stepper.plan is None and any(d.shape != s.shape for d, s in zip(self.static, batch)):
+            self.static = [b for b in batch]
+            B = self.static[0].shape[0]
+            if self.coeff.shape[0] != B:
+                self.coeff = torch.zeros((B, 1, 1), device=self.coeff.device)
+            return
         for dst, src in zip(self.static, batch):
             dst.copy_(src, non_blocking=True)
 
     def g_step(self):
-        """-> (l1, bin_div, att, disc, total) device scalars of this iteration."""
-        self.g_graph.replay()
+        """-> (l1, bin_div, att, disc, total) device scalars of this iteration (global-batch means when data parallel)."""
+        self.g_stepper.run()
         return self.g_out
 
     def d_step(self):
         """-> (loss_D, loss_gp) device scalars (Wasserstein estimate = -loss_D)."""
-        self.d_graph.replay()
+        B = self.coeff.shape[0]
+        c = torch.rand(B * self.world, generator=self._coeff_gen)      # one draw per GLOBAL sample, every rank the same stream
+        self.coeff.copy_(c[self.rank * B:(self.rank + 1) * B].view(B, 1, 1))
+        self.d_stepper.run()
         return self.d_out

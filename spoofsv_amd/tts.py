@@ -65,6 +65,13 @@ def _cla(x, conv, ln, s=None, act=0):
     return ops.pointwise_conv_ln_act(x, conv.weight, conv.bias, ln.weight, ln.bias, s, act)
 
 
+def _no_cut(name, x):
+    """Segment boundary hook of the forward pass.  The data-parallel step (train.SegmentedBackward) replaces it with a
+    function that detaches ``x`` here, so that backward runs segment by segment and each segment's gradient bucket can be
+    all-reduced while the next segment is still computing.  Without one the forward is a single tape."""
+    return x
+
+
 class textEncoder(nn.Module):
     def __init__(self, vocab_len, textemb_dim=128, hidden_dim=256):
         super().__init__()
@@ -81,12 +88,13 @@ class textEncoder(nn.Module):
         self.hc3 = highwayConv(dimension=2 * hidden_dim, kernel_size=1, dilation=1)
         self.hc4 = highwayConv(dimension=2 * hidden_dim, kernel_size=1, dilation=1)
 
-    def encode(self, inputs):
+    def encode(self, inputs, cut=_no_cut):
         """The un-split (B, 2*hidden, N) output; K is the first half, V the second (:138-139)."""
         x = self.textemb_layer(inputs)
         x = _cla(x, self.conv1, self.ln1, act=1)      # relu feeds conv2 (:130)
         x = _cla(x, self.conv2, self.ln2)
-        x = self.hci2(self.hci1(x))
+        x = cut("text_c1", self.hci1(x))
+        x = cut("text_c2", self.hci2(x))
         return self.hc4(self.hc3(self.hc2(self.hc1(x))))
 
     def forward(self, inputs):
@@ -155,6 +163,7 @@ class melSyn(nn.Module):
     def __init__(self, vocab_len, condition, spkemb_dim, textemb_dim=128, freq_bins=80, hidden_dim=256):
         super().__init__()
         self.hidden_dim = hidden_dim
+        self._cut = _no_cut
         self.text_encoder = textEncoder(vocab_len=vocab_len, textemb_dim=textemb_dim, hidden_dim=hidden_dim)
         self.audio_encoder = audioEncoder(freq_bins=freq_bins, hidden_dim=hidden_dim, condition=condition, spkemb_dim=spkemb_dim)
         self.audio_decoder = audioDecoder(freq_bins=freq_bins, hidden_dim=hidden_dim)
@@ -170,11 +179,11 @@ class melSyn(nn.Module):
             side = _side_stream(melspec.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                kv = self.text_encoder.encode(textid)
+                kv = self.text_encoder.encode(textid, self._cut)
             Q = self.audio_encoder(melspec, spkemb)
             cur.wait_stream(side)     # join; kv stays alive until backward, no record_stream (illegal under capture) needed
             RQ, A = ops.attention_train(kv, Q)
-            return self.audio_decoder(RQ), A
+            return self.audio_decoder(self._cut("dec_in", RQ)), A
 
         # ---- synthesis step (models/TTSModel.py:275-300) ---------------------------------------
         d = self.hidden_dim
@@ -232,6 +241,7 @@ class upsampling(nn.Module):
 class SSRN(nn.Module):
     def __init__(self, freq_bins, output_bins, ssrn_dim):
         super().__init__()
+        self._cut = _no_cut
         self.conv1 = nn.Conv1d(in_channels=freq_bins, out_channels=ssrn_dim, kernel_size=1)
         self.ln1 = nn.LayerNorm(normalized_shape=ssrn_dim)
         self.hc1 = highwayConv(dimension=ssrn_dim, kernel_size=3, dilation=1)
@@ -255,9 +265,68 @@ class SSRN(nn.Module):
         x = _cla(inputs, self.conv1, self.ln1)
         x = self.hc2(self.hc1(x))
         x = self.ups2(self.ups1(x))
-        x = _cla(x, self.conv2, self.ln2)
-        x = self.hc4(self.hc3(x))
+        x = self._cut("ssrn_mid", _cla(x, self.conv2, self.ln2))
+        x = self._cut("ssrn_tail", self.hc4(self.hc3(x)))
         x = _cla(x, self.conv3, self.ln3)             # no ReLU between ln3 and conv4 (:355)
         x = _cla(x, self.conv4, self.ln4, act=1)
         x = _cla(x, self.conv5, self.ln5, act=1)
         return _cla(x, self.conv6, self.ln6, act=2)
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel plan
+def _groups(module):
+    """Parameter groups of ``module`` in gradient-arena order (gradarena.py): per fused operator the conv weight, then the
+    block of small gradients its backward kernel emits as one array -- highwayConv: (ln1.w, ln1.b, ln2.w, ln2.b, conv.b);
+    1x1 conv + LayerNorm pairs ``convN`` / ``lnN``: (ln.w, ln.b, conv.b).  Everything else one group per parameter."""
+    groups, seen = [], set()
+
+    def take(ps):
+        ps = [p for p in ps if p is not None and id(p) not in seen]
+        seen.update(id(p) for p in ps)
+        if ps:
+            groups.append(ps)
+    for m in module.modules():
+        if isinstance(m, highwayConv):
+            take([m.conv.weight])
+            take([m.ln1.weight, m.ln1.bias, m.ln2.weight, m.ln2.bias, m.conv.bias])
+        else:
+            for name, child in m.named_children():
+                if name.startswith("conv") and isinstance(child, nn.Conv1d) and isinstance(getattr(m, "ln" + name[4:], None), nn.LayerNorm):
+                    ln = getattr(m, "ln" + name[4:])
+                    take([child.weight])
+                    take([ln.weight, ln.bias, child.bias])
+    for p in module.parameters():
+        take([p])
+    return groups
+
+
+def ddp_plan(model):
+    """``(plan, cuts)`` for ``train.SegmentedBackward``: gradient buckets in the order backward finishes them, and the names of
+    the forward cuts (see ``_no_cut``) that end each backward segment.  Bucket i is complete once segment i has run.
+
+    melSyn:  decoder | attention + audio encoder + text encoder hc1-4 | text encoder hci2 | text encoder hci1, head
+    SSRN:    513-wide 1x1 tail | the two C=512 highway layers | everything at C=256 (upsampling, head)"""
+    if hasattr(model, "ddp_plan"):
+        return model.ddp_plan()
+    if isinstance(model, melSyn):
+        te = model.text_encoder
+        upper = [te.hc1, te.hc2, te.hc3, te.hc4]
+        plan = [("audio_decoder", _groups(model.audio_decoder)),
+                ("audio_encoder+text_top", _groups(model.audio_encoder) + [g for m in upper for g in _groups(m)]),
+                ("text_hci2", _groups(te.hci2)),
+                ("text_hci1+head", _groups(te.hci1) + _groups(nn.ModuleList([te.textemb_layer])) +
+                 [g for g in _groups(te) if all(any(p is q for q in (te.conv1.weight, te.conv1.bias, te.ln1.weight, te.ln1.bias,
+                                                                      te.conv2.weight, te.conv2.bias, te.ln2.weight, te.ln2.bias)) for p in g)])]
+        cuts = ["dec_in", "text_c2", "text_c1"]
+    elif isinstance(model, SSRN):
+        tail = nn.ModuleDict({k: getattr(model, k) for k in ("conv3", "ln3", "conv4", "ln4", "conv5", "ln5", "conv6", "ln6")})
+        head = nn.ModuleDict({k: getattr(model, k) for k in ("conv1", "ln1", "hc1", "hc2", "ups1", "ups2", "conv2", "ln2")})
+        plan = [("tail_513", _groups(tail)), ("hc_512", _groups(model.hc3) + _groups(model.hc4)), ("head_256", _groups(head))]
+        cuts = ["ssrn_tail", "ssrn_mid"]
+    else:
+        return [("all", _groups(model))], []
+    have = {id(p) for _, gs in plan for g in gs for p in g}
+    missing = [n for n, p in model.named_parameters() if id(p) not in have]
+    if missing:
+        raise RuntimeError("ddp_plan: parameters without a bucket: %s" % ", ".join(missing))
+    return plan, cuts

@@ -1,0 +1,287 @@
+"""GPU tests of the data-parallel paths (BASELINE config 4): gradient arena, backward in segments with one
+all-reduce per gradient bucket, captured as several hipGraphs with the collectives between the replays; the adversarial
+(WGAN-GP) iterations under the same scheme.  The test box has ONE GPU: two ranks share it and talk over gloo; the driver's
+multi-GPU runs use RCCL through the same code."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _melsyn(seed=100, hidden=32, temb=16):
+    from spoofsv_amd import train
+    from spoofsv_amd.tts import melSyn
+    torch.manual_seed(seed)
+    m = melSyn(34, True, 200, textemb_dim=temb, freq_bins=80, hidden_dim=hidden)
+    m.apply(train.init_weights)
+    return m.to(DEV).train()
+
+
+def _ssrn(seed=101):
+    from spoofsv_amd import train
+    from spoofsv_amd.tts import SSRN
+    torch.manual_seed(seed)
+    m = SSRN(80, 65, 32)
+    m.apply(train.init_weights)
+    return m.to(DEV).train()
+
+
+def _grads(m):
+    torch.cuda.synchronize()
+    return {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("kind", ["text2mel", "ssrn"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_segmented_arena_step_is_bit_identical_to_the_plain_step(kind, graph):
+    """One rank: the step with the gradient arena and the segmented backward (tts.ddp_plan: 4 / 3 segments, as separate
+    hipGraphs when captured) runs exactly the kernels of the plain step, so gradients and post-step weights are bit-equal;
+    every gradient lives in the arena, and the forward's cut hook is gone after the step."""
+    from spoofsv_amd import train
+    if kind == "text2mel":
+        a, b = _melsyn(), _melsyn()
+        batch = list(train.synthetic_text2mel_batch(4, N=40, T=64, seed=3, device=DEV))       # B*T = 256: split-bf16 GEMMs + resident planes
+        gaw = train.guided_attention_mat(40, 64, device=DEV)
+    else:
+        a, b = _ssrn(), _ssrn()
+        batch = list(train.synthetic_ssrn_batch(4, T=40, out_bins=65, seed=3, device=DEV))
+        gaw = None
+    oa = train.FusedAdam(a.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=graph)
+    ob = train.FusedAdam(b.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=graph)
+    oa.refresh_resident_weights(); ob.refresh_resident_weights()
+    plain = train.TrainStep(kind, a, oa, batch, gaw, None, graph=False)
+    ddp = train.DataParallelRanks(model=b)
+    assert ddp.n_buckets == (4 if kind == "text2mel" else 3) and ddp.world == 1
+    seg = train.TrainStep(kind, b, ob, batch, gaw, ddp, graph=graph).prepare()
+    if graph:       # capture ran warm-up iterations on b: start both from the same state again
+        b.load_state_dict(a.state_dict())
+        for st in ob.state.values():
+            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+        ob._step_dev.zero_()
+        ob.refresh_resident_weights()
+        assert len(seg.stepper._graphs) == ddp.n_buckets + 1               # fwd+seg0 | seg1 | ... | Adam
+    for it in range(2):
+        la, lb = plain(), seg()
+        ga, gb = _grads(a), _grads(b)
+        for k in ga:
+            assert np.array_equal(ga[k], gb[k]), (it, k)
+        for x, y in zip(la, lb):
+            assert float(x) == float(y)
+    for (k, p), q in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(p, q), k
+    for p in b.parameters():
+        assert p.grad.data_ptr() == ddp.arena.slot(p).data_ptr()
+    from spoofsv_amd import tts
+    assert b._cut is tts._no_cut
+
+
+def _t2m_rank(rank, world, port, q, graph):
+    import torch.distributed as dist
+    from spoofsv_amd import train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _melsyn(100 + rank)                              # replicas start different; broadcast_parameters must fix that
+    ddp = train.DataParallelRanks(model=m)
+    ddp.broadcast_parameters(0)
+    opt = train.FusedAdam(m.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=graph)
+    opt.refresh_resident_weights()
+    mel, text, spk = train.synthetic_text2mel_batch(8, N=40, T=64, seed=3, device=DEV)
+    gaw = train.guided_attention_mat(40, 64, device=DEV)
+    sl = slice(4 * rank, 4 * rank + 4)                  # each rank takes its half of the global batch
+    w0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    step = train.TrainStep("text2mel", m, opt, [mel[sl], text[sl], spk[sl]], gaw, ddp, graph=graph).prepare()
+    if graph:
+        m.load_state_dict(w0)
+        for st in opt.state.values():
+            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+        opt._step_dev.zero_()
+        opt.refresh_resident_weights()
+    losses = [float(v) for v in step()]
+    grads = _grads(m)
+    step()
+    torch.cuda.synchronize()
+    q.put((rank, grads, losses, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(target, args, world=2):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_rank_segmented_step_equals_single_process_on_the_global_batch(graph):
+    """Two ranks, half the global batch each, backward in four segments with the bucket all-reduces between them (between the
+    hipGraph replays when captured): the averaged gradient is the one a single process computes on the whole batch, and the
+    replicas stay bit-identical through optimizer steps."""
+    from spoofsv_amd import train
+    m = _melsyn(100)
+    mel, text, spk = train.synthetic_text2mel_batch(8, N=40, T=64, seed=3, device=DEV)
+    gaw = train.guided_attention_mat(40, 64, device=DEV)
+    opt = train.FusedAdam(m.parameters(), 2e-4, (0.5, 0.9), 1e-6)
+    want_loss = [float(v) for v in train.TrainStep("text2mel", m, opt, [mel, text, spk], gaw, None)()]
+    want = _grads(m)
+    res = _spawn(_t2m_rank, (graph,))
+    for k in res[0][3]:
+        assert np.array_equal(res[0][3][k], res[1][3][k]), k           # replicas bit-identical after two steps
+    scale = max(float(np.abs(w).max()) for w in want.values())
+    for k, w in want.items():
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
+        # split-bf16 products over a different batch partition: agreement to a few 1e-4 of the gradient's own size
+        assert float(np.abs(res[0][1][k] - w).max()) <= 2e-5 * scale + 5e-4 * float(np.abs(w).max()), k
+    # per-rank losses average to the global-batch loss
+    mean_loss = [(a + b) / 2 for a, b in zip(res[0][2], res[1][2])]
+    for a, b in zip(mean_loss, want_loss):
+        assert abs(a - b) < 1e-5 * max(1.0, abs(b))
+
+
+# ---- adversarial (WGAN-GP) iterations, data parallel: BASELINE config 4 ----------------------------------------------------
+def _adv_build(kind, seed=21):
+    from spoofsv_amd import train
+    from spoofsv_amd.critic import linDisc, melDisc
+    torch.manual_seed(seed)
+    if kind == "text2mel":
+        m = _melsyn(seed)
+        d = melDisc(80, 16)
+    else:
+        m = _ssrn(seed)
+        d = linDisc(65, 16)
+    d.apply(train.init_weights)
+    return m, d.to(DEV).eval()                           # eval: no dropout RNG, so the two partitions see the same critic
+
+
+def _adv_batch(kind, B):
+    from spoofsv_amd import train
+    if kind == "text2mel":
+        return list(train.synthetic_text2mel_batch(B, N=40, T=64, seed=4, device=DEV)), train.guided_attention_mat(40, 64, device=DEV)
+    return list(train.synthetic_ssrn_batch(B, T=40, out_bins=65, seed=4, device=DEV)), None
+
+
+def _adv_run(kind, m, d, batch, gaw, ddp_syn, ddp_disc, graph):
+    """One G and one D iteration from the given weights; returns losses and the gradients each iteration produced."""
+    from spoofsv_amd import train
+    og = train.FusedAdam(m.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+    od = train.FusedAdam(d.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+    w_m = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    w_d = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    st = train.AdversarialGraphStep(kind, m, d, og, od, batch, gaw, 10.0, ddp_syn, ddp_disc, graph=graph, coeff_seed=9)
+    if graph:
+        m.load_state_dict(w_m); d.load_state_dict(w_d)
+        for o in (og, od):
+            for s in o.state.values():
+                s["exp_avg"].zero_(); s["exp_avg_sq"].zero_()
+            o._step_dev.zero_()
+            o.refresh_resident_weights()
+    g_out = [float(v) for v in st.g_step()]
+    g_grads = _grads(m)
+    d_out = [float(v) for v in st.d_step()]
+    torch.cuda.synchronize()
+    d_grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in d.named_parameters()}
+    st.g_step(); st.d_step()
+    torch.cuda.synchronize()
+    weights = {k: v.detach().cpu().numpy() for k, v in list(m.state_dict().items()) + [("disc." + k, v) for k, v in d.state_dict().items()]}
+    return g_out, g_grads, d_out, d_grads, weights
+
+
+def _adv_rank(rank, world, port, q, kind, graph):
+    import torch.distributed as dist
+    from spoofsv_amd import train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, d = _adv_build(kind)
+    batch, gaw = _adv_batch(kind, 8)
+    sl = slice(4 * rank, 4 * rank + 4)
+    ddp_syn = train.DataParallelRanks(model=m)
+    ddp_disc = train.DataParallelRanks(list(d.parameters()))
+    q.put((rank,) + _adv_run(kind, m, d, [b[sl] for b in batch], gaw, ddp_syn, ddp_disc, graph))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,graph", [("text2mel", True), ("ssrn", True), ("text2mel", False)])
+def test_two_rank_adversarial_iterations_equal_single_process_on_the_global_batch(kind, graph):
+    """BASELINE config 4 (train/adversarial_wasserstein_gp.py:183-196,261-322 under data parallelism): two ranks with half
+    the global batch each.  G iteration: the adaptive critic weight is formed from the all-reduced (global) loss terms and the
+    generator gradient buckets are all-reduced between the backward segments; D iteration: penalty coefficients drawn per
+    GLOBAL sample index, critic gradients and both loss scalars in one packed all-reduce.  Losses and gradients must equal
+    the single-process iteration on the whole batch; replicas stay bit-identical."""
+    m, d = _adv_build(kind)
+    batch, gaw = _adv_batch(kind, 8)
+    g_out, g_grads, d_out, d_grads, _ = _adv_run(kind, m, d, batch, gaw, None, None, graph=False)
+    res = _spawn(_adv_rank, (kind, graph))
+    for k in res[0][5]:
+        assert np.array_equal(res[0][5][k], res[1][5][k]), k           # replicas (generator and critic) bit-identical after 2 G + 2 D
+    for r in res:
+        for a, b in zip(r[1], g_out):                                  # (l1, bd, att, disc, total): global-batch values on every rank
+            assert abs(a - b) < 2e-5 * max(1.0, abs(b)), (r[1], g_out)
+        for a, b in zip(r[3], d_out):                                  # (loss_D, loss_gp)
+            assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (r[3], d_out)
+    scale = max(float(np.abs(w).max()) for w in g_grads.values())
+    for k, w in g_grads.items():
+        assert np.array_equal(res[0][2][k], res[1][2][k]), k
+        assert float(np.abs(res[0][2][k] - w).max()) <= 2e-5 * scale + 5e-4 * float(np.abs(w).max()), k
+    for k, w in d_grads.items():
+        if k in ("conv1.bias", "conv2.bias", "conv3.bias", "conv4.bias", "conv5.bias", "hc.conv.bias"):
+            continue                                                    # exactly-zero true gradients: rounding noise on both sides
+        a = res[0][4][k]
+        assert np.array_equal(a, res[1][4][k]), k
+        assert float(np.linalg.norm(a - w)) <= 3e-3 * max(1e-6, float(np.linalg.norm(w))), k
+
+
+# ---- the trainers under torchrun-style environments -------------------------------------------------------------------------
+def _harness_rank(rank, world, port, q, tmp, adversarial, capture):
+    import json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      SSV_DIST_BACKEND="gloo")
+    from spoofsv_amd import harness
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = json.load(open(os.path.join(root, "config.json")))
+    cfg.update(SRC_ROOT_DIR=tmp + os.sep, BATCH_SIZE=4, MAX_TEXT_LEN=24, MAX_FRAME_NUM=40, HIDDEN_DIM=32, TEXT_EMB_DIM=16, SSRN_DIM=32,
+               DISC_DIM=16, VAL_EVERY_ITER=2, SYNTHETIC_BATCHES_PER_EPOCH=3, MAX_ITERATIONS=5, RATIO=1, MULTI_GPU=True,
+               CAPTURE_GRAPHS=capture)
+    cfg["STFT"] = {"FFT_LENGTH": 128, "HOP_LENGTH": 32}
+    torch.manual_seed(1000 + rank)                      # ranks initialise differently; the trainer must broadcast rank 0's weights
+    if adversarial:
+        model, disc, logs = harness.adversarial_train("train_text2mel", "conditional", cfg, current_time="ddp")
+        extra = [v.detach().cpu().numpy() for v in disc.state_dict().values()]
+        hist = logs["loss_train_log_syn"] + logs["loss_train_log_disc"]
+    else:
+        model, hist = harness.ordinary_train("train_text2mel", "conditional", cfg, current_time="ddp")
+        extra = []
+    torch.cuda.synchronize()
+    q.put((rank, [v.detach().cpu().numpy() for v in model.state_dict().values()] + extra, hist))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("adversarial,capture", [(False, False), (True, False), (True, True)])
+def test_trainers_run_data_parallel_under_torchrun_environment(tmp_path, adversarial, capture):
+    """main.py's trainers launched one process per rank (RANK / WORLD_SIZE / LOCAL_RANK as torchrun exports them): they build
+    the process group themselves, shard the batches, keep the replicas identical (weights bit-equal on both ranks after 5
+    iterations, validation and checkpoint included), report the global-batch loss on every rank, and only rank 0 writes
+    checkpoints."""
+    res = _spawn(_harness_rank, (str(tmp_path), adversarial, capture))
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)
+    assert res[0][2] == res[1][2] and all(h == h for h in res[0][2]) and len(res[0][2]) == 5
+    sub = "adversarial" if adversarial else "not_adversarial"
+    cks = os.listdir(os.path.join(str(tmp_path), "checkpoints", "conditional", sub, "ddp"))
+    assert "text2mel_iteration_3.tar.pth" in cks and "text2mel_best_model.tar.pth" in cks

@@ -93,15 +93,47 @@ def test_generator_accepts_critic_gradient_like_oracle():
     torch.manual_seed(11)
     g = SSRN(80, 65, 16)
     g.apply(train.init_weights)
+    from oracle import critic_oracle as CO
     d = linDisc(65, 16).eval()                     # eval: no dropout, so both arms see the same critic
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in g.state_dict().items()}
     mel = torch.rand(2, 80, 16)
-    (-d(TO.ssrn(mel, sd))).mean().backward()
+    (-CO.critic(TO.ssrn(mel, sd), d.state_dict(), "lin", masks=False)).mean().backward()
     g = g.to("cuda:0").train()
     d = d.to("cuda:0")
     (-d(g(mel.cuda()))).mean().backward()
     bad = {k: rel_err(p.grad, sd[k].grad) for k, p in g.named_parameters() if rel_err(p.grad, sd[k].grad) > 3e-4}
     assert not bad, bad
+
+
+def test_validation_free_run_follows_weight_updates():
+    """The trainers validate the LIVE model through the cached column-incremental synthesizer (harness.validate).  FusedAdam
+    updates weights through raw pointers, so nothing bumps a version counter: the synthesizer's tap-major copies of the k=3
+    weights and the resident split planes must still follow.  Validate, take optimizer steps, validate again (same shapes ->
+    cached synthesizer, captured graph) and compare with the reference's prefix loop on the current weights."""
+    from spoofsv_amd import harness, train
+    from spoofsv_amd.tts import melSyn
+    torch.manual_seed(3)
+    m = melSyn(34, True, 200, textemb_dim=16, freq_bins=80, hidden_dim=32)
+    m.apply(train.init_weights)
+    m = m.to("cuda:0")
+    opt = train.FusedAdam(m.parameters(), 5e-3, (0.5, 0.9), 1e-6)             # a large step: stale weights would show clearly
+    mel, text, spk = train.synthetic_text2mel_batch(4, N=24, T=40, seed=2, device="cuda:0")
+    gaw = train.guided_attention_mat(24, 40, device="cuda:0")
+
+    def both():
+        m.eval()
+        with torch.no_grad():
+            yi, ai = harness._free_run(m, text, spk, 12, 80, incremental=True)
+            yp, ap = harness._free_run(m, text, spk, 12, 80, incremental=False)
+        m.train()
+        return yi, yp, ai, ap
+    y0i, y0p, _, _ = both()
+    assert rel_err(y0i, y0p) < 2e-4
+    for _ in range(3):
+        train.text2mel_step(m, opt, mel, text, spk, gaw)
+    y1i, y1p, a1i, a1p = both()
+    assert rel_err(y1p, y0p) > 1e-2                                            # the weights really moved
+    assert rel_err(y1i, y1p) < 2e-4 and rel_err(a1i, a1p) < 2e-4, (rel_err(y1i, y1p), rel_err(a1i, a1p))
 
 
 def test_main_cli_synthesize(tmp_path):
@@ -210,7 +242,9 @@ def test_adversarial_graph_step_matches_eager_generator_iteration():
         d = melDisc(80, 16)
         m.apply(train.init_weights); d.apply(train.init_weights)
         return m.to(dev).train(), d.to(dev).eval()
-    batch = train.synthetic_text2mel_batch(2, N=24, T=40, seed=4, device=dev)
+    # B*T = 256 >= 128: the convolutions run on the split-bf16 kernels with RESIDENT weight planes, whose addresses the
+    # captured graphs bake in -- restoring weights behind them must be followed by a refresh (harness does the same)
+    batch = train.synthetic_text2mel_batch(4, N=24, T=64, seed=4, device=dev)
     gaw = train.guided_attention_mat(186, 325, device=dev)
     # eager, as the reference spells it (host-side adaptive weight)
     m, d = build()
@@ -238,6 +272,7 @@ def test_adversarial_graph_step_matches_eager_generator_iteration():
     for st in og.state.values():
         st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
     og._step_dev.zero_()
+    og.refresh_resident_weights(); od.refresh_resident_weights()
     out = stepper.g_step()
     assert abs(float(out[4]) - float(loss)) < 1e-4 * abs(float(loss))
     worst = max(float((m2.state_dict()[k] - ref[k]).abs().max()) for k in ref)

@@ -640,57 +640,100 @@ def test_highway_gate_dd_matches_autograd_to_second_order(B, C, L):
         assert _close(got, want)
 
 
+def _critic_d_loss_hip(disc, real, fake, eps, masks=None):
+    """Critic loss with gradient penalty on the HIP critic; ``masks``: 9 injected dropout masks (3 calls x 3 sites) or None."""
+    import contextlib
+    from spoofsv_amd import critic
+    disc.zero_grad()
+    B = real.shape[0]
+    ctx = critic.injected_dropout_masks([m.cuda() for m in masks]) if masks is not None else contextlib.nullcontext()
+    with ctx:
+        r, f, e = real.cuda(), fake.cuda(), eps.cuda().view(B, 1, 1)
+        xhat = (e * r + (1 - e) * f).requires_grad_(True)
+        out = disc(xhat)
+        grad, = torch.autograd.grad(out, xhat, torch.ones_like(out), create_graph=True)
+        gp = torch.mean(10.0 * (torch.norm(grad, p=2, dim=(1, 2)) - 1) ** 2)
+        gp.backward()
+        loss_d = torch.mean(-disc(r) + disc(f)) if masks is None else None
+        if masks is not None:                       # the reference's call order: ground truth, then prediction (:313-314)
+            d_gt = disc(r)
+            loss_d = torch.mean(disc(f) - d_gt)
+        loss_d.backward()
+    return float(gp.detach()), float(loss_d.detach()), {n: p.grad.detach().cpu().clone() for n, p in disc.named_parameters()}
+
+
+def _critic_d_loss_oracle(sd, kind, real, fake, eps, masks):
+    from oracle import critic_oracle as CO
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    gp, loss_d = CO.critic_losses(fake, real, eps.view(-1), sd, kind, 10.0, masks=masks)
+    gp.backward()
+    loss_d.backward()
+    return float(gp.detach()), float(loss_d.detach()), {k: v.grad.detach().clone() for k, v in sd.items()}
+
+
+_CRITIC_ZERO_GRAD = ("conv1.bias", "conv2.bias", "conv3.bias", "conv4.bias", "hc.conv.bias")      # a bias feeding a LayerNorm
+
+
 def test_critic_gradient_penalty_full_size_lin_critic():
-    """linDisc at its real size (513 bins x 1300 frames, DISC_DIM 128): critic loss with gradient penalty, HIP ops vs the CPU
-    reference path.  Tolerance 3e-3 in the relative L2 norm per parameter (sums over 1300 columns in fp32)."""
+    """linDisc at its real size (513 bins x 1300 frames, DISC_DIM 128): critic losses with gradient penalty, HIP ops vs
+    oracle/critic_oracle.py (the reference's stock-op sequence on the CPU).  Tolerance 3e-3 in the relative L2 norm per
+    parameter (sums over 1300 columns in fp32)."""
     from spoofsv_amd.critic import linDisc
     torch.manual_seed(9)
     d = linDisc(513, 128).eval()
     B, T = 2, 1300
-    real, fake, eps = torch.rand(B, 513, T), torch.rand(B, 513, T), torch.rand(B, 1, 1)
-
-    def d_loss(disc, dev):
-        disc.zero_grad()
-        r, f, e = real.to(dev), fake.to(dev), eps.to(dev)
-        xhat = (e * r + (1 - e) * f).requires_grad_(True)
-        out = disc(xhat)
-        grad, = torch.autograd.grad(out, xhat, torch.ones_like(out), create_graph=True)
-        gp = ((grad.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean()
-        loss = disc(f).mean() - disc(r).mean() + 10.0 * gp
-        loss.backward()
-        return float(loss.detach()), {n: p.grad.detach().cpu().clone() for n, p in disc.named_parameters()}
-    want_loss, want = d_loss(d, "cpu")
-    got_loss, got = d_loss(d.cuda(), "cuda")
-    assert abs(got_loss - want_loss) <= 2e-4 * max(1.0, abs(want_loss))
+    real, fake, eps = torch.rand(B, 513, T), torch.rand(B, 513, T), torch.rand(B)
+    want_gp, want_ld, want = _critic_d_loss_oracle(d.state_dict(), "lin", real, fake, eps, False)
+    got_gp, got_ld, got = _critic_d_loss_hip(d.cuda(), real, fake, eps)
+    assert abs(got_gp - want_gp) <= 2e-4 * max(1.0, abs(want_gp)) and abs(got_ld - want_ld) <= 2e-4 * max(1.0, abs(want_ld))
     for n in want:
-        if n in ("conv1.bias", "conv2.bias", "conv3.bias", "conv4.bias", "hc.conv.bias"):
+        if n in _CRITIC_ZERO_GRAD:
             continue      # exactly-zero gradients (a bias in front of a LayerNorm): rounding noise on both sides
         assert float((got[n] - want[n]).norm()) <= 3e-3 * max(1e-6, float(want[n].norm())), n
 
 
-def test_critic_gradient_penalty_matches_cpu_reference_path():
-    """The whole critic, penalty and all (train/adversarial_wasserstein_gp.py:296-312), on the HIP ops versus the same module
-    on the CPU, where critic.py runs the reference's permute -> nn.LayerNorm -> permute ops.  eval(): no dropout RNG."""
+@pytest.mark.parametrize("kind,dims", [("lin", (3, 65, 64)), ("mel", (4, 80, 40))])
+def test_critic_with_dropout_active_matches_oracle_with_the_same_masks(kind, dims):
+    """The reference never calls disc.eval(): its critics always run with dropout.  The oracle (pinned against the
+    reference's critics in training mode, golden G11) draws the nine masks of one critic iteration; the HIP critic gets
+    exactly those masks injected and must give the same penalty, Wasserstein term and parameter gradients."""
+    from oracle import critic_oracle as CO
+    from spoofsv_amd.critic import linDisc, melDisc
+    B, Fb, T = dims
+    torch.manual_seed(5)
+    d = (linDisc if kind == "lin" else melDisc)(Fb, 32).train()
+    real, fake, eps = torch.rand(B, Fb, T), torch.rand(B, Fb, T), torch.rand(B)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    drawn = []
+    torch.manual_seed(77)
+    gp, ld = CO.critic_losses(fake, real, eps, sd, kind, 10.0, masks=None, drawn=drawn)
+    gp.backward(); ld.backward()
+    assert len(drawn) == 9 and sum(float((m == 0).sum()) for m in drawn) > 0
+    got_gp, got_ld, got = _critic_d_loss_hip(d.cuda(), real, fake, eps, masks=drawn)
+    assert abs(got_gp - float(gp)) <= 1e-4 * max(1.0, abs(float(gp))), (got_gp, float(gp))
+    assert abs(got_ld - float(ld)) <= 1e-4 * max(1.0, abs(float(ld))), (got_ld, float(ld))
+    for n, v in sd.items():
+        if n in _CRITIC_ZERO_GRAD:
+            continue
+        want = v.grad
+        assert float((got[n] - want).norm()) <= 2e-3 * max(1e-6, float(want.norm())), n
+    # and without injection the module draws its own masks: two calls differ (dropout really is active in train mode)
+    x = real.cuda()
+    assert not torch.equal(d(x), d(x))
+
+
+def test_critic_gradient_penalty_matches_oracle():
+    """The whole critic, penalty and all (train/adversarial_wasserstein_gp.py:296-312), on the HIP ops versus
+    oracle/critic_oracle.py (the reference's permute -> nn.LayerNorm -> permute ops on the CPU).  eval(): no dropout."""
     from spoofsv_amd.critic import linDisc
     torch.manual_seed(5)
     d = linDisc(65, 32).eval()
     B, T = 3, 64
-    real, fake, eps = torch.rand(B, 65, T), torch.rand(B, 65, T), torch.rand(B, 1, 1)
-
-    def d_loss(disc, dev):
-        disc.zero_grad()
-        r, f, e = real.to(dev), fake.to(dev), eps.to(dev)
-        xhat = (e * r + (1 - e) * f).requires_grad_(True)
-        out = disc(xhat)
-        grad, = torch.autograd.grad(out, xhat, torch.ones_like(out), create_graph=True)
-        gp = ((grad.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean()
-        loss = disc(f).mean() - disc(r).mean() + 10.0 * gp
-        loss.backward()
-        return float(loss), {n: p.grad.detach().cpu().clone() for n, p in disc.named_parameters()}
-    want_loss, want = d_loss(d, "cpu")
-    got_loss, got = d_loss(d.cuda(), "cuda")
-    assert abs(got_loss - want_loss) <= 1e-4 * max(1.0, abs(want_loss))
+    real, fake, eps = torch.rand(B, 65, T), torch.rand(B, 65, T), torch.rand(B)
+    want_gp, want_ld, want = _critic_d_loss_oracle(d.state_dict(), "lin", real, fake, eps, False)
+    got_gp, got_ld, got = _critic_d_loss_hip(d.cuda(), real, fake, eps)
+    assert abs(got_gp - want_gp) <= 1e-4 * max(1.0, abs(want_gp)) and abs(got_ld - want_ld) <= 1e-4 * max(1.0, abs(want_ld))
     for n in want:
-        if n in ("conv1.bias", "conv2.bias", "conv3.bias", "conv4.bias", "hc.conv.bias"):
-            continue      # a bias feeding a LayerNorm has an exactly-zero gradient; both sides hold rounding noise there
+        if n in _CRITIC_ZERO_GRAD:
+            continue
         assert float((got[n] - want[n]).norm()) <= 2e-3 * max(1e-6, float(want[n].norm())), n

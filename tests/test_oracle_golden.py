@@ -4,6 +4,7 @@ import numpy as np
 import torch
 
 from _golden import load, sub, t, rel_err
+from oracle import critic_oracle as CO
 from oracle import ge2e_oracle as GO
 from oracle import tts_oracle as TO
 
@@ -117,23 +118,23 @@ def test_ge2e_loss_and_known_answer():
 _ZERO_GRAD = ("conv1.bias", "hc.conv.bias", "conv2.bias", "conv3.bias", "conv4.bias", "conv5.bias")
 
 
-def _critic_grads_agree(module, want, tol):
-    for k, p in module.named_parameters():
+def _critic_grads_agree(sd, want, tol):
+    for k, p in sd.items():
         if k in _ZERO_GRAD:
             continue
         a, b = p.grad.detach().cpu().double(), want[k].double()
+        if float(b.norm()) == 0.0:         # exactly cancelling terms (e.g. the last LayerNorm's bias when no leaky-ReLU changes sign)
+            assert float(a.norm()) < 1e-6, k
+            continue
         assert float((a - b).norm() / b.norm()) < tol, (k, float((a - b).norm() / b.norm()))
 
 
 def test_adversarial_iteration_golden_cpu():
-    """G8: the oracle generator + this repo's critic (stock ops) reproduce the reference's G and D iterations."""
-    import torch.nn.functional as F
-    from spoofsv_amd.critic import melDisc
+    """G8: the oracle generator + the oracle critic reproduce the reference's G and D iterations (critic in eval mode)."""
     g = load("adversarial_iter.npz")
     sd = {n: v.clone().requires_grad_(True) for n, v in sub(g, "m0/").items()}
-    d = melDisc(80, 16)
-    d.load_state_dict(sub(g, "d0/"))
-    d.eval()
+    dsd = {n: v.clone().requires_grad_(True) for n, v in sub(g, "d0/").items()}
+    d = lambda x: CO.critic(x, dsd, "mel", masks=False)
     mel, text, spk, gaw = t(g["mel_gt"]), t(g["text"]), t(g["spk"]), t(g["gaw"])
     mel_in = torch.cat((torch.zeros_like(mel[:, :, :1]), mel[:, :, :-1]), dim=-1)
     opt = torch.optim.Adam(list(sd.values()), 2e-4, (0.5, 0.9), 1e-6)
@@ -148,22 +149,43 @@ def test_adversarial_iteration_golden_cpu():
     m1 = sub(g, "m1/")
     assert max(float((sd[k].detach() - m1[k]).abs().max()) for k in m1) < 1e-5      # 5 % of one Adam step (lr 2e-4)
     # D iteration with the stored interpolation coefficients
-    od = torch.optim.Adam(d.parameters(), 2e-4, (0.5, 0.9), 1e-6)
     sd1 = {k: v.clone() for k, v in m1.items()}
     with torch.no_grad():
         pred, _ = TO.melsyn_train(mel_in, text, spk, sd1)
-    d.zero_grad()          # the G iteration left gradients on the critic; the reference zeroes both optimizers (:264-265)
-    coeff = t(g["coeff"]).view(-1, 1, 1)
-    mid = (coeff * mel + (1 - coeff) * pred).requires_grad_(True)
-    out = d(mid)
-    grads = torch.autograd.grad(out, mid, torch.ones_like(out), retain_graph=True, create_graph=True)[0]
-    gp = torch.mean(10 * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
+    for v in dsd.values():
+        v.grad = None      # the G iteration left gradients on the critic; the reference zeroes both optimizers (:264-265)
+    gp, loss_d = CO.critic_losses(pred, mel, t(g["coeff"]), dsd, "mel", 10.0, masks=False)
     gp.backward()
-    loss_d = torch.mean(d(pred) - d(mel))
     loss_d.backward()
     assert abs(float(gp) - float(g["d_gp"])) < 1e-5 * max(1.0, abs(float(g["d_gp"])))
     assert abs(float(loss_d) - float(g["d_loss"])) < 1e-6 * max(1.0, abs(float(g["d_loss"])))
-    _critic_grads_agree(d, sub(g, "dgrad/"), 1e-4)
+    _critic_grads_agree(dsd, sub(g, "dgrad/"), 1e-4)
+
+
+def test_critic_iteration_with_dropout_active():
+    """G11: the reference's melDisc and linDisc in TRAINING mode (the only mode the reference runs them in): with the
+    stored seed the oracle draws the same dropout masks at the same sites, so the first call's output, its input gradient,
+    both losses and every critic gradient (penalty double-backward included) must reproduce."""
+    g = load("critic_dropout.npz")
+    for kind in ("mel", "lin"):
+        dsd = {n: v.clone().requires_grad_(True) for n, v in sub(g, kind + "/sd/").items()}
+        gt, pred, coeff = t(g[kind + "/gt"]), t(g[kind + "/pred"]), t(g[kind + "/coeff"])
+        torch.manual_seed(int(g[kind + "/seed"]))
+        drawn = []
+        gp, loss_d = CO.critic_losses(pred, gt, coeff, dsd, kind, 10.0, masks=None, drawn=drawn)
+        assert len(drawn) == 9 and all(0.0 < float((m == 0).float().mean()) < 0.15 for m in drawn[:2])     # p = 0.05 zeros
+        gp.backward()
+        loss_d.backward()
+        assert abs(float(gp) - float(g[kind + "/gp"])) < 1e-5 * max(1.0, abs(float(g[kind + "/gp"])))
+        assert abs(float(loss_d) - float(g[kind + "/loss_d"])) < 1e-6 * max(1.0, abs(float(g[kind + "/loss_d"])))
+        _critic_grads_agree(dsd, sub(g, kind + "/grad/"), 1e-4)
+        # the same masks injected reproduce the first call and its input gradient exactly
+        c = coeff.view(-1, 1, 1)
+        mid = (c * gt + (1 - c) * pred).requires_grad_(True)
+        out = CO.critic(mid, dsd, kind, masks=drawn[:3])
+        assert rel_err(out, t(g[kind + "/out_mid"])) < 1e-6
+        dmid, = torch.autograd.grad(out, mid, torch.ones_like(out))
+        assert rel_err(dmid, t(g[kind + "/dmid"])) < 1e-5
 
 
 def test_ge2e_training_iteration():

@@ -27,6 +27,7 @@ for (B, C, L) in [(32, 512, 186), (32, 256, 325), (32, 256, 650), (32, 256, 1300
     for G in os.environ.get("BENCH_LN_GROUPS", "16,32,64").split(","):      # "auto" = the library's own choice
         if G == "auto": os.environ.pop("SSV_LN_GROUPS", None)
         else: os.environ["SSV_LN_GROUPS"] = G
+        _lib.lib().ssv_reload_tuning()
         f = lambda: _lib.call("ssv_channel_ln_act_fwd", P(x), C * L, P(g), P(b), P(y), C * L, P(stats), B, C, L, 1, None, 0, st)
         bw = lambda: _lib.call("ssv_channel_ln_act_bwd", P(dy), C * L, P(x), C * L, P(stats), P(g), P(b), P(dx), C * L, P(pg), B, C, L, 1, P(ws), nb, st)
         tf, tb = timeit(f), timeit(bw)

@@ -20,6 +20,7 @@ for (B, Cin, Cout, L, k, d) in SHAPES:
         os.environ.pop("SSV_NNB_WIDE", None); os.environ.pop("SSV_NNB_TILE", None)
         if cfg[0] == "w": os.environ["SSV_NNB_WIDE"] = cfg[1:]
         if cfg[0] == "t": os.environ["SSV_NNB_TILE"] = cfg[1:]; os.environ["SSV_NNB_WIDE"] = "0,0,0"
+        _lib.lib().ssv_reload_tuning()
         run = lambda i: _lib.call("ssv_conv1d_fwd", P(xs[i % 8]), Cin * L, P(w), resident.lookup(w), None, None, P(ys[i % 8]), Cout * L, B, Cin, Cout, L, k, d, 0, P(ws), nb, st)
         for i in range(3): run(i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

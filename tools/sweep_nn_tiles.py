@@ -24,6 +24,7 @@ for (B, Cin, Cout, L, k) in SHAPES:
     for cfg in ["auto"] + ["%d,%d" % (wm, nt) for wm in (1, 2) for nt in (2, 4, 6, 7, 8)]:
         if cfg == "auto": os.environ.pop("SSV_NN_TILE", None); os.environ.pop("SSV_NNB_TILE", None)
         else: os.environ["SSV_NN_TILE"] = cfg; os.environ["SSV_NNB_TILE"] = cfg
+        _lib.lib().ssv_reload_tuning()
         run = lambda: _lib.call("ssv_conv1d_fwd", P(x), Cin * L, P(w), None, None, None, P(y), Cout * L, B, Cin, Cout, L, k, 1, 0, P(ws), nb, st)
         for _ in range(3): run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -32,6 +32,7 @@ for (B, Cin, Cout, L, k) in SHAPES:
         for kk, v in (("SSV_NT_PLAN", plan), ("SSV_NT_Z", z)):
             if v is None: os.environ.pop(kk, None)
             else: os.environ[kk] = v
+        _lib.lib().ssv_reload_tuning()            # the library reads its knobs once; tell it they changed
         nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, Cin, Cout, k)
         ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
         run = lambda: _lib.call("ssv_conv1d_bwd_weight", P(dy), Cout * L, P(x), Cin * L, P(dw), B, Cin, Cout, L, k, 1, 0, P(ws), nb, st)

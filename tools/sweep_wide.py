@@ -17,6 +17,7 @@ for (B, Cin, Cout, L, k) in SHAPES:
         os.environ.pop("SSV_NNB_WIDE", None); os.environ.pop("SSV_NNB_TILE", None)
         if cfg[0] == "w": os.environ["SSV_NNB_WIDE"] = cfg[1:]
         if cfg[0] == "t": os.environ["SSV_NNB_TILE"] = cfg[1:]; os.environ["SSV_NNB_WIDE"] = "0,0,0"
+        _lib.lib().ssv_reload_tuning()
         run = lambda: _lib.call("ssv_conv1d_fwd", P(x), Cin * L, P(w), None, None, None, P(y), Cout * L, B, Cin, Cout, L, k, 1, 0, P(ws), nb, st)
         for _ in range(3): run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
