@@ -64,6 +64,7 @@ int ssv_launch_ln_gate_fwd(const float*, long, const float*, long, const float*,
 int ssv_launch_ln_gate_bwd(const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*, const float*, float*, float*, long, float*, float*, int, int, int, hipStream_t);
 int ssv_ln_gate_bwd_nblk(int B, int L);
 int ssv_launch_ln_bwd2(const float*, long, const float*, long, const float*, long, const float*, const float*, float*, long, float*, long, float*, float*, int, int, int, hipStream_t);
+int ssv_reduce_partial_rows(const float* part, float* out, int n, int nblk, hipStream_t st);
 int ssv_launch_ln_gate_bwd2(const float*, const float*, long, const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*,
                             const float*, float*, long, float*, float*, long, float*, float*, int, int, int, hipStream_t);
 int ssv_launch_ln_act_fwd(const float*, long, const float*, const float*, float*, long, float*, int, int, int, int, hipStream_t);
@@ -248,9 +249,17 @@ static int dw_splits(int B, int M, int Nc, int k) {
 extern "C" size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int k) {
   return align256((size_t)dw_splits(B, Cout, Cin, k) * Cout * Cin * k * sizeof(float));
 }
+// part / pgrads / n2 / nblk: partial rows of another reduction (the LayerNorm / bias gradients of the same layer) summed by the
+// SAME launch that sums the weight-gradient slabs (highwayConv backward); part == nullptr: weight gradient only.
+static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, int B, int Cin, int Cout, int L, int k, int dilation,
+                                  int causal, void* ws, size_t ws_bytes, ssv_stream_t stream, const float* part, float* pgrads, int n2, int nblk);
 extern "C" int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* x, long x_bs, float* dw,
                                      int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                                      void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  return conv1d_bwd_weight_impl(dy, dy_bs, x, x_bs, dw, B, Cin, Cout, L, k, dilation, causal, ws, ws_bytes, stream, nullptr, nullptr, 0, 0);
+}
+static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, int B, int Cin, int Cout, int L, int k, int dilation,
+                                  int causal, void* ws, size_t ws_bytes, ssv_stream_t stream, const float* part, float* pgrads, int n2, int nblk) {
   SSV_CHECK(dy && x && dw && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_weight: bad argument");
   SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_bwd_weight: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -265,6 +274,10 @@ extern "C" int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* x
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
   if (ssv_precision() == 1 && (long)B * L >= 256 && ssv_nt_bf3_fits(g)) SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
   else SSV_TRY(ssv_launch_gemm_nt(g, st));
+  if (part) {
+    if (Z > 1 && nblk <= 768) return ssv_launch_reduce_pair((const float*)ws, dw, Cout, Cin, k, Z, part, pgrads, n2, nblk, st);
+    SSV_TRY(ssv_reduce_partial_rows(part, pgrads, n2, nblk, st));
+  }
   if (Z > 1) SSV_TRY(ssv_launch_reduce_slabs_perm((const float*)ws, dw, Cout, Cin, k, Z, st));
   return 0;
 }
@@ -361,10 +374,12 @@ extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* 
   char* base = (char*)ws;
   float* dH = (float*)(base + s.dh);
   // gate + both LayerNorms backward: dH (B,2C,L), the residual-path gradient dy*(1-g) into dx, parameter partials
-  SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, (float*)(base + s.part), pgrads, B, C, L, (hipStream_t)stream));
+  // (its partial rows are summed at the end, by the launch that also sums the weight-gradient slabs)
+  SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, (float*)(base + s.part), nullptr, B, C, L, (hipStream_t)stream));
   // dx += conv^T(dH)
   SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
-  return ssv_conv1d_bwd_weight(dH, (long)2 * C * L, x, x_bs, dw, B, C, 2 * C, L, k, dilation, causal, base + s.slabs, s.total - s.slabs, stream);
+  return conv1d_bwd_weight_impl(dH, (long)2 * C * L, x, x_bs, dw, B, C, 2 * C, L, k, dilation, causal, base + s.slabs, s.total - s.slabs, stream,
+                                (const float*)(base + s.part), pgrads, 6 * C, ssv_ln_gate_bwd_nblk(B, L));
 }
 
 // ---- attention -------------------------------------------------------------------------------------------

@@ -508,6 +508,8 @@ static int reduce_partials(float* part, float* out, int n, int nblk, hipStream_t
   return ssv_check_launch("reduce_partials_l2");
 }
 
+int ssv_reduce_partial_rows(const float* part, float* out, int n, int nblk, hipStream_t st) { return reduce_partials((float*)part, out, n, nblk, st); }
+
 // ------------------------------------------------------------------------------------------------
 // G = channel groups per 16-column tile (workgroup = 16 * G threads), CPT = channels per thread = ceil(C / G).
 // Measured (tools/bench_ln.py, B = 32): up to 256 channels 16 groups are best at every length; 512 channels run 15-25 %
@@ -553,6 +555,7 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
   LN_DISPATCH(true, C, L, CALL);
 #undef CALL
   SSV_TRY(ssv_check_launch("ln_gate_bwd"));
+  if (!pgrads) return 0;        // the caller sums the partial rows itself (fused with the weight-gradient slab sum)
   return reduce_partials(part, pgrads, 6 * C, (int)(grid.x * grid.y), st);
 }
 

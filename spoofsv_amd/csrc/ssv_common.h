@@ -93,6 +93,7 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 // ---- small helpers (misc.hip) ---------------------------------------------------------
 int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long slab_stride, hipStream_t st);
 int ssv_launch_reduce_slabs_perm(const float* slabs, float* out, int M, int Nc, int KT, int Z, hipStream_t st);
+int ssv_launch_reduce_pair(const float* slabs, float* out, int M, int Nc, int KT, int Z, const float* part, float* pout, int n2, int nblk, hipStream_t st);
 int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hipStream_t st);
 int ssv_launch_fill(float* p, float v, long n, hipStream_t st);
 

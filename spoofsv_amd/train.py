@@ -445,11 +445,12 @@ class PhasedStep:
     (RCCL collectives, which stay outside captures) are called between the replays.  ``graph=False`` runs everything
     eagerly, same order."""
 
-    def __init__(self, phases, graph=True, warmup=2):
+    def __init__(self, phases, graph=True, warmup=2, drain=None):
         self.phases = phases
         self.use_graph = graph
         self.plan = None
         self.warmup = warmup
+        self.drain = drain        # called after every eager phase WHILE CAPTURING: waits for the collectives it started
 
     def _eager(self):
         for _, fn in self.phases:
@@ -471,6 +472,11 @@ class PhasedStep:
             kind, fn = self.phases[i]
             if kind == "eager":
                 fn()
+                # nothing of this collective may still be running when the next capture begins: communication back ends
+                # work from threads of their own (gloo copies and synchronises there; RCCL's watchdog polls events)
+                if self.drain is not None:
+                    self.drain()
+                torch.cuda.synchronize()
                 plan.append(fn)
                 i += 1
                 continue
@@ -478,7 +484,9 @@ class PhasedStep:
             while j < len(self.phases) and self.phases[j][0] == "graph":
                 j += 1
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            # thread_local: only THIS thread's calls are checked against the capture; the communication back end's helper
+            # threads (see above) may touch the device while a later iteration's capture is in progress
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 for _, f in self.phases[i:j]:
                     f()
             plan.append(g.replay)
@@ -529,7 +537,7 @@ class TrainStep:
         elif ddp is not None:
             phases.append(("eager", ddp.all_reduce_grads))
         phases.append(("graph", self._adam))
-        self.stepper = PhasedStep(phases, graph=graph)
+        self.stepper = PhasedStep(phases, graph=graph, drain=ddp.finish if ddp is not None else None)
 
     def _forward_seg0(self):
         self.opt.zero_grad(set_to_none=True)
@@ -651,8 +659,12 @@ class AdversarialGraphStep:
         else:
             d_phases = [("graph", self._d_compute), ("graph", self._d_pack), ("eager", lambda: (ddp_disc.exchange(), ddp_disc.finish())),
                         ("graph", self._d_unpack_step)]
-        self.g_stepper = PhasedStep(g_phases, graph=graph)
-        self.d_stepper = PhasedStep(d_phases, graph=graph)
+        def drain():
+            for d in (ddp_syn, ddp_disc):
+                if d is not None:
+                    d.finish()
+        self.g_stepper = PhasedStep(g_phases, graph=graph, drain=drain)
+        self.d_stepper = PhasedStep(d_phases, graph=graph, drain=drain)
         if graph:
             # warm up both kinds alternately (as the training loop runs them), then capture
             s = torch.cuda.Stream()

@@ -116,13 +116,25 @@ def _spawn(target, args, world=2):
     q = ctx.Queue()
     port = 35500 + (os.getpid() % 2000)
     procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    import queue
+    import time
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    res, t0 = [], time.time()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > 280:                  # a rank died (its traceback is in the captured stderr) or hangs
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("rank process failed: exit codes %s after %.0f s" % ([p.exitcode for p in procs], time.time() - t0))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    return res
+    return sorted(res, key=lambda r: r[0])
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -189,7 +201,11 @@ def _adv_run(kind, m, d, batch, gaw, ddp_syn, ddp_disc, graph):
             o._step_dev.zero_()
             o.refresh_resident_weights()
     g_out = [float(v) for v in st.g_step()]
-    g_grads = _grads(m)
+    torch.cuda.synchronize()
+    if ddp_syn is not None:       # replayed graphs do not touch the Python-side .grad attributes: the gradients live in the arena
+        g_grads = {k: ddp_syn.arena.slot(p).detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+    else:
+        g_grads = _grads(m)
     d_out = [float(v) for v in st.d_step()]
     torch.cuda.synchronize()
     d_grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in d.named_parameters()}

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import load, sub, t, rel_err
+from _golden import load, sub, t, rel_err, rel_l2, worst_elementwise
 from oracle import ge2e_oracle as GO
 from oracle import tts_oracle as TO
 
@@ -65,9 +65,10 @@ def test_melsyn_train_golden():
     (l1 + bd + att).backward()
     bad = {}
     for n, gr in sub(g, "grad/").items():
-        e = rel_err(dict(m.named_parameters())[n].grad, gr)
-        if e > BWD_TOL:
-            bad[n] = e
+        got = dict(m.named_parameters())[n].grad
+        e, e2 = rel_err(got, gr), rel_l2(got, gr)
+        if e > BWD_TOL or e2 > 2 * BWD_TOL:            # max-norm AND relative L2: the bulk of small entries counts too
+            bad[n] = (e, e2)
     assert not bad, bad
 
 
@@ -127,12 +128,13 @@ def test_incremental_synthesis_matches_prefix_loop(condition, B, N, frames):
         Y0, A0 = harness._free_run(m, text, spk, frames, 80)
         Y1, A1 = synth.free_run_incremental(m, text, spk, frames)
     top = A0.topk(2, dim=1).values
-    decisive = bool(((top[:, 0] - top[:, 1]) > 1e-4).all())          # random tiny models can produce near ties
-    if decisive:
-        assert torch.equal(A0.argmax(1), A1.argmax(1))
+    near_tie = ((top[:, 0] - top[:, 1]) <= 1e-4).any(0)              # per frame, over the batch: random tiny models can produce near ties
+    cut = int(near_tie.nonzero()[0]) if near_tie.any() else frames   # frames before the first near tie cannot have forked
+    assert cut >= 1
+    assert torch.equal(A0.argmax(1)[:, :cut], A1.argmax(1)[:, :cut])
+    assert rel_err(Y1[:, :, :cut + 1], Y0[:, :, :cut + 1]) < 2e-4 and rel_err(A1[:, :, :cut + 1], A0[:, :, :cut + 1]) < 2e-4
+    if cut == frames:
         assert rel_err(Y1, Y0) < 2e-4 and rel_err(A1, A0) < 2e-4
-    else:
-        assert rel_err(Y1[:, :, 0], Y0[:, :, 0]) < 2e-4                # the first frame has no history to fork on
 
 
 def test_column_step_kernels_match_full_sequence_ops():
@@ -327,6 +329,25 @@ def test_ge2e_embedder_midsize_vs_oracle():
     assert rel_err(eg, eo) < 1e-4, rel_err(eg, eo)
 
 
+def test_ge2e_embedder_full_width_production_tiles_vs_oracle(precision):
+    """The embedder at its real width (hidden 768, projection 256, GE2E/config/config.yaml) on enough utterances that the
+    LSTM wavefront takes its production tile rule (128 x 64 tiles need cdiv(3072,128) * cdiv(N,64) * layers >= 512, i.e.
+    N >= 641 utterances in the steady state with 2-3 layers per launch; 704 utterances x 12 frames here) vs the CPU oracle."""
+    from spoofsv_amd.ge2e import SpeechEmbedder
+    torch.manual_seed(0)
+    m = SpeechEmbedder()
+    assert m.LSTM_stack.hidden_size == 768 and m.projection.out_features == 256
+    n = 704
+    assert (3072 // 128) * ((n + 63) // 64) * 2 >= 512
+    x = torch.randn(n, 12, 40)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    with torch.no_grad():
+        eo = GO.speech_embedder(x, m.state_dict())
+    eg = m.to(DEV).eval()(x.to(DEV))
+    tol = 2e-5 if precision == "fp32" else 1e-4
+    assert rel_err(eg, eo) < tol and rel_l2(eg, eo) < tol, (rel_err(eg, eo), rel_l2(eg, eo))
+
+
 def test_ge2e_loss_golden_and_known_answer():
     from spoofsv_amd.ge2e import GE2ELoss
     g = load("ge2e_loss.npz")
@@ -463,14 +484,106 @@ def test_ge2e_backward_edge_shapes_vs_oracle(layers, T):
         assert (p.grad.cpu() - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-6, (k, float((p.grad.cpu() - ref).abs().max()), float(ref.abs().max()))
 
 
-def test_config2_synthesize_full_size_vs_oracle(precision):
-    """BASELINE config 2: Text2Mel free-running synthesis of the first Harvard sentence + SSRN, full-size models with
-    seeded random weights (no trained checkpoint exists offline), one speaker code; GPU vs the CPU oracle.
-    Spectrograms within 1e-3 relative; attention indices exact wherever the oracle's top-2 margin exceeds the
-    arithmetic noise (the recorded minimum margin is asserted so the check cannot pass vacuously)."""
+_BENCH_ORACLE = {}
+
+
+def _bench_workload_oracle(kind, B):
+    """The bench workload (BASELINE config 3 shapes: hidden 256, N=186, T=325, 80 -> 513 x 1300) on the CPU oracle: forward,
+    the reference's losses, backward.  Computed once per session and shared by the two precision runs."""
+    key = (kind, B)
+    if key in _BENCH_ORACLE:
+        return _BENCH_ORACLE[key]
+    from spoofsv_amd import train
+    from spoofsv_amd.tts import SSRN, melSyn
+    torch.manual_seed(1234)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    if kind == "text2mel":
+        m = melSyn(34, True, 200, 128, 80, 256)
+        batch = train.synthetic_text2mel_batch(B, 186, 325, seed=0)
+        gaw = train.guided_attention_mat(186, 325)
+    else:
+        m = SSRN(80, 513, 256)
+        batch = train.synthetic_ssrn_batch(B, 325, seed=0)
+        gaw = None
+    m.apply(train.init_weights)
+    with torch.no_grad():                                  # LayerNorm affine parameters away from (1, 0): their gradients get exercised
+        gen = torch.Generator().manual_seed(7)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.LayerNorm):
+                mod.weight.add_(0.2 * torch.randn(mod.weight.shape, generator=gen))
+                mod.bias.add_(0.2 * torch.randn(mod.bias.shape, generator=gen))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    if kind == "text2mel":
+        mel, text, spk = batch
+        Y, A = TO.melsyn_train(train.shift_right(mel), text, spk, sd)
+        losses = TO.text2mel_losses(Y, A, mel, gaw)
+        outs = {"Y": Y.detach(), "A": A.detach()}
+    else:
+        mel, lin = batch
+        Y = TO.ssrn(mel, sd)
+        losses = TO.ssrn_losses(Y, lin)
+        outs = {"Y": Y.detach()}
+    sum(losses).backward()
+    rec = dict(model=m, batch=batch, gaw=gaw, outs=outs, losses=[float(l) for l in losses], grads={k: v.grad.detach() for k, v in sd.items()})
+    _BENCH_ORACLE[key] = rec
+    return rec
+
+
+@pytest.mark.parametrize("kind", ["text2mel", "ssrn"])
+def test_bench_workload_full_size_training_step_vs_oracle(kind, precision):
+    """The benchmark's own workload -- full width (hidden 256 / 512 / 513 channels), full depth (28 / 8 highway layers), full
+    length (N=186, T=325 -> 1300), B=8 utterances (B*L up to 10,400 columns per launch: the production tile choices, the wide
+    k=1 kernel, the batched weight-gradient slabs all fire) -- forward, the reference's losses and backward on the HIP path
+    against the CPU oracle.  This is where split-bf16 rounding accumulates through the stacked layers.  Bars (north_star: 1e-3
+    relative): outputs max-norm and L2; losses 1e-5; EVERY parameter gradient relative L2 <= 1e-3 and max-norm <= 1e-3, in
+    both arithmetic modes; plus an element-wise bound on the largest gradient tensors."""
+    from spoofsv_amd import ops, train
+    B = 8
+    o = _bench_workload_oracle(kind, B)
+    m = o["model"].to(DEV).train()
+    for p in m.parameters():
+        p.grad = None
+    if kind == "text2mel":
+        mel, text, spk = [b.to(DEV) for b in o["batch"]]
+        Y, A = m(train.shift_right(mel), text, spk)
+        l = train.text2mel_losses(Y, A, mel, o["gaw"].to(DEV))
+        assert rel_err(A, o["outs"]["A"]) < 1e-3 and rel_l2(A, o["outs"]["A"]) < 1e-3, (rel_err(A, o["outs"]["A"]), rel_l2(A, o["outs"]["A"]))
+    else:
+        mel, lin = [b.to(DEV) for b in o["batch"]]
+        Y = m(mel)
+        l = ops.spec_losses(Y, lin)
+    assert rel_err(Y, o["outs"]["Y"]) < 1e-3 and rel_l2(Y, o["outs"]["Y"]) < 1e-3, (rel_err(Y, o["outs"]["Y"]), rel_l2(Y, o["outs"]["Y"]))
+    for mine, ref in zip(l, o["losses"]):
+        assert abs(float(mine) - ref) < 1e-5 * max(1.0, abs(ref)), (float(mine), ref)
+    sum(l).backward()
+    torch.cuda.synchronize()
+    bad = {}
+    for k, p in m.named_parameters():
+        ref = o["grads"][k]
+        e2, em = rel_l2(p.grad, ref), rel_err(p.grad, ref)
+        if e2 > 1e-3 or em > 1e-3:
+            bad[k] = (e2, em)
+    assert not bad, bad
+    big = sorted(((p.numel(), k) for k, p in m.named_parameters()), reverse=True)[:6]
+    for _, k in big:        # element-wise: every entry within 5 % of itself, or of 5 % of the tensor's RMS for entries near zero
+        w = worst_elementwise(dict(m.named_parameters())[k].grad, o["grads"][k], floor=5e-2)
+        assert w < 5e-2, (k, w)
+    m.cpu()
+    for p in m.parameters():
+        p.grad = None
+
+
+_CONFIG2 = {}
+
+
+def _config2_oracle():
+    """BASELINE config 2 on the CPU oracle, computed once per session (the reference loop is O(T^2): ~1 min for 326 frames):
+    first Harvard sentence, speaker code 0.06, full-size seeded models, 1 + 325 decode steps."""
+    if _CONFIG2:
+        return _CONFIG2
     from spoofsv_amd import harness, train
     from spoofsv_amd.tts import SSRN, melSyn
-    steps = 96                                            # 97 frames: bounded so the O(T^2) CPU oracle stays ~10 s
+    steps = 325                                           # generate_test_utterances.py:108-116: MAX_FRAME_NUM further steps -> 326 frames
     vocab = "PE abcdefghijklmnopqrstuvwxyz-,.?'" + '"'
     ids = torch.tensor(harness.text2id("The birch canoe slid on the smooth planks.", vocab)).view(1, 1, -1)
     assert ids.shape[-1] == 43
@@ -486,11 +599,42 @@ def test_config2_synthesize_full_size_vs_oracle(precision):
     torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
     with torch.no_grad():
         Yo, Ao, pma_o = TO.synthesize_loop(ids, spk, sd1, steps)
-        lin_o = TO.ssrn(Yo, sd2)
         top = torch.topk(Ao, 2, dim=1).values
         margins = (top[:, 0] - top[:, 1])[0]               # per generated frame
-    m1, m2 = m1.to(DEV).eval(), m2.to(DEV).eval()
-    idg, spg = ids.to(DEV), spk.to(DEV)
+    _CONFIG2.update(steps=steps, ids=ids, spk=spk, m1=m1, m2=m2, sd2=sd2, Yo=Yo, Ao=Ao, pma_o=pma_o, margins=margins)
+    return _CONFIG2
+
+
+def _config2_check(c, Y, pma_g, m2, frames, tag):
+    """Indices must agree up to the first indecisive column (after one, trajectories may legitimately fork); the mel and linear
+    spectrograms are ALWAYS compared on the frames before the point where either the indices first differ or the oracle's
+    own top-2 margin drops under the arithmetic noise -- the encoder and decoder are causal, so those frames are final."""
+    margins, pma_o, Yo = c["margins"][:frames], c["pma_o"][:frames], c["Yo"][:, :, :frames]
+    safe = margins > 1e-3
+    assert int(safe.sum()) >= frames // 2, "too few decisive attention columns for a meaningful index check"
+    first_bad = next((i for i in range(frames) if not torch.equal(pma_g[i], pma_o[i])), None)
+    limit = int((~safe).nonzero()[0]) if (~safe).any() else frames
+    assert first_bad is None or first_bad >= limit, (tag, first_bad, limit, float(margins.min()))
+    cut = limit if first_bad is None else min(first_bad, limit)
+    assert cut >= 16, (tag, "the comparable prefix is too short to mean anything", cut)
+    assert rel_err(Y[:, :, :cut], Yo[:, :, :cut]) < 1e-3, (tag, cut, rel_err(Y[:, :, :cut], Yo[:, :, :cut]))
+    with torch.no_grad():
+        lin_o = TO.ssrn(Yo[:, :, :cut], c["sd2"])          # SSRN is not causal: run both arms on the same comparable prefix
+        lin = m2(Y[:, :, :cut].contiguous())
+    assert rel_err(lin, lin_o) < 1e-3 and rel_l2(lin, lin_o) < 1e-3, (tag, cut, rel_err(lin, lin_o), rel_l2(lin, lin_o))
+    return cut
+
+
+def test_config2_synthesize_full_size_vs_oracle(precision):
+    """BASELINE config 2: Text2Mel free-running synthesis of the first Harvard sentence + SSRN, full-size models with
+    seeded random weights (no trained checkpoint exists offline), one speaker code; GPU vs the CPU oracle.
+    Spectrograms within 1e-3 relative on every frame before the first indecisive attention column; attention indices exact
+    up to there (the recorded minimum margin is asserted so the check cannot pass vacuously).  The reference's own call
+    sequence (whole prefix per step, O(T^2)) runs 97 frames; the column-incremental path runs ALL 326 frames of config 2."""
+    c = _config2_oracle()
+    m1, m2 = c["m1"].to(DEV).eval(), c["m2"].to(DEV).eval()
+    idg, spg = c["ids"].to(DEV), c["spk"].to(DEV)
+    steps = 96
     with torch.no_grad():
         init = torch.zeros(1, 80, 1, device=DEV)
         Y, A, pma, K, V = m1(melspec=init, textid=idg, spkemb=spg, pma=torch.zeros(1, device=DEV).long())
@@ -500,28 +644,16 @@ def test_config2_synthesize_full_size_vs_oracle(precision):
             Y, A, pma = m1(melspec=inputs, textid=None, spkemb=spg, K=K, V=V, A_last=A, pma=pma)
             inputs = torch.cat((inputs, Y[:, :, -1:]), dim=-1)
             seq.append(pma.clone())
-        lin = m2(Y)
-    pma_g = torch.stack(seq).cpu()
-    safe = margins > 1e-3
-    assert int(safe.sum()) >= steps // 2, "too few decisive attention columns for a meaningful index check"
-    first_bad = None
-    for i in range(steps + 1):
-        if not torch.equal(pma_g[i], pma_o[i]):
-            first_bad = i
-            break
-    # indices must agree at least up to the first indecisive column (after one, trajectories may legitimately fork)
-    limit = int((~safe).nonzero()[0]) if (~safe).any() else steps + 1
-    assert first_bad is None or first_bad >= limit, (first_bad, limit, float(margins.min()))
-    if first_bad is None:
-        assert rel_err(Y, Yo) < 1e-3 and rel_err(lin, lin_o) < 1e-3, (rel_err(Y, Yo), rel_err(lin, lin_o))
-    # the same run on the column-incremental path (one new column per step, spoofsv_amd/synth.py)
+    _config2_check(c, Y.cpu(), torch.stack(seq).cpu(), lambda y: m2(y.to(DEV)).cpu(), steps + 1, "prefix loop")
+    # the same run on the column-incremental path (one new column per step, spoofsv_amd/synth.py): all 326 frames
     from spoofsv_amd import synth
-    Yi, Ai = synth.free_run_incremental(m1, idg, spg, steps + 1)
+    frames = c["steps"] + 1
+    with torch.no_grad():
+        Yi, Ai = synth.free_run_incremental(m1, idg, spg, frames)
     pma_i = Ai.argmax(1).t().cpu()                                  # frame t's arg-max is pma after step t
-    first_bad = next((i for i in range(steps + 1) if not torch.equal(pma_i[i], pma_o[i])), None)
-    assert first_bad is None or first_bad >= limit, (first_bad, limit, float(margins.min()))
-    if first_bad is None:
-        assert rel_err(Yi, Yo) < 1e-3 and rel_err(m2(Yi), lin_o) < 1e-3, (rel_err(Yi, Yo),)
+    assert tuple(Yi.shape) == (1, 80, 326)
+    _config2_check(c, Yi.cpu(), pma_i, lambda y: m2(y.to(DEV)).cpu(), frames, "incremental")
+    m1.cpu(); m2.cpu()
 
 
 @pytest.mark.parametrize("B,C,L,k,d,causal", [
