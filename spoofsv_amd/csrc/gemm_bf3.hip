@@ -176,12 +176,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   }
   const long aplane = (long)MB * nchunks_all * 512;
 
+  // uniform byte base (batch item / layer, tap, chunk) + a per-lane 32-bit byte offset: the saddr form of global_load
+  unsigned arowb[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) arowb[i] = (unsigned)(arow[i] * 2);
   auto loadA = [&](int set, int j, int ch) {
+    const long ub = ((long)b * p.sab + j * aplane + (long)ch * 512) * 2;                                  // wave-uniform
+    const char* __restrict__ hb = reinterpret_cast<const char*>(p.Ahi) + ub;
+    const char* __restrict__ lb = reinterpret_cast<const char*>(p.Alo) + ub;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-      const long off = (long)b * p.sab + j * aplane + arow[i] + ch * 512;
-      Ah_[set][j][i] = *reinterpret_cast<const uint4*>(p.Ahi + off);
-      Al_[set][j][i] = *reinterpret_cast<const uint4*>(p.Alo + off);
+      Ah_[set][j][i] = *reinterpret_cast<const uint4*>(hb + arowb[i]);
+      Al_[set][j][i] = *reinterpret_cast<const uint4*>(lb + arowb[i]);
     }
   };
   // Input staging, two halves.  prefetchX only ISSUES loads (raw values, addresses clamped into the batch item so every
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   //   [Xb + (ch*32 + i)*L]  (wave-uniform, scalar ALU)  +  [8*kg*L + column]  (per thread, computed once),
   // and the column mask is computed once; only a ragged last chunk (Kc % 32 != 0) needs per-channel clamps and masks.
   const int Lrow = (int)p.sxc;
-  unsigned voff[NX];
+  unsigned voff[NX], voffb[NX];
   bool cvs[NX];
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
@@ -200,15 +206,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     const int gcol = n0 + smin + col;
     cvs[r] = e < X_SLOTS && col < W && gcol >= 0 && gcol < p.Lx;
     voff[r] = (unsigned)((e < X_SLOTS ? 8 * kg : 0) * Lrow + min(max(gcol, 0), p.Lx - 1) * p.sxn);
-  }
+    voffb[r] = voff[r] * 4u;           // BYTE offset: a zero-extended 32-bit VGPR offset off a uniform base is the saddr form of
+  }                                    // global_load (no 64-bit VALU address per load, no VGPR pair per address)
   const bool ragged = (p.Kc & 31) != 0;
   auto prefetchX = [&](int ch) {
     if (!ragged || ch + 1 < nchunks) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float* __restrict__ rowp = ((EPI == 1 && X2b && ch >= p.xsplit) ? X2b : Xb) + (long)(ch * 32 + i) * Lrow;     // uniform
+        const char* __restrict__ rowp = (const char*)(((EPI == 1 && X2b && ch >= p.xsplit) ? X2b : Xb) + (long)(ch * 32 + i) * Lrow);     // uniform
 #pragma unroll
-        for (int r = 0; r < NX; ++r) rx[r][i] = rowp[voff[r]];
+        for (int r = 0; r < NX; ++r) rx[r][i] = *reinterpret_cast<const float*>(rowp + voffb[r]);
       }
     } else {                                                                   // last, partial chunk: clamp channels
 #pragma unroll
@@ -465,9 +472,9 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
     if (!ragged || ch + 1 < nchunks) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float* __restrict__ rowp = Xb + (long)(ch * 32 + i) * Lrow;     // wave-uniform
+        const char* __restrict__ rowp = reinterpret_cast<const char*>(Xb + (long)(ch * 32 + i) * Lrow);     // wave-uniform
 #pragma unroll
-        for (int r = 0; r < NX; ++r) rx[r][i] = rowp[voff[r]];
+        for (int r = 0; r < NX; ++r) rx[r][i] = *reinterpret_cast<const float*>(rowp + voff[r] * 4u);      // saddr form (see gemm_nn_bf3_kernel)
       }
     } else {
 #pragma unroll
@@ -735,8 +742,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   const bool rows_in_m = m0 + 64 * WM <= p.M, rows_in_c = c0 + NCH <= p.Nc;
 
   auto load8 = [&](const float* __restrict__ base, int off, float (&v)[8]) {
-    const f4u a = *reinterpret_cast<const f4u*>(base + (unsigned)off);
-    const f4u c = *reinterpret_cast<const f4u*>(base + (unsigned)off + 4);
+    // uniform base + zero-extended 32-bit BYTE offset (operands span < 2^30 elements): the saddr form of global_load
+    const char* __restrict__ q = reinterpret_cast<const char*>(base) + ((unsigned)off << 2);
+    const f4u a = *reinterpret_cast<const f4u*>(q);
+    const f4u c = *reinterpret_cast<const f4u*>(q + 16);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
   };
   auto load8_edge = [&](const float* __restrict__ base, int off, int span, int t, int len, bool row_ok, float (&v)[8]) -> int {
