@@ -87,6 +87,16 @@ int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_b
                            const float* gamma, const float* beta, float* dx, long dx_bs, float* pgrads,
                            int B, int C, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
 
+/* The whole backward of y = act(LN(conv1x1(x) [+ s])) (models/TTSModel.py:128-131, :173-180, :218-231, :343-361) in one call,
+ * so that the LayerNorm partial sums and the weight-gradient slabs share one reduction launch.  pre (B,Cout,L) dense and stats
+ * (B,2,L) are what the forward saved; dx may be NULL (first layer: the input needs no gradient); ds (B,Cout) = gradient of
+ * the broadcast term s, or NULL; pgrads (3,Cout) = dgamma, dbeta, dbias. */
+size_t ssv_pointwise_conv_ln_act_bwd_workspace(int B, int Cin, int Cout, int L);
+int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
+                                  const float* gamma, const float* beta, const float* pre, const float* stats,
+                                  float* dx, long dx_bs, float* dw, float* pgrads, float* ds,
+                                  int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
+
 /* ---- highwayConv ---------------------------------------------------------------------------------
  * Replaces highwayConv.forward, models/TTSModel.py:63-84:
  *   h = conv(x) (2C channels); y = sigmoid(LN1(h[:C])) * LN2(h[C:]) + (1 - sigmoid(LN1(h[:C]))) * x.

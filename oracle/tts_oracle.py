@@ -71,8 +71,9 @@ def _hci(x, sd, prefix, causal):
 def text_embedding(textid, sd, prefix, vocab_len):
     """textEmbedding.forward, TTSModel.py:25-35: one-hot scatter then Linear, (B,E,N)."""
     ids = textid.long()
-    one_hot = torch.zeros(ids.shape[0], vocab_len, ids.shape[2]).scatter_(
-        1, ids, torch.ones(ids.shape))
+    dt = sd[prefix + ".W.weight"].dtype                    # float32 as in the reference; float64 when the tests want an exact arm
+    one_hot = torch.zeros(ids.shape[0], vocab_len, ids.shape[2], dtype=dt).scatter_(
+        1, ids, torch.ones(ids.shape, dtype=dt))
     out = F.linear(one_hot.permute(0, 2, 1), sd[prefix + ".W.weight"], sd[prefix + ".W.bias"])
     return out.permute(0, 2, 1)
 
@@ -242,7 +243,7 @@ def text2mel_losses(Y, A, mel_gt, gaw):
     l1 = torch.mean(torch.abs(mel_gt - Y))
     bd = torch.mean(-mel_gt * torch.log(Y + 1e-8) - (1 - mel_gt) * torch.log(1 - Y + 1e-8))
     aug = F.pad(A, (0, gaw.shape[1] - A.shape[-1], 0, gaw.shape[0] - A.shape[-2]), value=-1)
-    mask = torch.ne(aug, -1).float()
+    mask = torch.ne(aug, -1).to(aug.dtype)
     att = torch.sum(mask * aug * gaw) / torch.sum(mask)
     return l1, bd, att
 

@@ -314,6 +314,37 @@ extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w,
   return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
 }
 
+// ---- 1x1 conv + LayerNorm (+ activation), whole backward ------------------------------------------------------------------
+// y = act(LN(conv1x1(x) [+ s])) -- models/TTSModel.py:128-131, :173-180, :218-231, :343-361.  One entry for the backward so that
+// the LayerNorm partial rows and the weight-gradient slabs are summed by ONE launch (as in ssv_highway_conv1d_bwd).
+struct PwWs { size_t dpre, part, wt, slabs, total; };
+static PwWs pw_ws(int B, int Cin, int Cout, int L) {
+  PwWs s;
+  s.dpre = 0;
+  s.part = s.dpre + align256((size_t)B * Cout * L * sizeof(float));
+  s.wt = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * Cout * sizeof(float));
+  s.slabs = s.wt + ssv_conv1d_bwd_data_workspace(Cin, Cout, 1);
+  s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, 1);
+  return s;
+}
+extern "C" size_t ssv_pointwise_conv_ln_act_bwd_workspace(int B, int Cin, int Cout, int L) { return pw_ws(B, Cin, Cout, L).total; }
+extern "C" int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed, const float* gamma,
+                                             const float* beta, const float* pre, const float* stats, float* dx, long dx_bs, float* dw, float* pgrads,
+                                             float* ds, int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dy && x && w && gamma && beta && pre && stats && dw && pgrads, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd: null argument");
+  SSV_CHECK(B > 0 && B <= 65535 && Cin > 0 && Cout > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd: bad shape");
+  const PwWs s = pw_ws(B, Cin, Cout, L);
+  SSV_CHECK(ws && ws_bytes >= s.total, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd: workspace too small (%zu < %zu)", ws_bytes, s.total);
+  char* base = (char*)ws;
+  float* dpre = (float*)(base + s.dpre);
+  const long pbs = (long)Cout * L;
+  SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, (float*)(base + s.part), nullptr, B, Cout, L, act, (hipStream_t)stream));
+  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, base + s.wt, s.slabs - s.wt, stream));
+  if (ds) SSV_TRY(ssv_rowsum(dpre, pbs, ds, B, Cout, L, stream));               // gradient of the broadcast (B, Cout, 1) term
+  return conv1d_bwd_weight_impl(dpre, pbs, x, x_bs, dw, B, Cin, Cout, L, 1, 1, 0, base + s.slabs, s.total - s.slabs, stream,
+                                (const float*)(base + s.part), pgrads, 3 * Cout, ssv_ln_gate_bwd_nblk(B, L));
+}
+
 // ---- second order (gradient penalty through the critics) and the gate forward alone ------------------------------------
 extern "C" size_t ssv_channel_ln_bwd2_workspace(int B, int C, int L) { return align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * C * sizeof(float)); }
 extern "C" int ssv_channel_ln_bwd2(const float* v, long v_bs, const float* gn, long gn_bs, const float* x, long x_bs, const float* stats,

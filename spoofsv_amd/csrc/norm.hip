@@ -576,6 +576,7 @@ int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs
   LN_DISPATCH(true, C, L, CALL);
 #undef CALL
   SSV_TRY(ssv_check_launch("ln_act_bwd"));
+  if (!pgrads) return 0;        // the caller sums the partial rows itself (fused with the weight-gradient slab sum)
   return reduce_partials(part, pgrads, 3 * C, (int)(grid.x * grid.y), st);
 }
 

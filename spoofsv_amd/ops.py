@@ -191,18 +191,14 @@ class PointwiseConvLnActFn(torch.autograd.Function):
         dy, dybs = _act3(dy, "grad")
         B, Cin, L = x.shape
         Cout = w.shape[0]
-        dpre = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
         pg = gradarena.grad_block((gamma, beta, ctx.bias_ref), 3, Cout, x.device)
-        nb = _lib.query("ssv_channel_ln_act_bwd_workspace", B, Cout, L)
+        dx = torch.empty((B, Cin, L), dtype=_F32, device=x.device) if ctx.need_dx else None
+        dw = gradarena.grad_like(w)
+        ds = torch.empty((B, Cout, 1), dtype=_F32, device=x.device) if ctx.has_s else None
+        nb = _lib.query("ssv_pointwise_conv_ln_act_bwd_workspace", B, Cin, Cout, L)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_channel_ln_act_bwd", _p(dy), dybs, _p(pre), Cout * L, _p(stats), _p(gamma), _p(beta),
-                  _p(dpre), Cout * L, _p(pg), B, Cout, L, ctx.act, _p(ws), nb, _stream())
-        dx = _conv_bwd_data(dpre, Cout * L, w, Cin, L) if ctx.need_dx else None
-        dw = _conv_bwd_weight(dpre, Cout * L, x, xbs, tuple(w.shape), out=gradarena.view(w))
-        ds = None
-        if ctx.has_s:
-            ds = torch.empty((B, Cout, 1), dtype=_F32, device=x.device)
-            _lib.call("ssv_rowsum", _p(dpre), Cout * L, _p(ds), B, Cout, L, _stream())
+        _lib.call("ssv_pointwise_conv_ln_act_bwd", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(gamma), _p(beta), _p(pre), _p(stats),
+                  _p(dx), Cin * L, _p(dw), _p(pg), _p(ds), B, Cin, Cout, L, ctx.act, _p(ws), nb, _stream())
         return dx, dw, pg[2], pg[0], pg[1], ds, None
 
 

@@ -27,6 +27,7 @@ class GraphSynthesizer:
         if model.training:
             raise RuntimeError("GraphSynthesizer needs the model in eval mode")
         self.model, self.B, self.N, self.T = model, batch, text_len, frames
+        self.addresses = _addresses(model)
         d, F = model.hidden_dim, model.audio_decoder.conv5.out_channels
         self.dev = device
         self.kv = torch.zeros((batch, 2 * d, text_len), device=device)
@@ -89,13 +90,24 @@ def _remember(cache, key, make):
     return g
 
 
+def _addresses(model):
+    """Where the model's parameters live.  A captured step holds these addresses: a model that was moved (``.cpu()`` and back,
+    ``load_state_dict(assign=True)``) needs a new capture, its old one would read freed memory."""
+    return tuple(p.data_ptr() for p in model.parameters())
+
+
+def _cached(cache, key, model, make):
+    g = _remember(cache, key, make)
+    if g.model is not model or g.addresses != _addresses(model):      # an id() can be reused after the first model is gone
+        cache.pop(key)
+        g = _remember(cache, key, make)
+    return g
+
+
 def free_run(model, text_id, spk_emb, frames):
     """Drop-in for the step-by-step loop: cached GraphSynthesizer per (model, batch, text length, frames)."""
     key = (id(model), text_id.shape[0], text_id.shape[2], frames)
-    g = _remember(_CACHE, key, lambda: GraphSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device))
-    if g.model is not model:                  # an id() can be reused after the first model is gone
-        _CACHE.pop(key)
-        g = _remember(_CACHE, key, lambda: GraphSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device))
+    g = _cached(_CACHE, key, model, lambda: GraphSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device))
     return g.run(text_id, spk_emb)
 
 
@@ -118,6 +130,7 @@ class IncrementalSynthesizer:
         from . import _lib
         self._lib, self._vp = _lib, ctypes.c_void_p
         self.model, self.B, self.N, self.T, self.dev = model, batch, text_len, frames, device
+        self.addresses = _addresses(model)
         enc, dec = model.audio_encoder, model.audio_decoder
         self.d, self.F = model.hidden_dim, dec.conv5.out_channels
         B, d, F = batch, self.d, self.F
@@ -253,9 +266,5 @@ _ICACHE = {}
 def free_run_incremental(model, text_id, spk_emb, frames):
     """Drop-in for the step-by-step loop on the column-incremental path (cached per model / batch / text length / frames)."""
     key = (id(model), text_id.shape[0], text_id.shape[2], frames)
-    make = lambda: IncrementalSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device)
-    g = _remember(_ICACHE, key, make)
-    if g.model is not model:
-        _ICACHE.pop(key)
-        g = _remember(_ICACHE, key, make)
+    g = _cached(_ICACHE, key, model, lambda: IncrementalSynthesizer(model, text_id.shape[0], text_id.shape[2], frames, text_id.device))
     return g.run(text_id, spk_emb)
