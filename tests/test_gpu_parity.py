@@ -534,15 +534,17 @@ def _bench_workload_oracle(kind, B):
 
 
 # Gradient agreement at full depth, measured (tools/grad_parity.py, B = 8), relative L2 per parameter tensor:
-#   exact-fp32 mode vs the float32 oracle: Text2Mel <= 5e-6, SSRN <= 4.7e-4 (median 3e-4);
-#   split-bf16 mode vs the float32 oracle: median 8e-4, worst 1.8e-3 (Text2Mel), 1.2e-3 (SSRN);
-#   the float32 ORACLE vs its own float64 evaluation: median 7e-4, worst 1.0e-3 (SSRN) -- LayerNorm-parameter gradients are sums
-#   with heavy cancellation, so two correct float32 evaluations already differ at the 1e-3 level.
-# Where the split-bf16 error comes from (tools/kernel_accuracy.py, layer_accuracy.py, tail_accuracy.py): every GEMM is within
-# 4.4e-6 of float64 (operands carry 16 mantissa bits) and a stack of 16 highway layers within 3.4e-5 -- but an operand error
-# is relative to the TERMS of a reduction, and the parameter gradients behind the loss head are sums over (batch, time) whose
-# terms cancel by a factor of a few hundred (a ReLU output with a positive mean times a LayerNorm-backward gradient that sums
-# to ~0), so 4e-6 per term becomes ~1e-3 of the result.  The exact-fp32 mode does not have this (products are exact).
+#   exact-fp32 mode vs the float64 oracle: Text2Mel <= 4e-6, SSRN <= 2.3e-4 (median 1.4e-4);
+#   split-bf16 mode vs the float64 oracle: median 8e-4, worst 1.8e-3 (Text2Mel), 1.3e-3 (SSRN);
+#   the float32 ORACLE vs its own float64 evaluation: Text2Mel 1e-6, SSRN median 2.9e-4, worst 4.3e-4 (1.0e-3 at B = 2).
+# Where it comes from (tools/kernel_accuracy.py, layer_accuracy.py, tail_accuracy.py, cancel_accuracy.py): every split-bf16
+# GEMM is within 4.4e-6 of float64 and a stack of 16 highway layers (smooth) within 3.4e-5, the exact-fp32 kernels 10x closer.
+# The 1e-3 level appears only behind a ReLU: an activation that lies within the forward rounding error of zero gets the other
+# side of the kink, its whole gradient term appears or disappears, and ONE such flip among N elements is a relative L2 error of
+# sqrt(2/N) -- 2.4e-3 for the (4, 256, 325) tensors of tail_accuracy.py.  The expected number of flips per ReLU layer is
+# N x (relative forward error): ~1 per layer for split-bf16 (3e-6) on Text2Mel's 0.7 M-element layers, ~0.7 for ANY float32
+# evaluation (1e-7) on SSRN's 5.3 M-element layers -- which is why the float32 oracle itself sits 3e-4..1e-3 from float64
+# there.  It is a property of the function being differentiated (discontinuous derivative), not an accumulating error.
 # Hence the bar is set against the float64 gradient: the HIP path may be off by at most the float32 reference's own error
 # plus a mode allowance (1e-4 exact fp32, 2.5e-3 split-bf16), and never by more than 4e-3.
 _GRAD_ALLOWANCE = {"fp32": 1e-4, "bf16x3": 2.5e-3}
