@@ -27,6 +27,10 @@
 #ifndef SSV_ABL
 #define SSV_ABL 0      // tuning builds only: 1 = weight-gradient kernel without its MFMAs
 #endif
+#ifndef SSV_NN_ABL
+#define SSV_NN_ABL 0   // tuning builds only (results are WRONG), bit mask on gemm_nn_bf3_kernel: 1 = no barrier in the chunk loop,
+#endif                 // 2 = no split / LDS write of the input tile, 4 = no input loads, 8 = no weight re-loads, 16 = one LDS fragment
+                       // address for all reads, 32 = epilogue stores never executed, 64 = a single K chunk (prologue + epilogue only)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned 16-byte load
@@ -128,7 +132,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   constexpr int NX = (X_SLOTS + 255) / 256;
   // two images of the staged input tile: the MFMAs of chunk c read image c & 1 while chunk c+1 is split into the other
   // one -- one barrier per chunk, and the split (VALU) runs under the MFMAs instead of between two barriers
-  __shared__ uint4 lds[2][2 * X_SLOTS];
+  // (the epilogue re-uses the memory to turn the accumulator tiles into row-contiguous stores: 4 waves x 16 rows x (BN + 4))
+  constexpr int IMG = 2 * X_SLOTS, EPI_U4 = 4 * 16 * (BN + 4) / 4;
+  constexpr int LDS_U4 = 2 * IMG > EPI_U4 ? 2 * IMG : EPI_U4;
+  __shared__ uint4 lds_all[LDS_U4];
+  uint4 (*lds)[IMG] = reinterpret_cast<uint4 (*)[IMG]>(lds_all);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);   // see ssv_xcd_order
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     const uint4* Xl = lds[ch & 1] + X_SLOTS;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int xs = kq * WX + t * 16 + nq + offj[j];
+      const int xs = (SSV_NN_ABL & 16) ? (kq * WX + nq) : (kq * WX + t * 16 + nq + offj[j]);
       const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
       const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
 #pragma unroll
@@ -311,13 +319,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
       for (int j = 0; j < KT; ++j) {
         tap(0, j, ch);
         __builtin_amdgcn_sched_barrier(0);      // keep the re-load behind this tap's MFMAs, and later taps' LDS reads behind it
-        if (more) loadA(0, j, ch + 1);
+        if (!(SSV_NN_ABL & 8) && more) loadA(0, j, ch + 1);
       }
       if (more) {
-        commitX(ch + 1);
-        if (ch + 2 < nchunks) prefetchX(ch + 2);
+        if (!(SSV_NN_ABL & 2)) commitX(ch + 1);
+        if (!(SSV_NN_ABL & 4) && ch + 2 < nchunks) prefetchX(ch + 2);
       }
-      __syncthreads();
+      if (!(SSV_NN_ABL & 1)) __syncthreads();
+      if ((SSV_NN_ABL & 64) && p.M > 0) break;
     }
   }
 
@@ -370,6 +379,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
           gsave[ci] = gi; gsave[HN + ci] = gf; gsave[2 * HN + ci] = gg; gsave[3 * HN + ci] = go;
         }
         Cb[(long)u * p.scm + gn] = go * tanhf(cn);
+      }
+    }
+    return;
+  }
+  if ((SSV_NN_ABL & 32) && p.M > 0) return;
+  if (p.scn == 1 && !(SSV_NN_ABL & 128)) {
+    // Row-contiguous stores.  An MFMA accumulator holds 4 rows x 1 column per lane, so storing it directly writes 64-byte
+    // pieces of 4 different rows per instruction (measured: the epilogue was 7.3 of 36.6 us at C = 256, L = 325).  The tile
+    // goes through LDS instead (free after the K loop): every wave parks its 16 x BN block row-major and reads it back as
+    // 16-byte vectors along the row -- a store instruction then covers up to 448 contiguous bytes of one or two rows.
+    constexpr int LDW = BN + 4;                                 // row pitch in floats: 16-byte aligned, bank-conflict free
+    float* stage = reinterpret_cast<float*>(lds_all) + wave * 16 * LDW;
+    __syncthreads();                                            // every wave is done reading the last chunk's image
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int rbase = m0 + wave * WM * 16 + i * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = rbase + kq * 4 + r;
+        const int gmc = min(gm, p.M - 1);
+        const int gb = p.perm_h ? (gmc & 3) * p.perm_h + (gmc >> 2) : gmc;
+        float add = 0.f;
+        if (p.bias) add += p.bias[gb];
+        if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gb];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) stage[(kq * 4 + r) * LDW + t * 16 + nq] = acc[i][t][r] + add;
+      }
+      // the block is private to the wave: no workgroup barrier, the LDS operations of one wave complete in order
+#pragma unroll
+      for (int it = 0; it < NT; ++it) {
+        const int e = lane + 64 * it;                           // 16-byte vector index in the 16 x BN block
+        const int row = e / (BN / 4), c4 = e % (BN / 4);
+        const int gm = rbase + row, gn = n0 + c4 * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * LDW + c4 * 4);
+        if (gm < p.M && gn < p.N) {
+          float* dst = Cb + (long)gm * p.scm + gn;
+          if (gn + 3 < p.N) {
+            f4u o = {v[0], v[1], v[2], v[3]};
+            if (Rb) { const f4u rr = *reinterpret_cast<const f4u*>(Rb + (long)gm * p.srm + gn); o += rr; }
+            *reinterpret_cast<f4u*>(dst) = o;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (gn + q < p.N) dst[q] = v[q] + (Rb ? Rb[(long)gm * p.srm + gn + q] : 0.f);
+          }
+        }
       }
     }
     return;
