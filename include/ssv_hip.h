@@ -337,6 +337,25 @@ int ssv_attention_column(const float* kv, long kv_bs, const float* q, int64_t* p
 /* End of a step: Y[:, :, t] = y_cur (B,F), mel_cur = y_cur (the next step's input frame, synthesize.py:108-109), t += 1. */
 int ssv_synth_column_advance(const float* y_cur, float* Y, float* mel_cur, int* t_dev, int B, int F, int T, ssv_stream_t stream);
 
+/* ---- Critic glue: what models/discriminator.py:24-41 does between its convolutions and LayerNorms ----------
+ * Dropout(p = 0.05) (always active: the reference never calls disc.eval()), leaky-ReLU(0.05), AvgPool1d, and the reduction of
+ * the gradient penalty (train/adversarial_wasserstein_gp.py:305-308).  Each is (piecewise) linear, hence differentiable to any
+ * order with ssv_mul / the pool adjoint.
+ * ssv_act_dropout_fwd: y = leaky_relu(x, slope) * keep / (1 - p); d = y / x's factor, saved for ssv_mul.  slope = 1: plain
+ * dropout, p = 0: plain leaky-ReLU.  The mask is Philox4x32-10 keyed by (seed, *ctr_dev); the call increments *ctr_dev on the
+ * stream, so a replayed hipGraph draws a fresh mask every iteration. */
+int ssv_act_dropout_fwd(const float* x, float* y, float* d, long n, float slope, float p, unsigned long long* ctr_dev, unsigned seed,
+                        ssv_stream_t stream);
+int ssv_mul(const float* x, const float* d, float* y, long n, ssv_stream_t stream);
+/* nn.AvgPool1d(kernel_size = k) on rows of length L (rows = B * C): Lo = L / k outputs per row; the adjoint spreads dy / k. */
+int ssv_avgpool1d_fwd(const float* x, float* y, long rows, int L, int k, ssv_stream_t stream);
+int ssv_avgpool1d_bwd(const float* dy, float* dx, long rows, int L, int k, ssv_stream_t stream);
+/* loss[0] = mean_b lam * (||g_b||_2 - 1)^2 for g (B, n); coef (B) = 2 lam (||g_b|| - 1) / (B ||g_b||) is saved for the backward
+ * dg = gout[0] * coef[b] * g.  Fixed summation order. */
+size_t ssv_grad_penalty_workspace(int B, long n);
+int ssv_grad_penalty_fwd(const float* g, float* loss, float* coef, int B, long n, float lam, void* ws, size_t ws_bytes, ssv_stream_t stream);
+int ssv_grad_penalty_bwd(const float* g, const float* coef, const float* gout, float* dg, int B, long n, ssv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,8 @@ def _ctype(decl):
     if "*" in d:
         return ctypes.c_char_p if d.replace(" ", "") == "constchar*" else ctypes.c_void_p
     base = d.split()[0] if d.split() else d
+    if base == "unsigned":
+        return ctypes.c_uint
     return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
             "ssv_stream_t": ctypes.c_void_p, "void": None}[base]
 

@@ -6,7 +6,8 @@ generator kernels do not.  On a ROCm device their heavy operators run on HIP ker
   * LayerNorm over channels and the highway gate -- ``ops.channel_ln_dd`` / ``ops.highway_gate_dd``: the fused forward and
     first-order backward kernels of the generator path plus hand-written second-order kernels (``ssv_channel_ln_bwd2``,
     ``ssv_highway_gate_bwd2``).
-Dropout, leaky-ReLU and the average pools stay torch ops (one small launch each, differentiable as they are).
+Dropout (its own Philox stream), leaky-ReLU and the average pools are HIP kernels too (csrc/critic.hip): each is piecewise
+linear, so 'multiply by the saved factor' / 'adjoint pool' makes them differentiable to any order.
 There is no CPU branch: a CPU tensor raises (the stock-op restatement used as the parity arm is oracle/critic_oracle.py).
 Same sub-module names as the reference, so ``disc_state_dict`` checkpoints interchange.  Dropout (p=0.05) is
 active whenever the module is in training mode, as in the reference (which never calls ``disc.eval()``).
@@ -15,7 +16,6 @@ import contextlib
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 
@@ -36,10 +36,12 @@ def injected_dropout_masks(masks):
         _MASKS = prev
 
 
-def _dropout(x, training):
-    if _MASKS is not None:
-        return x * _MASKS.pop(0)
-    return F.dropout(x, _P_DROP, training)
+def _act(x, training, slope=1.0, drop=True):
+    """dropout(leaky_relu(x, slope)) as ONE HIP kernel (ops.act_dropout); with injected masks the two factors are applied
+    separately (leaky-ReLU kernel, then the given mask)."""
+    if _MASKS is not None and drop:
+        return ops.mul_const(ops.act_dropout(x, slope, 0.0), _MASKS.pop(0))
+    return ops.act_dropout(x, slope, _P_DROP if (drop and training) else 0.0)
 
 
 def _conv(conv, x):
@@ -65,7 +67,7 @@ class _HighwayConvDropout(nn.Module):
 
     def forward(self, x):
         h = _conv(self.conv, x)
-        return _dropout(ops.highway_gate_dd(h, x, self.ln1.weight, self.ln1.bias, self.ln2.weight, self.ln2.bias), self.training)
+        return _act(ops.highway_gate_dd(h, x, self.ln1.weight, self.ln1.bias, self.ln2.weight, self.ln2.bias), self.training)
 
 
 def _ln(x, ln):
@@ -96,13 +98,15 @@ class _Disc(nn.Module):
         self.pl3 = nn.AdaptiveAvgPool1d(output_size=1)
 
     def forward(self, inputs):
-        x = _dropout(_ln(_conv(self.conv1, inputs), self.ln1), self.training)
+        tr = self.training
+        x = _act(_ln(_conv(self.conv1, inputs), self.ln1), tr)
         x = self.hc(x)
-        x = _ln(self.pl1(_conv(self.conv2, x)), self.ln2)
-        x = _dropout(F.leaky_relu(x, 0.05), self.training)
-        x = _ln(self.pl2(_conv(self.conv3, x)), self.ln3)
-        x = _ln(_conv(self.conv4, F.leaky_relu(x, 0.05)), self.ln4)
-        return self.pl3(_conv(self.conv5, F.leaky_relu(x, 0.05)))      # no sigmoid: Wasserstein critic
+        x = _ln(ops.avg_pool1d(_conv(self.conv2, x), self.pl1.kernel_size[0]), self.ln2)
+        x = _act(x, tr, slope=0.05)                                       # dp2(leaky_relu(.)), one kernel
+        x = _ln(ops.avg_pool1d(_conv(self.conv3, x), self.pl2.kernel_size[0]), self.ln3)
+        x = _ln(_conv(self.conv4, _act(x, tr, slope=0.05, drop=False)), self.ln4)
+        x = _conv(self.conv5, _act(x, tr, slope=0.05, drop=False))
+        return ops.avg_pool1d(x, x.shape[-1])                              # AdaptiveAvgPool1d(1); no sigmoid: Wasserstein critic
 
 
 class melDisc(_Disc):

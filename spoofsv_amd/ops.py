@@ -245,26 +245,46 @@ class Conv1dFn(torch.autograd.Function):
 # each is an autograd Function whose backward is written with the other two, which makes the op differentiable to any
 # order on the HIP kernels alone.  The bias gradient is a plain torch sum (already differentiable).
 class ConvFwdDD(torch.autograd.Function):
-    """y = conv1d(x, w) (no bias), kernel 1 or 3, "same" or causal zero padding."""
+    """y = conv1d(x, w) + bias, kernel 1 or 3, "same" or causal zero padding (the bias is added by the kernel's epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, w, k, dilation, causal):
+    def forward(ctx, x, w, bias, k, dilation, causal):
         x, xbs = _act3(x, "conv input")
         w = _c(w)
+        bias = _c(bias) if bias is not None else None
         B, Cin, L = x.shape
         y = torch.empty((B, w.shape[0], L), dtype=_F32, device=x.device)
-        _conv_fwd(x, xbs, w, None, None, y, w.shape[0] * L, k, dilation, causal)
+        _conv_fwd(x, xbs, w, bias, None, y, w.shape[0] * L, k, dilation, causal)
         ctx.save_for_backward(x, w)
-        ctx.cfg = (k, dilation, causal)
+        ctx.cfg = (k, dilation, causal, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        k, dilation, causal = ctx.cfg
+        k, dilation, causal, has_bias = ctx.cfg
         dx = ConvBwdDataDD.apply(dy, w, x.shape[1], k, dilation, causal) if ctx.needs_input_grad[0] else None
         dw = ConvBwdWeightDD.apply(dy, x, k, dilation, causal) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None, None
+        db = BiasGradFn.apply(dy) if (has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None, None
+
+
+class BiasGradFn(torch.autograd.Function):
+    """db[c] = sum_{b,t} dy[b,c,t] on the HIP row-sum kernels (fixed summation order); linear in dy."""
+
+    @staticmethod
+    def forward(ctx, dy):
+        dy, dybs = _act3(dy, "grad")
+        B, C, L = dy.shape
+        rows = torch.empty((B, C), dtype=_F32, device=dy.device)
+        _lib.call("ssv_rowsum", _p(dy), dybs, _p(rows), B, C, L, _stream())
+        ctx.dims = (B, C, L)
+        return _sum_over_batch(rows, B, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, L = ctx.dims
+        return g.view(1, C, 1).expand(B, C, L)
 
 
 class ConvBwdDataDD(torch.autograd.Function):
@@ -283,7 +303,7 @@ class ConvBwdDataDD(torch.autograd.Function):
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
         k, dilation, causal = ctx.cfg
-        g_dy = ConvFwdDD.apply(ddx, w, k, dilation, causal) if ctx.needs_input_grad[0] else None
+        g_dy = ConvFwdDD.apply(ddx, w, None, k, dilation, causal) if ctx.needs_input_grad[0] else None
         g_w = ConvBwdWeightDD.apply(dy, ddx, k, dilation, causal) if ctx.needs_input_grad[1] else None
         return g_dy, g_w, None, None, None, None
 
@@ -304,15 +324,141 @@ class ConvBwdWeightDD(torch.autograd.Function):
     def backward(ctx, ddw):
         dy, x = ctx.saved_tensors
         k, dilation, causal = ctx.cfg
-        g_dy = ConvFwdDD.apply(x, ddw, k, dilation, causal) if ctx.needs_input_grad[0] else None
+        g_dy = ConvFwdDD.apply(x, ddw, None, k, dilation, causal) if ctx.needs_input_grad[0] else None
         g_x = ConvBwdDataDD.apply(dy, ddw, x.shape[1], k, dilation, causal) if ctx.needs_input_grad[1] else None
         return g_dy, g_x, None, None, None
 
 
 def conv1d_dd(x, w, bias=None, k=1, dilation=1, causal=False):
-    """Conv1d (kernel 1 or 3) differentiable to any order on the HIP kernels; the bias is added with a torch op."""
-    y = ConvFwdDD.apply(x, w, k, dilation, bool(causal))
-    return y if bias is None else y + bias.view(1, -1, 1)
+    """Conv1d (kernel 1 or 3) differentiable to any order on the HIP kernels; the bias is added in the kernel's epilogue."""
+    return ConvFwdDD.apply(x, w, bias, k, dilation, bool(causal))
+
+
+# ------------------------------------------------------------------------------------------- critics: dropout / leaky-ReLU / pooling / penalty
+# models/discriminator.py:24-41 between the convolutions and LayerNorms, and train/adversarial_wasserstein_gp.py:305-308.  Each
+# op is (piecewise) linear, so its backward is "multiply by the saved factor" / "the adjoint pool", which is again one of these
+# ops: differentiable to any order on the HIP kernels (csrc/critic.hip).
+class MulConstFn(torch.autograd.Function):
+    """y = x * d with d a constant (a saved derivative factor or an injected dropout mask)."""
+
+    @staticmethod
+    def forward(ctx, x, d):
+        x, d = _c(_dev(x)), _c(d)
+        if x.shape != d.shape:
+            raise RuntimeError("mul_const: shapes %s and %s differ" % (tuple(x.shape), tuple(d.shape)))
+        y = torch.empty_like(x)
+        _lib.call("ssv_mul", _p(x), _p(d), _p(y), x.numel(), _stream())
+        ctx.save_for_backward(d)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (d,) = ctx.saved_tensors
+        return MulConstFn.apply(gy, d), None
+
+
+_DROP_CTR = {}        # device -> 1-element int64 tensor: number of dropout masks drawn so far (advanced on the stream by the kernel)
+
+
+class ActDropoutFn(torch.autograd.Function):
+    """y = dropout(leaky_relu(x, slope), p): one kernel draws the mask (Philox keyed by the device-side call counter, so a
+    replayed hipGraph gets a fresh mask each time), applies both and saves the combined factor for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, slope, p):
+        x = _c(_dev(x, "critic activation"))
+        y, d = torch.empty_like(x), torch.empty_like(x)
+        ctr = None
+        if p > 0:
+            key = (x.device.type, x.device.index)
+            if key not in _DROP_CTR:
+                _DROP_CTR[key] = torch.zeros(1, dtype=torch.int64, device=x.device)
+            ctr = _DROP_CTR[key]
+        _lib.call("ssv_act_dropout_fwd", _p(x), _p(y), _p(d), x.numel(), float(slope), float(p), _p(ctr), int(torch.cuda.initial_seed()) & 0xFFFFFFFF, _stream())
+        ctx.save_for_backward(d)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (d,) = ctx.saved_tensors
+        return MulConstFn.apply(gy, d), None, None
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """nn.AvgPool1d(kernel_size=k) on (B, C, L) (k = L: the AdaptiveAvgPool1d(1) of discriminator.py:38)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        x = _c(_dev(x, "pool input"))
+        B, C, L = x.shape
+        y = torch.empty((B, C, L // k), dtype=_F32, device=x.device)
+        _lib.call("ssv_avgpool1d_fwd", _p(x), _p(y), B * C, L, k, _stream())
+        ctx.cfg = (L, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L, k = ctx.cfg
+        return AvgPoolBwdFn.apply(gy, L, k), None
+
+
+class AvgPoolBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, L, k):
+        gy = _c(_dev(gy, "grad"))
+        B, C, Lo = gy.shape
+        dx = torch.empty((B, C, L), dtype=_F32, device=gy.device)
+        _lib.call("ssv_avgpool1d_bwd", _p(gy), _p(dx), B * C, L, k, _stream())
+        ctx.k = k
+        return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        return AvgPoolFn.apply(g, ctx.k), None, None
+
+
+class GradPenaltyFn(torch.autograd.Function):
+    """mean_b lam * (||g_b||_2 - 1)^2 over per-sample gradients g (B, ...), train/adversarial_wasserstein_gp.py:305-308."""
+
+    @staticmethod
+    def forward(ctx, g, lam):
+        g = _c(_dev(g, "penalty gradient"))
+        B = g.shape[0]
+        n = g.numel() // B
+        loss = torch.empty((1,), dtype=_F32, device=g.device)
+        coef = torch.empty((B,), dtype=_F32, device=g.device)
+        nb = _lib.query("ssv_grad_penalty_workspace", B, n)
+        ws = _ws(nb, g.device)
+        _lib.call("ssv_grad_penalty_fwd", _p(g), _p(loss), _p(coef), B, n, float(lam), _p(ws), nb, _stream())
+        ctx.save_for_backward(g, coef)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        g, coef = ctx.saved_tensors
+        B = g.shape[0]
+        dg = torch.empty_like(g)
+        _lib.call("ssv_grad_penalty_bwd", _p(g), _p(coef), _p(_c(gout)), _p(dg), B, g.numel() // B, _stream())
+        return dg, None
+
+
+def mul_const(x, d):
+    return MulConstFn.apply(x, d)
+
+
+def act_dropout(x, slope=1.0, p=0.0):
+    """dropout(leaky_relu(x, slope), p); slope = 1 and p = 0 is the identity."""
+    if slope == 1.0 and p == 0.0:
+        return x
+    return ActDropoutFn.apply(x, slope, p)
+
+
+def avg_pool1d(x, k):
+    return AvgPoolFn.apply(x, int(k))
+
+
+def grad_penalty(g, lam):
+    return GradPenaltyFn.apply(g, lam)[0]
 
 
 # ------------------------------------------------------------------------------------------- critics: LayerNorm / gate, twice differentiable

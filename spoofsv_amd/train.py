@@ -735,7 +735,7 @@ class AdversarialGraphStep:
         mid = (self.coeff * gt + (1 - self.coeff) * pred).requires_grad_(True)
         out = self.disc(mid)
         grads = torch.autograd.grad(outputs=out, inputs=mid, grad_outputs=torch.ones_like(out), retain_graph=True, create_graph=True)[0]
-        loss_gp = torch.mean(self.lam * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
+        loss_gp = ops.grad_penalty(grads, self.lam)          # mean(lam * (||grad||_2 - 1)^2), :305-308
         loss_gp.backward(torch.full_like(loss_gp, scale))
         # disc(pred) and disc(gt) as ONE critic call on the concatenated batch: the critic has no cross-sample operation
         # (LayerNorm is per column, dropout per element), so mean(disc(pred) - disc(gt)) is unchanged and the iteration runs

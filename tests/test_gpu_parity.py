@@ -892,3 +892,60 @@ def test_critic_gradient_penalty_matches_oracle():
         if n in _CRITIC_ZERO_GRAD:
             continue
         assert float((got[n] - want[n]).norm()) <= 2e-3 * max(1e-6, float(want[n].norm())), n
+
+
+def test_critic_glue_ops_match_torch_to_second_order():
+    """csrc/critic.hip against the torch expressions of models/discriminator.py:24-41 and adversarial_wasserstein_gp.py:305-308:
+    leaky-ReLU, AvgPool1d (also with a dropped tail and as the global mean), the gradient penalty -- values, gradients and
+    the gradient of a gradient (the penalty differentiates the critic's input gradient) -- and the dropout mask statistics."""
+    import torch.nn.functional as F
+    from spoofsv_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(3, 16, 37, device=DEV)
+
+    def second_order(f_mine, f_ref):
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        v = torch.randn_like(f_ref(b))
+        ga, = torch.autograd.grad(f_mine(a), a, v, create_graph=True)
+        gb, = torch.autograd.grad(f_ref(b), b, v, create_graph=True)
+        assert rel_err(f_mine(a), f_ref(b)) < 1e-6 and rel_err(ga, gb) < 1e-6
+        w = torch.randn_like(ga)
+        # linear ops: d<w, g>/dv is what the double backward of the penalty needs; check it through the upstream gradient
+        va = v.clone().requires_grad_(True)
+        vb = v.clone().requires_grad_(True)
+        ha, = torch.autograd.grad(f_mine(a), a, va, create_graph=True)
+        hb, = torch.autograd.grad(f_ref(b), b, vb, create_graph=True)
+        ra, = torch.autograd.grad((ha * w).sum(), va)
+        rb, = torch.autograd.grad((hb * w).sum(), vb)
+        assert rel_err(ra, rb) < 1e-6
+    second_order(lambda t: ops.act_dropout(t, 0.05, 0.0), lambda t: F.leaky_relu(t, 0.05))
+    second_order(lambda t: ops.avg_pool1d(t, 4), lambda t: F.avg_pool1d(t, 4))            # 37 = 9 * 4 + 1: the tail column is dropped
+    second_order(lambda t: ops.avg_pool1d(t, 37), lambda t: F.adaptive_avg_pool1d(t, 1))
+    mask = (torch.rand_like(x) > 0.3).float() / 0.7
+    second_order(lambda t: ops.mul_const(t, mask), lambda t: t * mask)
+    # gradient penalty: value and gradient
+    g1 = (2 * x).clone().requires_grad_(True)
+    g2 = (2 * x).clone().requires_grad_(True)
+    mine = ops.grad_penalty(g1, 10.0)
+    ref = torch.mean(10.0 * (torch.norm(g2, p=2, dim=(1, 2)) - 1) ** 2)
+    assert abs(float(mine) - float(ref)) < 1e-5 * abs(float(ref))
+    (3 * mine).backward(); (3 * ref).backward()
+    assert rel_err(g1.grad, g2.grad) < 1e-5
+    # dropout: kept values scaled by 1/(1-p), ~p of the entries zero, a new mask on every call -- also when replayed from a graph
+    big = torch.ones(64, 128, 325, device=DEV)
+    y1, y2 = ops.act_dropout(big, 1.0, 0.05), ops.act_dropout(big, 1.0, 0.05)
+    for y in (y1, y2):
+        zeros = float((y == 0).float().mean())
+        assert 0.045 < zeros < 0.055 and float(y.max()) == pytest.approx(1 / 0.95, rel=1e-6) and set(y.unique().tolist()) <= {0.0, float(y.max())}
+    assert not torch.equal(y1, y2)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.act_dropout(big, 1.0, 0.05)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        yg = ops.act_dropout(big, 1.0, 0.05)
+    g.replay(); a = yg.clone(); g.replay(); b = yg.clone()
+    assert not torch.equal(a, b) and 0.045 < float((b == 0).float().mean()) < 0.055

@@ -62,14 +62,14 @@ def idle_share(path):
 
 if __name__ == "__main__":
     d = sys.argv[1]
-    print(stats(glob.glob(d + "/*/*kernel_stats.csv")[0]))
-    tr = glob.glob(d + "/*/*kernel_trace.csv")
+    print(stats((glob.glob(d + "/*/*kernel_stats.csv") + glob.glob(d + "/*kernel_stats.csv"))[0]))
+    tr = glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv")
     if tr:
         print(by_shape(tr[0]))
         print(idle_share(tr[0]))
     if len(sys.argv) > 3:
-        f = counters(glob.glob(sys.argv[2] + "/*/*counter_collection.csv")[0], "FETCH_SIZE")
-        w = counters(glob.glob(sys.argv[3] + "/*/*counter_collection.csv")[0], "WRITE_SIZE")
+        f = counters((glob.glob(sys.argv[2] + "/*/*counter_collection.csv") + glob.glob(sys.argv[2] + "/*counter_collection.csv"))[0], "FETCH_SIZE")
+        w = counters((glob.glob(sys.argv[3] + "/*/*counter_collection.csv") + glob.glob(sys.argv[3] + "/*counter_collection.csv"))[0], "WRITE_SIZE")
         print("\nPMC (separate passes; units as reported by rocprofv3 = KiB; per-launch averages)")
         print("%12s %12s %7s  %s" % ("FETCH_KiB", "WRITE_KiB", "calls", "kernel"))
         for k in sorted(f, key=lambda k: -f[k][0])[:14]:
