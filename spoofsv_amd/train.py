@@ -459,6 +459,10 @@ class PhasedStep:
     def prepare(self):
         if not self.use_graph or self.plan is not None:
             return self
+        # The warm-up runs on a side stream and the capture on torch's capture stream: the parameters' AccumulateGrad nodes
+        # are created on the first and used on the second, which autograd reports on every backward call.  Intended here.
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
