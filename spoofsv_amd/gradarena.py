@@ -15,15 +15,17 @@ import weakref
 
 import torch
 
-_SLOTS = {}      # parameter data_ptr -> (arena weakref, offset, numel, shape)
+_SLOTS = {}      # parameter data_ptr -> (arena weakref, offset, numel, parameter weakref)
 
 
 def _entry(t):
     e = _SLOTS.get(t.data_ptr())
     if e is None or e[2] != t.numel():          # same storage start and size (nn.Linear weights arrive with a trailing unit axis)
         return None
-    arena = e[0]()
-    if arena is None:
+    arena, param = e[0](), e[3]()
+    if arena is None or param is None or param.data_ptr() != t.data_ptr():
+        # the arena or the parameter it was built for is gone (its memory may belong to another tensor by now), or the
+        # parameter was moved: the slot is stale
         _SLOTS.pop(t.data_ptr(), None)
         return None
     return arena, e[1], e[2]
@@ -93,7 +95,7 @@ class GradArena:
         ref = weakref.ref(self)
         for p in self.params:
             o, n = self.slots[id(p)]
-            _SLOTS[p.data_ptr()] = (ref, o, n, tuple(p.shape))
+            _SLOTS[p.data_ptr()] = (ref, o, n, weakref.ref(p))
 
     def release(self):
         for p in self.params:
