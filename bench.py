@@ -76,7 +76,8 @@ class Trainer:
             self.ddp = train.DataParallelRanks(model=self.model)
             self.ddp.broadcast_parameters(0)
         self.opt.refresh_resident_weights()
-        self.stepper = train.TrainStep(kind, self.model, self.opt, list(data), gaw, self.ddp, graph=use_graph)
+        self.stepper = train.TrainStep(kind, self.model, self.opt, list(data), gaw, self.ddp, graph=use_graph,
+                                       defer_wgrad=os.environ.get("SSV_DEFER_WGRAD", "1") != "0")
 
     def prepare(self):
         self.stepper.prepare()
@@ -199,6 +200,32 @@ def kernel_roofline(dev):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
+    def time_conv_dw_multi(B, C, L, k, njobs):
+        """ms per LAYER of the weight gradients of `njobs` equal-shaped layers computed by one launch + one reduction launch
+        (ssv_conv1d_bwd_weight_multi: what the training step does with its 16 C=256 layers), cold operands."""
+        from spoofsv_amd import _lib as L_
+        xs = [torch.randn(B, C, L, device=dev) for _ in range(njobs)]
+        dys = [torch.randn(B, 2 * C, L, device=dev) for _ in range(njobs)]
+        dws = [torch.empty(2 * C, C, k, device=dev) for _ in range(njobs)]
+        table = (L_.WgradJob * njobs)()
+        sh = (ctypes.c_int * 3)()
+        L_.call("ssv_conv_shifts", k, 1, 1, sh)
+        for t, x_, dy_, dw_ in zip(table, xs, dys, dws):
+            t.dy, t.x, t.dw, t.part, t.pgrads = dy_.data_ptr(), x_.data_ptr(), dw_.data_ptr(), None, None
+            t.shift[0], t.shift[1], t.shift[2] = sh[0], sh[1], sh[2]
+        tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
+        nb = L_.query("ssv_conv1d_bwd_weight_multi_workspace", njobs, B, C, 2 * C, k)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        run = lambda: L_.call("ssv_conv1d_bwd_weight_multi", P(tdev), njobs, 2 * C * L, C * L, B, C, 2 * C, L, k, 0, 0, P(ws), nb, st)
+        run(); run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 5 / njobs
+
     B, C, L, k = 32, 256, 325, 3
     ms = time_conv_fwd(B, C, L, k, 20)
     flops = 2.0 * B * L * (2 * C) * C * k
@@ -219,6 +246,12 @@ def kernel_roofline(dev):
         f_ = 2.0 * b_ * l_ * (2 * c_) * c_ * k
         a_ = f_ / (m_ * 1e-3) / 1e12
         others.append({"kernel": label, "us_per_launch": round(m_ * 1e3, 2), "achieved": round(a_, 2), "frac": round(a_ / peak, 4)})
+    if split:
+        m_ = time_conv_dw_multi(32, 256, 325, 3, 16)
+        a_ = flops / (m_ * 1e-3) / 1e12
+        others.append({"kernel": "Conv1d weight gradient C=256->512 L=325, 16 layers in one launch (gemm_nt_bf3_kernel<3,2,4> with a job table, "
+                                 "2 slabs per layer, + reduce_pair_multi): per layer", "us_per_launch": round(m_ * 1e3, 2), "achieved": round(a_, 2),
+                       "frac": round(a_ / peak, 4)})
     return {"bound": "mfma", "kernel": name + ", dilated Conv1d fwd B=32 C=256->512 L=325",
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "peak_note": "bf16 dense 2500 TFLOP/s / 3" if split else "fp32-input MFMA dense",

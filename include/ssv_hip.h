@@ -97,6 +97,40 @@ int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const float* x, l
                                   float* dx, long dx_bs, float* dw, float* pgrads, float* ds,
                                   int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
 
+/* ---- Weight gradients of several equal-shaped conv layers in ONE launch ------------------------------------------
+ * The weight gradient is off the critical path of backward (nothing downstream reads dW), and a single layer's reduction over
+ * (batch, time) must be cut into Z slabs only to fill the chip (C = 256, L = 325: 16 output tiles x 32 slabs = 49 MiB of partial
+ * sums written and read back per layer).  A trainer can therefore run backward with the *_bwd_data entries below (LayerNorm /
+ * gate backward + data gradient only; dH and the LayerNorm partial rows are left in caller-owned buffers), collect one job per
+ * layer, and hand all layers of one shape to ssv_conv1d_bwd_weight_multi: njobs x tiles x Z workgroups with a Z that is njobs
+ * times smaller, then one reduction launch for all jobs (slabs -> dw, partial rows -> pgrads).  Same arithmetic per product;
+ * only the slab boundaries (hence the fp32 summation order over the batch) differ from the one-layer entry.
+ * jobs_dev: device array of njobs jobs.  Per job: dy (B,Cout,L) = dH, x (B,Cin,L), dw (Cout,Cin,k) out, part (nblk, n2) partial
+ * rows or NULL, pgrads (n2) out or NULL, shift[j] = (j - j0) * dilation as ssv_conv_shifts returns them.
+ * Split-bf16 mode only, B*L >= 256 (ssv_conv1d_bwd_weight_multi_ok). */
+typedef struct {
+  const float* dy; const float* x; float* dw; const float* part; float* pgrads;
+  int shift[3]; int pad_;
+} ssv_wgrad_job;
+int ssv_conv_shifts(int k, int dilation, int causal, int* shift3);
+int ssv_conv1d_bwd_weight_multi_ok(int B, int Cin, int Cout, int L, int k);
+int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int Cout, int k);          /* the Z the entry will use */
+size_t ssv_conv1d_bwd_weight_multi_workspace(int njobs, int B, int Cin, int Cout, int k);
+int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int njobs, long dy_bs, long x_bs, int B, int Cin, int Cout, int L, int k,
+                                int n2, int nblk, void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* highwayConv backward without the weight gradient: dx, plus dh (B,2C,L) dense and part (ssv_ln_partial_rows(B,L), 6C) for the job. */
+int ssv_ln_partial_rows(int B, int L);
+size_t ssv_highway_conv1d_bwd_data_workspace(int B, int C, int L, int k);
+int ssv_highway_conv1d_bwd_data(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
+                                const float* g1, const float* b1, const float* g2, const float* b2, const float* h, const float* stats,
+                                float* dx, long dx_bs, float* dh, float* part, int B, int C, int L, int k, int dilation, int causal,
+                                void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* The same for y = act(LN(conv1x1(x) [+ s])): dx (may be NULL), ds (may be NULL), dpre (B,Cout,L) dense and part (rows, 3 Cout). */
+size_t ssv_pointwise_conv_ln_act_bwd_data_workspace(int B, int Cin, int Cout, int L);
+int ssv_pointwise_conv_ln_act_bwd_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* gamma, const float* beta,
+                                       const float* pre, const float* stats, float* dx, long dx_bs, float* ds, float* dpre, float* part,
+                                       int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
+
 /* ---- highwayConv ---------------------------------------------------------------------------------
  * Replaces highwayConv.forward, models/TTSModel.py:63-84:
  *   h = conv(x) (2C channels); y = sigmoid(LN1(h[:C])) * LN2(h[C:]) + (1 - sigmoid(LN1(h[:C]))) * x.

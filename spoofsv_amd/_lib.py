@@ -28,6 +28,12 @@ class PackJob(ctypes.Structure):
                 ("first_block", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
+class WgradJob(ctypes.Structure):
+    """Mirror of ``ssv_wgrad_job``."""
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("part", ctypes.c_void_p),
+                ("pgrads", ctypes.c_void_p), ("shift", ctypes.c_int * 3), ("pad_", ctypes.c_int)]
+
+
 def _ctype(decl):
     d = decl.strip()
     if "*" in d:

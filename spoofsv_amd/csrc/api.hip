@@ -110,6 +110,7 @@ static GemmNT nt_zero() {
   g.C = nullptr; g.scz = g.scm = 0; g.scc = 1; g.scj = 0;
   g.M = g.Nc = 0; g.KT = 1; g.B = 1; g.Z = 1; g.bstep = 1;
   g.shift[0] = g.shift[1] = g.shift[2] = 0;
+  g.jobs = nullptr; g.njobs = 0;
   return g;
 }
 
@@ -282,6 +283,45 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
   return 0;
 }
 
+// ---- several equal-shaped weight gradients in one launch (see include/ssv_hip.h) ------------------------------------------
+extern "C" int ssv_conv_shifts(int k, int dilation, int causal, int* shift3) { return conv_shifts(k, dilation, causal, shift3); }
+extern "C" int ssv_conv1d_bwd_weight_multi_ok(int B, int Cin, int Cout, int L, int k) {
+  if (ssv_precision() != 1 || (k != 1 && k != 3) || (long)B * L < 256 || L < 8) return 0;
+  GemmNT g = nt_zero();
+  g.sab = (long)Cout * L; g.sam = L; g.La = L; g.sxb = (long)Cin * L; g.sxc = L; g.Lx = L;
+  g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = 1; g.bstep = 1;
+  return ssv_nt_bf3_fits(g) ? 1 : 0;
+}
+extern "C" int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int Cout, int k) {
+  const int kt = k == 3 ? 3 : 1;
+  const long tiles = (long)ssv_nt_bf3_tiles(kt, Cout, Cin) * (njobs > 0 ? njobs : 1);
+  int z = ssv_cdiv(ssv_nt_bf3_target(kt, Cout, Cin), tiles);
+  if (z > B) z = B;
+  if (z < 1) z = 1;
+  return z;
+}
+extern "C" size_t ssv_conv1d_bwd_weight_multi_workspace(int njobs, int B, int Cin, int Cout, int k) {
+  return align256((size_t)njobs * ssv_conv1d_bwd_weight_multi_splits(njobs, B, Cin, Cout, k) * Cout * Cin * k * sizeof(float));
+}
+extern "C" int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int njobs, long dy_bs, long x_bs, int B, int Cin, int Cout, int L, int k,
+                                           int n2, int nblk, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(jobs_dev && njobs > 0 && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_weight_multi: bad argument");
+  SSV_CHECK(ssv_conv1d_bwd_weight_multi_ok(B, Cin, Cout, L, k), SSV_UNSUPPORTED, "conv1d_bwd_weight_multi: shape or arithmetic mode not supported");
+  SSV_CHECK(n2 == 0 || nblk <= 768, SSV_UNSUPPORTED, "conv1d_bwd_weight_multi: %d partial rows (max 768)", nblk);
+  SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_weight_multi_workspace(njobs, B, Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_bwd_weight_multi: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int Z = ssv_conv1d_bwd_weight_multi_splits(njobs, B, Cin, Cout, k);
+  const long n = (long)Cout * Cin * k;
+  GemmNT g = nt_zero();
+  g.A = nullptr; g.sab = dy_bs; g.sam = L; g.La = L;
+  g.X = nullptr; g.sxb = x_bs; g.sxc = L; g.Lx = L;
+  g.C = (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = 1; g.scj = Cin;                 // slabs [job][z][m][j][c]
+  g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
+  g.jobs = jobs_dev; g.njobs = njobs;
+  SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
+  return ssv_launch_reduce_pair_multi(jobs_dev, njobs, (const float*)ws, Cout, Cin, k, Z, n2, nblk, st);
+}
+
 // ---- LayerNorm over channels ------------------------------------------------------------------------
 extern "C" size_t ssv_channel_ln_act_fwd_workspace(int B, int C, int L) { (void)B; (void)C; (void)L; return 256; }   // none needed; kept in the ABI
 extern "C" int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const float* beta, float* y, long y_bs, float* stats,
@@ -411,6 +451,30 @@ extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* 
   SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
   return conv1d_bwd_weight_impl(dH, (long)2 * C * L, x, x_bs, dw, B, C, 2 * C, L, k, dilation, causal, base + s.slabs, s.total - s.slabs, stream,
                                 (const float*)(base + s.part), pgrads, 6 * C, ssv_ln_gate_bwd_nblk(B, L));
+}
+
+extern "C" int ssv_ln_partial_rows(int B, int L) { return ssv_ln_gate_bwd_nblk(B, L); }
+extern "C" size_t ssv_highway_conv1d_bwd_data_workspace(int B, int C, int L, int k) { (void)B; (void)L; return ssv_conv1d_bwd_data_workspace(C, 2 * C, k); }
+extern "C" int ssv_highway_conv1d_bwd_data(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
+                                           const float* g1, const float* b1, const float* g2, const float* b2, const float* h, const float* stats,
+                                           float* dx, long dx_bs, float* dh, float* part, int B, int C, int L, int k, int dilation, int causal,
+                                           void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dy && x && w && g1 && b1 && g2 && b2 && h && stats && dx && dh && part, SSV_BAD_SHAPE, "highway_conv1d_bwd_data: null argument");
+  SSV_CHECK(B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_conv1d_bwd_data: bad shape B=%d C=%d L=%d", B, C, L);
+  SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dx, dx_bs, part, nullptr, B, C, L, (hipStream_t)stream));
+  return ssv_conv1d_bwd_data(dh, (long)2 * C * L, w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream);
+}
+extern "C" size_t ssv_pointwise_conv_ln_act_bwd_data_workspace(int B, int Cin, int Cout, int L) { (void)B; (void)L; return ssv_conv1d_bwd_data_workspace(Cin, Cout, 1); }
+extern "C" int ssv_pointwise_conv_ln_act_bwd_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* gamma, const float* beta,
+                                                  const float* pre, const float* stats, float* dx, long dx_bs, float* ds, float* dpre, float* part,
+                                                  int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(dy && w && gamma && beta && pre && stats && dpre && part, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd_data: null argument");
+  SSV_CHECK(B > 0 && B <= 65535 && Cin > 0 && Cout > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd_data: bad shape");
+  const long pbs = (long)Cout * L;
+  SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, part, nullptr, B, Cout, L, act, (hipStream_t)stream));
+  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, ws, ws_bytes, stream));
+  if (ds) SSV_TRY(ssv_rowsum(dpre, pbs, ds, B, Cout, L, stream));
+  return 0;
 }
 
 // ---- attention -------------------------------------------------------------------------------------------

@@ -757,7 +757,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);   // a slab's tiles share an XCD
-  const int bxx = (int)(wg % gridDim.x), z = (int)(wg / gridDim.x);
+  const int bxx = (int)(wg % gridDim.x);
+  int z = (int)(wg / gridDim.x);
+  // operands: the launch's own, or those of job z / Z (several equal-shaped layers in one launch, see GemmNT)
+  const float* __restrict__ Ap = p.A;
+  const float* __restrict__ Xp = p.X;
+  float* __restrict__ Cp = p.C;
+  int shj[3] = {p.shift[0], p.shift[1], p.shift[2]};
+  if (p.jobs) {
+    const int job = z / p.Z;
+    z -= job * p.Z;
+    const ssv_wgrad_job jb = p.jobs[job];
+    Ap = jb.dy; Xp = jb.x; Cp = p.C + (long)job * p.Z * p.scz;
+    shj[0] = jb.shift[0]; shj[1] = jb.shift[1]; shj[2] = jb.shift[2];
+  }
   const int mt = bxx % mtiles, ct = bxx / mtiles;
   const int m0 = mt * 64 * WM, c0 = ct * NCH;
   const int tchunks = (p.La + KB - 1) / KB;
@@ -842,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
   for (int k = 1; k < 4; ++k) next_chunk(cb[k - 1], ct0[k - 1], cb[k], ct0[k]);
   auto a_edge = [&](int t0) __attribute__((always_inline)) -> bool { return !(rows_in_m && t0 + KB <= p.La); };
-  auto x_edge = [&](int t0, int j) __attribute__((always_inline)) -> bool { return !(rows_in_c && t0 + p.shift[j] >= 0 && t0 + KB + p.shift[j] <= p.Lx); };
+  auto x_edge = [&](int t0, int j) __attribute__((always_inline)) -> bool { return !(rows_in_c && t0 + shj[j] >= 0 && t0 + KB + shj[j] <= p.Lx); };
 
   auto loadA = [&](int b, int t0) __attribute__((always_inline)) {                                         // -> ra (/ ma)
     const int base = b * (int)p.sab + t0;
@@ -850,14 +863,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) load8(p.A, base + arow[i] + s2 * 32, ra[i][s2]);
+        for (int s2 = 0; s2 < KS; ++s2) load8(Ap, base + arow[i] + s2 * 32, ra[i][s2]);
     } else {
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const bool ok = m0 + wave * WM * 16 + i * 16 + nq < p.M;
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2)
-          ma[i][s2] = load8_edge(p.A, base + arow[i] + s2 * 32, a_span, t0 + s2 * 32 + 8 * kq, p.La, ok, ra[i][s2]);
+          ma[i][s2] = load8_edge(Ap, base + arow[i] + s2 * 32, a_span, t0 + s2 * 32 + 8 * kq, p.La, ok, ra[i][s2]);
       }
     }
   };
@@ -876,15 +889,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   };
   auto loadX = [&](auto set, int b, int t0, int j) __attribute__((always_inline)) {                        // -> rx[set] (/ mx[set])
     constexpr int S = decltype(set)::value;
-    const int base = b * (int)p.sxb + t0 + p.shift[j];
+    const int base = b * (int)p.sxb + t0 + shj[j];
     if (!x_edge(t0, j)) {
 #pragma unroll
-      for (int r = 0; r < NX; ++r) load8(p.X, base + xrow[r], rx[S][r]);
+      for (int r = 0; r < NX; ++r) load8(Xp, base + xrow[r], rx[S][r]);
     } else {
 #pragma unroll
       for (int r = 0; r < NX; ++r) {
         const int f = tid + 256 * r;
-        mx[S][r] = load8_edge(p.X, base + xrow[r], x_span, t0 + p.shift[j] + 8 * (f % KG), p.Lx, c0 + f / KG < p.Nc, rx[S][r]);
+        mx[S][r] = load8_edge(Xp, base + xrow[r], x_span, t0 + shj[j] + 8 * (f % KG), p.Lx, c0 + f / KG < p.Nc, rx[S][r]);
       }
     }
   };
@@ -979,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
   }
 
-  float* __restrict__ Cz = p.C + (long)z * p.scz;
+  float* __restrict__ Cz = Cp + (long)z * p.scz;
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1042,7 +1055,9 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
   int wm, ntc;
   ssv_nt_bf3_tile(g.KT, g.M, g.Nc, &wm, &ntc);
   const int mtiles = ssv_cdiv(g.M, 64 * wm);
-  const dim3 grid(mtiles * ssv_cdiv(g.Nc, 16 * ntc), 1, g.Z);
+  const int nz = g.jobs ? g.njobs * g.Z : g.Z;
+  SSV_CHECK(nz <= 65535, SSV_UNSUPPORTED, "gemm_nt_bf3: %d slabs exceed grid.z", nz);
+  const dim3 grid(mtiles * ssv_cdiv(g.Nc, 16 * ntc), 1, nz);
 #define SSV_NT(K_, A_, C_) if (g.KT == K_ && wm == A_ && ntc == C_) { hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_>), grid, dim3(256), 0, st, g, mtiles); return ssv_check_launch("gemm_nt_bf3"); }
   SSV_NT(3, 2, 4) SSV_NT(3, 2, 2) SSV_NT(3, 1, 4) SSV_NT(3, 1, 2)
   SSV_NT(1, 2, 6) SSV_NT(1, 2, 4) SSV_NT(1, 2, 2) SSV_NT(1, 1, 6) SSV_NT(1, 1, 4) SSV_NT(1, 1, 2)

@@ -139,6 +139,7 @@ static int launch_cfg(const GemmNT& g, hipStream_t st, int smin, int span) {
 }
 
 int ssv_launch_gemm_nt(const GemmNT& g, hipStream_t st) {
+  SSV_CHECK(!g.jobs, SSV_UNSUPPORTED, "gemm_nt: job tables need the split-bf16 kernel");
   SSV_CHECK(g.M > 0 && g.Nc > 0 && g.La > 0 && g.B > 0 && g.Z > 0 && g.bstep > 0, SSV_BAD_SHAPE,
             "gemm_nt: empty problem M=%d Nc=%d La=%d B=%d Z=%d", g.M, g.Nc, g.La, g.B, g.Z);
   SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nt: kernel_size %d not supported (1 or 3)", g.KT);

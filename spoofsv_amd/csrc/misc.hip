@@ -85,6 +85,55 @@ int ssv_launch_reduce_pair(const float* slabs, float* out, int M, int Nc, int KT
   return ssv_check_launch("reduce_pair");
 }
 
+// reduce_pair_kernel for every job of a batched weight-gradient launch: blockIdx.y = job.
+__global__ __launch_bounds__(256) void reduce_pair_multi_kernel(const ssv_wgrad_job* __restrict__ jobs, const float* __restrict__ slabs, int Nc, int KT, long n,
+                                                                int Z, int nA, int n2, int nblk) {
+  __shared__ float red[8][32];
+  const ssv_wgrad_job jb = jobs[blockIdx.y];
+  const float* __restrict__ s = slabs + (long)blockIdx.y * Z * n;
+  if ((int)blockIdx.x < nA) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0.f, a1 = 0.f;
+    int z = 0;
+    for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + i]; a1 += s[(long)(z + 1) * n + i]; }
+    if (z < Z) a0 += s[(long)z * n + i];
+    const int c = (int)(i % Nc);
+    const long mj = i / Nc;
+    const int j = (int)(mj % KT);
+    const long m = mj / KT;
+    jb.dw[(m * Nc + c) * KT + j] = a0 + a1;
+    return;
+  }
+  if (!jb.part) return;
+  const float* __restrict__ part = jb.part;
+  const int li = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int i = ((int)blockIdx.x - nA) * 32 + li;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n2) {
+    int k = rg;
+    for (; k + 24 < nblk; k += 32) {
+      s0 += part[(long)k * n2 + i]; s1 += part[(long)(k + 8) * n2 + i];
+      s2 += part[(long)(k + 16) * n2 + i]; s3 += part[(long)(k + 24) * n2 + i];
+    }
+    for (; k < nblk; k += 8) s0 += part[(long)k * n2 + i];
+  }
+  red[rg][li] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && i < n2) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][li];
+    jb.pgrads[i] = t;
+  }
+}
+int ssv_launch_reduce_pair_multi(const ssv_wgrad_job* jobs, int njobs, const float* slabs, int M, int Nc, int KT, int Z, int n2, int nblk, hipStream_t st) {
+  const long n = (long)M * Nc * KT;
+  const int nA = ssv_cdiv(n, 256), nB = n2 > 0 ? ssv_cdiv(n2, 32) : 0;
+  hipLaunchKernelGGL(reduce_pair_multi_kernel, dim3(nA + nB, njobs), dim3(256), 0, st, jobs, slabs, Nc, KT, n, Z, nA, n2, nblk);
+  return ssv_check_launch("reduce_pair_multi");
+}
+
 // ---- wt[c][o][j] = w[o][c][j]: weights for the data gradient ---------------------------------------
 __global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int KT) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index into wt

@@ -43,6 +43,9 @@ struct GemmNT {
   float* C; long scz, scm, scc, scj;
   int M, Nc, KT, B, Z, bstep;
   int shift[3];
+  // several problems of one shape in one launch (split-bf16 kernel only): grid.z = njobs * Z, entry z belongs to job z / Z and
+  // takes A = jobs[job].dy, X = jobs[job].x, the job's shifts, and slab (z % Z) of the job's slab region C + job * Z * scz
+  const ssv_wgrad_job* jobs; int njobs;
 };
 int ssv_launch_gemm_nt(const GemmNT& g, hipStream_t st);
 
@@ -94,6 +97,7 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long slab_stride, hipStream_t st);
 int ssv_launch_reduce_slabs_perm(const float* slabs, float* out, int M, int Nc, int KT, int Z, hipStream_t st);
 int ssv_launch_reduce_pair(const float* slabs, float* out, int M, int Nc, int KT, int Z, const float* part, float* pout, int n2, int nblk, hipStream_t st);
+int ssv_launch_reduce_pair_multi(const ssv_wgrad_job* jobs, int njobs, const float* slabs, int M, int Nc, int KT, int Z, int n2, int nblk, hipStream_t st);
 int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hipStream_t st);
 int ssv_launch_fill(float* p, float v, long n, hipStream_t st);
 

@@ -65,6 +65,93 @@ def _needs_grad(ctx):
     return any(ctx.needs_input_grad)
 
 
+# ------------------------------------------------------------------------------------------- deferred weight gradients
+class DeferredWgrad:
+    """Weight gradients of equal-shaped layers, collected during backward and computed by ONE launch per shape at ``flush``
+    (include/ssv_hip.h, "Weight gradients of several equal-shaped conv layers in ONE launch"): nothing downstream in backward
+    reads a dW, and a single layer must cut its reduction over (batch, time) into up to B slabs just to fill the chip.  While
+    an instance is active (``with deferred:``), the fused operators run only the LayerNorm / gate backward and the data
+    gradient, and queue a job; the step that owns the instance calls ``flush`` before anything reads the gradients (end of a
+    backward segment: before the bucket's all-reduce / Adam).  Results differ from the immediate path only in the fp32
+    summation order over the batch (other slab boundaries).
+
+    Job tables travel host -> device through pinned buffers that belong to the instance: slot i serves the i-th launch of a
+    step (``begin_step`` rewinds).  They are allocated during the eager warm-up iterations; a hipGraph capture re-uses them (a
+    capture cannot allocate pinned memory, and the copy node reads the pinned table at every replay, so it must stay intact)."""
+
+    def __init__(self):
+        self.jobs = {}
+        self.slots = []                # [pinned uint8 table, device table, event after the last eager copy]
+        self.cursor = 0
+
+    def __enter__(self):
+        global _DEFER
+        self._prev, _DEFER = _DEFER, self
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER
+        _DEFER = self._prev
+        return False
+
+    def begin_step(self):
+        self.cursor = 0
+
+    @staticmethod
+    def accepts(B, Cin, Cout, L, k, nblk):
+        return nblk <= 768 and bool(_lib.lib().ssv_conv1d_bwd_weight_multi_ok(B, Cin, Cout, L, k))
+
+    def add(self, dy, dy_bs, x, x_bs, dw, part, pg, k, dilation, causal, n2, nblk):
+        B, Cin, L = x.shape
+        key = (B, Cin, dy.shape[1], L, k, dy_bs, x_bs, n2, nblk, x.device)
+        sh = (ctypes.c_int * 3)()
+        _lib.call("ssv_conv_shifts", k, dilation, int(causal), sh)
+        # dw and pg are what the caller hands to autograd, which adopts a returned gradient as ``p.grad`` only while nobody else
+        # holds the tensor OBJECT or a view of it (otherwise it clones -- here: the not yet computed values).  The queue keeps
+        # the address and the STORAGE alive, not the tensors.
+        self.jobs.setdefault(key, []).append((dy, x, part, dw.data_ptr(), pg.data_ptr(), (dw.untyped_storage(), pg.untyped_storage()), tuple(sh)))
+
+    def _slot(self, nbytes, dev):
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self.cursor == len(self.slots):
+            if capturing:
+                raise RuntimeError("DeferredWgrad: run one eager iteration before capturing (job tables are pinned buffers, "
+                                   "which cannot be allocated during a hipGraph capture)")
+            cap = max(4096, nbytes)
+            self.slots.append([torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=dev), None])
+        slot = self.slots[self.cursor]
+        if slot[0].numel() < nbytes or slot[1].device != dev:
+            raise RuntimeError("DeferredWgrad: the sequence of weight-gradient launches changed between iterations")
+        if slot[2] is not None and not capturing:
+            slot[2].synchronize()          # the previous iteration's copy out of this pinned table has executed
+        self.cursor += 1
+        return slot
+
+    def flush(self):
+        """One weight-gradient launch (+ one reduction launch) per queued shape, on the current stream."""
+        for key, jobs in self.jobs.items():
+            B, Cin, Cout, L, k, dy_bs, x_bs, n2, nblk, dev = key
+            n = len(jobs)
+            table = (_lib.WgradJob * n)()
+            for t, (dy, x, part, dw_ptr, pg_ptr, _, sh) in zip(table, jobs):
+                t.dy, t.x, t.dw, t.part, t.pgrads = dy.data_ptr(), x.data_ptr(), dw_ptr, part.data_ptr(), pg_ptr
+                t.shift[0], t.shift[1], t.shift[2] = sh
+            raw = bytes(table)
+            slot = self._slot(len(raw), dev)
+            slot[0][:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            slot[1].copy_(slot[0], non_blocking=True)
+            if not torch.cuda.is_current_stream_capturing():
+                slot[2] = torch.cuda.Event()
+                slot[2].record()
+            nb = _lib.query("ssv_conv1d_bwd_weight_multi_workspace", n, B, Cin, Cout, k)
+            ws = _ws(nb, dev)
+            _lib.call("ssv_conv1d_bwd_weight_multi", _p(slot[1]), n, dy_bs, x_bs, B, Cin, Cout, L, k, n2, nblk, _p(ws), nb, _stream())
+        self.jobs = {}
+
+
+_DEFER = None
+
+
 # ------------------------------------------------------------------------------------------- highway
 class HighwayConvFn(torch.autograd.Function):
     """highwayConv.forward, models/TTSModel.py:63-84 (conv -> 2x LayerNorm over channels -> gate)."""
@@ -102,6 +189,17 @@ class HighwayConvFn(torch.autograd.Function):
         dw = gradarena.grad_like(w)
         bias = ctx.bias_ref
         pg = gradarena.grad_block((g1, b1, g2, b2, bias), 6, C, x.device) if bias is not None else torch.empty((6, C), dtype=_F32, device=x.device)
+        nblk = _lib.query("ssv_ln_partial_rows", B, L)
+        if _DEFER is not None and _DEFER.accepts(B, C, 2 * C, L, k, nblk):
+            # LayerNorm / gate backward + data gradient now; the weight gradient joins the other layers of this shape at flush
+            dh = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
+            part = torch.empty((nblk, 6 * C), dtype=_F32, device=x.device)
+            nb = _lib.query("ssv_highway_conv1d_bwd_data_workspace", B, C, L, k)
+            ws = _ws(nb, x.device)
+            _lib.call("ssv_highway_conv1d_bwd_data", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
+                      _p(h), _p(stats), _p(dx), C * L, _p(dh), _p(part), B, C, L, k, dilation, causal, _p(ws), nb, _stream())
+            _DEFER.add(dh, 2 * C * L, x, xbs, dw, part, pg, k, dilation, causal, 6 * C, nblk)
+            return dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3], None, None, None
         nb = _lib.query("ssv_highway_conv1d_bwd_workspace", B, C, L, k)
         ws = _ws(nb, x.device)
         _lib.call("ssv_highway_conv1d_bwd", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
@@ -195,6 +293,16 @@ class PointwiseConvLnActFn(torch.autograd.Function):
         dx = torch.empty((B, Cin, L), dtype=_F32, device=x.device) if ctx.need_dx else None
         dw = gradarena.grad_like(w)
         ds = torch.empty((B, Cout, 1), dtype=_F32, device=x.device) if ctx.has_s else None
+        nblk = _lib.query("ssv_ln_partial_rows", B, L)
+        if _DEFER is not None and _DEFER.accepts(B, Cin, Cout, L, 1, nblk):
+            dpre = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
+            part = torch.empty((nblk, 3 * Cout), dtype=_F32, device=x.device)
+            nb = _lib.query("ssv_pointwise_conv_ln_act_bwd_data_workspace", B, Cin, Cout, L)
+            ws = _ws(nb, x.device)
+            _lib.call("ssv_pointwise_conv_ln_act_bwd_data", _p(dy), dybs, _p(w), resident.lookup(w), _p(gamma), _p(beta), _p(pre), _p(stats),
+                      _p(dx), Cin * L, _p(ds), _p(dpre), _p(part), B, Cin, Cout, L, ctx.act, _p(ws), nb, _stream())
+            _DEFER.add(dpre, Cout * L, x, xbs, dw, part, pg, 1, 1, 0, 3 * Cout, nblk)
+            return dx, dw, pg[2], pg[0], pg[1], ds, None
         nb = _lib.query("ssv_pointwise_conv_ln_act_bwd_workspace", B, Cin, Cout, L)
         ws = _ws(nb, x.device)
         _lib.call("ssv_pointwise_conv_ln_act_bwd", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(gamma), _p(beta), _p(pre), _p(stats),

@@ -407,7 +407,7 @@ class Cuts:
         return leaf
 
 
-def backward_segments(cuts, roots, side_roots=None, ddp=None):
+def backward_segments(cuts, roots, side_roots=None, ddp=None, defer=None):
     """The backward pass as a list of closures, one per segment.  Segment 0 differentiates ``roots`` (``[(tensor, grad)]``,
     grad None = 1) down to the nearest cuts; segment i continues from cut ``cuts.names[i-1]`` with the gradient that arrived
     at its leaf, plus the ``side_roots[name]`` that join the tape there (the attention loss of Text2Mel).  Every parameter
@@ -417,7 +417,12 @@ def backward_segments(cuts, roots, side_roots=None, ddp=None):
     def run(pairs):
         ts = [t for t, _ in pairs]
         gs = [g for _, g in pairs]
-        torch.autograd.backward(ts, gs)
+        if defer is None:
+            torch.autograd.backward(ts, gs)
+            return
+        with defer:                       # weight gradients of this segment: queued, then one launch per layer shape
+            torch.autograd.backward(ts, gs)
+        defer.flush()
 
     arena = ddp is not None and ddp.arena is not None
 
@@ -522,8 +527,10 @@ class TrainStep:
     segments of ``tts.ddp_plan`` and every gradient bucket's all-reduce is started right after its segment, overlapping the
     remaining segments; Adam follows the last collective.  ``out`` holds the iteration's loss terms (device scalars)."""
 
-    def __init__(self, kind, model, opt, batch=None, gaw=None, ddp=None, graph=False):
+    def __init__(self, kind, model, opt, batch=None, gaw=None, ddp=None, graph=False, defer_wgrad=False):
         self.kind, self.model, self.opt, self.gaw, self.ddp = kind, model, opt, gaw, ddp
+        # weight gradients of equal-shaped layers batched into one launch per backward segment (ops.DeferredWgrad)
+        self.defer = ops.DeferredWgrad() if defer_wgrad else None
         self.static = [b.clone() for b in batch] if (graph and batch is not None) else None
         self.batch = self.static if self.static is not None else batch
         self.out = self.att = None
@@ -546,6 +553,8 @@ class TrainStep:
     def _forward_seg0(self):
         self.opt.zero_grad(set_to_none=True)
         self.cuts.reset()
+        if self.defer is not None:
+            self.defer.begin_step()
         scale = self.ddp.grad_scale if (self.ddp is not None and self.ddp.arena is not None) else 1.0
         seed = lambda t: (t, torch.full_like(t, scale))
         if self.kind == "text2mel":
@@ -555,16 +564,16 @@ class TrainStep:
             l1, bd, la = text2mel_losses(pred, att, mel, self.gaw)
             self.out, self.att = (l1.detach(), bd.detach(), la.detach()), att.detach()
             if "dec_in" in self.cuts.rec:
-                segs = backward_segments(self.cuts, [seed(l1 + bd)], {"dec_in": [seed(la)]}, self.ddp)
+                segs = backward_segments(self.cuts, [seed(l1 + bd)], {"dec_in": [seed(la)]}, self.ddp, self.defer)
             else:
-                segs = backward_segments(self.cuts, [seed(l1 + bd + la)], None, self.ddp)
+                segs = backward_segments(self.cuts, [seed(l1 + bd + la)], None, self.ddp, self.defer)
         else:
             mel, lin = self.batch
             with _cuts_installed(self.model, self.cuts):
                 pred = self.model(mel)
             l1, bd = ops.spec_losses(pred, lin)
             self.out = (l1.detach(), bd.detach())
-            segs = backward_segments(self.cuts, [seed(l1 + bd)], None, self.ddp)
+            segs = backward_segments(self.cuts, [seed(l1 + bd)], None, self.ddp, self.defer)
         self._segs = segs
         segs[0]()
 
@@ -626,8 +635,9 @@ class AdversarialGraphStep:
     """
 
     def __init__(self, kind, model, disc, opt_syn, opt_disc, batch, gaw=None, lam=10.0, ddp_syn=None, ddp_disc=None, graph=True,
-                 coeff_seed=0):
+                 coeff_seed=0, defer_wgrad=False):
         self.kind, self.model, self.disc, self.opt_syn, self.opt_disc = kind, model, disc, opt_syn, opt_disc
+        self.defer = ops.DeferredWgrad() if defer_wgrad else None          # generator iterations only (see TrainStep)
         self.static = [b.clone() for b in batch]
         self.gaw, self.lam = gaw, float(lam)
         self.ddp_syn, self.ddp_disc = ddp_syn, ddp_disc
@@ -705,6 +715,8 @@ class AdversarialGraphStep:
         torch.stack([l1.detach(), bd.detach(), la.detach() if la is not None else l1.detach() * 0, ld.detach()], out=self.scalars)
 
     def _g_backward0(self):
+        if self.defer is not None:
+            self.defer.begin_step()
         l1, bd, la, ld = self._g_terms
         g = self.scalars                                             # global-batch means when data parallel
         base_g = g[0] + g[1] + g[2]
@@ -713,9 +725,9 @@ class AdversarialGraphStep:
         seed = lambda t: (t, torch.full_like(t, scale))
         top = l1 + bd + weight * ld
         if "dec_in" in self.cuts.rec:
-            segs = backward_segments(self.cuts, [seed(top)], {"dec_in": [seed(la)]}, self.ddp_syn)
+            segs = backward_segments(self.cuts, [seed(top)], {"dec_in": [seed(la)]}, self.ddp_syn, self.defer)
         else:
-            segs = backward_segments(self.cuts, [seed(top + la if la is not None else top)], None, self.ddp_syn)
+            segs = backward_segments(self.cuts, [seed(top + la if la is not None else top)], None, self.ddp_syn, self.defer)
         self._segs = segs
         segs[0]()
         total = base_g + weight * g[3]

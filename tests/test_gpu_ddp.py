@@ -301,3 +301,44 @@ def test_trainers_run_data_parallel_under_torchrun_environment(tmp_path, adversa
     sub = "adversarial" if adversarial else "not_adversarial"
     cks = os.listdir(os.path.join(str(tmp_path), "checkpoints", "conditional", sub, "ddp"))
     assert "text2mel_iteration_3.tar.pth" in cks and "text2mel_best_model.tar.pth" in cks
+
+
+@pytest.mark.parametrize("kind", ["text2mel", "ssrn"])
+@pytest.mark.parametrize("graph,seg", [(False, False), (True, False), (True, True)])
+def test_deferred_batched_weight_gradients_match_the_immediate_step(kind, graph, seg):
+    """ops.DeferredWgrad: backward runs only the LayerNorm / gate backward and the data gradients, the weight gradients of all
+    equal-shaped layers of a segment are computed by one launch each at the segment's end (fewer, longer slabs).  Same
+    products; only the fp32 summation order over the batch differs: losses identical, every gradient within 2e-6 of its
+    tensor's largest entry, weights after two steps within 1e-6."""
+    from spoofsv_amd import train
+    if kind == "text2mel":
+        a, b = _melsyn(), _melsyn()
+        batch = list(train.synthetic_text2mel_batch(8, N=40, T=64, seed=3, device=DEV))      # B*T = 512: the split-bf16 kernels, 4 slabs
+        gaw = train.guided_attention_mat(40, 64, device=DEV)
+    else:
+        a, b = _ssrn(), _ssrn()
+        batch = list(train.synthetic_ssrn_batch(8, T=40, out_bins=65, seed=3, device=DEV))
+        gaw = None
+    oa = train.FusedAdam(a.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=graph)
+    ob = train.FusedAdam(b.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=graph)
+    oa.refresh_resident_weights(); ob.refresh_resident_weights()
+    plain = train.TrainStep(kind, a, oa, batch, gaw, None, graph=False)
+    ddp = train.DataParallelRanks(model=b) if seg else None
+    deferred = train.TrainStep(kind, b, ob, batch, gaw, ddp, graph=graph, defer_wgrad=True).prepare()
+    if graph:
+        b.load_state_dict(a.state_dict())
+        for st in ob.state.values():
+            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+        ob._step_dev.zero_()
+        ob.refresh_resident_weights()
+    for it in range(2):
+        la, lb = plain(), deferred()
+        for x, y in zip(la, lb):
+            assert float(x) == float(y)
+        if it == 0:
+            torch.cuda.synchronize()
+            for (k, p), q in zip(a.named_parameters(), b.parameters()):
+                g = ddp.arena.slot(q) if seg else q.grad
+                assert g is not None and float((p.grad - g).abs().max()) <= 2e-6 * float(p.grad.abs().max()) + 1e-12, k
+    for (k, p), q in zip(a.state_dict().items(), b.state_dict().values()):
+        assert float((p - q).abs().max()) < 1e-6, k
