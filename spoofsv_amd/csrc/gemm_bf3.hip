@@ -25,7 +25,8 @@
 #include <stdio.h>
 #include "ssv_common.h"
 #ifndef SSV_ABL
-#define SSV_ABL 0      // tuning builds only: 1 = weight-gradient kernel without its MFMAs
+#define SSV_ABL 0      // tuning builds only (WRONG results), weight-gradient kernel: 1 = without its MFMAs, 2 = dH fragments not split (raw bits
+                       // re-used as operands), 4 = input tile not split before the LDS write, 6 = both, 8 = epilogue never executed
 #endif
 #ifndef SSV_NN_ABL
 #define SSV_NN_ABL 0   // tuning builds only (results are WRONG), bit mask on gemm_nn_bf3_kernel: 1 = no barrier in the chunk loop,
@@ -879,7 +880,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) split8(ra[i][s2], ah[i][s2], al[i][s2]);
+        for (int s2 = 0; s2 < KS; ++s2) {
+          if (SSV_ABL & 2) { ah[i][s2] = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&ra[i][s2][0])); al[i][s2] = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&ra[i][s2][4])); }
+          else split8(ra[i][s2], ah[i][s2], al[i][s2]);
+        }
     } else {
 #pragma unroll
       for (int i = 0; i < WM; ++i)
@@ -911,7 +915,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       const int f = tid + 256 * r;
       const int kg = f % KG, c = f / KG;
       uint4 h, l;
-      if (!edge) split8(rx[S][r], h, l);
+      if (SSV_ABL & 4) { h = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[S][r][0])); l = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[S][r][4])); }
+      else if (!edge) split8(rx[S][r], h, l);
       else split_edge(rx[S][r], mx[S][r], h, l);
       Xh[kg * NCH + (c ^ kg)] = h; Xl[kg * NCH + (c ^ kg)] = l;          // XOR swizzle, see the slot comment above
     }
@@ -945,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
           for (int i = 0; i < WM; ++i) {
             const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[i][s2]);
             const bf16x8 a_l = __builtin_bit_cast(bf16x8, al[i][s2]);
-#if SSV_ABL == 1
+#if (SSV_ABL & 1)
             acc[i][j][q][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a_l).x ^ __builtin_bit_cast(uint4, bh).x ^ __builtin_bit_cast(uint4, a_h).y ^ __builtin_bit_cast(uint4, bl).y);
 #else
             acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, bh, acc[i][j][q], 0, 0, 0);
@@ -992,6 +997,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
   }
 
+  if ((SSV_ABL & 8) && p.M > 0) return;
   float* __restrict__ Cz = Cp + (long)z * p.scz;
 #pragma unroll
   for (int i = 0; i < WM; ++i)
