@@ -77,6 +77,10 @@ def lib():
         raise RuntimeError(
             "libssv_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C spoofsv_amd/csrc`).  There is no CPU/torch fallback for the HIP hot path." % LIBPATH)
+    # PyTorch ships a HIP runtime of its own (torch/lib/libamdhip64.so); libssv_hip.so names the same SONAME.  Whichever is
+    # loaded first serves both -- and a process where the system runtime came first and torch initialised the device second
+    # fails its first kernel launch with "no ROCm-capable device".  Load torch's first, always.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIBPATH)
     _protos = parse_header()
     missing = [n for n in _protos if not hasattr(L, n)]
