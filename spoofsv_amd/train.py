@@ -393,7 +393,8 @@ class Cuts:
     detached (so a ``backward`` call stops there) and the pair (tensor on the tape, detached leaf) is remembered."""
 
     def __init__(self, names):
-        self.names = list(names)
+        self.groups = [[n] if isinstance(n, str) else list(n) for n in names]      # cuts that end the same backward segment
+        self.names = [n for g in self.groups for n in g]
         self.rec = {}
 
     def reset(self):
@@ -431,12 +432,18 @@ def backward_segments(cuts, roots, side_roots=None, ddp=None, defer=None):
         if arena:
             ddp.adopt_bucket(0)
     segs = [seg0]
-    for i, name in enumerate(cuts.names):
-        def seg(name=name, i=i):
-            x, leaf = cuts.rec[name]
-            pairs = [(x, leaf.grad)] + [(t, g if g is not None else torch.ones_like(t)) for t, g in side_roots.get(name, [])]
+    for i, group in enumerate(cuts.groups):
+        def seg(group=group, i=i):
+            pairs = []
+            for name in group:
+                if name in cuts.rec:
+                    x, leaf = cuts.rec[name]
+                    pairs.append((x, leaf.grad))
+                    pairs += [(t, g if g is not None else torch.ones_like(t)) for t, g in side_roots.get(name, [])]
             run(pairs)
-            leaf.grad = None
+            for name in group:
+                if name in cuts.rec:
+                    cuts.rec[name][1].grad = None
             if arena:
                 ddp.adopt_bucket(i + 1)
         segs.append(seg)
@@ -537,7 +544,7 @@ class TrainStep:
         seg = ddp is not None and ddp.arena is not None
         self.cuts = Cuts(ddp.cut_names if seg else [])
         self._segs = None
-        nseg = len(self.cuts.names) + 1
+        nseg = len(self.cuts.groups) + 1
         phases = [("graph", self._forward_seg0)]
         if seg:
             for i in range(nseg):
@@ -658,7 +665,7 @@ class AdversarialGraphStep:
         else:
             g_phases = [("graph", self._g_forward), ("eager", lambda: ddp_syn.all_reduce_mean_(self.scalars)), ("graph", self._g_backward0)]
             if seg:
-                nseg = len(self.cuts.names) + 1
+                nseg = len(self.cuts.groups) + 1
                 for i in range(nseg):
                     if i > 0:
                         g_phases.append(("graph", lambda i=i: self._segs[i]()))

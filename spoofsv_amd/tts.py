@@ -93,7 +93,8 @@ class textEncoder(nn.Module):
         x = self.textemb_layer(inputs)
         x = _cla(x, self.conv1, self.ln1, act=1)      # relu feeds conv2 (:130)
         x = _cla(x, self.conv2, self.ln2)
-        x = cut("text_c1", self.hci1(x))
+        x = cut("text_c0", self.hci1.hc1(x))                     # (hci1 spelled out: its first layer closes the LAST gradient bucket)
+        x = cut("text_c1", self.hci1.hc4(self.hci1.hc3(self.hci1.hc2(x))))
         x = cut("text_c2", self.hci2(x))
         return self.hc4(self.hc3(self.hc2(self.hc1(x))))
 
@@ -120,7 +121,7 @@ class audioEncoder(nn.Module):
         self.hc1 = highwayConv(dimension=hidden_dim, kernel_size=3, dilation=3, causal=True)
         self.hc2 = highwayConv(dimension=hidden_dim, kernel_size=3, dilation=3, causal=True)
 
-    def forward(self, inputs, spk=None):
+    def forward(self, inputs, spk=None, cut=_no_cut):
         s = p = None
         if self.condition:
             # nn.Linear on the (B, D, 1) speaker code == a 1x1 convolution over a length-1 sequence
@@ -129,8 +130,12 @@ class audioEncoder(nn.Module):
         x = _cla(inputs, self.conv1, self.ln1, s, act=1)
         x = _cla(x, self.conv2, self.ln2, act=1)
         x = _cla(x, self.conv3, self.ln3, p)
-        x = self.hci2(self.hci1(x))
-        return self.hc2(self.hc1(x))
+        # (the two increments spelled out: the data-parallel step cuts the tape in step with the text encoder's cuts, so that
+        # every backward segment has an audio part and a text part to run side by side on the two streams)
+        h1, h2 = self.hci1, self.hci2
+        x = cut("audio_c1", h1.hc2(h1.hc1(x)))
+        x = cut("audio_c2", h2.hc2(h2.hc1(h1.hc4(h1.hc3(x)))))
+        return self.hc2(self.hc1(h2.hc4(h2.hc3(x))))
 
 
 class audioDecoder(nn.Module):
@@ -180,7 +185,7 @@ class melSyn(nn.Module):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 kv = self.text_encoder.encode(textid, self._cut)
-            Q = self.audio_encoder(melspec, spkemb)
+            Q = self.audio_encoder(melspec, spkemb, self._cut)
             cur.wait_stream(side)     # join; kv stays alive until backward, no record_stream (illegal under capture) needed
             RQ, A = ops.attention_train(kv, Q)
             return self.audio_decoder(self._cut("dec_in", RQ)), A
@@ -304,25 +309,31 @@ def ddp_plan(model):
     """``(plan, cuts)`` for ``train.SegmentedBackward``: gradient buckets in the order backward finishes them, and the names of
     the forward cuts (see ``_no_cut``) that end each backward segment.  Bucket i is complete once segment i has run.
 
-    melSyn:  decoder | attention + audio encoder + text encoder hc1-4 | text encoder hci2 | text encoder hci1, head
-    SSRN:    513-wide 1x1 tail | the two C=512 highway layers | everything at C=256 (upsampling, head)"""
+    melSyn:  decoder | attention + audio top 4 + text hc1-4 | audio middle 4 + text hci2 | audio head + text hci1.hc2-4 |
+             text hci1.hc1 + head.  Every middle segment ends at one cut in the text encoder AND one in the audio encoder, so its
+             backward still runs the two branches side by side on the model's two streams.
+    SSRN:    513-wide 1x1 tail | the two C=512 highway layers | everything at C=256 (upsampling, head)
+    A cut entry is a list of cut names that end the same segment.  Sizing rule: the all-reduce of bucket i runs under segment
+    i+1, so the LAST bucket (exposed) is kept small (7.6 MB) and the one before it has a last segment long enough to hide under
+    (one C=512 highway layer + the head, ~0.3 ms)."""
     if hasattr(model, "ddp_plan"):
         return model.ddp_plan()
     if isinstance(model, melSyn):
-        te = model.text_encoder
-        upper = [te.hc1, te.hc2, te.hc3, te.hc4]
+        te, ae = model.text_encoder, model.audio_encoder
+        G = lambda *mods: [g for m in mods for g in _groups(m)]
+        named = lambda m, *names: [g for g in _groups(m) if all(any(p is q for n in names for q in getattr(m, n).parameters()) for p in g)]
         plan = [("audio_decoder", _groups(model.audio_decoder)),
-                ("audio_encoder+text_top", _groups(model.audio_encoder) + [g for m in upper for g in _groups(m)]),
-                ("text_hci2", _groups(te.hci2)),
-                ("text_hci1+head", _groups(te.hci1) + _groups(nn.ModuleList([te.textemb_layer])) +
-                 [g for g in _groups(te) if all(any(p is q for q in (te.conv1.weight, te.conv1.bias, te.ln1.weight, te.ln1.bias,
-                                                                      te.conv2.weight, te.conv2.bias, te.ln2.weight, te.ln2.bias)) for p in g)])]
-        cuts = ["dec_in", "text_c2", "text_c1"]
+                ("audio_top+text_top", G(ae.hc2, ae.hc1, ae.hci2.hc4, ae.hci2.hc3, te.hc4, te.hc3, te.hc2, te.hc1)),
+                ("audio_mid+text_hci2", G(ae.hci2.hc2, ae.hci2.hc1, ae.hci1.hc4, ae.hci1.hc3, te.hci2)),
+                ("audio_head+text_hci1.hc2-4", G(ae.hci1.hc2, ae.hci1.hc1) + named(ae, "conv3", "ln3", "conv2", "ln2", "conv1", "ln1") +
+                 (named(ae, "fc1", "fc2") if ae.condition else []) + G(te.hci1.hc4, te.hci1.hc3, te.hci1.hc2)),
+                ("text_hci1.hc1+head", G(te.hci1.hc1, te.textemb_layer) + named(te, "conv2", "ln2", "conv1", "ln1"))]
+        cuts = [["dec_in"], ["text_c2", "audio_c2"], ["text_c1", "audio_c1"], ["text_c0"]]
     elif isinstance(model, SSRN):
         tail = nn.ModuleDict({k: getattr(model, k) for k in ("conv3", "ln3", "conv4", "ln4", "conv5", "ln5", "conv6", "ln6")})
         head = nn.ModuleDict({k: getattr(model, k) for k in ("conv1", "ln1", "hc1", "hc2", "ups1", "ups2", "conv2", "ln2")})
         plan = [("tail_513", _groups(tail)), ("hc_512", _groups(model.hc3) + _groups(model.hc4)), ("head_256", _groups(head))]
-        cuts = ["ssrn_tail", "ssrn_mid"]
+        cuts = [["ssrn_tail"], ["ssrn_mid"]]
     else:
         return [("all", _groups(model))], []
     have = {id(p) for _, gs in plan for g in gs for p in g}

@@ -38,7 +38,7 @@ def _grads(m):
 @pytest.mark.parametrize("kind", ["text2mel", "ssrn"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_segmented_arena_step_is_bit_identical_to_the_plain_step(kind, graph):
-    """One rank: the step with the gradient arena and the segmented backward (tts.ddp_plan: 4 / 3 segments, as separate
+    """One rank: the step with the gradient arena and the segmented backward (tts.ddp_plan: 5 / 3 segments, as separate
     hipGraphs when captured) runs exactly the kernels of the plain step, so gradients and post-step weights are bit-equal;
     every gradient lives in the arena, and the forward's cut hook is gone after the step."""
     from spoofsv_amd import train
@@ -55,7 +55,7 @@ def test_segmented_arena_step_is_bit_identical_to_the_plain_step(kind, graph):
     oa.refresh_resident_weights(); ob.refresh_resident_weights()
     plain = train.TrainStep(kind, a, oa, batch, gaw, None, graph=False)
     ddp = train.DataParallelRanks(model=b)
-    assert ddp.n_buckets == (4 if kind == "text2mel" else 3) and ddp.world == 1
+    assert ddp.n_buckets == (5 if kind == "text2mel" else 3) and ddp.world == 1
     seg = train.TrainStep(kind, b, ob, batch, gaw, ddp, graph=graph).prepare()
     if graph:       # capture ran warm-up iterations on b: start both from the same state again
         b.load_state_dict(a.state_dict())
@@ -139,7 +139,7 @@ def _spawn(target, args, world=2):
 
 @pytest.mark.parametrize("graph", [False, True])
 def test_two_rank_segmented_step_equals_single_process_on_the_global_batch(graph):
-    """Two ranks, half the global batch each, backward in four segments with the bucket all-reduces between them (between the
+    """Two ranks, half the global batch each, backward in five segments with the bucket all-reduces between them (between the
     hipGraph replays when captured): the averaged gradient is the one a single process computes on the whole batch, and the
     replicas stay bit-identical through optimizer steps."""
     from spoofsv_amd import train
