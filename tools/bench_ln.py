@@ -34,6 +34,7 @@ for (B, C, L) in [(32, 512, 186), (32, 256, 325), (32, 256, 650), (32, 256, 1300
         line += "  G%s act f %.1f (%.2f) b %.1f (%.2f)" % (G, tf, 2 * n / tf / 1e6, tb, 3 * n / tb / 1e6)
         if C <= 512:
             gb = lambda: _lib.call("ssv_highway_gate_bwd", P(dy), C * L, P(x), C * L, P(g), P(b), P(g), P(b), P(h), P(stats), P(dh), P(dx), C * L, P(pg), B, C, L, P(wg), ng, st)
-            tg = timeit(gb)
-            line += " gate-b %.1f (%.2f)" % (tg, 7 * n / tg / 1e6)
+            gf = lambda: _lib.call("ssv_highway_gate_fwd", P(h), P(x), C * L, P(g), P(b), P(g), P(b), P(stats), P(y), C * L, B, C, L, st)
+            tg, tgf = timeit(gb), timeit(gf)
+            line += " gate-f %.1f (%.2f) gate-b %.1f (%.2f)" % (tgf, 4 * n / tgf / 1e6, tg, 7 * n / tg / 1e6)
     print(line, flush=True)
