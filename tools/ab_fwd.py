@@ -8,7 +8,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 dev = "cuda:0"
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 out = []
-for (B, C, L, k) in [(32, 256, 325, 3), (32, 512, 186, 3), (32, 256, 1300, 3)]:
+for (B, C, L, k) in [(32, 256, 325, 3), (32, 512, 186, 3), (32, 256, 1300, 3), (32, 512, 1300, 3)]:
     nset = 12 if L <= 400 else 3
     xs = [torch.randn(B, C, L, device=dev) for _ in range(nset)]
     hs = [torch.empty(B, 2 * C, L, device=dev) for _ in range(nset)]
