@@ -370,7 +370,13 @@ def _segmented_iteration(net, x, y, ddp):
     phases = []
     for i, seg in enumerate(segs):
         phases.append(("graph", seg))
-        phases.append(("eager", lambda i=i: (order.append(i), ddp.start_bucket(i))))
+        def hand_over(i=i):
+            # bucket i goes to its all-reduce while the rest of backward has not run: its gradients exist, later buckets' do not
+            assert all(p.grad is not None for p in ddp.bucket_params[i])
+            assert all(p.grad is None for later in ddp.bucket_params[i + 1:] for p in later)
+            order.append(i)
+            ddp.start_bucket(i)
+        phases.append(("eager", hand_over))
     phases.append(("eager", ddp.finish))
     train.PhasedStep(phases, graph=False).run()
     assert order == [0, 1, 2] and net._cut("x", loss) is loss          # hook restored after the forward
