@@ -17,23 +17,53 @@ int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long 
 }
 
 // Slabs stored [z][m][j][c] (channels contiguous: the weight-gradient kernel's lanes write 64-byte runs), output in the
-// weight layout out[m][c][j] = sum_z slab[z][m][j][c].  Threads walk the slab order, so the Z large reads are coalesced.
+// weight layout out[m][c][j] = sum_z slab[z][m][j][c].  A thread owns one (m, c) and all KT taps: the Z reads per tap are
+// coalesced along c, and the workgroup's 256 * KT results are one contiguous run of `out`, written as 16-byte vectors
+// through LDS.  (One thread per slab element wrote 4 bytes at a 12-byte stride, the three taps of a line from three
+// different waves: WRITE_SIZE was 3x the gradient.)  Summation order per element: pairs of slabs, as before.
+__device__ __forceinline__ void reduce_perm_block(const float* __restrict__ s, float* __restrict__ out, int Nc, int KT, long n, int Z, int block,
+                                                  float* __restrict__ stage /* [256 * 3] */) {
+  const long P = n / KT;                                      // (m, c) pairs
+  const long q = (long)block * 256 + threadIdx.x;
+  if (KT == 1) {
+    if (q >= P) return;
+    float a0 = 0.f, a1 = 0.f;
+    int z = 0;
+    for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + q]; a1 += s[(long)(z + 1) * n + q]; }
+    if (z < Z) a0 += s[(long)z * n + q];
+    out[q] = a0 + a1;
+    return;
+  }
+  if (q < P) {
+    const long m = q / Nc;
+    const int c = (int)(q % Nc);
+    for (int j = 0; j < KT; ++j) {
+      const long i = (m * KT + j) * Nc + c;
+      float a0 = 0.f, a1 = 0.f;
+      int z = 0;
+      for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + i]; a1 += s[(long)(z + 1) * n + i]; }
+      if (z < Z) a0 += s[(long)z * n + i];
+      stage[threadIdx.x * KT + j] = a0 + a1;
+    }
+  }
+  __syncthreads();
+  const long o0 = (long)block * 256 * KT;                      // first output element of this workgroup
+  const long cnt = (P - (long)block * 256 < 256 ? P - (long)block * 256 : 256) * KT;
+  float* __restrict__ dst = out + o0;
+  if ((reinterpret_cast<size_t>(dst) & 15) == 0) {
+    for (long f = threadIdx.x * 4; f + 3 < cnt; f += 1024) *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(stage + f);
+    for (long f = (cnt & ~3L) + threadIdx.x; f < cnt; f += 256) dst[f] = stage[f];
+  } else {
+    for (long f = threadIdx.x; f < cnt; f += 256) dst[f] = stage[f];
+  }
+}
 __global__ __launch_bounds__(256) void reduce_slabs_perm_kernel(const float* __restrict__ s, float* __restrict__ out, int Nc, int KT, long n, int Z) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float a0 = 0.f, a1 = 0.f;
-  int z = 0;
-  for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + i]; a1 += s[(long)(z + 1) * n + i]; }
-  if (z < Z) a0 += s[(long)z * n + i];
-  const int c = (int)(i % Nc);
-  const long mj = i / Nc;
-  const int j = (int)(mj % KT);
-  const long m = mj / KT;
-  out[(m * Nc + c) * KT + j] = a0 + a1;
+  __shared__ __attribute__((aligned(16))) float stage[256 * 3];
+  reduce_perm_block(s, out, Nc, KT, n, Z, (int)blockIdx.x, stage);
 }
 int ssv_launch_reduce_slabs_perm(const float* slabs, float* out, int M, int Nc, int KT, int Z, hipStream_t st) {
   const long n = (long)M * Nc * KT;
-  hipLaunchKernelGGL(reduce_slabs_perm_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, slabs, out, Nc, KT, n, Z);
+  hipLaunchKernelGGL(reduce_slabs_perm_kernel, dim3(ssv_cdiv((long)M * Nc, 256)), dim3(256), 0, st, slabs, out, Nc, KT, n, Z);
   return ssv_check_launch("reduce_slabs_perm");
 }
 
@@ -44,18 +74,9 @@ int ssv_launch_reduce_slabs_perm(const float* slabs, float* out, int M, int Nc, 
 __global__ __launch_bounds__(256) void reduce_pair_kernel(const float* __restrict__ s, float* __restrict__ out, int Nc, int KT, long n, int Z, int nA,
                                                           const float* __restrict__ part, float* __restrict__ pout, int n2, int nblk) {
   __shared__ float red[8][32];
+  __shared__ __attribute__((aligned(16))) float stage[256 * 3];
   if ((int)blockIdx.x < nA) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a0 = 0.f, a1 = 0.f;
-    int z = 0;
-    for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + i]; a1 += s[(long)(z + 1) * n + i]; }
-    if (z < Z) a0 += s[(long)z * n + i];
-    const int c = (int)(i % Nc);
-    const long mj = i / Nc;
-    const int j = (int)(mj % KT);
-    const long m = mj / KT;
-    out[(m * Nc + c) * KT + j] = a0 + a1;
+    reduce_perm_block(s, out, Nc, KT, n, Z, (int)blockIdx.x, stage);
     return;
   }
   const int li = threadIdx.x & 31, rg = threadIdx.x >> 5;
@@ -80,7 +101,7 @@ __global__ __launch_bounds__(256) void reduce_pair_kernel(const float* __restric
 }
 int ssv_launch_reduce_pair(const float* slabs, float* out, int M, int Nc, int KT, int Z, const float* part, float* pout, int n2, int nblk, hipStream_t st) {
   const long n = (long)M * Nc * KT;
-  const int nA = ssv_cdiv(n, 256), nB = ssv_cdiv(n2, 32);
+  const int nA = ssv_cdiv((long)M * Nc, 256), nB = ssv_cdiv(n2, 32);
   hipLaunchKernelGGL(reduce_pair_kernel, dim3(nA + nB), dim3(256), 0, st, slabs, out, Nc, KT, n, Z, nA, part, pout, n2, nblk);
   return ssv_check_launch("reduce_pair");
 }
@@ -91,18 +112,9 @@ __global__ __launch_bounds__(256) void reduce_pair_multi_kernel(const ssv_wgrad_
   __shared__ float red[8][32];
   const ssv_wgrad_job jb = jobs[blockIdx.y];
   const float* __restrict__ s = slabs + (long)blockIdx.y * Z * n;
+  __shared__ __attribute__((aligned(16))) float stage[256 * 3];
   if ((int)blockIdx.x < nA) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a0 = 0.f, a1 = 0.f;
-    int z = 0;
-    for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + i]; a1 += s[(long)(z + 1) * n + i]; }
-    if (z < Z) a0 += s[(long)z * n + i];
-    const int c = (int)(i % Nc);
-    const long mj = i / Nc;
-    const int j = (int)(mj % KT);
-    const long m = mj / KT;
-    jb.dw[(m * Nc + c) * KT + j] = a0 + a1;
+    reduce_perm_block(s, jb.dw, Nc, KT, n, Z, (int)blockIdx.x, stage);
     return;
   }
   if (!jb.part) return;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256) void reduce_pair_multi_kernel(const ssv_wgrad_
 }
 int ssv_launch_reduce_pair_multi(const ssv_wgrad_job* jobs, int njobs, const float* slabs, int M, int Nc, int KT, int Z, int n2, int nblk, hipStream_t st) {
   const long n = (long)M * Nc * KT;
-  const int nA = ssv_cdiv(n, 256), nB = n2 > 0 ? ssv_cdiv(n2, 32) : 0;
+  const int nA = ssv_cdiv((long)M * Nc, 256), nB = n2 > 0 ? ssv_cdiv(n2, 32) : 0;
   hipLaunchKernelGGL(reduce_pair_multi_kernel, dim3(nA + nB, njobs), dim3(256), 0, st, jobs, slabs, Nc, KT, n, Z, nA, n2, nblk);
   return ssv_check_launch("reduce_pair_multi");
 }
