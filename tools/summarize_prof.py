@@ -16,6 +16,13 @@ def counters(path, name):
         k = r["Kernel_Name"]
         acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     return acc
+def counters_by_shape(path, name):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name: continue
+        k = (r["Kernel_Name"].split("(")[0][:60], r["Grid_Size"])
+        acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    return acc
 def by_shape(path, top=22):
     """Kernel time per (kernel, grid): separates the launch shapes that share one template instantiation."""
     acc = collections.defaultdict(lambda: [0, 0.0])
@@ -74,3 +81,10 @@ if __name__ == "__main__":
         print("%12s %12s %7s  %s" % ("FETCH_KiB", "WRITE_KiB", "calls", "kernel"))
         for k in sorted(f, key=lambda k: -f[k][0])[:14]:
             print("%12.1f %12.1f %7d  %s" % (f[k][0] / f[k][1], w[k][0] / max(1, w[k][1]), f[k][1], k[:110]))
+        fs = counters_by_shape((glob.glob(sys.argv[2] + "/*/*counter_collection.csv") + glob.glob(sys.argv[2] + "/*counter_collection.csv"))[0], "FETCH_SIZE")
+        wsz = counters_by_shape((glob.glob(sys.argv[3] + "/*/*counter_collection.csv") + glob.glob(sys.argv[3] + "/*counter_collection.csv"))[0], "WRITE_SIZE")
+        print("\nPMC per launch shape (grid = total threads), the GEMM and reduction kernels")
+        print("%12s %12s %7s  %s" % ("FETCH_KiB", "WRITE_KiB", "calls", "kernel  grid"))
+        for k in sorted(fs, key=lambda k: -fs[k][0]):
+            if "gemm_n" in k[0] or "reduce_" in k[0]:
+                print("%12.1f %12.1f %7d  %s  %s" % (fs[k][0] / fs[k][1], wsz[k][0] / max(1, wsz[k][1]) if k in wsz else -1, fs[k][1], k[0], k[1]))
