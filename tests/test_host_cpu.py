@@ -502,3 +502,36 @@ def test_trainers_refuse_what_they_do_not_implement():
     from spoofsv_amd.critic import melDisc
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         melDisc(80, 16)(torch.zeros(1, 80, 8))                        # the critics have no stock-op branch either
+
+
+def _pad_worker(rank, world, port, q):
+    from spoofsv_amd import harness
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, N = (20, 9) if rank == 0 else (14, 12)                    # each rank's own longest item
+    sp = {"data_0": torch.ones(3, 80, T), "data_1": torch.ones(3, 1, N, dtype=torch.int64), "data_2": torch.ones(3, 200, 1),
+          "data_3": torch.ones(3, 513, 4 * T)}
+    out = harness._pad_to_global(sp, world)
+    q.put((rank, {k: tuple(v.shape) for k, v in out.items()}, float(out["data_0"].sum()), int(out["data_1"].sum()), float(out["data_3"].sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_rank_batches_are_padded_to_the_global_longest_item_gloo_world2():
+    """every rank zero-pads its shard to the longest mel / text of the GLOBAL batch (one all-reduce(max)), so the
+    mean-type losses see the shapes a single process would give the whole batch (data/dataset.py:215-224 pads per batch)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, shapes, s0, s1, s3 in res:
+        assert shapes == {"data_0": (3, 80, 20), "data_1": (3, 1, 12), "data_2": (3, 200, 1), "data_3": (3, 513, 80)}, (rank, shapes)
+        T, N = (20, 9) if rank == 0 else (14, 12)
+        assert s0 == 3 * 80 * T and s1 == 3 * N and s3 == 3 * 513 * 4 * T        # padding is zeros ('P' = id 0 for the text)
