@@ -3,7 +3,7 @@
 (the numbers behind tests/test_gpu_parity.py::test_bench_workload_full_size_training_step_vs_oracle)."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import spoofsv_amd
 from _golden import rel_err, rel_l2

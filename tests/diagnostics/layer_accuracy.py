@@ -2,7 +2,7 @@
 """Diagnostic (GPU box): gradient error of a stack of n highway layers vs a float64 CPU evaluation, both arithmetic modes."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import spoofsv_amd
 from oracle import tts_oracle as TO

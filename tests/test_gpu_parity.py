@@ -533,7 +533,7 @@ def _bench_workload_oracle(kind, B):
     return rec
 
 
-# Gradient agreement at full depth, measured (tools/grad_parity.py, B = 8), relative L2 per parameter tensor:
+# Gradient agreement at full depth, measured (tests/diagnostics/grad_parity.py, B = 8), relative L2 per parameter tensor:
 #   exact-fp32 mode vs the float64 oracle: Text2Mel <= 4e-6, SSRN <= 2.3e-4 (median 1.4e-4);
 #   split-bf16 mode vs the float64 oracle: median 8e-4, worst 1.8e-3 (Text2Mel), 1.3e-3 (SSRN);
 #   the float32 ORACLE vs its own float64 evaluation: Text2Mel 1e-6, SSRN median 2.9e-4, worst 4.3e-4 (1.0e-3 at B = 2).
