@@ -252,13 +252,33 @@ def kernel_roofline(dev):
         others.append({"kernel": "Conv1d weight gradient C=256->512 L=325, 16 layers in one launch (gemm_nt_bf3_kernel<3,2,4> with a job table, "
                                  "2 slabs per layer, + reduce_pair_multi): per layer", "us_per_launch": round(m_ * 1e3, 2), "achieved": round(a_, 2),
                        "frac": round(a_ / peak, 4)})
+    lib_ref = None
+    if split:
+        # reference point, not a baseline of the path: ONE plain bf16 product of the headline shape (operands already bf16 and
+        # resident, no split, no bias) through the vendor library (hipBLASLt behind torch.bmm).  The split-bf16 arithmetic needs
+        # three such products per fp32 product, so a library-based implementation of the same arithmetic costs >= 3x this time.
+        a16 = torch.randn(B, 2 * C, C * k, device=dev).bfloat16()
+        x16 = torch.randn(B, C * k, L, device=dev).bfloat16()
+        o16 = torch.empty(B, 2 * C, L, device=dev, dtype=torch.bfloat16)
+        for _ in range(5):
+            torch.bmm(a16, x16, out=o16)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            torch.bmm(a16, x16, out=o16)
+        e1.record()
+        torch.cuda.synchronize()
+        lus = e0.elapsed_time(e1) / 50 * 1e3
+        lib_ref = {"what": "torch.bmm (hipBLASLt) bf16 x bf16 -> bf16, same M x K x N x batch, ONE product", "us_per_launch": round(lus, 2),
+                   "tflops_one_product": round(flops / lus / 1e6, 1), "us_for_three_products": round(3 * lus, 2),
+                   "algorithmic_tflops_if_three_products": round(flops / (3 * lus) / 1e6, 1)}
     return {"bound": "mfma", "kernel": name + ", dilated Conv1d fwd B=32 C=256->512 L=325",
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "peak_note": "bf16 dense 2500 TFLOP/s / 3" if split else "fp32-input MFMA dense",
             "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
             "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4),
             **pmc_traffic(split),
-            "others": others}
+            "others": others, "library_reference": lib_ref}
 
 
 def pmc_traffic(split):
