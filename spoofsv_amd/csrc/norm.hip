@@ -30,6 +30,23 @@ __device__ __forceinline__ float group_sum(float v, float* red, int col, int g) 
   return s;
 }
 
+// N sums in ONE LDS round trip (two barriers for all of them instead of two per sum): `red` is [N][G][16].  Per value the G
+// partials are added in the same order as group_sum does, so results are bit-identical to N separate calls.
+template <int G, int N>
+__device__ __forceinline__ void group_sums(float (&v)[N], float* red, int col, int g) {
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) red[(k * G + g) * 16 + col] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) s += red[(k * G + i) * 16 + col];
+    v[k] = s;
+  }
+}
+
 // Sum over the 16 columns (16 consecutive lanes share one channel group = one DPP row): VALU only, no LDS traffic
 // (the backward kernels make 3 of these per element).
 __device__ __forceinline__ float col_sum(float v) { return ssv_row16_sum(v); }
@@ -53,7 +70,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_fwd_kernel(
     const float* __restrict__ H, long h_bs, const float* __restrict__ X, long x_bs,
     const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
     float* __restrict__ Y, long y_bs, float* __restrict__ stats, int C, int L) {
-  __shared__ float red[16 * G];
+  __shared__ float red[2 * 16 * G];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -74,8 +91,9 @@ __global__ __launch_bounds__(16 * G) void ln_gate_fwd_kernel(
     s1 += h1[i]; s2 += h2[i];
   }
   const float inv = 1.f / (float)C;
-  const float mu1 = group_sum<G>(s1, red, col, g) * inv;
-  const float mu2 = group_sum<G>(s2, red, col, g) * inv;
+  float ms[2] = {s1, s2};
+  group_sums<G, 2>(ms, red, col, g);
+  const float mu1 = ms[0] * inv, mu2 = ms[1] * inv;
   float q1 = 0.f, q2 = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
@@ -83,8 +101,9 @@ __global__ __launch_bounds__(16 * G) void ln_gate_fwd_kernel(
     const float d1 = v ? h1[i] - mu1 : 0.f, d2 = v ? h2[i] - mu2 : 0.f;
     q1 += d1 * d1; q2 += d2 * d2;
   }
-  const float r1 = rsqrtf(group_sum<G>(q1, red, col, g) * inv + LN_EPS);
-  const float r2 = rsqrtf(group_sum<G>(q2, red, col, g) * inv + LN_EPS);
+  float qs[2] = {q1, q2};
+  group_sums<G, 2>(qs, red, col, g);
+  const float r1 = rsqrtf(qs[0] * inv + LN_EPS), r2 = rsqrtf(qs[1] * inv + LN_EPS);
   if (!tv) return;
   if (g == 0 && stats) {
     float* sb = stats + (long)b * 4 * L + t;
@@ -111,7 +130,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
     const float* __restrict__ stats,
     const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
     float* __restrict__ dH, float* __restrict__ dXres, long dx_bs, float* __restrict__ part, int C, int L) {
-  __shared__ float red[16 * G];
+  __shared__ float red[4 * 16 * G];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -159,8 +178,9 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
     sa1 += a1[i]; sah1 += a1[i] * xh1[i]; sa2 += a2[i]; sah2 += a2[i] * xh2[i];
   }
   const float inv = 1.f / (float)C;
-  const float m1 = group_sum<G>(sa1, red, col, g) * inv, mh1 = group_sum<G>(sah1, red, col, g) * inv;
-  const float m2 = group_sum<G>(sa2, red, col, g) * inv, mh2 = group_sum<G>(sah2, red, col, g) * inv;
+  float gs[4] = {sa1, sah1, sa2, sah2};
+  group_sums<G, 4>(gs, red, col, g);
+  const float m1 = gs[0] * inv, mh1 = gs[1] * inv, m2 = gs[2] * inv, mh2 = gs[3] * inv;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = g + G * i;
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
     const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs, const float* __restrict__ stats,
     const float* __restrict__ gam, const float* __restrict__ bet,
     float* __restrict__ dX, long dx_bs, float* __restrict__ part, int C, int L, int act) {
-  __shared__ float red[16 * G];
+  __shared__ float red[2 * 16 * G];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -260,7 +280,9 @@ __global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
     sa += a[i]; sah += a[i] * xh[i];
   }
   const float inv = 1.f / (float)C;
-  const float m = group_sum<G>(sa, red, col, g) * inv, mh = group_sum<G>(sah, red, col, g) * inv;
+  float gs[2] = {sa, sah};
+  group_sums<G, 2>(gs, red, col, g);
+  const float m = gs[0] * inv, mh = gs[1] * inv;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = g + G * i;
@@ -284,7 +306,7 @@ __global__ __launch_bounds__(16 * G) void ln_bwd2_kernel(
     const float* __restrict__ V, long v_bs, const float* __restrict__ GN, long gn_bs, const float* __restrict__ X, long x_bs,
     const float* __restrict__ stats, const float* __restrict__ gam,
     float* __restrict__ dGN, long dgn_bs, float* __restrict__ dX, long dx_bs, float* __restrict__ part, int C, int L) {
-  __shared__ float red[16 * G];
+  __shared__ float red[5 * 16 * G];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -311,9 +333,9 @@ __global__ __launch_bounds__(16 * G) void ln_bwd2_kernel(
     }
   }
   const float inv = 1.f / (float)C;
-  const float m_v = group_sum<G>(sv, red, col, g) * inv, m_vx = group_sum<G>(svx, red, col, g) * inv;
-  const float m_a = group_sum<G>(sa, red, col, g) * inv, m_ax = group_sum<G>(sax, red, col, g) * inv;
-  const float m_va = group_sum<G>(sva, red, col, g) * inv;
+  float gs[5] = {sv, svx, sa, sax, sva};
+  group_sums<G, 5>(gs, red, col, g);
+  const float m_v = gs[0] * inv, m_vx = gs[1] * inv, m_a = gs[2] * inv, m_ax = gs[3] * inv, m_va = gs[4] * inv;
   const float s_c = r * (m_va - m_v * m_a - m_vx * m_ax);            // s_col / C
   const float mw = m_v * m_ax + m_a * m_vx, mwx = 2.f * m_vx * m_ax;
   float* pblk = part + ((long)by * gridDim.x + bx) * C;
@@ -348,7 +370,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd2_kernel(
     const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
     float* __restrict__ dGY, long dgy_bs, float* __restrict__ dH, float* __restrict__ dX, long dx_bs,
     float* __restrict__ part, int C, int L) {
-  __shared__ float red[16 * G];
+  __shared__ float red[10 * 16 * G];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -397,8 +419,9 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd2_kernel(
     }
   }
   const float inv = 1.f / (float)C;
+  group_sums<G, 10>(s, red, col, g);
 #pragma unroll
-  for (int k = 0; k < 10; ++k) s[k] = group_sum<G>(s[k], red, col, g) * inv;
+  for (int k = 0; k < 10; ++k) s[k] *= inv;
   const float sc1 = r1 * (s[4] - s[0] * s[2] - s[1] * s[3]), sc2 = r2 * (s[9] - s[5] * s[7] - s[6] * s[8]);
   const float mw1 = s[0] * s[3] + s[2] * s[1], mwx1 = 2.f * s[1] * s[3];
   const float mw2 = s[5] * s[8] + s[7] * s[6], mwx2 = 2.f * s[6] * s[8];
@@ -431,8 +454,9 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd2_kernel(
     v1[i] = -r1 * xh1[i] * sc1 - r1 * r1 * (w1 - mw1 - xh1[i] * mwx1);
     v2[i] = -r2 * xh2[i] * sc2 - r2 * r2 * (w2 - mw2 - xh2[i] * mwx2);
   }
-  const float mb1 = group_sum<G>(sb1, red, col, g) * inv, mbx1 = group_sum<G>(sbx1, red, col, g) * inv;
-  const float mb2 = group_sum<G>(sb2, red, col, g) * inv, mbx2 = group_sum<G>(sbx2, red, col, g) * inv;
+  float bs[4] = {sb1, sbx1, sb2, sbx2};
+  group_sums<G, 4>(bs, red, col, g);
+  const float mb1 = bs[0] * inv, mbx1 = bs[1] * inv, mb2 = bs[2] * inv, mbx2 = bs[3] * inv;
   float* __restrict__ dH1 = dH + hb;
   float* __restrict__ dH2 = dH1 + cl;
 #pragma unroll
