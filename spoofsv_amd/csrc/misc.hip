@@ -37,13 +37,27 @@ __device__ __forceinline__ void reduce_perm_block(const float* __restrict__ s, f
   if (q < P) {
     const long m = q / Nc;
     const int c = (int)(q % Nc);
-    for (int j = 0; j < KT; ++j) {
-      const long i = (m * KT + j) * Nc + c;
-      float a0 = 0.f, a1 = 0.f;
+    if (KT == 3) {                                            // the three taps side by side: three independent chains of loads in flight
+      const long i0 = (m * 3) * Nc + c, i1 = i0 + Nc, i2 = i1 + Nc;
+      float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f;
       int z = 0;
-      for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + i]; a1 += s[(long)(z + 1) * n + i]; }
-      if (z < Z) a0 += s[(long)z * n + i];
-      stage[threadIdx.x * KT + j] = a0 + a1;
+#pragma unroll 2
+      for (; z + 1 < Z; z += 2) {
+        const float* __restrict__ s0 = s + (long)z * n;
+        const float* __restrict__ s1 = s0 + n;
+        a0 += s0[i0]; a1 += s1[i0]; b0 += s0[i1]; b1 += s1[i1]; c0 += s0[i2]; c1 += s1[i2];
+      }
+      if (z < Z) { const float* __restrict__ s0 = s + (long)z * n; a0 += s0[i0]; b0 += s0[i1]; c0 += s0[i2]; }
+      stage[threadIdx.x * 3] = a0 + a1; stage[threadIdx.x * 3 + 1] = b0 + b1; stage[threadIdx.x * 3 + 2] = c0 + c1;
+    } else {
+      for (int j = 0; j < KT; ++j) {
+        const long i = (m * KT + j) * Nc + c;
+        float a0 = 0.f, a1 = 0.f;
+        int z = 0;
+        for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + i]; a1 += s[(long)(z + 1) * n + i]; }
+        if (z < Z) a0 += s[(long)z * n + i];
+        stage[threadIdx.x * KT + j] = a0 + a1;
+      }
     }
   }
   __syncthreads();
