@@ -12,7 +12,7 @@ def run(force):
     env = dict(os.environ)
     env.pop("SSV_NNB_FORCE", None)
     if force: env["SSV_NNB_FORCE"] = force
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-adversarial", "--steps", steps, "--warmup", "3"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-adversarial", "--no-fp32", "--no-ge2e", "--steps", steps, "--warmup", "3"],
                          env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
     d = json.loads(out)
     return d["ms_per_step"], d["config"]["text2mel_ms"], d["config"]["ssrn_ms"]
