@@ -13,11 +13,6 @@
 //   ln_act_* : y = act(LN(x)), act in {none, relu, sigmoid}
 #include <stdlib.h>
 #include "ssv_common.h"
-#ifdef SSV_LN_WT
-#define LN_ST(dst, v) __hip_atomic_store(&(dst), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   /* global_store ... sc1: written through the L2 */
-#else
-#define LN_ST(dst, v) ((dst) = (v))
-#endif
 
 #define LN_EPS 1e-5f
 
@@ -123,7 +118,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_fwd_kernel(
       const float n1 = (h1[i] - mu1) * r1 * g1[c] + b1[c];
       const float n2 = (h2[i] - mu2) * r2 * g2[c] + b2[c];
       const float s = sigmoidf_(n1);
-      LN_ST(Yb[o0 + i * ostep], s * n2 + (1.f - s) * Xb[o0 + i * ostep]);
+      Yb[o0 + i * ostep] = s * n2 + (1.f - s) * Xb[o0 + i * ostep];
     }
   }
 }
@@ -174,7 +169,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
       const float s = sigmoidf_(n1);
       dn2 = dy * s;
       dn1 = dy * (n2 - x) * s * (1.f - s);
-      LN_ST(dXb[o0 + i * ostep], dy * (1.f - s));
+      dXb[o0 + i * ostep] = dy * (1.f - s);
     }
     // per-channel parameter-gradient partials over this block's 16 columns
     const float p0 = col_sum(dn1 * xh1[i]), p1 = col_sum(dn1), p2 = col_sum(dn2 * xh2[i]), p3 = col_sum(dn2);
@@ -192,7 +187,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
     const bool v = tv && c < C;
     const float d1 = v ? r1 * (a1[i] - m1 - xh1[i] * mh1) : 0.f;
     const float d2 = v ? r2 * (a2[i] - m2 - xh2[i] * mh2) : 0.f;
-    if (v) { LN_ST(dHb1[o0 + i * ostep], d1); LN_ST(dHb2[o0 + i * ostep], d2); }
+    if (v) { dHb1[o0 + i * ostep] = d1; dHb2[o0 + i * ostep] = d2; }
     const float q0 = col_sum(d1), q1 = col_sum(d2);
     if (col == 0 && c < C) { pblk[4 * C + c] = q0; pblk[5 * C + c] = q1; }
   }
@@ -238,7 +233,7 @@ __global__ __launch_bounds__(16 * G) void ln_act_fwd_kernel(
       float n = (x[i] - mu) * r * gam[c] + bet[c];
       if (act == 1) n = fmaxf(n, 0.f);
       else if (act == 2) n = sigmoidf_(n);
-      LN_ST(Yb[o0 + i * ostep], n);
+      Yb[o0 + i * ostep] = n;
     }
   }
 }
@@ -293,7 +288,7 @@ __global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
     const int c = g + G * i;
     const bool v = tv && c < C;
     const float d = v ? r * (a[i] - m - xh[i] * mh) : 0.f;
-    if (v) LN_ST(dXb[o0 + i * ostep], d);
+    if (v) dXb[o0 + i * ostep] = d;
     const float q0 = col_sum(d);
     if (col == 0 && c < C) pblk[2 * C + c] = q0;
   }
