@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--no-ge2e", action="store_true", help="skip the GE2E (config 5) figures on the line")
     ap.add_argument("--ge2e", action="store_true", help="measure BASELINE config 5 (GE2E speaker embedder) instead and print its JSON line")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
-                    help="conv GEMM arithmetic: split-bf16 MFMA (default, ~1e-5 rel) or exact fp32 MFMA")
+    ap.add_argument("--precision", choices=["f16x2", "bf16x3", "fp32"], default="f16x2",
+                    help="conv GEMM arithmetic: split-fp16 MFMA with power-of-two operand scales (default, ~2^-22 per product = fp32-grade), "
+                         "split-bf16 MFMA (~2^-16, narrower than the reference: opt-in) or exact fp32 MFMA")
     return ap.parse_args()
 
 
@@ -152,14 +153,20 @@ def kernel_roofline(dev):
     640 MB > the 256 MB Infinity Cache), because in the step each layer reads and writes tensors of its own.
     Algorithmic FLOPs per launch = 2*B*L*(2C)*C*k."""
     import ctypes
-    from spoofsv_amd import _lib, resident
+    from spoofsv_amd import _lib, ops, resident
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    f16 = _lib.precision() == 2
+    # split-fp16: the operands' scale lists exist before the launch in the training step (the producing LayerNorm kernel
+    # writes them), so they are prepared outside the timed region here as well
+    amax = lambda ts: [ops.amax_of(t) if f16 else None for t in ts]
+    na = ops._AMAX_PIECES if f16 else 0
 
     def time_conv_fwd(B, C, L, k, nset):
         """ms per launch of the forward conv C -> 2C, cold operands, resident weights."""
         xs = [torch.randn(B, C, L, device=dev) for _ in range(nset)]
         ys = [torch.empty(B, 2 * C, L, device=dev) for _ in range(nset)]
+        xa = amax(xs)
         w = torch.randn(2 * C, C, k, device=dev) * 0.05
         bias = torch.randn(2 * C, device=dev)
         rw = resident.ResidentWeights([w])
@@ -167,7 +174,7 @@ def kernel_roofline(dev):
         wp = resident.lookup(w)
         nb = _lib.query("ssv_conv1d_fwd_workspace", C, 2 * C, k)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        run = lambda i: _lib.call("ssv_conv1d_fwd", P(xs[i]), C * L, P(w), wp, P(bias), None, P(ys[i]), 2 * C * L, B, C, 2 * C, L, k, 1, 1,
+        run = lambda i: _lib.call("ssv_conv1d_fwd", P(xs[i]), C * L, P(xa[i]), na, P(w), wp, P(bias), None, P(ys[i]), 2 * C * L, B, C, 2 * C, L, k, 1, 1,
                                   P(ws), nb, st)
         for i in range(nset):
             run(i)
@@ -185,10 +192,12 @@ def kernel_roofline(dev):
         """ms per call of the weight gradient of the same conv (gemm_nt_bf3_kernel + its slab reduction), cold operands."""
         xs = [torch.randn(B, C, L, device=dev) for _ in range(nset)]
         dys = [torch.randn(B, 2 * C, L, device=dev) for _ in range(nset)]
+        xa, dya = amax(xs), amax(dys)
         dw = torch.empty(2 * C, C, k, device=dev)
         nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, C, 2 * C, k)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        run = lambda i: _lib.call("ssv_conv1d_bwd_weight", P(dys[i]), 2 * C * L, P(xs[i]), C * L, P(dw), B, C, 2 * C, L, k, 1, 1, P(ws), nb, st)
+        run = lambda i: _lib.call("ssv_conv1d_bwd_weight", P(dys[i]), 2 * C * L, P(dya[i]), na, P(xs[i]), C * L, P(xa[i]), na, P(dw), B, C, 2 * C, L, k, 1, 1,
+                                  P(ws), nb, st)
         for i in range(nset):
             run(i)
         reps = 3 * nset
@@ -207,12 +216,15 @@ def kernel_roofline(dev):
         xs = [torch.randn(B, C, L, device=dev) for _ in range(njobs)]
         dys = [torch.randn(B, 2 * C, L, device=dev) for _ in range(njobs)]
         dws = [torch.empty(2 * C, C, k, device=dev) for _ in range(njobs)]
+        xa, dya = amax(xs), amax(dys)
         table = (L_.WgradJob * njobs)()
         sh = (ctypes.c_int * 3)()
         L_.call("ssv_conv_shifts", k, 1, 1, sh)
-        for t, x_, dy_, dw_ in zip(table, xs, dys, dws):
+        for t, x_, dy_, dw_, xa_, dya_ in zip(table, xs, dys, dws, xa, dya):
             t.dy, t.x, t.dw, t.part, t.pgrads = dy_.data_ptr(), x_.data_ptr(), dw_.data_ptr(), None, None
             t.shift[0], t.shift[1], t.shift[2] = sh[0], sh[1], sh[2]
+            if f16:
+                t.dy_amax, t.x_amax, t.dy_namax, t.x_namax = dya_.data_ptr(), xa_.data_ptr(), dya_.numel(), xa_.numel()
         tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
         nb = L_.query("ssv_conv1d_bwd_weight_multi_workspace", njobs, B, C, 2 * C, k)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)

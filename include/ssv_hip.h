@@ -29,13 +29,30 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 1 */
+int ssv_version(void);            /* ABI version, currently 2 (1 + split-fp16 operand scales) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
-/* Arithmetic of the conv GEMMs: 0 = fp32-in MFMA (bit-exact fp32 fma chains), 1 = split-bf16 MFMA (each fp32
- * operand as bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate; ~1e-5 relative; default; env
- * SSV_PRECISION=fp32 selects 0 at load).  Returns the previous mode.  Process-wide. */
+/* Arithmetic of the conv GEMMs (the reference computes in fp32: requirements.txt:5, nn.Conv1d at models/TTSModel.py:59):
+ *   0 = fp32-in MFMA: bit-exact fp32 fma chains (157 TFLOP/s peak);
+ *   1 = split-bf16 MFMA: each fp32 operand as bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate; ~2^-16 per
+ *       product -- NARROWER than the reference's arithmetic, opt-in only;
+ *   2 = split-fp16 MFMA (default): each operand is scaled by a power of two (per tensor / per batch item, from its
+ *       maximum magnitude) and split into fp16 hi+lo = 22 significand bits, three fp16 MFMAs per product (every
+ *       fp16 x fp16 product is exact in fp32), fp32 accumulate, result rescaled; ~2^-22 per product = fp32-grade at
+ *       the bf16/fp16 MFMA rate.  The LSTM products of the GE2E embedder stay on the split-bf16 arithmetic in this mode.
+ * Env SSV_PRECISION = fp32 | bf16x3 | f16x2 selects the mode at load.  Returns the previous mode.  Process-wide.
+ *
+ * Operand scales (mode 2).  A kernel that reads an fp32 tensor as an MFMA operand needs max |x| BEFORE it starts.  The
+ * convention: a "scale list" of x (B, C, L) is `namax` floats per batch item, items consecutive, whose maximum per item
+ * is max |x(b)| -- partial maxima, in any partition.  The LayerNorm / gate kernels write such a list for their output as
+ * a by-product (ssv_amax_rows(L) entries per item: one per 16-column tile), ssv_absmax computes one for any tensor, and
+ * every entry below that takes `*_amax, *_namax` arguments accepts NULL, 0: it then computes the list itself in its
+ * workspace (one extra small launch).  Outside mode 2 the arguments are ignored (amax outputs are still written). */
 int ssv_set_precision(int mode);
+int ssv_get_precision(void);
+int ssv_amax_rows(int L);         /* entries per batch item of the lists the LayerNorm / gate kernels write: ceil(L / 16) */
+/* amax[b * namax + i] = max |x| over the i-th of namax equal pieces of item b (n dense floats at x + b * x_bs). */
+int ssv_absmax(const float* x, long x_bs, int B, long n, float* amax, int namax, ssv_stream_t stream);
 /* Tuning knobs (SSV_NNB_TILE, SSV_NT_Z, SSV_LN_GROUPS, ... -- tile / slab overrides used by tools/sweep_*.py) are read
  * from the environment once, at first use; a tuning script that changes them inside one process calls this to re-read. */
 void ssv_reload_tuning(void);
@@ -50,19 +67,20 @@ void ssv_reload_tuning(void);
  * ssv_conv_pack_multi (see "Resident pre-split weights" below) -- then the call skips its own weight split.  The
  * caller vouches that the planes are current for w. */
 size_t ssv_conv1d_fwd_workspace(int Cin, int Cout, int k);   /* holds the pre-split weights */
-int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const void* w_packed, const float* bias, const float* bias_b,
-                   float* y, long y_bs, int B, int Cin, int Cout, int L, int k, int dilation, int causal,
+int ssv_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
+                   const float* bias_b, float* y, long y_bs, int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                    void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* dx = conv1d_transpose(dy, w) [+ dx_add if non-NULL, same layout as dx]; ws holds w transposed. */
 size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k);
-int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* dx_add, float* dx, long dx_bs,
+int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* dy_amax, int dy_namax, const float* w, const void* w_packed,
+                        const float* dx_add, float* dx, long dx_bs,
                         int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                         void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* dw(o,c,j) = sum_{b,t} dy(b,o,t) x(b,c,t+(j-j0)*dilation); split over the batch into slabs, summed
  * in a fixed order (bitwise reproducible). */
 size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int k);
-int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* x, long x_bs, float* dw,
-                          int B, int Cin, int Cout, int L, int k, int dilation, int causal,
+int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* dy_amax, int dy_namax, const float* x, long x_bs, const float* x_amax, int x_namax,
+                          float* dw, int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                           void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* out(b,c) = sum_t x(b,c,t): gradient of a (B,C,1) broadcast term / of a bias per batch item. */
 int ssv_rowsum(const float* x, long x_bs, float* out, int B, int C, int L, ssv_stream_t stream);
@@ -77,8 +95,9 @@ int ssv_copy_rows(const float* src, long src_bs, float* dst, long dst_bs, int B,
  * models/TTSModel.py:129-131, :175-180, :219-231, :344-361.  act: 0 none, 1 relu, 2 sigmoid.
  * stats (B,2,L) = mean, rstd: saved for backward (may be NULL for inference). */
 size_t ssv_channel_ln_act_fwd_workspace(int B, int C, int L);
+/* y_amax (may be NULL): scale list of y, ssv_amax_rows(L) entries per item, for the convolution that reads y next. */
 int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const float* beta,
-                           float* y, long y_bs, float* stats, int B, int C, int L, int act,
+                           float* y, long y_bs, float* y_amax, float* stats, int B, int C, int L, int act,
                            void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L);
 /* dx: gradient w.r.t. the pre-LN input; pgrads (3,C) = dgamma, dbeta, sum_{b,t} dx (bias gradient of
@@ -92,7 +111,8 @@ int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_b
  * (B,2,L) are what the forward saved; dx may be NULL (first layer: the input needs no gradient); ds (B,Cout) = gradient of
  * the broadcast term s, or NULL; pgrads (3,Cout) = dgamma, dbeta, dbias. */
 size_t ssv_pointwise_conv_ln_act_bwd_workspace(int B, int Cin, int Cout, int L);
-int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
+int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* x_amax, int x_namax,
+                                  const float* w, const void* w_packed,
                                   const float* gamma, const float* beta, const float* pre, const float* stats,
                                   float* dx, long dx_bs, float* dw, float* pgrads, float* ds,
                                   int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
@@ -111,6 +131,8 @@ int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const float* x, l
 typedef struct {
   const float* dy; const float* x; float* dw; const float* part; float* pgrads;
   int shift[3]; int pad_;
+  const float* dy_amax; const float* x_amax;   /* split-fp16 (mode 2): the two operands' scale lists, WHOLE lists (all batch items) ... */
+  int dy_namax, x_namax;                       /* ... and their total entry counts (B * entries per item); ignored in the other modes */
 } ssv_wgrad_job;
 int ssv_conv_shifts(int k, int dilation, int causal, int* shift3);
 int ssv_conv1d_bwd_weight_multi_ok(int B, int Cin, int Cout, int L, int k);
@@ -123,27 +145,27 @@ int ssv_ln_partial_rows(int B, int L);
 size_t ssv_highway_conv1d_bwd_data_workspace(int B, int C, int L, int k);
 int ssv_highway_conv1d_bwd_data(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
                                 const float* g1, const float* b1, const float* g2, const float* b2, const float* h, const float* stats,
-                                float* dx, long dx_bs, float* dh, float* part, int B, int C, int L, int k, int dilation, int causal,
-                                void* ws, size_t ws_bytes, ssv_stream_t stream);
+                                float* dx, long dx_bs, float* dh, float* dh_amax, float* part, int B, int C, int L, int k, int dilation, int causal,
+                                void* ws, size_t ws_bytes, ssv_stream_t stream);   /* dh_amax (B * ssv_amax_rows(L), may be NULL): scale list of dh for the job */
 /* The same for y = act(LN(conv1x1(x) [+ s])): dx (may be NULL), ds (may be NULL), dpre (B,Cout,L) dense and part (rows, 3 Cout). */
 size_t ssv_pointwise_conv_ln_act_bwd_data_workspace(int B, int Cin, int Cout, int L);
 int ssv_pointwise_conv_ln_act_bwd_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* gamma, const float* beta,
-                                       const float* pre, const float* stats, float* dx, long dx_bs, float* ds, float* dpre, float* part,
-                                       int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
+                                       const float* pre, const float* stats, float* dx, long dx_bs, float* ds, float* dpre, float* dpre_amax,
+                                       float* part, int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
 
 /* ---- highwayConv ---------------------------------------------------------------------------------
  * Replaces highwayConv.forward, models/TTSModel.py:63-84:
  *   h = conv(x) (2C channels); y = sigmoid(LN1(h[:C])) * LN2(h[C:]) + (1 - sigmoid(LN1(h[:C]))) * x.
  * h (B,2C,L) dense and stats (B,4,L) = mean1, rstd1, mean2, rstd2 are saved for backward. */
 size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k);
-int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const void* w_packed, const float* bias,
+int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
                            const float* g1, const float* b1, const float* g2, const float* b2,
-                           float* h, float* stats, float* y, long y_bs,
+                           float* h, float* stats, float* y, long y_bs, float* y_amax,
                            int B, int C, int L, int k, int dilation, int causal,
-                           void* ws, size_t ws_bytes, ssv_stream_t stream);
+                           void* ws, size_t ws_bytes, ssv_stream_t stream);   /* y_amax: as in ssv_channel_ln_act_fwd */
 size_t ssv_highway_conv1d_bwd_workspace(int B, int C, int L, int k);
 /* Outputs: dx (B,C,L), dw (2C,C,k), pgrads (6,C) = dgamma1, dbeta1, dgamma2, dbeta2, dbias[:C], dbias[C:]. */
-int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
+int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed,
                            const float* g1, const float* b1, const float* g2, const float* b2,
                            const float* h, const float* stats, float* dx, long dx_bs, float* dw, float* pgrads,
                            int B, int C, int L, int k, int dilation, int causal,
@@ -202,10 +224,10 @@ int ssv_attention_apply(const float* v, long kv_bs, const float* a, int a_T, flo
  * Replaces upsampling.deconv, models/TTSModel.py:309,314.  w: (Cin, Cout, 2) as nn.ConvTranspose1d.
  * y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t). */
 size_t ssv_deconv1d_k2s2_fwd_workspace(int Cin, int Cout);   /* pre-split weights of both taps */
-int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
+int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const float* bias, float* y, long y_bs,
                           int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout);
-int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w,
+int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* dy_amax, int dy_namax, const float* x, long x_bs, const float* w,
                           float* dx, long dx_bs, float* dw, float* dbias,
                           int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
 
@@ -230,13 +252,16 @@ int ssv_guided_att_loss_bwd(const float* gaw, int gaw_T, const float* gscale, fl
  * refresh ALL of them with one launch after each optimizer step; the conv entry points then take that buffer as
  * w_packed.  A job table is planned once on the host (ssv_conv_pack_plan), copied to the device by the caller, and
  * replayed by ssv_conv_pack_multi (safe inside hipGraph capture). */
-typedef struct { const float* w; void* planes; int M, K, Kpad, KT; long sm, sk; int first_block, pad_; } ssv_pack_job;
-size_t ssv_conv_pack_bytes(int Cout, int Cin, int k);   /* forward + transposed planes of one weight (Cout,Cin,k) */
+typedef struct { const float* w; void* planes; int M, K, Kpad, KT; long sm, sk; int first_block, pad_; float* inv_out; } ssv_pack_job;
+size_t ssv_conv_pack_bytes(int Cout, int Cin, int k);   /* forward + transposed planes of one weight (Cout,Cin,k) + their two inverse scales (mode 2) */
 /* Fills 2*n HOST jobs (forward, transposed per weight) for weights w[i] (DEVICE pointers, torch layout (Cout,Cin,k))
  * and their DEVICE buffers planes[i]; returns the number of workgroups ssv_conv_pack_multi must launch, or < 0. */
 int ssv_conv_pack_plan(int n, const float* const* w, void* const* planes, const int* Cout, const int* Cin, const int* k,
                        ssv_pack_job* jobs_host);
-int ssv_conv_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, ssv_stream_t stream);
+/* The planes are written in the arithmetic mode in force at the call (bf16 or scaled fp16 halves): re-pack after ssv_set_precision.
+ * ws (mode 2 only): ssv_conv_pack_multi_workspace(njobs) bytes for the weights' partial maxima. */
+size_t ssv_conv_pack_multi_workspace(int njobs);
+int ssv_conv_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, void* ws, size_t ws_bytes, ssv_stream_t stream);
 
 /* ---- Adam -------------------------------------------------------------------------------------------
  * Replaces optim.Adam(...).step(), train/ordinary.py:182,238 (config.json:41-46), for many tensors in
@@ -337,7 +362,7 @@ int ssv_channel_ln_bwd2(const float* v, long v_bs, const float* gn, long gn_bs, 
  * separate differentiable ops): h (B,2C,L) dense, y = sigmoid(LN1(h[:C])) * LN2(h[C:]) + (1 - sigmoid(..)) * x;
  * stats (B,4,L) saved for ssv_highway_gate_bwd. */
 int ssv_highway_gate_fwd(const float* h, const float* x, long x_bs, const float* g1, const float* b1, const float* g2, const float* b2,
-                         float* stats, float* y, long y_bs, int B, int C, int L, ssv_stream_t stream);
+                         float* stats, float* y, long y_bs, float* y_amax, int B, int C, int L, ssv_stream_t stream);
 /* For (dh, dxres) = ssv_highway_gate_bwd(gy; h, x) and upstreams vh (B,2C,L dense), vx: gradients of <vh, dh> + <vx, dxres>
  * w.r.t. gy (d_gy), h (d_h, dense), x (d_x) and pgrads (4,C) = dgamma1, dbeta1, dgamma2, dbeta2. */
 size_t ssv_highway_gate_bwd2_workspace(int B, int C, int L);

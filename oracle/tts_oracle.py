@@ -22,6 +22,54 @@ import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------- helpers
+class kink_sides:
+    """Test hook around the model and loss functions below: which side of its kink every ReLU input, and every |gt - y| of
+    the L1 loss, lies on.
+
+    ``with kink_sides() as r:`` records, per F.relu / abs-mean call in call order, ``r.taps[i] = (x > 0, rms of x, x)``.
+    ``with kink_sides(force=masks):`` replaces the i-th ReLU by ``x * masks[i]`` and the L1 loss's ``|d|`` by ``d * (2 masks[i] -
+    1)``, i.e. evaluates the function (and, through autograd, its gradient) with every element held on the GIVEN side.  The
+    gradient of a network with ReLUs and an L1 loss is discontinuous where such an argument crosses zero, so two correct
+    evaluations whose forward values differ by rounding noise can disagree by a whole gradient term there; forcing the sides
+    makes their gradients comparable (tests/test_gpu_parity.py::test_bench_workload_full_size_training_step_vs_oracle)."""
+    active = None
+
+    def __init__(self, force=None):
+        self.force = None if force is None else list(force)
+        self.taps = []
+
+    def __enter__(self):
+        kink_sides.active = self
+        return self
+
+    def __exit__(self, *exc):
+        kink_sides.active = None
+        return False
+
+
+def _relu(x):
+    r = kink_sides.active
+    if r is None:
+        return F.relu(x)
+    if r.force is not None:
+        return x * r.force.pop(0).to(x.dtype)
+    xd = x.detach()
+    r.taps.append((xd > 0, float(xd.pow(2).mean().sqrt()), xd))
+    return F.relu(x)
+
+
+def _abs_mean(d):
+    """mean |d| (the L1 loss, train/ordinary.py:230,249) behind the same hook."""
+    r = kink_sides.active
+    if r is None:
+        return torch.mean(torch.abs(d))
+    if r.force is not None:
+        return torch.mean(d * (2 * r.force.pop(0).to(d.dtype) - 1))
+    dd = d.detach()
+    r.taps.append((dd > 0, float(dd.pow(2).mean().sqrt()), dd))
+    return torch.mean(torch.abs(d))
+
+
 def _ln_channels(x, w, b, eps=1e-5):
     """LayerNorm over the channel axis of a (B, C, T) tensor.
 
@@ -84,7 +132,7 @@ def text_encoder(textid, sd, prefix="text_encoder"):
     vocab_len = sd[prefix + ".textemb_layer.W.weight"].shape[1]
     x = text_embedding(textid, sd, prefix + ".textemb_layer", vocab_len)
     x = _ln_channels(_pw(x, sd, prefix + ".conv1"), sd[prefix + ".ln1.weight"], sd[prefix + ".ln1.bias"])
-    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv2"), sd[prefix + ".ln2.weight"], sd[prefix + ".ln2.bias"])
+    x = _ln_channels(_pw(_relu(x), sd, prefix + ".conv2"), sd[prefix + ".ln2.weight"], sd[prefix + ".ln2.bias"])
     x = _hci(x, sd, prefix + ".hci1", False)
     x = _hci(x, sd, prefix + ".hci2", False)
     x = highway_conv(x, sd, prefix + ".hc1", 3, 1)
@@ -107,8 +155,8 @@ def audio_encoder(mel, spk, sd, prefix="audio_encoder"):
     if cond:
         x = x + F.linear(spk.permute(0, 2, 1), sd[prefix + ".fc1.weight"], sd[prefix + ".fc1.bias"]).permute(0, 2, 1)
     x = _ln_channels(x, sd[prefix + ".ln1.weight"], sd[prefix + ".ln1.bias"])
-    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv2"), sd[prefix + ".ln2.weight"], sd[prefix + ".ln2.bias"])
-    x = _pw(F.relu(x), sd, prefix + ".conv3")
+    x = _ln_channels(_pw(_relu(x), sd, prefix + ".conv2"), sd[prefix + ".ln2.weight"], sd[prefix + ".ln2.bias"])
+    x = _pw(_relu(x), sd, prefix + ".conv3")
     if cond:
         x = x + F.linear(spk.permute(0, 2, 1), sd[prefix + ".fc2.weight"], sd[prefix + ".fc2.bias"]).permute(0, 2, 1)
     x = _ln_channels(x, sd[prefix + ".ln3.weight"], sd[prefix + ".ln3.bias"])
@@ -127,9 +175,9 @@ def audio_decoder(rq, sd, prefix="audio_decoder"):
     x = highway_conv(x, sd, prefix + ".hc1", 3, 1, True)
     x = highway_conv(x, sd, prefix + ".hc2", 3, 1, True)
     x = _ln_channels(_pw(x, sd, prefix + ".conv2"), sd[prefix + ".ln2.weight"], sd[prefix + ".ln2.bias"])
-    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv3"), sd[prefix + ".ln3.weight"], sd[prefix + ".ln3.bias"])
-    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv4"), sd[prefix + ".ln4.weight"], sd[prefix + ".ln4.bias"])
-    x = _ln_channels(_pw(F.relu(x), sd, prefix + ".conv5"), sd[prefix + ".ln5.weight"], sd[prefix + ".ln5.bias"])
+    x = _ln_channels(_pw(_relu(x), sd, prefix + ".conv3"), sd[prefix + ".ln3.weight"], sd[prefix + ".ln3.bias"])
+    x = _ln_channels(_pw(_relu(x), sd, prefix + ".conv4"), sd[prefix + ".ln4.weight"], sd[prefix + ".ln4.bias"])
+    x = _ln_channels(_pw(_relu(x), sd, prefix + ".conv5"), sd[prefix + ".ln5.weight"], sd[prefix + ".ln5.bias"])
     return torch.sigmoid(x)
 
 
@@ -216,8 +264,8 @@ def ssrn(mel, sd):
     x = highway_conv(x, sd, "hc4", 3, 1)
     x = _ln_channels(_pw(x, sd, "conv3"), sd["ln3.weight"], sd["ln3.bias"])
     x = _ln_channels(_pw(x, sd, "conv4"), sd["ln4.weight"], sd["ln4.bias"])
-    x = _ln_channels(_pw(F.relu(x), sd, "conv5"), sd["ln5.weight"], sd["ln5.bias"])
-    x = _ln_channels(_pw(F.relu(x), sd, "conv6"), sd["ln6.weight"], sd["ln6.bias"])
+    x = _ln_channels(_pw(_relu(x), sd, "conv5"), sd["ln5.weight"], sd["ln5.bias"])
+    x = _ln_channels(_pw(_relu(x), sd, "conv6"), sd["ln6.weight"], sd["ln6.bias"])
     return torch.sigmoid(x)
 
 
@@ -240,7 +288,7 @@ def text2mel_losses(Y, A, mel_gt, gaw):
     -1 entries are masked out again (:232-234); softmax outputs are never -1, so this is
     sum(A * gaw[:N,:T]) / (B*N*T).
     """
-    l1 = torch.mean(torch.abs(mel_gt - Y))
+    l1 = _abs_mean(Y - mel_gt)
     bd = torch.mean(-mel_gt * torch.log(Y + 1e-8) - (1 - mel_gt) * torch.log(1 - Y + 1e-8))
     aug = F.pad(A, (0, gaw.shape[1] - A.shape[-1], 0, gaw.shape[0] - A.shape[-2]), value=-1)
     mask = torch.ne(aug, -1).to(aug.dtype)
@@ -250,7 +298,7 @@ def text2mel_losses(Y, A, mel_gt, gaw):
 
 def ssrn_losses(P, lin_gt):
     """train/ordinary.py:249-252.  Returns (l1, bin_div)."""
-    l1 = torch.mean(torch.abs(lin_gt - P))
+    l1 = _abs_mean(P - lin_gt)
     bd = torch.mean(-lin_gt * torch.log(P + 1e-8) - (1 - lin_gt) * torch.log(1 - P + 1e-8))
     return l1, bd
 

@@ -25,13 +25,14 @@ class PackJob(ctypes.Structure):
     """Mirror of ``ssv_pack_job``."""
     _fields_ = [("w", ctypes.c_void_p), ("planes", ctypes.c_void_p), ("M", ctypes.c_int), ("K", ctypes.c_int),
                 ("Kpad", ctypes.c_int), ("KT", ctypes.c_int), ("sm", ctypes.c_long), ("sk", ctypes.c_long),
-                ("first_block", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("first_block", ctypes.c_int), ("pad_", ctypes.c_int), ("inv_out", ctypes.c_void_p)]
 
 
 class WgradJob(ctypes.Structure):
     """Mirror of ``ssv_wgrad_job``."""
     _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("part", ctypes.c_void_p),
-                ("pgrads", ctypes.c_void_p), ("shift", ctypes.c_int * 3), ("pad_", ctypes.c_int)]
+                ("pgrads", ctypes.c_void_p), ("shift", ctypes.c_int * 3), ("pad_", ctypes.c_int),
+                ("dy_amax", ctypes.c_void_p), ("x_amax", ctypes.c_void_p), ("dy_namax", ctypes.c_int), ("x_namax", ctypes.c_int)]
 
 
 def _ctype(decl):
@@ -92,6 +93,11 @@ def lib():
         fn.argtypes = argtypes
     _lib = L
     return L
+
+
+def precision():
+    """Arithmetic mode of the conv GEMMs: 0 fp32, 1 split-bf16, 2 split-fp16 (include/ssv_hip.h, ssv_set_precision)."""
+    return lib().ssv_get_precision()
 
 
 def call(name, *args):

@@ -28,7 +28,7 @@ static int g_precision = -1;
 int ssv_precision() {
   if (g_precision < 0) {
     const char* e = getenv("SSV_PRECISION");
-    g_precision = (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) ? 0 : 1;
+    g_precision = (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) ? 0 : (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? 1 : 2;
   }
   return g_precision;
 }
@@ -52,23 +52,25 @@ const char* ssv_tuning(int knob) {
 extern "C" void ssv_reload_tuning(void) { load_knobs(); }
 extern "C" int ssv_set_precision(int mode) {
   const int prev = ssv_precision();
-  g_precision = mode ? 1 : 0;
+  g_precision = mode <= 0 ? 0 : (mode == 1 ? 1 : 2);
   return prev;
 }
-extern "C" int ssv_version(void) { return 1; }
+extern "C" int ssv_get_precision(void) { return ssv_precision(); }
+extern "C" int ssv_version(void) { return 2; }
 extern "C" const char* ssv_arch(void) { return "gfx950"; }
 extern "C" const char* ssv_last_error(void) { return g_err; }
 
 // launchers defined in the other translation units
-int ssv_launch_ln_gate_fwd(const float*, long, const float*, long, const float*, const float*, const float*, const float*, float*, long, float*, int, int, int, hipStream_t);
-int ssv_launch_ln_gate_bwd(const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*, const float*, float*, float*, long, float*, float*, int, int, int, hipStream_t);
+// last argument of the four LayerNorm launchers: where the kernel leaves its tiles' max |output| (ssv_amax_rows(L) per batch item), or null
+int ssv_launch_ln_gate_fwd(const float*, long, const float*, long, const float*, const float*, const float*, const float*, float*, long, float*, int, int, int, hipStream_t, float* = nullptr);
+int ssv_launch_ln_gate_bwd(const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*, const float*, float*, float*, long, float*, float*, int, int, int, hipStream_t, float* = nullptr);
 int ssv_ln_gate_bwd_nblk(int B, int L);
 int ssv_launch_ln_bwd2(const float*, long, const float*, long, const float*, long, const float*, const float*, float*, long, float*, long, float*, float*, int, int, int, hipStream_t);
 int ssv_reduce_partial_rows(const float* part, float* out, int n, int nblk, hipStream_t st);
 int ssv_launch_ln_gate_bwd2(const float*, const float*, long, const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*,
                             const float*, float*, long, float*, float*, long, float*, float*, int, int, int, hipStream_t);
-int ssv_launch_ln_act_fwd(const float*, long, const float*, const float*, float*, long, float*, int, int, int, int, hipStream_t);
-int ssv_launch_ln_act_bwd(const float*, long, const float*, long, const float*, const float*, const float*, float*, long, float*, float*, int, int, int, int, hipStream_t);
+int ssv_launch_ln_act_fwd(const float*, long, const float*, const float*, float*, long, float*, int, int, int, int, hipStream_t, float* = nullptr);
+int ssv_launch_ln_act_bwd(const float*, long, const float*, long, const float*, const float*, const float*, float*, long, float*, float*, int, int, int, int, hipStream_t, float* = nullptr);
 int ssv_launch_softmax_cols(float*, int, int, int, hipStream_t);
 int ssv_launch_softmax_cols_bwd(const float*, float*, const float*, float, int, int, int, hipStream_t);
 int ssv_launch_lstm_in_transpose(const float*, float*, int, int, int, hipStream_t);
@@ -111,13 +113,44 @@ static GemmNT nt_zero() {
   g.M = g.Nc = 0; g.KT = 1; g.B = 1; g.Z = 1; g.bstep = 1;
   g.shift[0] = g.shift[1] = g.shift[2] = 0;
   g.jobs = nullptr; g.njobs = 0;
+  g.f16 = 0; g.a_amax = g.x_amax = nullptr; g.a_namax = g.x_namax = 0;
   return g;
 }
 
 // ---- Conv1d ----------------------------------------------------------------------------------------
 static inline int pad32(int n) { return (n + 31) & ~31; }
 static inline size_t split_bytes(int rows, int K, int k) { return align256((size_t)k * ((rows + 15) / 16 * 16) * pad32(K) * sizeof(unsigned short)); }
-static inline bool use_bf3(int B, int L, int Cin, int Cout) { return ssv_precision() == 1 && (long)B * L >= 128 && Cin >= 8 && Cout >= 16; }
+static inline bool use_bf3(int B, int L, int Cin, int Cout) { return ssv_precision() >= 1 && (long)B * L >= 128 && Cin >= 8 && Cout >= 16; }
+static inline bool use_f16() { return ssv_precision() == 2; }
+
+// ---- split-fp16 operand scales (ssv_common.h, "split-fp16") ------------------------------------------------------------
+// A list of partial maxima of |x|: n entries per batch item, items consecutive.  Either the caller's (written by the kernel
+// that produced x, or by ssv_absmax) or computed here into `fb`, SSV_AMAX_FB_FLOATS floats of the call's workspace.
+#define SSV_AMAX_FB_FLOATS 4096
+#define SSV_F16_AUX_BYTES (SSV_F16_AUX_FLOATS * sizeof(float))
+static const size_t AMAX_FB_BYTES = SSV_AMAX_FB_FLOATS * sizeof(float);
+struct AmaxList { const float* p; int n; };
+static int amax_of(const float* x, long x_bs, int B, long n_item, const float* given, int ngiven, float* fb, AmaxList* out, hipStream_t st) {
+  if (given) {
+    SSV_CHECK(ngiven > 0, SSV_BAD_SHAPE, "operand scale list given with %d entries per item", ngiven);
+    out->p = given; out->n = ngiven;
+    return 0;
+  }
+  SSV_CHECK(fb, SSV_BAD_SHAPE, "split-fp16: no operand scales given and no workspace to compute them in");
+  SSV_CHECK(B <= SSV_AMAX_FB_FLOATS, SSV_UNSUPPORTED, "split-fp16: batch %d needs caller-provided operand scales (ssv_absmax)", B);
+  int npb = SSV_AMAX_FB_FLOATS / B;
+  if (npb > 64) npb = 64;
+  const long pieces = (n_item + 4095) / 4096;
+  if (npb > pieces) npb = (int)(pieces > 0 ? pieces : 1);
+  SSV_TRY(ssv_launch_absmax(x, x_bs, B, n_item, fb, npb, st));
+  out->p = fb; out->n = npb;
+  return 0;
+}
+extern "C" int ssv_amax_rows(int L) { return ssv_cdiv(L, 16); }
+extern "C" int ssv_absmax(const float* x, long x_bs, int B, long n, float* amax, int namax, ssv_stream_t stream) {
+  SSV_CHECK(x && amax && B > 0 && B <= 65535 && n > 0 && namax > 0 && namax <= 65535, SSV_BAD_SHAPE, "absmax: bad argument");
+  return ssv_launch_absmax(x, x_bs, B, n, amax, namax, (hipStream_t)stream);
+}
 
 static GemmNNB nnb_zero() {
   GemmNNB g;
@@ -132,20 +165,34 @@ static GemmNNB nnb_zero() {
   g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
   g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0;
   g.gates_out = nullptr;
+  g.f16 = 0; g.a_inv = nullptr; g.x_amax = nullptr; g.x_namax = 0; g.x_amax_bs = 0;
   return g;
 }
 
 // y = conv(x, w): shared by forward (rows = Cout) and data gradient (rows = Cin, transposed weights, negated shifts)
 // `packed`: resident pre-split planes of this operand (hi plane, then lo plane), or null -> split into ws here.
+// split-fp16: `a_inv` = where the resident planes keep 2^-ea (packed only); xa_given / xa_n = the caller's scale list of x or
+// null; the tail of ws (conv_aux_bytes: after `ws_main` bytes) holds the pack kernel's aux floats and the fallback list.
+static inline size_t conv_aux_bytes() { return SSV_F16_AUX_BYTES + AMAX_FB_BYTES; }
 static int conv_nn(const float* x, long x_bs, const float* w, const void* packed, long w_sm, long w_sk, const float* bias, const float* bias_b,
                    const float* r, long r_bs, float* y, long y_bs, int B, int K, int M, int L, int k, const int* shift,
-                   bool bf3, void* ws, hipStream_t st) {
+                   bool bf3, void* ws, hipStream_t st, const float* a_inv = nullptr, const float* xa_given = nullptr, int xa_n = 0, size_t ws_main = 0) {
   if (bf3) {
     const int Kpad = pad32(K);
     const unsigned short* hi = (const unsigned short*)(packed ? packed : ws);
     const unsigned short* lo = (const unsigned short*)((const char*)hi + split_bytes(M, K, k));
-    if (!packed) SSV_TRY(ssv_launch_pack_split(w, (void*)hi, (void*)lo, M, K, Kpad, k, w_sm, w_sk, 1, 0, st));
+    const bool f16 = use_f16();
+    float* aux = ws ? (float*)((char*)ws + ws_main) : nullptr;
+    if (!packed) {
+      if (f16) { SSV_TRY(ssv_launch_pack_split_f16(w, (long)M * K * k, (void*)hi, (void*)lo, M, K, Kpad, k, w_sm, w_sk, 1, aux, st)); a_inv = aux + 64; }
+      else SSV_TRY(ssv_launch_pack_split(w, (void*)hi, (void*)lo, M, K, Kpad, k, w_sm, w_sk, 1, 0, st));
+    }
     GemmNNB g = nnb_zero();
+    if (f16) {
+      AmaxList xa;
+      SSV_TRY(amax_of(x, x_bs, B, (long)K * L, xa_given, xa_n, aux ? aux + SSV_F16_AUX_FLOATS : nullptr, &xa, st));
+      g.f16 = 1; g.a_inv = a_inv; g.x_amax = xa.p; g.x_namax = xa.n; g.x_amax_bs = xa.n;
+    }
     g.Ahi = hi; g.Alo = lo; g.Kpad = Kpad;
     g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
     g.C = y; g.scb = y_bs; g.scm = L;
@@ -171,8 +218,14 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
   return ssv_launch_gemm_nn(g, st);
 }
 
-extern "C" size_t ssv_conv1d_fwd_workspace(int Cin, int Cout, int k) { return 2 * split_bytes(Cout, Cin, k); }
-extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const void* w_packed, const float* bias, const float* bias_b, float* y, long y_bs,
+// where the resident planes of a (Cout, Cin, k) weight keep 2^-ea of the forward / transposed planes (split-fp16)
+static size_t pack_bytes(int Cout, int Cin, int k) { return 2 * split_bytes(Cout, Cin, k) + 2 * split_bytes(Cin, Cout, k) + 256; }
+static const float* packed_inv(const void* w_packed, int Cout, int Cin, int k, int transposed) {
+  return w_packed ? (const float*)((const char*)w_packed + pack_bytes(Cout, Cin, k) - 256 + (transposed ? 128 : 0)) : nullptr;
+}
+extern "C" size_t ssv_conv1d_fwd_workspace(int Cin, int Cout, int k) { return 2 * split_bytes(Cout, Cin, k) + conv_aux_bytes(); }
+extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
+                              const float* bias_b, float* y, long y_bs,
                               int B, int Cin, int Cout, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes,
                               ssv_stream_t stream) {
   SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_fwd: bad argument B=%d Cin=%d Cout=%d L=%d", B, Cin, Cout, L);
@@ -180,19 +233,24 @@ extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* w, const v
   int shift[3];
   SSV_TRY(conv_shifts(k, dilation, causal, shift));
   const bool bf3 = use_bf3(B, L, Cin, Cout);
-  if (bf3 && !w_packed) SSV_CHECK(ws && ws_bytes >= ssv_conv1d_fwd_workspace(Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_fwd: workspace too small");
-  return conv_nn(x, x_bs, w, w_packed, (long)Cin * k, k, bias, bias_b, nullptr, 0, y, y_bs, B, Cin, Cout, L, k, shift, bf3, ws, (hipStream_t)stream);
+  if (bf3 && (!w_packed || (use_f16() && !x_amax)))
+    SSV_CHECK(ws && ws_bytes >= ssv_conv1d_fwd_workspace(Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_fwd: workspace too small");
+  return conv_nn(x, x_bs, w, w_packed, (long)Cin * k, k, bias, bias_b, nullptr, 0, y, y_bs, B, Cin, Cout, L, k, shift, bf3, ws, (hipStream_t)stream,
+                 packed_inv(w_packed, Cout, Cin, k, 0), x_amax, x_namax, 2 * split_bytes(Cout, Cin, k));
 }
 
-extern "C" size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k) {
+static size_t bwd_data_main(int Cin, int Cout, int k) {
   const size_t a = align256((size_t)Cin * Cout * k * sizeof(float)), b = 2 * split_bytes(Cin, Cout, k);
   return a > b ? a : b;
 }
-extern "C" int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* dx_add, float* dx, long dx_bs,
+extern "C" size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k) { return bwd_data_main(Cin, Cout, k) + conv_aux_bytes(); }
+extern "C" int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* dy_amax, int dy_namax, const float* w, const void* w_packed,
+                                   const float* dx_add, float* dx, long dx_bs,
                                    int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                                    void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dy && w && dx && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_data: bad argument");
-  SSV_CHECK(w_packed || (ws && ws_bytes >= ssv_conv1d_bwd_data_workspace(Cin, Cout, k)), SSV_BAD_SHAPE, "conv1d_bwd_data: workspace too small");
+  SSV_CHECK((w_packed && !(use_f16() && !dy_amax)) || (ws && ws_bytes >= ssv_conv1d_bwd_data_workspace(Cin, Cout, k)), SSV_BAD_SHAPE,
+            "conv1d_bwd_data: workspace too small");
   int shift[3];
   SSV_TRY(conv_shifts(k, dilation, causal, shift));
   for (int j = 0; j < 3; ++j) shift[j] = -shift[j];
@@ -200,11 +258,11 @@ extern "C" int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* w, 
   // the transposed planes follow the forward planes in a resident buffer (ssv_conv_pack_bytes)
   const void* pk = w_packed ? (const char*)w_packed + 2 * split_bytes(Cout, Cin, k) : nullptr;
   return conv_nn(dy, dy_bs, w, pk, k, (long)Cin * k, nullptr, nullptr, dx_add, dx_bs, dx, dx_bs, B, Cout, Cin, L, k, shift,
-                 use_bf3(B, L, Cout, Cin), ws, (hipStream_t)stream);
+                 use_bf3(B, L, Cout, Cin), ws, (hipStream_t)stream, packed_inv(w_packed, Cout, Cin, k, 1), dy_amax, dy_namax, bwd_data_main(Cin, Cout, k));
 }
 
 // ---- resident pre-split weights ------------------------------------------------------------------------------------
-extern "C" size_t ssv_conv_pack_bytes(int Cout, int Cin, int k) { return 2 * split_bytes(Cout, Cin, k) + 2 * split_bytes(Cin, Cout, k); }
+extern "C" size_t ssv_conv_pack_bytes(int Cout, int Cin, int k) { return pack_bytes(Cout, Cin, k); }
 extern "C" int ssv_conv_pack_plan(int n, const float* const* w, void* const* planes, const int* Cout, const int* Cin, const int* k,
                                   ssv_pack_job* jobs) {
   SSV_CHECK(n > 0 && w && planes && Cout && Cin && k && jobs, SSV_BAD_SHAPE, "conv_pack_plan: bad argument");
@@ -220,15 +278,19 @@ extern "C" int ssv_conv_pack_plan(int n, const float* const* w, void* const* pla
       j.sm = tr ? k[i] : (long)Cin[i] * k[i];            // element (m, kk, tap) = w[m*sm + kk*sk + tap]
       j.sk = tr ? (long)Cin[i] * k[i] : k[i];
       j.first_block = (int)blocks; j.pad_ = 0;
+      j.inv_out = (float*)((char*)planes[i] + pack_bytes(Cout[i], Cin[i], k[i]) - 256 + (tr ? 128 : 0));
       blocks += ssv_pack_job_blocks(j);
       SSV_CHECK(blocks < (1L << 30), SSV_UNSUPPORTED, "conv_pack_plan: too many elements");
     }
   }
   return (int)blocks;
 }
-extern "C" int ssv_conv_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, ssv_stream_t stream) {
-  SSV_CHECK(jobs_dev && njobs > 0 && nblocks > 0, SSV_BAD_SHAPE, "conv_pack_multi: bad argument");
-  return ssv_launch_pack_multi(jobs_dev, njobs, nblocks, (hipStream_t)stream);
+extern "C" size_t ssv_conv_pack_multi_workspace(int njobs) { return align256((size_t)(njobs / 2) * SSV_PACK_AMAX_PER_WEIGHT * sizeof(float)); }
+extern "C" int ssv_conv_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(jobs_dev && njobs > 0 && njobs % 2 == 0 && nblocks > 0, SSV_BAD_SHAPE, "conv_pack_multi: bad argument");
+  const bool f16 = use_f16();
+  SSV_CHECK(!f16 || (ws && ws_bytes >= ssv_conv_pack_multi_workspace(njobs)), SSV_BAD_SHAPE, "conv_pack_multi: workspace too small");
+  return ssv_launch_pack_multi(jobs_dev, njobs, nblocks, f16 ? (float*)ws : nullptr, (hipStream_t)stream);
 }
 
 // Number of batch slabs the weight gradient is split into: enough workgroups to fill the chip (2 per CU), no more --
@@ -247,20 +309,23 @@ static int dw_splits(int B, int M, int Nc, int k) {
   if (z < 1) z = 1;
   return z;
 }
-extern "C" size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int k) {
-  return align256((size_t)dw_splits(B, Cout, Cin, k) * Cout * Cin * k * sizeof(float));
-}
+static size_t bwd_weight_main(int B, int Cin, int Cout, int k) { return align256((size_t)dw_splits(B, Cout, Cin, k) * Cout * Cin * k * sizeof(float)); }
+extern "C" size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int k) { return bwd_weight_main(B, Cin, Cout, k) + 2 * AMAX_FB_BYTES; }
 // part / pgrads / n2 / nblk: partial rows of another reduction (the LayerNorm / bias gradients of the same layer) summed by the
 // SAME launch that sums the weight-gradient slabs (highwayConv backward); part == nullptr: weight gradient only.
+// dy_amax / x_amax (n entries per batch item each): the operands' scale lists for the split-fp16 arithmetic, or null (computed here).
 static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, int B, int Cin, int Cout, int L, int k, int dilation,
-                                  int causal, void* ws, size_t ws_bytes, ssv_stream_t stream, const float* part, float* pgrads, int n2, int nblk);
-extern "C" int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* x, long x_bs, float* dw,
-                                     int B, int Cin, int Cout, int L, int k, int dilation, int causal,
+                                  int causal, void* ws, size_t ws_bytes, ssv_stream_t stream, const float* part, float* pgrads, int n2, int nblk,
+                                  const float* dy_amax, int dy_namax, const float* x_amax, int x_namax);
+extern "C" int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* dy_amax, int dy_namax, const float* x, long x_bs, const float* x_amax, int x_namax,
+                                     float* dw, int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                                      void* ws, size_t ws_bytes, ssv_stream_t stream) {
-  return conv1d_bwd_weight_impl(dy, dy_bs, x, x_bs, dw, B, Cin, Cout, L, k, dilation, causal, ws, ws_bytes, stream, nullptr, nullptr, 0, 0);
+  return conv1d_bwd_weight_impl(dy, dy_bs, x, x_bs, dw, B, Cin, Cout, L, k, dilation, causal, ws, ws_bytes, stream, nullptr, nullptr, 0, 0,
+                                dy_amax, dy_namax, x_amax, x_namax);
 }
 static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, int B, int Cin, int Cout, int L, int k, int dilation,
-                                  int causal, void* ws, size_t ws_bytes, ssv_stream_t stream, const float* part, float* pgrads, int n2, int nblk) {
+                                  int causal, void* ws, size_t ws_bytes, ssv_stream_t stream, const float* part, float* pgrads, int n2, int nblk,
+                                  const float* dy_amax, int dy_namax, const float* x_amax, int x_namax) {
   SSV_CHECK(dy && x && dw && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_weight: bad argument");
   SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_bwd_weight: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -273,8 +338,16 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
   if (Z == 1) { g.C = dw; g.scz = n; g.scm = (long)Cin * k; g.scc = k; g.scj = 1; }
   else { g.C = (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = 1; g.scj = Cin; }     // slabs [z][m][j][c]
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
-  if (ssv_precision() == 1 && (long)B * L >= 256 && ssv_nt_bf3_fits(g)) SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
-  else SSV_TRY(ssv_launch_gemm_nt(g, st));
+  if (ssv_precision() >= 1 && (long)B * L >= 256 && ssv_nt_bf3_fits(g)) {
+    if (use_f16()) {
+      float* fb = (float*)((char*)ws + bwd_weight_main(B, Cin, Cout, k));
+      AmaxList la, lx;
+      SSV_TRY(amax_of(dy, dy_bs, B, (long)Cout * L, dy_amax, dy_namax, fb, &la, st));
+      SSV_TRY(amax_of(x, x_bs, B, (long)Cin * L, x_amax, x_namax, fb + SSV_AMAX_FB_FLOATS, &lx, st));
+      g.f16 = 1; g.a_amax = la.p; g.a_namax = la.n * B; g.x_amax = lx.p; g.x_namax = lx.n * B;
+    }
+    SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
+  } else SSV_TRY(ssv_launch_gemm_nt(g, st));
   if (part) {
     if (Z > 1 && nblk <= 768) return ssv_launch_reduce_pair((const float*)ws, dw, Cout, Cin, k, Z, part, pgrads, n2, nblk, st);
     SSV_TRY(ssv_reduce_partial_rows(part, pgrads, n2, nblk, st));
@@ -286,7 +359,7 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
 // ---- several equal-shaped weight gradients in one launch (see include/ssv_hip.h) ------------------------------------------
 extern "C" int ssv_conv_shifts(int k, int dilation, int causal, int* shift3) { return conv_shifts(k, dilation, causal, shift3); }
 extern "C" int ssv_conv1d_bwd_weight_multi_ok(int B, int Cin, int Cout, int L, int k) {
-  if (ssv_precision() != 1 || (k != 1 && k != 3) || (long)B * L < 256 || L < 8) return 0;
+  if (ssv_precision() < 1 || (k != 1 && k != 3) || (long)B * L < 256 || L < 8) return 0;
   GemmNT g = nt_zero();
   g.sab = (long)Cout * L; g.sam = L; g.La = L; g.sxb = (long)Cin * L; g.sxc = L; g.Lx = L;
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = 1; g.bstep = 1;
@@ -318,18 +391,19 @@ extern "C" int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int nj
   g.C = (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = 1; g.scj = Cin;                 // slabs [job][z][m][j][c]
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
   g.jobs = jobs_dev; g.njobs = njobs;
+  g.f16 = use_f16() ? 1 : 0;                     // the jobs carry their operands' scale lists (the caller saw to that)
   SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
   return ssv_launch_reduce_pair_multi(jobs_dev, njobs, (const float*)ws, Cout, Cin, k, Z, n2, nblk, st);
 }
 
 // ---- LayerNorm over channels ------------------------------------------------------------------------
 extern "C" size_t ssv_channel_ln_act_fwd_workspace(int B, int C, int L) { (void)B; (void)C; (void)L; return 256; }   // none needed; kept in the ABI
-extern "C" int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const float* beta, float* y, long y_bs, float* stats,
+extern "C" int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const float* beta, float* y, long y_bs, float* y_amax, float* stats,
                                       int B, int C, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && gamma && beta && y && B > 0 && C > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "channel_ln_act_fwd: bad argument");
   SSV_CHECK(B <= 65535, SSV_UNSUPPORTED, "channel_ln_act_fwd: batch %d exceeds grid.y", B);
   (void)ws; (void)ws_bytes;
-  return ssv_launch_ln_act_fwd(x, x_bs, gamma, beta, y, y_bs, stats, B, C, L, act, (hipStream_t)stream);
+  return ssv_launch_ln_act_fwd(x, x_bs, gamma, beta, y, y_bs, stats, B, C, L, act, (hipStream_t)stream, y_amax);
 }
 extern "C" size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L) {
   return align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * C * sizeof(float));
@@ -346,29 +420,31 @@ extern "C" size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k) {
   (void)B; (void)L;
   return ssv_conv1d_fwd_workspace(C, 2 * C, k);
 }
-extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* w, const void* w_packed, const float* bias, const float* g1, const float* b1,
-                                      const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
-                                      int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
+                                      const float* g1, const float* b1, const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
+                                      float* y_amax, int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w && g1 && b1 && g2 && b2 && h && y, SSV_BAD_SHAPE, "highway_conv1d_fwd: null argument");
-  SSV_TRY(ssv_conv1d_fwd(x, x_bs, w, w_packed, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
-  return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
+  SSV_TRY(ssv_conv1d_fwd(x, x_bs, x_amax, x_namax, w, w_packed, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
+  return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream, y_amax);
 }
 
 // ---- 1x1 conv + LayerNorm (+ activation), whole backward ------------------------------------------------------------------
 // y = act(LN(conv1x1(x) [+ s])) -- models/TTSModel.py:128-131, :173-180, :218-231, :343-361.  One entry for the backward so that
 // the LayerNorm partial rows and the weight-gradient slabs are summed by ONE launch (as in ssv_highway_conv1d_bwd).
-struct PwWs { size_t dpre, part, wt, slabs, total; };
+struct PwWs { size_t dpre, part, amax, wt, slabs, total; };
 static PwWs pw_ws(int B, int Cin, int Cout, int L) {
   PwWs s;
   s.dpre = 0;
   s.part = s.dpre + align256((size_t)B * Cout * L * sizeof(float));
-  s.wt = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * Cout * sizeof(float));
+  s.amax = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * Cout * sizeof(float));
+  s.wt = s.amax + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * sizeof(float));     // max |dpre| per LayerNorm tile (split-fp16 scales)
   s.slabs = s.wt + ssv_conv1d_bwd_data_workspace(Cin, Cout, 1);
   s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, 1);
   return s;
 }
 extern "C" size_t ssv_pointwise_conv_ln_act_bwd_workspace(int B, int Cin, int Cout, int L) { return pw_ws(B, Cin, Cout, L).total; }
-extern "C" int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed, const float* gamma,
+extern "C" int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* x_amax, int x_namax, const float* w,
+                                             const void* w_packed, const float* gamma,
                                              const float* beta, const float* pre, const float* stats, float* dx, long dx_bs, float* dw, float* pgrads,
                                              float* ds, int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dy && x && w && gamma && beta && pre && stats && dw && pgrads, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd: null argument");
@@ -378,11 +454,13 @@ extern "C" int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const 
   char* base = (char*)ws;
   float* dpre = (float*)(base + s.dpre);
   const long pbs = (long)Cout * L;
-  SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, (float*)(base + s.part), nullptr, B, Cout, L, act, (hipStream_t)stream));
-  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, base + s.wt, s.slabs - s.wt, stream));
+  float* da = use_f16() ? (float*)(base + s.amax) : nullptr;
+  const int dn = ssv_cdiv(L, 16);
+  SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, (float*)(base + s.part), nullptr, B, Cout, L, act, (hipStream_t)stream, da));
+  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, da, dn, w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, base + s.wt, s.slabs - s.wt, stream));
   if (ds) SSV_TRY(ssv_rowsum(dpre, pbs, ds, B, Cout, L, stream));               // gradient of the broadcast (B, Cout, 1) term
   return conv1d_bwd_weight_impl(dpre, pbs, x, x_bs, dw, B, Cin, Cout, L, 1, 1, 0, base + s.slabs, s.total - s.slabs, stream,
-                                (const float*)(base + s.part), pgrads, 3 * Cout, ssv_ln_gate_bwd_nblk(B, L));
+                                (const float*)(base + s.part), pgrads, 3 * Cout, ssv_ln_gate_bwd_nblk(B, L), da, dn, x_amax, x_namax);
 }
 
 // ---- second order (gradient penalty through the critics) and the gate forward alone ------------------------------------
@@ -395,9 +473,9 @@ extern "C" int ssv_channel_ln_bwd2(const float* v, long v_bs, const float* gn, l
   return ssv_launch_ln_bwd2(v, v_bs, gn, gn_bs, x, x_bs, stats, gamma, d_gn, dgn_bs, d_x, dx_bs, (float*)ws, dgamma, B, C, L, (hipStream_t)stream);
 }
 extern "C" int ssv_highway_gate_fwd(const float* h, const float* x, long x_bs, const float* g1, const float* b1, const float* g2, const float* b2,
-                                    float* stats, float* y, long y_bs, int B, int C, int L, ssv_stream_t stream) {
+                                    float* stats, float* y, long y_bs, float* y_amax, int B, int C, int L, ssv_stream_t stream) {
   SSV_CHECK(h && x && g1 && b1 && g2 && b2 && y && B > 0 && B <= 65535 && C > 0 && L > 0, SSV_BAD_SHAPE, "highway_gate_fwd: bad argument");
-  return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream);
+  return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream, y_amax);
 }
 extern "C" size_t ssv_highway_gate_bwd2_workspace(int B, int C, int L) { return align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 4 * C * sizeof(float)); }
 extern "C" int ssv_highway_gate_bwd2(const float* vh, const float* vx, long vx_bs, const float* gy, long gy_bs, const float* h, const float* x, long x_bs,
@@ -423,18 +501,20 @@ extern "C" int ssv_highway_gate_bwd(const float* dy, long dy_bs, const float* x,
   return ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dxres, dx_bs, (float*)ws, pgrads, B, C, L, (hipStream_t)stream);
 }
 
-struct HwWs { size_t dh, part, wt, slabs, total; };
+struct HwWs { size_t dh, part, amax, wt, slabs, total; };
 static HwWs hw_ws(int B, int C, int L, int k) {
   HwWs s;
   s.dh = 0;
   s.part = s.dh + align256((size_t)B * 2 * C * L * sizeof(float));
-  s.wt = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float));
+  s.amax = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float));
+  s.wt = s.amax + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * sizeof(float));      // max |dH| per LayerNorm tile (split-fp16 scales)
   s.slabs = s.wt + ssv_conv1d_bwd_data_workspace(C, 2 * C, k);
   s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, C, 2 * C, k);
   return s;
 }
 extern "C" size_t ssv_highway_conv1d_bwd_workspace(int B, int C, int L, int k) { return hw_ws(B, C, L, k).total; }
-extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed, const float* g1, const float* b1,
+extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed,
+                                      const float* g1, const float* b1,
                                       const float* g2, const float* b2, const float* h, const float* stats, float* dx, long dx_bs, float* dw,
                                       float* pgrads, int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes,
                                       ssv_stream_t stream) {
@@ -446,33 +526,35 @@ extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* 
   float* dH = (float*)(base + s.dh);
   // gate + both LayerNorms backward: dH (B,2C,L), the residual-path gradient dy*(1-g) into dx, parameter partials
   // (its partial rows are summed at the end, by the launch that also sums the weight-gradient slabs)
-  SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, (float*)(base + s.part), nullptr, B, C, L, (hipStream_t)stream));
+  float* da = use_f16() ? (float*)(base + s.amax) : nullptr;
+  const int dn = ssv_cdiv(L, 16);
+  SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, (float*)(base + s.part), nullptr, B, C, L, (hipStream_t)stream, da));
   // dx += conv^T(dH)
-  SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
+  SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, da, dn, w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
   return conv1d_bwd_weight_impl(dH, (long)2 * C * L, x, x_bs, dw, B, C, 2 * C, L, k, dilation, causal, base + s.slabs, s.total - s.slabs, stream,
-                                (const float*)(base + s.part), pgrads, 6 * C, ssv_ln_gate_bwd_nblk(B, L));
+                                (const float*)(base + s.part), pgrads, 6 * C, ssv_ln_gate_bwd_nblk(B, L), da, dn, x_amax, x_namax);
 }
 
 extern "C" int ssv_ln_partial_rows(int B, int L) { return ssv_ln_gate_bwd_nblk(B, L); }
 extern "C" size_t ssv_highway_conv1d_bwd_data_workspace(int B, int C, int L, int k) { (void)B; (void)L; return ssv_conv1d_bwd_data_workspace(C, 2 * C, k); }
 extern "C" int ssv_highway_conv1d_bwd_data(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
                                            const float* g1, const float* b1, const float* g2, const float* b2, const float* h, const float* stats,
-                                           float* dx, long dx_bs, float* dh, float* part, int B, int C, int L, int k, int dilation, int causal,
+                                           float* dx, long dx_bs, float* dh, float* dh_amax, float* part, int B, int C, int L, int k, int dilation, int causal,
                                            void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dy && x && w && g1 && b1 && g2 && b2 && h && stats && dx && dh && part, SSV_BAD_SHAPE, "highway_conv1d_bwd_data: null argument");
   SSV_CHECK(B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_conv1d_bwd_data: bad shape B=%d C=%d L=%d", B, C, L);
-  SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dx, dx_bs, part, nullptr, B, C, L, (hipStream_t)stream));
-  return ssv_conv1d_bwd_data(dh, (long)2 * C * L, w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream);
+  SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dx, dx_bs, part, nullptr, B, C, L, (hipStream_t)stream, dh_amax));
+  return ssv_conv1d_bwd_data(dh, (long)2 * C * L, dh_amax, ssv_cdiv(L, 16), w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream);
 }
 extern "C" size_t ssv_pointwise_conv_ln_act_bwd_data_workspace(int B, int Cin, int Cout, int L) { (void)B; (void)L; return ssv_conv1d_bwd_data_workspace(Cin, Cout, 1); }
 extern "C" int ssv_pointwise_conv_ln_act_bwd_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* gamma, const float* beta,
-                                                  const float* pre, const float* stats, float* dx, long dx_bs, float* ds, float* dpre, float* part,
-                                                  int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+                                                  const float* pre, const float* stats, float* dx, long dx_bs, float* ds, float* dpre, float* dpre_amax,
+                                                  float* part, int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dy && w && gamma && beta && pre && stats && dpre && part, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd_data: null argument");
   SSV_CHECK(B > 0 && B <= 65535 && Cin > 0 && Cout > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd_data: bad shape");
   const long pbs = (long)Cout * L;
-  SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, part, nullptr, B, Cout, L, act, (hipStream_t)stream));
-  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, ws, ws_bytes, stream));
+  SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, part, nullptr, B, Cout, L, act, (hipStream_t)stream, dpre_amax));
+  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, dpre_amax, ssv_cdiv(L, 16), w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, ws, ws_bytes, stream));
   if (ds) SSV_TRY(ssv_rowsum(dpre, pbs, ds, B, Cout, L, stream));
   return 0;
 }
@@ -500,13 +582,22 @@ extern "C" int ssv_attention_train_fwd(const float* k, const float* v, long kv_b
   SSV_TRY(ssv_launch_softmax_cols(a, B, N, T, st));
   return ssv_attention_apply(v, kv_bs, a, T, r, r_bs, B, d, N, T, stream);
 }
-extern "C" size_t ssv_attention_train_bwd_workspace(int B, int d, int N, int T) { (void)d; return align256((size_t)B * N * T * sizeof(float)); }
+extern "C" size_t ssv_attention_train_bwd_workspace(int B, int d, int N, int T) { (void)d; return align256((size_t)B * N * T * sizeof(float)) + 2 * AMAX_FB_BYTES; }
 // Per-batch-item products reduced over time (attention dV, dK): the split-bf16 weight-gradient kernel with one slab per batch
 // item and no slab sum (21 -> ~100 TFLOP/s at d = 256, N = 186, T = 325; the fp32 kernel's 128 x 96 tiles leave the chip idle).
-static int nt_per_batch(GemmNT& g, int T, hipStream_t st) {
+// fb: 2 * SSV_AMAX_FB_FLOATS floats of workspace for the operands' scale lists (split-fp16)
+static int nt_per_batch(GemmNT& g, int T, hipStream_t st, float* fb) {
   g.KT = 1;
   g.scj = 1;
-  if (ssv_precision() == 1 && (long)g.B * T >= 256 && ssv_nt_bf3_fits(g)) return ssv_launch_gemm_nt_bf3(g, st);
+  if (ssv_precision() >= 1 && (long)g.B * T >= 256 && ssv_nt_bf3_fits(g)) {
+    if (use_f16()) {
+      AmaxList la, lx;
+      SSV_TRY(amax_of(g.A, g.sab, g.B, (long)g.M * T, nullptr, 0, fb, &la, st));
+      SSV_TRY(amax_of(g.X, g.sxb, g.B, (long)g.Nc * T, nullptr, 0, fb + SSV_AMAX_FB_FLOATS, &lx, st));
+      g.f16 = 1; g.a_amax = la.p; g.a_namax = la.n * g.B; g.x_amax = lx.p; g.x_namax = lx.n * g.B;
+    }
+    return ssv_launch_gemm_nt_bf3(g, st);
+  }
   return ssv_launch_gemm_nt(g, st);
 }
 
@@ -518,6 +609,7 @@ extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float*
   SSV_CHECK(ws && ws_bytes >= ssv_attention_train_bwd_workspace(B, d, N, T), SSV_BAD_SHAPE, "attention_train_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* dA = (float*)ws;
+  float* fb = (float*)((char*)ws + align256((size_t)B * N * T * sizeof(float)));
   {  // dA(b,n,t) = sum_c v(b,c,n) dr(b,c,t)
     GemmNN g = nn_zero();
     g.A = v; g.sab = kv_bs; g.sam = 1; g.sac = N;
@@ -532,7 +624,7 @@ extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float*
     g.X = a; g.sxb = (long)N * T; g.sxc = T; g.Lx = T;
     g.C = dv; g.scz = dkv_bs; g.scm = N; g.scc = 1;
     g.M = d; g.Nc = N; g.B = B; g.Z = B; g.bstep = B;
-    SSV_TRY(nt_per_batch(g, T, st));
+    SSV_TRY(nt_per_batch(g, T, st, fb));
   }
   SSV_TRY(ssv_launch_softmax_cols_bwd(a, dA, da_ext, 1.f / sqrtf((float)d), B, N, T, st));   // dA now holds dScores
   {  // dk(b,c,n) = sum_t q(b,c,t) ds(b,n,t)
@@ -541,7 +633,7 @@ extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float*
     g.X = dA; g.sxb = (long)N * T; g.sxc = T; g.Lx = T;
     g.C = dk; g.scz = dkv_bs; g.scm = N; g.scc = 1;
     g.M = d; g.Nc = N; g.B = B; g.Z = B; g.bstep = B;
-    SSV_TRY(nt_per_batch(g, T, st));
+    SSV_TRY(nt_per_batch(g, T, st, fb));
   }
   {  // dq(b,c,t) = sum_n k(b,c,n) ds(b,n,t) + dq_add
     GemmNN g = nn_zero();
@@ -559,8 +651,8 @@ extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float*
 // Split-bf16 path of the two deconvolution halves: both taps' weights are split by ONE pack launch (tap-major planes);
 // tap j is a k=1 product whose output (forward) or input (data gradient) columns have stride 2.
 static size_t deconv_pack_bytes(int rows, int K) { return 2 * split_bytes(rows, K, 2); }
-extern "C" size_t ssv_deconv1d_k2s2_fwd_workspace(int Cin, int Cout) { return deconv_pack_bytes(Cout, Cin); }
-extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
+extern "C" size_t ssv_deconv1d_k2s2_fwd_workspace(int Cin, int Cout) { return deconv_pack_bytes(Cout, Cin) + conv_aux_bytes(); }
+extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const float* bias, float* y, long y_bs,
                                      int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "deconv1d_k2s2_fwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -570,9 +662,16 @@ extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* w, 
     const size_t tap = (size_t)((Cout + 15) / 16 * 16) * Kpad;                    // elements of one tap's plane
     unsigned short* hi = (unsigned short*)ws;
     unsigned short* lo = (unsigned short*)((char*)ws + split_bytes(Cout, Cin, 2));
-    SSV_TRY(ssv_launch_pack_split(w, hi, lo, Cout, Cin, Kpad, 2, 2, (long)2 * Cout, 1, 0, st));   // (m=o, k=c, tap j) = w[c][o][j]
+    const bool f16 = use_f16();
+    float* aux = (float*)((char*)ws + deconv_pack_bytes(Cout, Cin));
+    AmaxList xa = {nullptr, 0};
+    if (f16) {
+      SSV_TRY(ssv_launch_pack_split_f16(w, (long)Cin * Cout * 2, hi, lo, Cout, Cin, Kpad, 2, 2, (long)2 * Cout, 1, aux, st));
+      SSV_TRY(amax_of(x, x_bs, B, (long)Cin * L, x_amax, x_namax, aux + SSV_F16_AUX_FLOATS, &xa, st));
+    } else SSV_TRY(ssv_launch_pack_split(w, hi, lo, Cout, Cin, Kpad, 2, 2, (long)2 * Cout, 1, 0, st));   // (m=o, k=c, tap j) = w[c][o][j]
     for (int j = 0; j < 2; ++j) {               // y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t)
       GemmNNB g = nnb_zero();
+      if (f16) { g.f16 = 1; g.a_inv = aux + 64; g.x_amax = xa.p; g.x_namax = xa.n; g.x_amax_bs = xa.n; }
       g.Ahi = hi + j * tap; g.Alo = lo + j * tap; g.Kpad = Kpad;
       g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
       g.C = y + j; g.scb = y_bs; g.scm = (long)2 * L; g.scn = 2;
@@ -596,9 +695,9 @@ extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* w, 
 static int deconv_splits(int B, int Cin, int Cout) { return dw_splits(B, Cin, Cout, 1); }
 extern "C" size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout) {
   return align256((size_t)deconv_splits(B, Cin, Cout) * Cin * Cout * 2 * sizeof(float)) + align256((size_t)B * Cout * sizeof(float)) +
-         deconv_pack_bytes(Cin, Cout);
+         deconv_pack_bytes(Cin, Cout) + conv_aux_bytes();
 }
-extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, float* dx, long dx_bs,
+extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* dy_amax, int dy_namax, const float* x, long x_bs, const float* w, float* dx, long dx_bs,
                                      float* dw, float* dbias, int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dy && x && w && dx && dw && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "deconv1d_k2s2_bwd: bad argument");
   SSV_CHECK(ws && ws_bytes >= ssv_deconv1d_k2s2_bwd_workspace(B, Cin, Cout), SSV_BAD_SHAPE, "deconv1d_k2s2_bwd: workspace too small");
@@ -612,10 +711,17 @@ extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* x
   unsigned short* lo = (unsigned short*)((char*)hi + split_bytes(Cin, Cout, 2));
   const int Kpad = pad32(Cout);
   const size_t tap = (size_t)((Cin + 15) / 16 * 16) * Kpad;
-  if (bf3) SSV_TRY(ssv_launch_pack_split(w, hi, lo, Cin, Cout, Kpad, 2, (long)2 * Cout, 2, 1, 0, st));   // (m=c, k=o, tap j) = w[c][o][j]
+  const bool f16 = bf3 && use_f16();
+  float* aux = (float*)((char*)hi + deconv_pack_bytes(Cin, Cout));
+  AmaxList ya = {nullptr, 0};
+  if (f16) {
+    SSV_TRY(ssv_launch_pack_split_f16(w, (long)Cin * Cout * 2, hi, lo, Cin, Cout, Kpad, 2, (long)2 * Cout, 2, 1, aux, st));
+    SSV_TRY(amax_of(dy, dy_bs, B, (long)Cout * 2 * L, dy_amax, dy_namax, aux + SSV_F16_AUX_FLOATS, &ya, st));
+  } else if (bf3) SSV_TRY(ssv_launch_pack_split(w, hi, lo, Cin, Cout, Kpad, 2, (long)2 * Cout, 2, 1, 0, st));   // (m=c, k=o, tap j) = w[c][o][j]
   for (int j = 0; j < 2; ++j) {
     if (bf3) {                                 // dx(b,c,t) (+)= sum_o w[c,o,j] dy(b,o,2t+j)
       GemmNNB g = nnb_zero();
+      if (f16) { g.f16 = 1; g.a_inv = aux + 64; g.x_amax = ya.p; g.x_namax = ya.n; g.x_amax_bs = ya.n; }
       g.Ahi = hi + j * tap; g.Alo = lo + j * tap; g.Kpad = Kpad;
       g.X = dy + j; g.sxb = dy_bs; g.sxc = (long)2 * L; g.sxn = 2; g.Lx = L;
       g.C = dx; g.scb = dx_bs; g.scm = L;
@@ -780,14 +886,14 @@ extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const floa
             ssv_lstm_fwd_workspace(Bn, T, F, H, layers));
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
-  if (ssv_precision() == 1 && lstm_wave_ok(Bn, H) && !ssv_tuning(SSV_T_LSTM_SEQUENTIAL))
+  if (ssv_precision() >= 1 && lstm_wave_ok(Bn, H) && !ssv_tuning(SSV_T_LSTM_SEQUENTIAL))
     return lstm_fwd_wave(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, base, st);
   float* xt = (float*)(base + s.xt);
   float* xp = (float*)(base + s.xp);
   float* seq[2] = {(float*)(base + s.seq0), (float*)(base + s.seq1)};
   float* gbuf = (float*)(base + s.g);
   float* cbuf = (float*)(base + s.c);
-  const bool bf3 = ssv_precision() == 1 && Bn >= 64 && H >= 32;
+  const bool bf3 = ssv_precision() >= 1 && Bn >= 64 && H >= 32;
   SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));    // [T][F][Bn]
   if (bf3) SSV_TRY(ssv_launch_fill(gbuf, 0.f, (long)H * Bn, st));
   const float* in = xt;
@@ -903,7 +1009,7 @@ extern "C" int ssv_lstm_train_fwd(const float* x, const float* const* w_ih, cons
                                   const float* const* b_hh, float* h_last, void* saved, int Bn, int T, int F, int H, int layers,
                                   void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w_ih && w_hh && b_ih && b_hh && h_last && saved && Bn > 0 && T > 0 && F > 0 && H > 0 && layers > 0, SSV_BAD_SHAPE, "lstm_train_fwd: bad argument");
-  SSV_CHECK(ssv_precision() == 1 && H % 32 == 0 && Bn >= 8, SSV_UNSUPPORTED, "lstm_train_fwd: needs the split-bf16 mode, batch >= 8 and hidden %% 32 == 0");
+  SSV_CHECK(ssv_precision() >= 1 && H % 32 == 0 && Bn >= 8, SSV_UNSUPPORTED, "lstm_train_fwd: needs a split (bf16 / fp16) mode, batch >= 8 and hidden %% 32 == 0");
   SSV_CHECK(ws && ws_bytes >= ssv_lstm_train_fwd_workspace(Bn, T, F, H, layers), SSV_BAD_SHAPE, "lstm_train_fwd: workspace too small");
   const LstmSaved sv = lstm_saved(Bn, T, F, H, layers);
   char* sb = (char*)saved;
@@ -950,7 +1056,7 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
                             float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh,
                             int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dh_last && saved && w_ih && w_hh && dw_ih && dw_hh && db_ih && db_hh && Bn > 0 && T > 0 && F > 0 && H > 0 && layers > 0, SSV_BAD_SHAPE, "lstm_bwd: bad argument");
-  SSV_CHECK(ssv_precision() == 1 && H % 32 == 0 && Bn >= 8, SSV_UNSUPPORTED, "lstm_bwd: needs the split-bf16 mode, batch >= 8 and hidden %% 32 == 0");
+  SSV_CHECK(ssv_precision() >= 1 && H % 32 == 0 && Bn >= 8, SSV_UNSUPPORTED, "lstm_bwd: needs a split (bf16 / fp16) mode, batch >= 8 and hidden %% 32 == 0");
   const LstmBwdWs s = lstm_bwd_ws(Bn, T, F, H, layers);
   SSV_CHECK(ws && ws_bytes >= s.total, SSV_BAD_SHAPE, "lstm_bwd: workspace too small (%zu < %zu)", ws_bytes, s.total);
   hipStream_t st = (hipStream_t)stream;

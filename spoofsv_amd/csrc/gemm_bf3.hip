@@ -47,6 +47,57 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
   hi = __builtin_bit_cast(uint4, h);
   lo = __builtin_bit_cast(uint4, l);
 }
+// split-fp16 (ssv_common.h, "split-fp16"): hi = fp16(v s), lo = fp16(v s - hi); s is a power of two, so v s is exact and
+// v s - hi is an exact fp32 number: the only roundings are the two conversions.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ void split8h(const float (&v)[8], float s, uint4& hi, uint4& lo) {
+  f16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 t = (_Float16)(v[i] * s);
+    h[i] = t;
+    l[i] = (_Float16)__builtin_fmaf(v[i], s, -(float)t);
+  }
+  hi = __builtin_bit_cast(uint4, h);
+  lo = __builtin_bit_cast(uint4, l);
+}
+template <int F16>
+__device__ __forceinline__ void split8s(const float (&v)[8], float s, uint4& hi, uint4& lo) {
+  if constexpr (F16) split8h(v, s, hi, lo); else split8(v, hi, lo);
+}
+// one 16x16x32 MFMA on 16-byte operand fragments: bf16 or fp16 inputs, fp32 accumulate
+template <int F16>
+__device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ---- partial maxima of |x| (split-fp16 operand scales) ----------------------------------------------------------------
+// grid (npb, B): workgroup (i, b) scans the i-th of npb equal pieces of item b (n dense floats at x + b * x_bs) and writes
+// out[b * npb + i].  A maximum is order-independent, so the result does not depend on the partition.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long x_bs, long n, float* __restrict__ out, int npb) {
+  __shared__ float sm[4];
+  const float* __restrict__ xb = x + (long)blockIdx.y * x_bs;
+  const long piece = (((n + npb - 1) / npb) + 3) & ~3L;
+  const long lo = (long)blockIdx.x * piece, hi = min(lo + piece, n);
+  float v = 0.f;
+  if ((((size_t)xb) & 15) == 0) {
+    long i = lo + 4L * threadIdx.x;
+    for (; i + 3 < hi; i += 1024) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(xb + i);
+      v = fmaxf(fmaxf(v, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
+    }
+    for (; i < hi; ++i) v = fmaxf(v, fabsf(xb[i]));              // at most 3 elements, one thread
+  } else {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) v = fmaxf(v, fabsf(xb[i]));
+  }
+  v = ssv_wg_max<4>(v, sm);
+  if (threadIdx.x == 0) out[(long)blockIdx.y * npb + blockIdx.x] = v;
+}
+int ssv_launch_absmax(const float* x, long x_bs, int B, long n, float* out, int npb, hipStream_t st) {
+  hipLaunchKernelGGL(absmax_kernel, dim3(npb, B), dim3(256), 0, st, x, x_bs, n, out, npb);
+  return ssv_check_launch("absmax");
+}
 
 // ---- weight pre-split ---------------------------------------------------------------------------------------------
 // Source w[m*sm + k*sk + j*sj] (M x K per tap j).  Output: bf16 hi / lo planes in MFMA FRAGMENT ORDER,
@@ -72,6 +123,34 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
   hi[d] = h;
   lo[d] = (__bf16)(v - (float)h);
 }
+// split-fp16 planes of ONE dense weight: same element map; the scale comes from the 64 partial maxima at aux (written by
+// absmax_kernel just before), the inverse scale goes to aux[64] for the GEMM's epilogue.
+__global__ __launch_bounds__(256) void pack_split_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                             int M, int K, int Kpad, int KT, long sm, long sk, long sj, float* __restrict__ aux) {
+  __shared__ float smx[4];
+  float sc, inv;
+  ssv_pow2_scale(ssv_list_max<4>(aux, 64, smx), sc, inv);
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) aux[64] = inv;
+  const int MB = (M + 15) >> 4, NCH = Kpad >> 5;
+  const long n = (long)KT * MB * NCH * 512;
+  if (i >= n) return;
+  const int e = (int)(i & 7), r16 = (int)((i >> 3) & 15), kg = (int)((i >> 7) & 3);
+  const long blk = i >> 9;
+  const int ch = (int)(blk % NCH), mb = (int)((blk / NCH) % MB), j = (int)(blk / ((long)NCH * MB));
+  const int m = mb * 16 + r16, k = ch * 32 + kg * 8 + e;
+  const float v = (m < M && k < K) ? w[(long)m * sm + (long)k * sk + (long)j * sj] : 0.f;
+  const _Float16 h = (_Float16)(v * sc);
+  hi[i] = h;
+  lo[i] = (_Float16)__builtin_fmaf(v, sc, -(float)h);
+}
+int ssv_launch_pack_split_f16(const float* w, long w_elems, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, float* aux,
+                              hipStream_t st) {
+  SSV_TRY(ssv_launch_absmax(w, 0, 1, w_elems, aux, 64, st));
+  const long n = (long)KT * ((M + 15) / 16 * 16) * Kpad;
+  hipLaunchKernelGGL(pack_split_f16_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, (_Float16*)hi, (_Float16*)lo, M, K, Kpad, KT, sm, sk, sj, aux);
+  return ssv_check_launch("pack_split_f16");
+}
 int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st,
                           int nch_total, int ch_off) {
   const long n = (long)KT * ((M + 15) / 16 * 16) * Kpad;
@@ -84,13 +163,34 @@ int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int 
 // Many weights in one launch (resident pre-split weights, ssv_conv_pack_multi): workgroup -> job by binary search over
 // the jobs' first_block, then the same element map as pack_split_kernel, 1024 elements per workgroup.
 #define PACK_PER_BLOCK 1024
-__global__ __launch_bounds__(256) void pack_multi_kernel(const ssv_pack_job* __restrict__ jobs, int njobs) {
+// split-fp16: partial maxima of every weight first (grid (SSV_PACK_AMAX_PER_WEIGHT, njobs / 2); the forward job 2i and the
+// transposed job 2i + 1 read the same dense tensor of M K KT floats), then the pack kernel scales by the resulting power of two
+// and leaves 2^-e at the job's inv_out for the GEMM epilogues.
+__global__ __launch_bounds__(256) void pack_amax_multi_kernel(const ssv_pack_job* __restrict__ jobs, float* __restrict__ amax) {
+  __shared__ float sm[4];
+  const ssv_pack_job j = jobs[2 * blockIdx.y];
+  const long n = (long)j.M * j.K * j.KT;
+  const long piece = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * piece, hi = min(lo + piece, n);
+  float v = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) v = fmaxf(v, fabsf(j.w[i]));
+  v = ssv_wg_max<4>(v, sm);
+  if (threadIdx.x == 0) amax[(long)blockIdx.y * gridDim.x + blockIdx.x] = v;
+}
+template <int F16>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const ssv_pack_job* __restrict__ jobs, int njobs, const float* __restrict__ amax) {
+  __shared__ float smx[4];
   int lo = 0, hi = njobs - 1;
   while (lo < hi) {                                   // last job with first_block <= blockIdx.x
     const int mid = (lo + hi + 1) >> 1;
     if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const ssv_pack_job j = jobs[lo];
+  float sc = 1.f, inv = 1.f;
+  if constexpr (F16) {
+    ssv_pow2_scale(ssv_list_max<4>(amax + (long)(lo >> 1) * SSV_PACK_AMAX_PER_WEIGHT, SSV_PACK_AMAX_PER_WEIGHT, smx), sc, inv);
+    if ((int)blockIdx.x == j.first_block && threadIdx.x == 0 && j.inv_out) *j.inv_out = inv;
+  }
   const int MB = (j.M + 15) >> 4, NCH = j.Kpad >> 5;
   const long n = (long)j.KT * MB * NCH * 512;
   __bf16* __restrict__ hip = (__bf16*)j.planes;
@@ -105,17 +205,29 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const ssv_pack_job* __r
     const int ch = (int)(blk % NCH), mb = (int)((blk / NCH) % MB), tap = (int)(blk / ((long)NCH * MB));
     const int m = mb * 16 + r16, k = ch * 32 + kg * 8 + e;
     const float v = (m < j.M && k < j.K) ? j.w[(long)m * j.sm + (long)k * j.sk + tap] : 0.f;
-    const __bf16 h = (__bf16)v;
-    hip[i] = h;
-    lop[i] = (__bf16)(v - (float)h);
+    if constexpr (F16) {
+      const _Float16 h = (_Float16)(v * sc);
+      reinterpret_cast<_Float16*>(hip)[i] = h;
+      reinterpret_cast<_Float16*>(lop)[i] = (_Float16)__builtin_fmaf(v, sc, -(float)h);
+    } else {
+      const __bf16 h = (__bf16)v;
+      hip[i] = h;
+      lop[i] = (__bf16)(v - (float)h);
+    }
   }
 }
 int ssv_pack_job_blocks(const ssv_pack_job& j) {
   const long n = (long)j.KT * ((j.M + 15) / 16) * (j.Kpad / 32) * 512;
   return (int)((n + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK);
 }
-int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, hipStream_t st) {
-  hipLaunchKernelGGL(pack_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs);
+int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, float* amax_ws, hipStream_t st) {
+  if (amax_ws) {
+    hipLaunchKernelGGL(pack_amax_multi_kernel, dim3(SSV_PACK_AMAX_PER_WEIGHT, njobs / 2), dim3(256), 0, st, jobs_dev, amax_ws);
+    SSV_TRY(ssv_check_launch("pack_amax_multi"));
+    hipLaunchKernelGGL(pack_multi_kernel<1>, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs, (const float*)amax_ws);
+  } else {
+    hipLaunchKernelGGL(pack_multi_kernel<0>, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs, (const float*)nullptr);
+  }
   return ssv_check_launch("pack_multi");
 }
 
@@ -124,8 +236,9 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 // (L2-resident, pre-split, fragment-shaped 16-byte loads) into MFMA operand registers, one K chunk ahead (two register
 // sets, the chunk loop is unrolled by two).  Only the input tile, which all four waves share, is staged in LDS -- this
 // removes 2/3 of the LDS writes and 1/4 of the LDS reads of a version that staged both operands.
-template <int KT, int WM, int NT, int EPI>
+template <int KT, int WM, int NT, int EPI, int F16>
 __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
+  static_assert(!(EPI && F16), "the LSTM epilogue runs on the split-bf16 arithmetic");
   constexpr int BM = 64 * WM, BN = 16 * NT;
   constexpr int HALO = (KT == 1) ? 0 : 54;
   constexpr int WX = ((BN + HALO + 15) / 16) * 16;         // staged columns, plane = WX*16 B = multiple of 256 B
@@ -137,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   constexpr int IMG = 2 * X_SLOTS, EPI_U4 = 4 * 16 * (BN + 4) / 4;
   constexpr int LDS_U4 = 2 * IMG > EPI_U4 ? 2 * IMG : EPI_U4;
   __shared__ uint4 lds_all[LDS_U4];
+  __shared__ float amax_sm[4];
   uint4 (*lds)[IMG] = reinterpret_cast<uint4 (*)[IMG]>(lds_all);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,6 +332,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     voffb[r] = voff[r] * 4u;           // BYTE offset: a zero-extended 32-bit VGPR offset off a uniform base is the saddr form of
   }                                    // global_load (no 64-bit VALU address per load, no VGPR pair per address)
   const bool ragged = (p.Kc & 31) != 0;
+  // split-fp16: xs = 2^ex scales the input while it is split, us = 2^-(ea + ex) the accumulators in the epilogue
+  float xs = 1.f, us = 1.f;
+  auto scales = [&]() {
+    if constexpr (F16) {
+      float inv;
+      ssv_pow2_scale(ssv_list_max<4>(p.x_amax + (long)b * p.x_amax_bs, p.x_namax, amax_sm), xs, inv);
+      us = inv * *p.a_inv;
+    }
+  };
   auto prefetchX = [&](int ch) {
     if (!ragged || ch + 1 < nchunks) {
 #pragma unroll
@@ -255,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
           for (int i = 0; i < 8; ++i) v[i] = (cvs[r] && ch * 32 + 8 * kg + i < p.Kc) ? rx[r][i] : 0.f;
         }
         uint4 h, l;
-        split8(v, h, l);
+        split8s<F16>(v, xs, h, l);
         Xh[e] = h; Xl[e] = l;            // slot index = kg*WX + col = e
       }
     }
@@ -270,16 +393,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     const uint4* Xl = lds[ch & 1] + X_SLOTS;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int xs = (SSV_NN_ABL & 16) ? (kq * WX + nq) : (kq * WX + t * 16 + nq + offj[j]);
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
+      const int xs_ = (SSV_NN_ABL & 16) ? (kq * WX + nq) : (kq * WX + t * 16 + nq + offj[j]);
+      const uint4 bh = Xh[xs_];
+      const uint4 bl = Xl[xs_];
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, Ah_[set][j][i]);
-        const bf16x8 al = __builtin_bit_cast(bf16x8, Al_[set][j][i]);
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[i][t], 0, 0, 0);
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[i][t], 0, 0, 0);
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[i][t], 0, 0, 0);
+        acc[i][t] = mma16<F16>(Al_[set][j][i], bh, acc[i][t]);
+        acc[i][t] = mma16<F16>(Ah_[set][j][i], bl, acc[i][t]);
+        acc[i][t] = mma16<F16>(Ah_[set][j][i], bh, acc[i][t]);
       }
     }
   };
@@ -290,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
     if (nchunks > 0) {
       loadA(0, 0, 0);
       prefetchX(0);
+      scales();
       commitX(0);
       if (nchunks > 1) { prefetchX(1); loadA(1, 0, 1); }
     }
@@ -311,6 +433,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
 #pragma unroll
     for (int j = 0; j < KT; ++j) loadA(0, j, 0);
     prefetchX(0);
+    scales();
     commitX(0);
     if (nchunks > 1) prefetchX(1);
     __syncthreads();
@@ -405,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
         if (p.bias) add += p.bias[gb];
         if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gb];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) stage[(kq * 4 + r) * LDW + t * 16 + nq] = acc[i][t][r] + add;
+        for (int t = 0; t < NT; ++t) stage[(kq * 4 + r) * LDW + t * 16 + nq] = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add;
       }
       // the block is private to the wave: no workgroup barrier, the LDS operations of one wave complete in order
 #pragma unroll
@@ -444,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
       for (int t = 0; t < NT; ++t) {
         const int gn = n0 + t * 16 + nq;
         if (gn >= p.N) continue;
-        float v = acc[i][t][r] + add;
+        float v = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add;
         if (Rb) v += Rb[(long)gm * p.srm + gn];
         Cb[(long)gm * p.scm + (long)gn * p.scn] = v;
       }
@@ -458,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
 // weight tile, so both operands are staged in LDS once per workgroup and the L2 bytes per MAC drop by ~2x (128 x 336 tile:
 // 16 B/clk/CU at the full MFMA rate).  Same LDS image layout [k-group][row][8 x bf16] (conflict-free b128 reads), same
 // "issue raw loads, mask at commit" staging and hoisted addressing as above.
-template <int KT, int WM, int NT, int NWN>
+template <int KT, int WM, int NT, int NWN, int F16>
 __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int T = 256 * NWN;
   constexpr int BM = 64 * WM, BN = 16 * NT * NWN;
@@ -467,6 +590,7 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
   constexpr int A_SLOTS = KT * 4 * BM, X_SLOTS = 4 * WX;
   constexpr int NA = (A_SLOTS + T - 1) / T, NX = (X_SLOTS + T - 1) / T;
   __shared__ uint4 lds[2 * A_SLOTS + 2 * X_SLOTS];
+  __shared__ float amax_sm[4 * NWN];
   uint4* Ah = lds;
   uint4* Al = lds + A_SLOTS;
   uint4* Xh = lds + 2 * A_SLOTS;
@@ -517,6 +641,7 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
     voff[r] = (unsigned)((e < X_SLOTS ? 8 * kg : 0) * Lrow + min(max(gcol, 0), p.Lx - 1));
   }
   const bool ragged = (p.Kc & 31) != 0;
+  float xs = 1.f, us = 1.f;           // split-fp16 scales, see gemm_nn_bf3_kernel
 
   auto prefetch = [&](int ch) {
 #pragma unroll
@@ -562,7 +687,7 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
           for (int i = 0; i < 8; ++i) v[i] = (((cvmask >> r) & 1) && ch * 32 + 8 * kg + i < p.Kc) ? rx[r][i] : 0.f;
         }
         uint4 h, l;
-        split8(v, h, l);
+        split8s<F16>(v, xs, h, l);
         Xh[e] = h; Xl[e] = l;
       }
     }
@@ -575,6 +700,11 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
   const int xcol = kq * WX + wn * NT * 16 + nq;
 
   prefetch(0);
+  if constexpr (F16) {
+    float inv;
+    ssv_pow2_scale(ssv_list_max<4 * NWN>(p.x_amax + (long)b * p.x_amax_bs, p.x_namax, amax_sm), xs, inv);
+    us = inv * *p.a_inv;
+  }
   for (int ch = 0; ch < nchunks; ++ch) {
     __syncthreads();
     commit(ch);
@@ -582,22 +712,22 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
     if (ch + 1 < nchunks) prefetch(ch + 1);
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
-      bf16x8 ah[WM], al[WM];
+      uint4 ah[WM], al[WM];
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
-        ah[i] = __builtin_bit_cast(bf16x8, Ah[j * 4 * BM + arow + i * 16]);
-        al[i] = __builtin_bit_cast(bf16x8, Al[j * 4 * BM + arow + i * 16]);
+        ah[i] = Ah[j * 4 * BM + arow + i * 16];
+        al[i] = Al[j * 4 * BM + arow + i * 16];
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int xs = xcol + t * 16 + offj[j];
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
+        const int xs_ = xcol + t * 16 + offj[j];
+        const uint4 bh = Xh[xs_];
+        const uint4 bl = Xl[xs_];
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][t], 0, 0, 0);
-          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][t], 0, 0, 0);
-          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][t], 0, 0, 0);
+          acc[i][t] = mma16<F16>(al[i], bh, acc[i][t]);
+          acc[i][t] = mma16<F16>(ah[i], bl, acc[i][t]);
+          acc[i][t] = mma16<F16>(ah[i], bh, acc[i][t]);
         }
       }
     }
@@ -618,7 +748,7 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
       for (int t = 0; t < NT; ++t) {
         const int gn = n0 + wn * NT * 16 + t * 16 + nq;
         if (gn >= p.N) continue;
-        float v = acc[i][t][r] + add;
+        float v = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add;
         if (Rb) v += Rb[(long)gm * p.srm + gn];
         Cb[(long)gm * p.scm + gn] = v;
       }
@@ -628,7 +758,8 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
 template <int KT, int WM, int NT, int NWN>
 static int launch_nnbw(const GemmNNB& g, hipStream_t st, int smin, int span) {
   const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT * NWN);
-  hipLaunchKernelGGL((gemm_nn_bf3w_kernel<KT, WM, NT, NWN>), dim3(mtiles * ntiles, g.B), dim3(256 * NWN), 0, st, g, mtiles, smin, span);
+  if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3w_kernel<KT, WM, NT, NWN, 1>), dim3(mtiles * ntiles, g.B), dim3(256 * NWN), 0, st, g, mtiles, smin, span);
+  else hipLaunchKernelGGL((gemm_nn_bf3w_kernel<KT, WM, NT, NWN, 0>), dim3(mtiles * ntiles, g.B), dim3(256 * NWN), 0, st, g, mtiles, smin, span);
   return ssv_check_launch("gemm_nn_bf3w");
 }
 
@@ -637,11 +768,12 @@ static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT);
   if constexpr (KT == 1) {
     if (g.epi == 1) {
-      hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 1>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+      hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 1, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
       return ssv_check_launch("gemm_nn_bf3_lstm");
     }
   }
-  hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+  if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0, 1>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+  else hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
   return ssv_check_launch("gemm_nn_bf3");
 }
 
@@ -729,6 +861,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   for (int j = 1; j < g.KT; ++j) { smin = g.shift[j] < smin ? g.shift[j] : smin; smax = g.shift[j] > smax ? g.shift[j] : smax; }
   const int span = smax - smin;
   SSV_CHECK(span <= 54, SSV_UNSUPPORTED, "gemm_nn_bf3: dilation halo %d exceeds 54", span);
+  SSV_CHECK(!g.f16 || (!g.epi && g.a_inv && g.x_amax && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales and no LSTM epilogue");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
 }
 
@@ -743,7 +876,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
 //     16 staging registers instead of 48 (staging all taps at once put the 128 x 64 x 3 tile at 256 VGPRs with spills,
 //     and every scratch reload waits for vmcnt(0), i.e. for the whole prefetch in flight).
 // Loads are issued raw, one step (input) or one chunk (A) ahead, with no branch in the prefetch (see load8/fix8).
-template <int KT, int WM, int NTC>
+template <int KT, int WM, int NTC, int F16>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
   constexpr int KB = 64, KG = KB / 8, KS = KB / 32;         // time steps per chunk, k-groups, MFMA k-steps
   constexpr int NCH = 16 * NTC;
@@ -755,6 +888,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   // write slots 1 KB apart -- one bank set, an 8-way conflict that cost more than the step's MFMAs.  With it they land on
   // 8 distinct 16-byte bank groups, and the fragment reads (16 consecutive channels per quarter wave) stay conflict-free.
   __shared__ uint4 lds[2][2 * X_SLOTS];
+  __shared__ float amax_sm[8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);   // a slab's tiles share an XCD
@@ -765,13 +899,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   const float* __restrict__ Xp = p.X;
   float* __restrict__ Cp = p.C;
   int shj[3] = {p.shift[0], p.shift[1], p.shift[2]};
+  const float* __restrict__ a_amax = p.a_amax;
+  const float* __restrict__ x_amax = p.x_amax;
+  int a_namax = p.a_namax, x_namax = p.x_namax;
   if (p.jobs) {
     const int job = z / p.Z;
     z -= job * p.Z;
     const ssv_wgrad_job jb = p.jobs[job];
     Ap = jb.dy; Xp = jb.x; Cp = p.C + (long)job * p.Z * p.scz;
     shj[0] = jb.shift[0]; shj[1] = jb.shift[1]; shj[2] = jb.shift[2];
+    a_amax = jb.dy_amax; x_amax = jb.x_amax; a_namax = jb.dy_namax; x_namax = jb.x_namax;
   }
+  // split-fp16: one power-of-two scale per operand tensor (the reduction runs over the batch), undone in the epilogue
+  float as = 1.f, xs = 1.f, us = 1.f;
+  auto scales = [&]() {
+    if constexpr (F16) {
+      float ia, ix;
+      ssv_pow2_scale(ssv_list_max<4>(a_amax, a_namax, amax_sm), as, ia);
+      ssv_pow2_scale(ssv_list_max<4>(x_amax, x_namax, amax_sm + 4), xs, ix);
+      us = ia * ix;
+    }
+  };
   const int mt = bxx % mtiles, ct = bxx / mtiles;
   const int m0 = mt * 64 * WM, c0 = ct * NCH;
   const int tchunks = (p.La + KB - 1) / KB;
@@ -824,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     const int m = row_ok ? (int)((0xFFu << sl) & (0xFFu >> sh) & 0xFFu) : 0;
     return m | ((off - oc) << 8);
   };
-  auto split_edge = [&](const float (&raw)[8], int meta, uint4& h, uint4& l) {
+  auto split_edge = [&](const float (&raw)[8], int meta, float sc, uint4& h, uint4& l) {
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = raw[i];
@@ -841,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = ((meta >> i) & 1) ? v[i] : 0.f;
-    split8(v, h, l);
+    split8s<F16>(v, sc, h, l);
   };
 
   // chunk cursors (wave-uniform): batch item and first time step of chunks n .. n+3
@@ -882,13 +1030,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) {
           if (SSV_ABL & 2) { ah[i][s2] = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&ra[i][s2][0])); al[i][s2] = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&ra[i][s2][4])); }
-          else split8(ra[i][s2], ah[i][s2], al[i][s2]);
+          else split8s<F16>(ra[i][s2], as, ah[i][s2], al[i][s2]);
         }
     } else {
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) split_edge(ra[i][s2], ma[i][s2], ah[i][s2], al[i][s2]);
+        for (int s2 = 0; s2 < KS; ++s2) split_edge(ra[i][s2], ma[i][s2], as, ah[i][s2], al[i][s2]);
     }
   };
   auto loadX = [&](auto set, int b, int t0, int j) __attribute__((always_inline)) {                        // -> rx[set] (/ mx[set])
@@ -916,8 +1064,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       const int kg = f % KG, c = f / KG;
       uint4 h, l;
       if (SSV_ABL & 4) { h = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[S][r][0])); l = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[S][r][4])); }
-      else if (!edge) split8(rx[S][r], h, l);
-      else split_edge(rx[S][r], mx[S][r], h, l);
+      else if (!edge) split8s<F16>(rx[S][r], xs, h, l);
+      else split_edge(rx[S][r], mx[S][r], xs, h, l);
       Xh[kg * NCH + (c ^ kg)] = h; Xl[kg * NCH + (c ^ kg)] = l;          // XOR swizzle, see the slot comment above
     }
   };
@@ -943,19 +1091,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
         const int kg = s2 * 4 + kq;
 #pragma unroll
         for (int q = 0; q < NTC; ++q) {
-          const int xs = kg * NCH + ((q * 16 + nq) ^ kg);
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, Xh[xs]);
-          const bf16x8 bl = __builtin_bit_cast(bf16x8, Xl[xs]);
+          const int xs_ = kg * NCH + ((q * 16 + nq) ^ kg);
+          const uint4 bh = Xh[xs_];
+          const uint4 bl = Xl[xs_];
 #pragma unroll
           for (int i = 0; i < WM; ++i) {
-            const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[i][s2]);
-            const bf16x8 a_l = __builtin_bit_cast(bf16x8, al[i][s2]);
+            const uint4 a_h = ah[i][s2];
+            const uint4 a_l = al[i][s2];
 #if (SSV_ABL & 1)
-            acc[i][j][q][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a_l).x ^ __builtin_bit_cast(uint4, bh).x ^ __builtin_bit_cast(uint4, a_h).y ^ __builtin_bit_cast(uint4, bl).y);
+            acc[i][j][q][0] += __builtin_bit_cast(float, a_l.x ^ bh.x ^ a_h.y ^ bl.y);
 #else
-            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, bh, acc[i][j][q], 0, 0, 0);
-            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, bl, acc[i][j][q], 0, 0, 0);
-            acc[i][j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, bh, acc[i][j][q], 0, 0, 0);
+            acc[i][j][q] = mma16<F16>(a_l, bh, acc[i][j][q]);
+            acc[i][j][q] = mma16<F16>(a_h, bl, acc[i][j][q]);
+            acc[i][j][q] = mma16<F16>(a_h, bh, acc[i][j][q]);
 #endif
           }
         }
@@ -983,6 +1131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     loadA(cb[0], ct0[0]);
     loadX(P0{}, cb[0], ct0[0], 0);
     if (steps > 1) loadX(P1{}, cb[1 / KT], ct0[1 / KT], 1 % KT);
+    scales();
     splitA(ct0[0]);
     commitX(P0{}, ct0[0], 0);
     if (steps > 2) loadX(P0{}, cb[2 / KT], ct0[2 / KT], 2 % KT);
@@ -1010,7 +1159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
         for (int q = 0; q < NTC; ++q) {
           const int gc = c0 + q * 16 + nq;
-          if (gc < p.Nc) Cz[(long)gm * p.scm + (long)gc * p.scc + (long)j * p.scj] = acc[i][j][q][r];
+          if (gc < p.Nc) Cz[(long)gm * p.scm + (long)gc * p.scc + (long)j * p.scj] = F16 ? acc[i][j][q][r] * us : acc[i][j][q][r];
         }
     }
 }
@@ -1064,7 +1213,11 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
   const int nz = g.jobs ? g.njobs * g.Z : g.Z;
   SSV_CHECK(nz <= 65535, SSV_UNSUPPORTED, "gemm_nt_bf3: %d slabs exceed grid.z", nz);
   const dim3 grid(mtiles * ssv_cdiv(g.Nc, 16 * ntc), 1, nz);
-#define SSV_NT(K_, A_, C_) if (g.KT == K_ && wm == A_ && ntc == C_) { hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_>), grid, dim3(256), 0, st, g, mtiles); return ssv_check_launch("gemm_nt_bf3"); }
+  SSV_CHECK(!g.f16 || g.jobs || (g.a_amax && g.x_amax && g.a_namax > 0 && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_nt_bf3: split-fp16 needs both operand scales");
+#define SSV_NT(K_, A_, C_) if (g.KT == K_ && wm == A_ && ntc == C_) { \
+    if (g.f16) hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_, 1>), grid, dim3(256), 0, st, g, mtiles); \
+    else hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_, 0>), grid, dim3(256), 0, st, g, mtiles); \
+    return ssv_check_launch("gemm_nt_bf3"); }
   SSV_NT(3, 2, 4) SSV_NT(3, 2, 2) SSV_NT(3, 1, 4) SSV_NT(3, 1, 2)
   SSV_NT(1, 2, 6) SSV_NT(1, 2, 4) SSV_NT(1, 2, 2) SSV_NT(1, 1, 6) SSV_NT(1, 1, 4) SSV_NT(1, 1, 2)
 #undef SSV_NT

@@ -69,8 +69,9 @@ template <int CPT, int G>
 __global__ __launch_bounds__(16 * G) void ln_gate_fwd_kernel(
     const float* __restrict__ H, long h_bs, const float* __restrict__ X, long x_bs,
     const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
-    float* __restrict__ Y, long y_bs, float* __restrict__ stats, int C, int L) {
+    float* __restrict__ Y, long y_bs, float* __restrict__ stats, float* __restrict__ amax, int C, int L) {
   __shared__ float red[2 * 16 * G];
+  __shared__ float amx[G / 4];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -104,22 +105,31 @@ __global__ __launch_bounds__(16 * G) void ln_gate_fwd_kernel(
   float qs[2] = {q1, q2};
   group_sums<G, 2>(qs, red, col, g);
   const float r1 = rsqrtf(qs[0] * inv + LN_EPS), r2 = rsqrtf(qs[1] * inv + LN_EPS);
-  if (!tv) return;
-  if (g == 0 && stats) {
-    float* sb = stats + (long)b * 4 * L + t;
-    sb[0] = mu1; sb[L] = r1; sb[2L * L] = mu2; sb[3L * L] = r2;
-  }
-  const float* __restrict__ Xb = X + (long)b * x_bs;
-  float* __restrict__ Yb = Y + (long)b * y_bs;
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = g + G * i;
-    if (c < C) {
-      const float n1 = (h1[i] - mu1) * r1 * g1[c] + b1[c];
-      const float n2 = (h2[i] - mu2) * r2 * g2[c] + b2[c];
-      const float s = sigmoidf_(n1);
-      Yb[o0 + i * ostep] = s * n2 + (1.f - s) * Xb[o0 + i * ostep];
+  float am = 0.f;
+  if (tv) {
+    if (g == 0 && stats) {
+      float* sb = stats + (long)b * 4 * L + t;
+      sb[0] = mu1; sb[L] = r1; sb[2L * L] = mu2; sb[3L * L] = r2;
     }
+    const float* __restrict__ Xb = X + (long)b * x_bs;
+    float* __restrict__ Yb = Y + (long)b * y_bs;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = g + G * i;
+      if (c < C) {
+        const float n1 = (h1[i] - mu1) * r1 * g1[c] + b1[c];
+        const float n2 = (h2[i] - mu2) * r2 * g2[c] + b2[c];
+        const float s = sigmoidf_(n1);
+        const float yv = s * n2 + (1.f - s) * Xb[o0 + i * ostep];
+        Yb[o0 + i * ostep] = yv;
+        am = fmaxf(am, fabsf(yv));
+      }
+    }
+  }
+  // split-fp16 operand scale of the NEXT convolution: this tile's max |y| (one entry per workgroup, ssv_amax_rows(L) per item)
+  if (amax) {
+    am = ssv_wg_max<G / 4>(am, amx);
+    if (threadIdx.x == 0) amax[(long)b * gridDim.x + bx] = am;
   }
 }
 
@@ -129,8 +139,10 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
     const float* __restrict__ dY, long dy_bs, const float* __restrict__ H, const float* __restrict__ X, long x_bs,
     const float* __restrict__ stats,
     const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
-    float* __restrict__ dH, float* __restrict__ dXres, long dx_bs, float* __restrict__ part, int C, int L) {
+    float* __restrict__ dH, float* __restrict__ dXres, long dx_bs, float* __restrict__ part, float* __restrict__ amax, int C, int L) {
   __shared__ float red[4 * 16 * G];
+  __shared__ float amx[G / 4];
+  float am = 0.f;
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -188,8 +200,13 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
     const float d1 = v ? r1 * (a1[i] - m1 - xh1[i] * mh1) : 0.f;
     const float d2 = v ? r2 * (a2[i] - m2 - xh2[i] * mh2) : 0.f;
     if (v) { dHb1[o0 + i * ostep] = d1; dHb2[o0 + i * ostep] = d2; }
+    am = fmaxf(am, fmaxf(fabsf(d1), fabsf(d2)));
     const float q0 = col_sum(d1), q1 = col_sum(d2);
     if (col == 0 && c < C) { pblk[4 * C + c] = q0; pblk[5 * C + c] = q1; }
+  }
+  if (amax) {                                    // max |dH| of this tile: operand scale of the two conv gradients (split-fp16)
+    am = ssv_wg_max<G / 4>(am, amx);
+    if (threadIdx.x == 0) amax[(long)b * gridDim.x + bx] = am;
   }
 }
 
@@ -197,8 +214,9 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
 template <int CPT, int G>
 __global__ __launch_bounds__(16 * G) void ln_act_fwd_kernel(
     const float* __restrict__ X, long x_bs, const float* __restrict__ gam, const float* __restrict__ bet,
-    float* __restrict__ Y, long y_bs, float* __restrict__ stats, int C, int L, int act) {
+    float* __restrict__ Y, long y_bs, float* __restrict__ stats, float* __restrict__ amax, int C, int L, int act) {
   __shared__ float red[16 * G];
+  __shared__ float amx[G / 4];
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -223,18 +241,25 @@ __global__ __launch_bounds__(16 * G) void ln_act_fwd_kernel(
     q += d * d;
   }
   const float r = rsqrtf(group_sum<G>(q, red, col, g) * inv + LN_EPS);
-  if (!tv) return;
-  if (g == 0 && stats) { stats[(long)b * 2 * L + t] = mu; stats[(long)b * 2 * L + L + t] = r; }
-  float* __restrict__ Yb = Y + (long)b * y_bs;
+  float am = 0.f;
+  if (tv) {
+    if (g == 0 && stats) { stats[(long)b * 2 * L + t] = mu; stats[(long)b * 2 * L + L + t] = r; }
+    float* __restrict__ Yb = Y + (long)b * y_bs;
 #pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = g + G * i;
-    if (c < C) {
-      float n = (x[i] - mu) * r * gam[c] + bet[c];
-      if (act == 1) n = fmaxf(n, 0.f);
-      else if (act == 2) n = sigmoidf_(n);
-      Yb[o0 + i * ostep] = n;
+    for (int i = 0; i < CPT; ++i) {
+      const int c = g + G * i;
+      if (c < C) {
+        float n = (x[i] - mu) * r * gam[c] + bet[c];
+        if (act == 1) n = fmaxf(n, 0.f);
+        else if (act == 2) n = sigmoidf_(n);
+        Yb[o0 + i * ostep] = n;
+        am = fmaxf(am, fabsf(n));
+      }
     }
+  }
+  if (amax) {                                    // see ln_gate_fwd_kernel
+    am = ssv_wg_max<G / 4>(am, amx);
+    if (threadIdx.x == 0) amax[(long)b * gridDim.x + bx] = am;
   }
 }
 
@@ -243,8 +268,10 @@ template <int CPT, int G>
 __global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
     const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs, const float* __restrict__ stats,
     const float* __restrict__ gam, const float* __restrict__ bet,
-    float* __restrict__ dX, long dx_bs, float* __restrict__ part, int C, int L, int act) {
+    float* __restrict__ dX, long dx_bs, float* __restrict__ part, float* __restrict__ amax, int C, int L, int act) {
   __shared__ float red[2 * 16 * G];
+  __shared__ float amx[G / 4];
+  float am = 0.f;
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -289,8 +316,13 @@ __global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
     const bool v = tv && c < C;
     const float d = v ? r * (a[i] - m - xh[i] * mh) : 0.f;
     if (v) dXb[o0 + i * ostep] = d;
+    am = fmaxf(am, fabsf(d));
     const float q0 = col_sum(d);
     if (col == 0 && c < C) pblk[2 * C + c] = q0;
+  }
+  if (amax) {                                    // see ln_gate_bwd_kernel
+    am = ssv_wg_max<G / 4>(am, amx);
+    if (threadIdx.x == 0) amax[(long)b * gridDim.x + bx] = am;
   }
 }
 
@@ -559,9 +591,9 @@ static int ln_groups(int C, bool bwd) {
 
 int ssv_launch_ln_gate_fwd(const float* H, long h_bs, const float* X, long x_bs, const float* g1, const float* b1,
                            const float* g2, const float* b2, float* Y, long y_bs, float* stats, int B, int C, int L,
-                           hipStream_t st) {
+                           hipStream_t st, float* amax) {
   dim3 grid(ssv_cdiv(L, 16), B);
-#define CALL(N, G) hipLaunchKernelGGL((ln_gate_fwd_kernel<N, G>), grid, dim3(16 * G), 0, st, H, h_bs, X, x_bs, g1, b1, g2, b2, Y, y_bs, stats, C, L)
+#define CALL(N, G) hipLaunchKernelGGL((ln_gate_fwd_kernel<N, G>), grid, dim3(16 * G), 0, st, H, h_bs, X, x_bs, g1, b1, g2, b2, Y, y_bs, stats, amax, C, L)
   if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
   LN_DISPATCH(false, C, L, CALL);
 #undef CALL
@@ -572,9 +604,9 @@ int ssv_ln_gate_bwd_nblk(int B, int L) { return B * ssv_cdiv(L, 16); }
 
 int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const float* X, long x_bs, const float* stats,
                            const float* g1, const float* b1, const float* g2, const float* b2, float* dH, float* dXres,
-                           long dx_bs, float* part, float* pgrads /* [6][C] */, int B, int C, int L, hipStream_t st) {
+                           long dx_bs, float* part, float* pgrads /* [6][C] */, int B, int C, int L, hipStream_t st, float* amax) {
   dim3 grid(ssv_cdiv(L, 16), B);
-#define CALL(N, G) hipLaunchKernelGGL((ln_gate_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, C, L)
+#define CALL(N, G) hipLaunchKernelGGL((ln_gate_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L)
   if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
   LN_DISPATCH(true, C, L, CALL);
 #undef CALL
@@ -584,9 +616,9 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
 }
 
 int ssv_launch_ln_act_fwd(const float* X, long x_bs, const float* gam, const float* bet, float* Y, long y_bs, float* stats,
-                          int B, int C, int L, int act, hipStream_t st) {
+                          int B, int C, int L, int act, hipStream_t st, float* amax) {
   dim3 grid(ssv_cdiv(L, 16), B);
-#define CALL(N, G) hipLaunchKernelGGL((ln_act_fwd_kernel<N, G>), grid, dim3(16 * G), 0, st, X, x_bs, gam, bet, Y, y_bs, stats, C, L, act)
+#define CALL(N, G) hipLaunchKernelGGL((ln_act_fwd_kernel<N, G>), grid, dim3(16 * G), 0, st, X, x_bs, gam, bet, Y, y_bs, stats, amax, C, L, act)
   LN_DISPATCH(false, C, L, CALL);
 #undef CALL
   return ssv_check_launch("ln_act_fwd");
@@ -594,9 +626,9 @@ int ssv_launch_ln_act_fwd(const float* X, long x_bs, const float* gam, const flo
 
 int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs, const float* stats, const float* gam,
                           const float* bet, float* dX, long dx_bs, float* part, float* pgrads /* [3][C] */, int B, int C,
-                          int L, int act, hipStream_t st) {
+                          int L, int act, hipStream_t st, float* amax) {
   dim3 grid(ssv_cdiv(L, 16), B);
-#define CALL(N, G) hipLaunchKernelGGL((ln_act_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, C, L, act)
+#define CALL(N, G) hipLaunchKernelGGL((ln_act_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, amax, C, L, act)
   LN_DISPATCH(true, C, L, CALL);
 #undef CALL
   SSV_TRY(ssv_check_launch("ln_act_bwd"));

@@ -46,6 +46,10 @@ struct GemmNT {
   // several problems of one shape in one launch (split-bf16 kernel only): grid.z = njobs * Z, entry z belongs to job z / Z and
   // takes A = jobs[job].dy, X = jobs[job].x, the job's shifts, and slab (z % Z) of the job's slab region C + job * Z * scz
   const ssv_wgrad_job* jobs; int njobs;
+  // split-fp16 arithmetic (split-bf16 kernel only): both operands are scaled while they are split, by the power of two that
+  // the maximum over ALL entries of their partial-maxima lists gives (the reduction runs over the batch, so one scale per
+  // tensor); with a job table the lists are the job's (dy_amax / x_amax, n_amax entries each side as stored in the job).
+  int f16; const float* a_amax; int a_namax; const float* x_amax; int x_namax;
 };
 int ssv_launch_gemm_nt(const GemmNT& g, hipStream_t st);
 
@@ -74,6 +78,10 @@ struct GemmNNB {
   // training (gates_out != null, lstm_D = number of frames): the activated gates i, f, g, o are saved as
   // gates_out[layer][frame][gate*H + u][N] (torch row order) and cstate is [layer][frame][H][N] (c_{t-1} read, c_t written)
   float* gates_out;
+  // split-fp16 arithmetic (f16 = 1, see "split-fp16" below; conv products only, not the LSTM epilogue): the planes hold fp16
+  // hi / lo of A * 2^ea and *a_inv = 2^-ea (written by the pack kernels); X is scaled by 2^ex while it is split, with ex from
+  // the maximum of the x_namax partial maxima |X| at x_amax + b * x_amax_bs (x_amax_bs = 0: one list for every batch item).
+  int f16; const float* a_inv; const float* x_amax; int x_namax; long x_amax_bs;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
@@ -82,16 +90,23 @@ bool ssv_nt_bf3_fits(const GemmNT& g);          // operands addressable with the
 // (two matrices side by side along K, e.g. [W_ih | W_hh]); 0, 0 = the plane holds this source only.
 int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st,
                           int nch_total = 0, int ch_off = 0);
+// split-fp16 planes of one dense weight (w_elems floats at w): partial maxima -> aux[0..63], 2^-ea -> aux[64]; then the planes
+int ssv_launch_pack_split_f16(const float* w, long w_elems, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, float* aux, hipStream_t st);
+#define SSV_F16_AUX_FLOATS 128          // floats of aux the call above needs (64 partial maxima, the inverse scale, padding)
+#define SSV_AMAX_FALLBACK 64            // partial maxima an internally computed |x| list has (one list for the whole tensor)
+// partial maxima of |x| for B items of n dense floats each (item stride x_bs): out[b * npb + i], i < npb
+int ssv_launch_absmax(const float* x, long x_bs, int B, long n, float* out, int npb, hipStream_t st);
 int ssv_nt_bf3_tiles(int KT, int M, int Nc);
 int ssv_nt_bf3_target(int KT, int M, int Nc);  // workgroups to aim for when choosing the slab count   // output tiles of the weight-gradient kernel for this problem
-int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA (default)
+int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA, 2 = split-fp16 MFMA with power-of-two operand scales (default)
 // Tuning knobs from the environment (SSV_NT_Z, SSV_NNB_TILE, ...): read ONCE at first use -- a launch must not cost
 // half a dozen getenv() scans of the environment block -- and again only when a tuning script calls ssv_reload_tuning().
 enum { SSV_T_NT_Z, SSV_T_NT_FORCE, SSV_T_LSTM_SEQUENTIAL, SSV_T_NNB_WIDE, SSV_T_NNB_TILE, SSV_T_NNB_FORCE, SSV_T_NT_PLAN, SSV_T_NN_TILE,
        SSV_T_LN_GROUPS, SSV_T_COUNT };
 const char* ssv_tuning(int knob);          // value of the knob or nullptr
 int ssv_pack_job_blocks(const ssv_pack_job& j);           // workgroups one job of ssv_conv_pack_multi takes
-int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, hipStream_t st);
+int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, float* amax_ws, hipStream_t st);   // amax_ws != null: split-fp16 planes
+#define SSV_PACK_AMAX_PER_WEIGHT 32     // partial maxima per weight in amax_ws (njobs / 2 weights)
 
 // ---- small helpers (misc.hip) ---------------------------------------------------------
 int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long slab_stride, hipStream_t st);
@@ -111,6 +126,40 @@ static inline int ssv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ unsigned ssv_xcd_order(unsigned lin, unsigned total) {
   const unsigned xcd = lin & 7u, idx = lin >> 3, q = total >> 3, r = total & 7u;
   return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
+// ---- split-fp16 ("f16x2") arithmetic -------------------------------------------------------------
+// An fp32 operand x is scaled by a power of two s = 2^e chosen per tensor (or per batch item) so that max |x| s lies in
+// [2^14, 2^15), then split as hi = fp16(x s), lo = fp16(x s - hi): 22 significand bits for every element within 2^-17 of
+// the maximum (lo stays a normal fp16 number), an absolute error of 2^-40 of the maximum below that.  A product is
+// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_16x16x32_f16 (each fp16 x fp16 product is exact in fp32; the dropped
+// lo*lo term is 2^-22 relative), fp32 accumulate, and the result is multiplied by 2^-(ea + eb).  Same three MFMAs per
+// product as the split-bf16 mode at ~2^-22 instead of ~2^-16: fp32-grade results at the bf16 MFMA rate.
+// amax -> (2^e, 2^-e): exponent field E of amax (value in [2^(E-127), 2^(E-126))) -> e = 141 - E.
+__device__ __forceinline__ void ssv_pow2_scale(float amax, float& scale, float& inv) {
+  int E = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  E = min(max(E, 15), 254);
+  scale = __uint_as_float((unsigned)(268 - E) << 23);
+  inv = __uint_as_float((unsigned)(E - 14) << 23);
+}
+// maximum of a per-thread value over the workgroup (NW waves); sm: NW floats of LDS nobody else uses around the call
+template <int NW>
+__device__ __forceinline__ float ssv_wg_max(float v, float* sm) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sm[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) r = fmaxf(r, sm[i]);
+  return r;
+}
+// maximum of the n floats at p (every thread of an NW-wave workgroup gets it)
+template <int NW>
+__device__ __forceinline__ float ssv_list_max(const float* __restrict__ p, int n, float* sm) {
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64 * NW) v = fmaxf(v, p[i]);
+  return ssv_wg_max<NW>(v, sm);
 }
 
 // ---- cross-lane sums on the VALU (DPP) ---------------------------------------------------

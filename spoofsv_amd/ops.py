@@ -59,6 +59,45 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# ------------------------------------------------------------------------------------------- split-fp16 operand scales
+# include/ssv_hip.h, "Operand scales (mode 2)": a kernel that reads an fp32 tensor as an MFMA operand needs a list of partial
+# maxima of |x| (n entries per batch item).  The LayerNorm / gate kernels write one for their output as a by-product; it
+# travels to the consumer as an attribute of the output tensor (with the tensor's version, so an in-place edit voids it).  A
+# tensor without one (data, a view, the output of another kernel) gets an ``ssv_absmax`` launch.  Other arithmetic modes: None.
+_AMAX_PIECES = 8
+
+
+def _f16():
+    return _lib.precision() == 2
+
+
+def _amax_out(B, L, device):
+    """Buffer for the scale list a LayerNorm / gate kernel writes for its (B, C, L) output."""
+    return torch.empty((B, (L + 15) // 16), dtype=_F32, device=device)
+
+
+def _tag(y, amax):
+    y._ssv_amax = (amax, y._version)
+    return y
+
+
+def amax_of(x):
+    """Scale list of ``x`` (B, C, L): the producer's, or computed here."""
+    h = getattr(x, "_ssv_amax", None)
+    if h is not None and h[1] == x._version and h[0].shape[0] == x.shape[0] and h[0].device == x.device:
+        return h[0]
+    xd, xbs = _act3(x.detach(), "operand")
+    B, C, L = xd.shape
+    out = torch.empty((B, _AMAX_PIECES), dtype=_F32, device=xd.device)
+    _lib.call("ssv_absmax", _p(xd), xbs, B, C * L, _p(out), _AMAX_PIECES, _stream())
+    return out               # NOT remembered on x: buffers that kernels update through raw pointers keep their version
+
+
+def _an(a):
+    """(pointer, entries per item) of a scale list or (None, 0)."""
+    return (None, 0) if a is None else (_p(a), a.shape[1])
+
+
 def _needs_grad(ctx):
     """True when autograd will call backward for this node (inside Function.forward grad mode is always
     off, so the tape's own bookkeeping is the reliable signal)."""
@@ -101,7 +140,7 @@ class DeferredWgrad:
     def accepts(B, Cin, Cout, L, k, nblk):
         return nblk <= 768 and bool(_lib.lib().ssv_conv1d_bwd_weight_multi_ok(B, Cin, Cout, L, k))
 
-    def add(self, dy, dy_bs, x, x_bs, dw, part, pg, k, dilation, causal, n2, nblk):
+    def add(self, dy, dy_bs, x, x_bs, dw, part, pg, k, dilation, causal, n2, nblk, dy_amax=None, x_amax=None):
         B, Cin, L = x.shape
         key = (B, Cin, dy.shape[1], L, k, dy_bs, x_bs, n2, nblk, x.device)
         sh = (ctypes.c_int * 3)()
@@ -109,7 +148,8 @@ class DeferredWgrad:
         # dw and pg are what the caller hands to autograd, which adopts a returned gradient as ``p.grad`` only while nobody else
         # holds the tensor OBJECT or a view of it (otherwise it clones -- here: the not yet computed values).  The queue keeps
         # the address and the STORAGE alive, not the tensors.
-        self.jobs.setdefault(key, []).append((dy, x, part, dw.data_ptr(), pg.data_ptr(), (dw.untyped_storage(), pg.untyped_storage()), tuple(sh)))
+        self.jobs.setdefault(key, []).append((dy, x, part, dw.data_ptr(), pg.data_ptr(), (dw.untyped_storage(), pg.untyped_storage()), tuple(sh),
+                                              dy_amax, x_amax))
 
     def _slot(self, nbytes, dev):
         capturing = torch.cuda.is_current_stream_capturing()
@@ -133,9 +173,14 @@ class DeferredWgrad:
             B, Cin, Cout, L, k, dy_bs, x_bs, n2, nblk, dev = key
             n = len(jobs)
             table = (_lib.WgradJob * n)()
-            for t, (dy, x, part, dw_ptr, pg_ptr, _, sh) in zip(table, jobs):
+            f16 = _f16()
+            for t, (dy, x, part, dw_ptr, pg_ptr, _, sh, dy_amax, x_amax) in zip(table, jobs):
                 t.dy, t.x, t.dw, t.part, t.pgrads = dy.data_ptr(), x.data_ptr(), dw_ptr, part.data_ptr(), pg_ptr
                 t.shift[0], t.shift[1], t.shift[2] = sh
+                if f16:
+                    if dy_amax is None or x_amax is None:
+                        raise RuntimeError("DeferredWgrad: a job was queued without operand scales in the split-fp16 mode")
+                    t.dy_amax, t.x_amax, t.dy_namax, t.x_namax = dy_amax.data_ptr(), x_amax.data_ptr(), dy_amax.numel(), x_amax.numel()
             raw = bytes(table)
             slot = self._slot(len(raw), dev)
             slot[0][:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
@@ -157,7 +202,7 @@ class HighwayConvFn(torch.autograd.Function):
     """highwayConv.forward, models/TTSModel.py:63-84 (conv -> 2x LayerNorm over channels -> gate)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, g1, b1, g2, b2, k, dilation, causal):
+    def forward(ctx, x, w, bias, g1, b1, g2, b2, k, dilation, causal, x_amax=None, y_amax=None):
         x, xbs = _act3(x, "highwayConv input")
         B, C, L = x.shape
         w, bias, g1, b1, g2, b2 = map(_c, (w, bias, g1, b1, g2, b2))
@@ -169,10 +214,11 @@ class HighwayConvFn(torch.autograd.Function):
         stats = torch.empty((B, 4, L), dtype=_F32, device=x.device) if train else None
         nb = _lib.query("ssv_highway_conv1d_fwd_workspace", B, C, L, k)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_highway_conv1d_fwd", _p(x), xbs, _p(w), resident.lookup(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
-                  _p(h), _p(stats), _p(y), C * L, B, C, L, k, dilation, int(causal), _p(ws), nb, _stream())
+        _lib.call("ssv_highway_conv1d_fwd", _p(x), xbs, *_an(x_amax), _p(w), resident.lookup(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
+                  _p(h), _p(stats), _p(y), C * L, _p(y_amax), B, C, L, k, dilation, int(causal), _p(ws), nb, _stream())
         if train:
             ctx.save_for_backward(x, w, g1, b1, g2, b2, h, stats)
+            ctx.x_amax = x_amax
             ctx.cfg = (k, dilation, int(causal))
             ctx.bias_ref = bias           # only its address is used (gradient-arena lookup); not needed by the kernels
         return y
@@ -194,46 +240,49 @@ class HighwayConvFn(torch.autograd.Function):
             # LayerNorm / gate backward + data gradient now; the weight gradient joins the other layers of this shape at flush
             dh = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
             part = torch.empty((nblk, 6 * C), dtype=_F32, device=x.device)
+            f16 = _f16()
+            dh_amax = _amax_out(B, L, x.device) if f16 else None
+            x_amax = (ctx.x_amax if ctx.x_amax is not None else amax_of(x)) if f16 else None
             nb = _lib.query("ssv_highway_conv1d_bwd_data_workspace", B, C, L, k)
             ws = _ws(nb, x.device)
             _lib.call("ssv_highway_conv1d_bwd_data", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
-                      _p(h), _p(stats), _p(dx), C * L, _p(dh), _p(part), B, C, L, k, dilation, causal, _p(ws), nb, _stream())
-            _DEFER.add(dh, 2 * C * L, x, xbs, dw, part, pg, k, dilation, causal, 6 * C, nblk)
-            return dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3], None, None, None
+                      _p(h), _p(stats), _p(dx), C * L, _p(dh), _p(dh_amax), _p(part), B, C, L, k, dilation, causal, _p(ws), nb, _stream())
+            _DEFER.add(dh, 2 * C * L, x, xbs, dw, part, pg, k, dilation, causal, 6 * C, nblk, dh_amax, x_amax)
+            return (dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3]) + (None,) * 5
         nb = _lib.query("ssv_highway_conv1d_bwd_workspace", B, C, L, k)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_highway_conv1d_bwd", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
+        _lib.call("ssv_highway_conv1d_bwd", _p(dy), dybs, _p(x), xbs, *_an(ctx.x_amax), _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
                   _p(h), _p(stats), _p(dx), C * L, _p(dw), _p(pg), B, C, L, k, dilation, causal,
                   _p(ws), nb, _stream())
-        return dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3], None, None, None
+        return (dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3]) + (None,) * 5
 
 
 # ------------------------------------------------------------------------------------------- conv
-def _conv_fwd(x, xbs, w, bias, bias_b, y, ybs, k, dilation, causal):
+def _conv_fwd(x, xbs, w, bias, bias_b, y, ybs, k, dilation, causal, x_amax=None):
     B, Cin, L = x.shape
     nb = _lib.query("ssv_conv1d_fwd_workspace", Cin, w.shape[0], k)
     ws = _ws(nb, x.device)
-    _lib.call("ssv_conv1d_fwd", _p(x), xbs, _p(w), resident.lookup(w), _p(bias), _p(bias_b), _p(y), ybs, B, Cin, w.shape[0], L,
+    _lib.call("ssv_conv1d_fwd", _p(x), xbs, *_an(x_amax), _p(w), resident.lookup(w), _p(bias), _p(bias_b), _p(y), ybs, B, Cin, w.shape[0], L,
               k, dilation, int(causal), _p(ws), nb, _stream())
 
 
-def _conv_bwd_data(dy, dybs, w, Cin, L, k=1, dilation=1, causal=0):
+def _conv_bwd_data(dy, dybs, w, Cin, L, k=1, dilation=1, causal=0, dy_amax=None):
     B, Cout = dy.shape[0], w.shape[0]
     dx = torch.empty((B, Cin, L), dtype=_F32, device=dy.device)
     nb = _lib.query("ssv_conv1d_bwd_data_workspace", Cin, Cout, k)
     ws = _ws(nb, dy.device)
-    _lib.call("ssv_conv1d_bwd_data", _p(dy), dybs, _p(w), resident.lookup(w), None, _p(dx), Cin * L, B, Cin, Cout, L, k, dilation,
+    _lib.call("ssv_conv1d_bwd_data", _p(dy), dybs, *_an(dy_amax), _p(w), resident.lookup(w), None, _p(dx), Cin * L, B, Cin, Cout, L, k, dilation,
               int(causal), _p(ws), nb, _stream())
     return dx
 
 
-def _conv_bwd_weight(dy, dybs, x, xbs, wshape, k=1, dilation=1, causal=0, out=None):
+def _conv_bwd_weight(dy, dybs, x, xbs, wshape, k=1, dilation=1, causal=0, out=None, dy_amax=None, x_amax=None):
     B, Cin, L = x.shape
     Cout = wshape[0]
     dw = out if out is not None else torch.empty(wshape, dtype=_F32, device=x.device)
     nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, Cin, Cout, k)
     ws = _ws(nb, x.device)
-    _lib.call("ssv_conv1d_bwd_weight", _p(dy), dybs, _p(x), xbs, _p(dw), B, Cin, Cout, L, k, dilation, int(causal),
+    _lib.call("ssv_conv1d_bwd_weight", _p(dy), dybs, *_an(dy_amax), _p(x), xbs, *_an(x_amax), _p(dw), B, Cin, Cout, L, k, dilation, int(causal),
               _p(ws), nb, _stream())
     return dw
 
@@ -255,7 +304,7 @@ class PointwiseConvLnActFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w, bias, gamma, beta, s, act):
+    def forward(ctx, x, w, bias, gamma, beta, s, act, x_amax=None, y_amax=None):
         x, xbs = _act3(x, "conv input")
         B, Cin, L = x.shape
         w, bias, gamma, beta = map(_c, (w, bias, gamma, beta))
@@ -269,13 +318,14 @@ class PointwiseConvLnActFn(torch.autograd.Function):
         pre = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
         y = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
         stats = torch.empty((B, 2, L), dtype=_F32, device=x.device) if train else None
-        _conv_fwd(x, xbs, w, bias, sb, pre, Cout * L, 1, 1, 0)
+        _conv_fwd(x, xbs, w, bias, sb, pre, Cout * L, 1, 1, 0, x_amax)
         nbl = _lib.query("ssv_channel_ln_act_fwd_workspace", B, Cout, L)
         wsl = _ws(nbl, x.device)
-        _lib.call("ssv_channel_ln_act_fwd", _p(pre), Cout * L, _p(gamma), _p(beta), _p(y), Cout * L, _p(stats),
+        _lib.call("ssv_channel_ln_act_fwd", _p(pre), Cout * L, _p(gamma), _p(beta), _p(y), Cout * L, _p(y_amax), _p(stats),
                   B, Cout, L, act, _p(wsl), nbl, _stream())
         if train:
             ctx.save_for_backward(x, w, gamma, beta, pre, stats)
+            ctx.x_amax = x_amax
             ctx.act = act
             ctx.bias_ref = bias
             ctx.has_s = s is not None
@@ -297,17 +347,20 @@ class PointwiseConvLnActFn(torch.autograd.Function):
         if _DEFER is not None and _DEFER.accepts(B, Cin, Cout, L, 1, nblk):
             dpre = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
             part = torch.empty((nblk, 3 * Cout), dtype=_F32, device=x.device)
+            f16 = _f16()
+            dpre_amax = _amax_out(B, L, x.device) if f16 else None
+            x_amax = (ctx.x_amax if ctx.x_amax is not None else amax_of(x)) if f16 else None
             nb = _lib.query("ssv_pointwise_conv_ln_act_bwd_data_workspace", B, Cin, Cout, L)
             ws = _ws(nb, x.device)
             _lib.call("ssv_pointwise_conv_ln_act_bwd_data", _p(dy), dybs, _p(w), resident.lookup(w), _p(gamma), _p(beta), _p(pre), _p(stats),
-                      _p(dx), Cin * L, _p(ds), _p(dpre), _p(part), B, Cin, Cout, L, ctx.act, _p(ws), nb, _stream())
-            _DEFER.add(dpre, Cout * L, x, xbs, dw, part, pg, 1, 1, 0, 3 * Cout, nblk)
-            return dx, dw, pg[2], pg[0], pg[1], ds, None
+                      _p(dx), Cin * L, _p(ds), _p(dpre), _p(dpre_amax), _p(part), B, Cin, Cout, L, ctx.act, _p(ws), nb, _stream())
+            _DEFER.add(dpre, Cout * L, x, xbs, dw, part, pg, 1, 1, 0, 3 * Cout, nblk, dpre_amax, x_amax)
+            return dx, dw, pg[2], pg[0], pg[1], ds, None, None, None
         nb = _lib.query("ssv_pointwise_conv_ln_act_bwd_workspace", B, Cin, Cout, L)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_pointwise_conv_ln_act_bwd", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(gamma), _p(beta), _p(pre), _p(stats),
+        _lib.call("ssv_pointwise_conv_ln_act_bwd", _p(dy), dybs, _p(x), xbs, *_an(ctx.x_amax), _p(w), resident.lookup(w), _p(gamma), _p(beta), _p(pre), _p(stats),
                   _p(dx), Cin * L, _p(dw), _p(pg), _p(ds), B, Cin, Cout, L, ctx.act, _p(ws), nb, _stream())
-        return dx, dw, pg[2], pg[0], pg[1], ds, None
+        return dx, dw, pg[2], pg[0], pg[1], ds, None, None, None
 
 
 class Conv1dFn(torch.autograd.Function):
@@ -315,16 +368,17 @@ class Conv1dFn(torch.autograd.Function):
     models/TTSModel.py:174,179 (`fc(spk.permute(0,2,1)).permute(0,2,1)`)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, k, dilation, causal):
+    def forward(ctx, x, w, bias, k, dilation, causal, x_amax=None):
         x, xbs = _act3(x, "conv input")
         B, Cin, L = x.shape
         w = _c(w)
         bias = _c(bias) if bias is not None else None
         Cout = w.shape[0]
         y = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
-        _conv_fwd(x, xbs, w, bias, None, y, Cout * L, k, dilation, causal)
+        _conv_fwd(x, xbs, w, bias, None, y, Cout * L, k, dilation, causal, x_amax)
         if _needs_grad(ctx):
             ctx.save_for_backward(x, w)
+            ctx.x_amax = x_amax
             ctx.cfg = (k, dilation, int(causal), ctx.needs_input_grad[0], bias is not None)
             ctx.bias_ref = bias
         return y
@@ -337,14 +391,15 @@ class Conv1dFn(torch.autograd.Function):
         dy, dybs = _act3(dy, "grad")
         B, Cin, L = x.shape
         Cout = w.shape[0]
-        dx = _conv_bwd_data(dy, dybs, w, Cin, L, k, dilation, causal) if need_dx else None
-        dw = _conv_bwd_weight(dy, dybs, x, xbs, tuple(w.shape), k, dilation, causal, out=gradarena.view(w))
+        dy_amax = amax_of(dy) if _f16() else None
+        dx = _conv_bwd_data(dy, dybs, w, Cin, L, k, dilation, causal, dy_amax) if need_dx else None
+        dw = _conv_bwd_weight(dy, dybs, x, xbs, tuple(w.shape), k, dilation, causal, out=gradarena.view(w), dy_amax=dy_amax, x_amax=ctx.x_amax)
         db = None
         if has_bias:
             rows = torch.empty((B, Cout), dtype=_F32, device=x.device)
             _lib.call("ssv_rowsum", _p(dy), dybs, _p(rows), B, Cout, L, _stream())
             db = _sum_over_batch(rows, B, Cout, out=gradarena.view(ctx.bias_ref))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------- conv, any-order differentiable
@@ -594,7 +649,7 @@ class ChannelLnDD(torch.autograd.Function):
         stats = torch.empty((B, 2, L), dtype=_F32, device=x.device)
         nb = _lib.query("ssv_channel_ln_act_fwd_workspace", B, C, L)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_channel_ln_act_fwd", _p(x), xbs, _p(gamma), _p(beta), _p(y), C * L, _p(stats), B, C, L, 0, _p(ws), nb, _stream())
+        _lib.call("ssv_channel_ln_act_fwd", _p(x), xbs, _p(gamma), _p(beta), _p(y), C * L, None, _p(stats), B, C, L, 0, _p(ws), nb, _stream())
         ctx.save_for_backward(x, gamma, beta, stats)
         return y
 
@@ -653,7 +708,7 @@ class HighwayGateDD(torch.autograd.Function):
         g1, b1, g2, b2 = map(_c, (g1, b1, g2, b2))
         y = torch.empty((B, C, L), dtype=_F32, device=x.device)
         stats = torch.empty((B, 4, L), dtype=_F32, device=x.device)
-        _lib.call("ssv_highway_gate_fwd", _p(h), _p(x), xbs, _p(g1), _p(b1), _p(g2), _p(b2), _p(stats), _p(y), C * L, B, C, L, _stream())
+        _lib.call("ssv_highway_gate_fwd", _p(h), _p(x), xbs, _p(g1), _p(b1), _p(g2), _p(b2), _p(stats), _p(y), C * L, None, B, C, L, _stream())
         ctx.save_for_backward(h, x, g1, b1, g2, b2, stats)
         return y
 
@@ -836,7 +891,7 @@ class DeconvK2S2Fn(torch.autograd.Function):
     """nn.ConvTranspose1d(C, C, kernel_size=2, stride=2), models/TTSModel.py:309,314."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, x_amax=None):
         x, xbs = _act3(x, "deconv input")
         B, Cin, L = x.shape
         w, bias = _c(w), _c(bias)
@@ -846,7 +901,7 @@ class DeconvK2S2Fn(torch.autograd.Function):
         y = torch.empty((B, Cout, 2 * L), dtype=_F32, device=x.device)
         nb = _lib.query("ssv_deconv1d_k2s2_fwd_workspace", Cin, Cout)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_deconv1d_k2s2_fwd", _p(x), xbs, _p(w), _p(bias), _p(y), Cout * 2 * L, B, Cin, Cout, L, _p(ws), nb, _stream())
+        _lib.call("ssv_deconv1d_k2s2_fwd", _p(x), xbs, *_an(x_amax), _p(w), _p(bias), _p(y), Cout * 2 * L, B, Cin, Cout, L, _p(ws), nb, _stream())
         if _needs_grad(ctx):
             ctx.save_for_backward(x, w)
             ctx.bias_ref = bias
@@ -864,9 +919,9 @@ class DeconvK2S2Fn(torch.autograd.Function):
         db = gradarena.grad_like(ctx.bias_ref)
         nb = _lib.query("ssv_deconv1d_k2s2_bwd_workspace", B, Cin, Cout)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, _p(x), xbs, _p(w), _p(dx), Cin * L, _p(dw), _p(db),
+        _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, None, 0, _p(x), xbs, _p(w), _p(dx), Cin * L, _p(dw), _p(db),
                   B, Cin, Cout, L, _p(ws), nb, _stream())
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 # ------------------------------------------------------------------------------------------- losses
@@ -923,16 +978,36 @@ class GuidedAttLossFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------- functional
+def _bf3_shape(x):
+    """The conv kernels run their MFMA arithmetic only from B * L >= 128 on (speaker codes, L = 1, take the fp32 kernel)."""
+    return x.dim() == 3 and x.shape[0] * x.shape[2] >= 128
+
+
 def highway_conv1d(x, w, bias, g1, b1, g2, b2, k, dilation, causal):
-    return HighwayConvFn.apply(x, w, bias, g1, b1, g2, b2, k, dilation, causal)
+    if not (_f16() and _bf3_shape(x)):
+        return HighwayConvFn.apply(x, w, bias, g1, b1, g2, b2, k, dilation, causal)
+    ya = _amax_out(x.shape[0], x.shape[2], x.device)
+    return _tag(HighwayConvFn.apply(x, w, bias, g1, b1, g2, b2, k, dilation, causal, amax_of(x), ya), ya)
+
+
+RELU_TAP = None      # diagnostics / tests: a list that receives (y > 0) of every fused-ReLU output, in call order
 
 
 def pointwise_conv_ln_act(x, w, bias, gamma, beta, s=None, act=0):
-    return PointwiseConvLnActFn.apply(x, w, bias, gamma, beta, s, act)
+    if not (_f16() and _bf3_shape(x)):
+        y = PointwiseConvLnActFn.apply(x, w, bias, gamma, beta, s, act)
+    else:
+        ya = _amax_out(x.shape[0], x.shape[2], x.device)
+        y = _tag(PointwiseConvLnActFn.apply(x, w, bias, gamma, beta, s, act, amax_of(x), ya), ya)
+    if RELU_TAP is not None and act == 1:
+        RELU_TAP.append(y.detach() > 0)
+    return y
 
 
 def conv1d(x, w, bias, k=1, dilation=1, causal=False):
-    return Conv1dFn.apply(x, w, bias, k, dilation, causal)
+    if not (_f16() and _bf3_shape(x)):
+        return Conv1dFn.apply(x, w, bias, k, dilation, causal)
+    return Conv1dFn.apply(x, w, bias, k, dilation, causal, amax_of(x))
 
 
 def text_embed(ids, w, bias):
@@ -944,7 +1019,9 @@ def attention_train(kv, q):
 
 
 def deconv1d_k2s2(x, w, bias):
-    return DeconvK2S2Fn.apply(x, w, bias)
+    if not (_f16() and _bf3_shape(x)):
+        return DeconvK2S2Fn.apply(x, w, bias)
+    return DeconvK2S2Fn.apply(x, w, bias, amax_of(x))
 
 
 def spec_losses(y, gt):

@@ -82,6 +82,8 @@ class ResidentWeights:
         self._jobs = torch.empty(raw.size, dtype=torch.uint8, device=dev)
         self._jobs.copy_(host, non_blocking=False)
         self._nblocks, self._njobs = nblocks, 2 * n
+        self._ws_bytes = int(_lib.query("ssv_conv_pack_multi_workspace", 2 * n))
+        self._ws = torch.empty(max(self._ws_bytes, 256), dtype=torch.uint8, device=dev)      # the weights' partial maxima (split-fp16)
         for p, t in zip(self.params, self._planes):
             e = _Entry()
             e.param, e.planes, e.version, e.shape, e.ptr = p, t, -1, tuple(p.shape), ctypes.c_void_p(t.data_ptr())
@@ -94,7 +96,8 @@ class ResidentWeights:
         if not self.params:
             return
         self._build()
-        _lib.call("ssv_conv_pack_multi", ctypes.c_void_p(self._jobs.data_ptr()), self._njobs, self._nblocks, stream)
+        _lib.call("ssv_conv_pack_multi", ctypes.c_void_p(self._jobs.data_ptr()), self._njobs, self._nblocks,
+                  ctypes.c_void_p(self._ws.data_ptr()), self._ws_bytes, stream)
         for p in self.params:
             e = _REG.get(p.data_ptr())
             if e is not None and e.owner is self:

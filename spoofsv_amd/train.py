@@ -404,6 +404,8 @@ class Cuts:
         if name not in self.names or not x.requires_grad:
             return x
         leaf = x.detach().requires_grad_(True)
+        if hasattr(x, "_ssv_amax"):              # the producer's operand-scale list (ops.amax_of) stays valid: same storage, same version
+            leaf._ssv_amax = x._ssv_amax
         self.rec[name] = (x, leaf)
         return leaf
 

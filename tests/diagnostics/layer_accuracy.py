@@ -25,7 +25,7 @@ for n in (1, 2, 4, 8, 16):
     for i, sd in enumerate(sds):
         h = TO.highway_conv(h, sd, "hc", 3, 3 ** (i % 4), True)
     h.backward(dy.double())
-    for prec in ("bf16x3", "fp32"):
+    for prec in ("f16x2", "bf16x3", "fp32"):
         spoofsv_amd.set_precision(prec)
         ls = [l.cuda() for l in layers]
         for l in ls:

@@ -28,10 +28,12 @@ def test_header_declares_expected_entry_points():
 
 def test_library_exports_every_declared_symbol():
     L = _lib.lib()                      # raises if a declared symbol is missing
-    assert L.ssv_version() == 1
+    assert L.ssv_version() == 2
     assert L.ssv_arch() == b"gfx950"
     prev = L.ssv_set_precision(0)
-    assert L.ssv_set_precision(prev) == 0
+    assert prev == 2 and L.ssv_get_precision() == 0          # split-fp16 is the default arithmetic
+    assert L.ssv_set_precision(prev) == 0 and L.ssv_get_precision() == 2
+    assert L.ssv_amax_rows(325) == 21 and L.ssv_amax_rows(1300) == 82
     raw = ctypes.CDLL(_lib.LIBPATH)
     for name in _lib.parse_header():
         assert hasattr(raw, name), name
@@ -58,16 +60,16 @@ def test_bad_arguments_fail_before_the_device():
     null = ctypes.c_void_p(0)
     one = ctypes.c_void_p(16)           # non-null dummy, never dereferenced: the checks come first
     # empty problem -> -1
-    rc = L.ssv_conv1d_fwd(one, 0, one, null, null, null, one, 0, 0, 4, 4, 8, 3, 1, 0, null, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 0, null, 0, one, null, null, null, one, 0, 0, 4, 4, 8, 3, 1, 0, null, 0, null)
     assert rc == -1 and b"conv1d_fwd" in L.ssv_last_error()
     # unsupported kernel size -> -2
-    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, null, one, 64, 1, 4, 4, 16, 5, 1, 0, null, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 64, null, 0, one, null, null, null, one, 64, 1, 4, 4, 16, 5, 1, 0, null, 0, null)
     assert rc == -2 and b"kernel_size" in L.ssv_last_error()
     # dilation halo beyond the staged tile -> -2
-    rc = L.ssv_conv1d_fwd(one, 64, one, null, null, null, one, 64, 1, 4, 4, 16, 3, 28, 0, null, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 64, null, 0, one, null, null, null, one, 64, 1, 4, 4, 16, 3, 28, 0, null, 0, null)
     assert rc == -2
     # workspace too small -> -1
-    rc = L.ssv_conv1d_bwd_data(one, 64, one, null, null, one, 64, 1, 4, 4, 16, 3, 1, 0, one, 8, null)
+    rc = L.ssv_conv1d_bwd_data(one, 64, null, 0, one, null, null, one, 64, 1, 4, 4, 16, 3, 1, 0, one, 8, null)
     assert rc == -1 and b"workspace" in L.ssv_last_error()
     with pytest.raises(RuntimeError):
         _lib.call("ssv_ge2e_loss_fwd", one, one, one, one, null, 4, 1, 8, one, 1 << 20, null)   # M must be > 1
@@ -117,7 +119,9 @@ def test_conv_pack_plan_is_host_only_and_consistent():
     assert (t.M, t.K, t.KT, t.sm, t.sk) == (256, 512, 3, 3, 768)
     fwd_bytes = 2 * 3 * 512 * 256 * 2
     assert t.planes - j.planes == fwd_bytes
-    assert L.ssv_conv_pack_bytes(512, 256, 3) == 2 * fwd_bytes
+    assert L.ssv_conv_pack_bytes(512, 256, 3) == 2 * fwd_bytes + 256       # + the two inverse scales of the split-fp16 planes
+    assert j.inv_out - j.planes == 2 * fwd_bytes and t.inv_out - j.inv_out == 128
+    assert L.ssv_conv_pack_multi_workspace(2 * n) >= 4 * 32 * n
     # ragged weight: K padded to 32, rows to 16
     r = jobs[2]
     assert (r.M, r.K, r.Kpad, r.KT) == (80, 513, 544, 1)

@@ -11,12 +11,13 @@ from oracle import tts_oracle as TO
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # BASELINE.json north_star: 1e-3 relative on spectrograms.  "fp32": fp32-input MFMA, an exact fp32 fma chain
-# (differences to the CPU come from summation order only).  "bf16x3": split-bf16 MFMA, ~2^-17 per product.
-TOLS = {"fp32": (2e-5, 3e-4), "bf16x3": (1e-4, 5e-4)}
-FWD_TOL, BWD_TOL = TOLS["bf16x3"]
+# (differences to the CPU come from summation order only).  "f16x2" (the default arithmetic): split-fp16 MFMA with power-of-two
+# operand scales, ~2^-22 per product -- held to the SAME bars as exact fp32.  "bf16x3": split-bf16 MFMA, ~2^-17 per product.
+TOLS = {"fp32": (2e-5, 3e-4), "f16x2": (2e-5, 3e-4), "bf16x3": (1e-4, 5e-4)}
+FWD_TOL, BWD_TOL = TOLS["f16x2"]
 
 
-@pytest.fixture(autouse=True, params=["bf16x3", "fp32"])
+@pytest.fixture(autouse=True, params=["f16x2", "bf16x3", "fp32"])
 def precision(request):
     import spoofsv_amd
     global FWD_TOL, BWD_TOL
@@ -513,10 +514,26 @@ def _bench_workload_oracle(kind, B):
             if isinstance(mod, torch.nn.LayerNorm):
                 mod.weight.add_(0.2 * torch.randn(mod.weight.shape, generator=gen))
                 mod.bias.add_(0.2 * torch.randn(mod.bias.shape, generator=gen))
-    rec = dict(model=m, batch=batch, gaw=gaw)
+    rec = dict(model=m, batch=batch, gaw=gaw, kind=kind)
     for dt, tag in ((torch.float32, ""), (torch.float64, "64")):
-        sd = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
-        cast = lambda t: t.to(dt) if t.is_floating_point() else t
+        with TO.kink_sides() as sides:
+            outs, losses, grads = _oracle_pass(rec, dt)
+        rec.update({"outs" + tag: outs, "losses" + tag: losses, "grads" + tag: grads, "kinks" + tag: sides.taps})
+    _BENCH_ORACLE[key] = rec
+    return rec
+
+
+def _oracle_pass(rec, dt, force=None):
+    """Forward, losses and backward of the oracle on the record's model and batch in dtype ``dt``; ``force``: the ReLU sides to
+    hold (oracle/tts_oracle.py::kink_sides)."""
+    from spoofsv_amd import train
+    m, batch, gaw, kind = rec["model"], rec["batch"], rec["gaw"], rec["kind"]
+    sd = {k: v.detach().clone().cpu().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+    cast = lambda t: t.to(dt) if t.is_floating_point() else t
+    ctx = TO.kink_sides(force=force) if force is not None else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
         if kind == "text2mel":
             mel, text, spk = [cast(b) for b in batch]
             Y, A = TO.melsyn_train(train.shift_right(mel), text, spk, sd)
@@ -528,9 +545,10 @@ def _bench_workload_oracle(kind, B):
             losses = TO.ssrn_losses(Y, lin)
             outs = {"Y": Y.detach()}
         sum(losses).backward()
-        rec.update({"outs" + tag: outs, "losses" + tag: [float(l.detach()) for l in losses], "grads" + tag: {k: v.grad.detach() for k, v in sd.items()}})
-    _BENCH_ORACLE[key] = rec
-    return rec
+    finally:
+        if ctx is not None:
+            ctx.__exit__()
+    return outs, [float(l.detach()) for l in losses], {k: v.grad.detach() for k, v in sd.items()}
 
 
 # Gradient agreement at full depth, measured (tests/diagnostics/grad_parity.py, B = 8), relative L2 per parameter tensor:
@@ -545,9 +563,16 @@ def _bench_workload_oracle(kind, B):
 # N x (relative forward error): ~1 per layer for split-bf16 (3e-6) on Text2Mel's 0.7 M-element layers, ~0.7 for ANY float32
 # evaluation (1e-7) on SSRN's 5.3 M-element layers -- which is why the float32 oracle itself sits 3e-4..1e-3 from float64
 # there.  It is a property of the function being differentiated (discontinuous derivative), not an accumulating error.
-# Hence the bar is set against the float64 gradient: the HIP path may be off by at most the float32 reference's own error
-# plus a mode allowance (1e-4 exact fp32, 2.5e-3 split-bf16), and never by more than 4e-3.
-_GRAD_ALLOWANCE = {"fp32": 1e-4, "bf16x3": 2.5e-3}
+# Round 3: the test therefore compares gradients ON THE SAME SIDE OF EVERY KINK -- the ReLUs and the L1 loss |gt - y| (the
+# second one was found this round: the last layer's LayerNorm bias gradient, which no GEMM touches, sat at 1e-5 in one mode and
+# 6e-8 in another).  The HIP forward reports the sign of every ReLU output (ops.RELU_TAP) and of y - gt; where one differs from
+# the float64 oracle's, the argument must be rounding noise (|x| below _KINK_NOISE x the tensor's rms: such an element's side
+# is not determined at this precision -- measured on Text2Mel: 2 of 4 M ReLU inputs at 9e-7 for split-fp16, none for exact
+# fp32, which is luck, not accuracy); the float64 oracle is then re-evaluated with every kink held on the HIP path's side
+# (oracle kink_sides(force=...)), and EVERY parameter gradient must be within the mode allowance of THAT gradient in relative
+# L2 -- no "plus the float32 oracle's own error" term any more, and the fp32-grade modes (exact fp32, split-fp16) share one bar.
+_GRAD_ALLOWANCE = {"fp32": 2e-5, "f16x2": 2e-5, "bf16x3": 5e-4}
+_KINK_NOISE = {"fp32": 1e-5, "f16x2": 1e-5, "bf16x3": 1e-3}
 
 
 @pytest.mark.parametrize("kind", ["text2mel", "ssrn"])
@@ -555,16 +580,18 @@ def test_bench_workload_full_size_training_step_vs_oracle(kind, precision):
     """The benchmark's own workload -- full width (hidden 256 / 512 / 513 channels), full depth (28 / 8 highway layers), full
     length (N=186, T=325 -> 1300), B=8 utterances (B*L up to 10,400 columns per launch: the production tile choices, the wide
     k=1 kernel, the batched weight-gradient slabs all fire) -- forward, the reference's losses and backward on the HIP path
-    against the CPU oracle.  This is where split-bf16 rounding accumulates through the stacked layers.  Bars: outputs (north_star:
-    1e-3 relative) max-norm and L2 <= 2e-4 (2e-5 in exact fp32); losses 1e-5; EVERY parameter gradient, relative L2 against the
-    float64 oracle, within the float32 oracle's own error plus the mode allowance above."""
+    against the CPU oracle.  This is where rounding accumulates through the stacked layers.  Bars: outputs (north_star:
+    1e-3 relative) max-norm and L2 <= 2e-5 (2e-4 split-bf16); losses 1e-5; ReLU sides equal to the float64 oracle's except at
+    rounding-noise pre-activations; EVERY parameter gradient, relative L2 against the float64 oracle on the same ReLU sides,
+    within the mode allowance above (2e-5 for exact fp32 AND split-fp16)."""
     from spoofsv_amd import ops, train
     B = 8
     o = _bench_workload_oracle(kind, B)
     m = o["model"].to(DEV).train()
     for p in m.parameters():
         p.grad = None
-    out_tol = 2e-5 if precision == "fp32" else 2e-4
+    out_tol = 2e-4 if precision == "bf16x3" else 2e-5
+    ops.RELU_TAP = []
     if kind == "text2mel":
         mel, text, spk = [b.to(DEV) for b in o["batch"]]
         Y, A = m(train.shift_right(mel), text, spk)
@@ -575,22 +602,80 @@ def test_bench_workload_full_size_training_step_vs_oracle(kind, precision):
         Y = m(mel)
         l = ops.spec_losses(Y, lin)
     assert rel_err(Y, o["outs"]["Y"]) < out_tol and rel_l2(Y, o["outs"]["Y"]) < out_tol, (rel_err(Y, o["outs"]["Y"]), rel_l2(Y, o["outs"]["Y"]))
+    sides, ops.RELU_TAP = [t.cpu() for t in ops.RELU_TAP] + [(Y.detach() > (mel if kind == "text2mel" else lin)).cpu()], None
     for mine, ref in zip(l, o["losses"]):
         assert abs(float(mine) - ref) < 1e-5 * max(1.0, abs(ref)), (float(mine), ref)
     sum(l).backward()
     torch.cuda.synchronize()
+    _check_grads_on_hip_sides(o, m, sides, precision, "full-size %s" % kind)
+    m.cpu()
+    for p in m.parameters():
+        p.grad = None
+
+
+def _check_grads_on_hip_sides(o, m, sides, precision, what):
+    """Kink sides (ReLUs, L1 loss) equal to the float64 oracle's except where the argument is rounding noise; then every parameter
+    gradient of ``m`` against the float64 oracle evaluated on the HIP path's sides (see the comment above _GRAD_ALLOWANCE)."""
+    assert len(sides) == len(o["kinks64"]) and all(a.shape == b[0].shape for a, b in zip(sides, o["kinks64"]))
+    flips = 0
+    for i, (mine, (ref, rms, pre)) in enumerate(zip(sides, o["kinks64"])):
+        d = mine != ref
+        n = int(d.sum())
+        flips += n
+        if n:
+            assert float(pre[d].abs().max()) < _KINK_NOISE[precision] * rms, ("kink", i, n, float(pre[d].abs().max()), rms)
+    exact = o["grads64"] if flips == 0 else _oracle_pass(o, torch.float64, force=sides)[2]
     bad, worst = {}, 0.0
     for k, p in m.named_parameters():
-        exact = o["grads64"][k]
-        e_hip, e_ref = rel_l2(p.grad, exact), rel_l2(o["grads"][k], exact)
+        e_hip = rel_l2(p.grad, exact[k])
         worst = max(worst, e_hip)
-        if e_hip > e_ref + _GRAD_ALLOWANCE[precision] or e_hip > 4e-3:
-            bad[k] = (e_hip, e_ref)
-    assert not bad, (worst, bad)
+        if e_hip > _GRAD_ALLOWANCE[precision]:
+            bad[k] = e_hip
+    print("%s %s: %d kink sides (ReLU / L1) differ from float64 (all at noise level), worst gradient rel L2 %.2e" % (what, precision, flips, worst))
+    assert not bad, (worst, flips, bad)
     big = sorted(((p.numel(), k) for k, p in m.named_parameters()), reverse=True)[:6]
     for _, k in big:        # element-wise: every entry within 5 % (split-bf16: 20 %) of itself, or of 5 % of the tensor's RMS for entries near zero
-        w = worst_elementwise(dict(m.named_parameters())[k].grad, o["grads64"][k], floor=5e-2)
-        assert w < (5e-2 if precision == "fp32" else 2e-1), (k, w)
+        w = worst_elementwise(dict(m.named_parameters())[k].grad, exact[k], floor=5e-2)
+        assert w < (2e-1 if precision == "bf16x3" else 5e-2), (k, w)
+
+
+@pytest.mark.parametrize("kind", ["text2mel", "ssrn"])
+def test_bench_configuration_captured_step_with_batched_weight_gradients_vs_oracle(kind, precision):
+    """The configuration bench.py times, not a relative of it: ``train.TrainStep(graph=True, defer_wgrad=True)`` on resident
+    pre-split weights (``FusedAdam.refresh_resident_weights``) -- one captured hipGraph holding forward, losses, backward with
+    the weight gradients of equal-shaped layers in job-table launches, and the fused Adam -- at full width / depth / length,
+    B = 8.  The optimizer's learning rate is 0, so the weights stay the oracle's through warm-up, capture and replay; the
+    gradients a REPLAY leaves behind are held to the same bars as the eager step above, against the float64 oracle
+    (train/ordinary.py:221-254)."""
+    from spoofsv_amd import ops, train
+    B = 8
+    o = _bench_workload_oracle(kind, B)
+    m = o["model"].to(DEV).train()
+    for p in m.parameters():
+        p.grad = None
+    opt = train.FusedAdam(m.parameters(), 0.0, (0.5, 0.9), 1e-6, capturable=True)
+    opt.refresh_resident_weights()
+    batch = [b.to(DEV) for b in o["batch"]]
+    gaw = o["gaw"].to(DEV) if o["gaw"] is not None else None
+    st = train.TrainStep(kind, m, opt, batch, gaw, None, graph=True, defer_wgrad=True)
+    ops.RELU_TAP = []
+    try:
+        st.prepare()                                      # eager warm-up iterations, then the capture
+    finally:
+        taps, ops.RELU_TAP = ops.RELU_TAP, None
+    sides = [t.cpu() for t in taps[:len(o["kinks64"]) - 1]]      # the first eager iteration's (the weights never change: lr = 0)
+    for p in m.parameters():                              # the replay must (re)write every gradient
+        if p.grad is not None:
+            p.grad.fill_(float("nan"))
+    out = st()
+    torch.cuda.synchronize()
+    with torch.no_grad():                                 # the L1 loss's sides, from the same (unchanged) weights
+        Yh = m(train.shift_right(batch[0]), batch[1], batch[2])[0] if kind == "text2mel" else m(batch[0])
+    sides.append((Yh > (batch[0] if kind == "text2mel" else batch[1])).cpu())
+    for mine, ref in zip(out, o["losses"]):
+        assert abs(float(mine) - ref) < 1e-5 * max(1.0, abs(ref)), (float(mine), ref)
+    _check_grads_on_hip_sides(o, m, sides, precision, "bench configuration %s" % kind)
+    del st, opt
     m.cpu()
     for p in m.parameters():
         p.grad = None
