@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-adversarial", action="store_true", help="skip the extra WGAN-GP cycle timing")
     ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 timing of the same step")
     ap.add_argument("--no-ge2e", action="store_true", help="skip the GE2E (config 5) figures on the line")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the isolated-kernel roofline measurements (profiling runs)")
     ap.add_argument("--ge2e", action="store_true", help="measure BASELINE config 5 (GE2E speaker embedder) instead and print its JSON line")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--precision", choices=["f16x2", "bf16x3", "fp32"], default="f16x2",
@@ -330,8 +331,9 @@ def cpu_baseline():
         pass
     torch.set_num_threads(cores)
     out = {"host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
-    times = {}
+    times, first = {}, {}
     for kind, b in (("text2mel", B_PER_GPU), ("ssrn", B_PER_GPU)):
+        torch.manual_seed(1234)                    # the weights of Trainer(kind, ...): same seed, same construction order
         if kind == "text2mel":
             m = melSyn(34, True, 200, 128, 80, 256)
             mel, text, spk = train.synthetic_text2mel_batch(b, N_TEXT, T_MEL, seed=0)
@@ -344,16 +346,18 @@ def cpu_baseline():
         plist = list(sd.values())
         opt = torch.optim.Adam(plist, 2e-4, (0.5, 0.9), 1e-6)
 
+        log = first.setdefault(kind, [])
+
         def one():
             opt.zero_grad()
             if kind == "text2mel":
                 Y, A = TO.melsyn_train(train.shift_right(mel), text, spk, sd)
-                l1, bd, la = TO.text2mel_losses(Y, A, mel, gaw)
-                (l1 + bd + la).backward()
+                ls = TO.text2mel_losses(Y, A, mel, gaw)
             else:
-                l1, bd = TO.ssrn_losses(TO.ssrn(mel, sd), lin)
-                (l1 + bd).backward()
+                ls = TO.ssrn_losses(TO.ssrn(mel, sd), lin)
+            sum(ls).backward()
             opt.step()
+            log.append([float(v.detach()) for v in ls])
         one()
         t0 = time.time()
         reps = 4
@@ -363,7 +367,8 @@ def cpu_baseline():
     fps = 1.0 / (times["text2mel"] + times["ssrn"])
     out.update({"value": round(fps, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": "1 warm-up + 4 timed train steps each of Text2Mel and SSRN at the workload's own batch (B=%d), N=186, T=325, fp32, torch CPU ops" % B_PER_GPU,
-                "text2mel_fps": round(1.0 / times["text2mel"], 1), "ssrn_fps": round(1.0 / times["ssrn"], 1)})
+                "text2mel_fps": round(1.0 / times["text2mel"], 1), "ssrn_fps": round(1.0 / times["ssrn"], 1),
+                "first_losses": {k: v[:2] for k, v in first.items()}})       # popped by main() after the parity check
     return out
 
 
@@ -455,7 +460,10 @@ def main():
     use_graph = not args.no_graph
     import spoofsv_amd
     spoofsv_amd.set_precision(args.precision)
-    use_bf3_mode = args.precision == "bf16x3"
+    dtype_note = {"f16x2": "f32 (conv GEMMs: fp32 operands scaled by a power of two and split into fp16 hi+lo = 22 significand bits, three exact "
+                           "fp16 MFMAs per product, fp32 accumulate: ~2^-22 per product, gradients within 3e-6 of float64 = the exact-fp32 path's level)",
+                  "bf16x3": "f32 (conv GEMMs: split-bf16 hi+lo operands, fp32 accumulate: ~2^-16 per product, NARROWER than the reference's fp32)",
+                  "fp32": "f32"}[args.precision]
 
     def barrier():
         if world > 1:
@@ -489,6 +497,7 @@ def main():
     split = {"text2mel": timed([t2m], args.steps, 0), "ssrn": timed([ssr], args.steps, 0)}      # per model, not part of `value`
     frames_per_step = args.batch * T_MEL * world
     loss_t2m, loss_ssrn = t2m.loss, ssr.loss
+    first = {"text2mel": t2m.first_losses(), "ssrn": ssr.first_losses()}      # iterations 0 and 1, for the oracle check below
     if not (loss_t2m == loss_t2m and loss_ssrn == loss_ssrn):
         raise SystemExit("non-finite loss in the benchmark step")
     ddp_note = "none"
@@ -498,7 +507,7 @@ def main():
     res = {"metric": "mel-frames/sec (Text2Mel+SSRN train)", "value": round(frames_per_step / per_step, 1), "unit": "mel-frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 (conv GEMMs: split-bf16 hi+lo operands, fp32 accumulate)" if use_bf3_mode else "f32", "data": "synthetic",
+           "dtype": dtype_note, "data": "synthetic",
            "config": {"workload": "train_text2mel + train_ssrn (train/ordinary.py step: fwd, l1+bin-div+guided-att losses, bwd, Adam), "
                                   "batch %d utterances/GPU, N=186, T=325, 80 mel -> 513x1300 linear, hidden 256, random-init" % args.batch,
                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
@@ -520,28 +529,48 @@ def main():
                     "adversarial_note": "ms per iteration averaged over 1 G : 5 D cycles (RATIO=5), WGAN-GP critics on twice-differentiable HIP kernels, "
                                         "hipGraph replay" + ("; data parallel: global adaptive weight, bucketed generator all-reduce, packed critic all-reduce" if world > 1 else "")})
         torch.cuda.empty_cache()
-    if world == 1 and use_bf3_mode and not args.no_fp32:
-        # the same step in the exact-fp32 arithmetic mode (v_mfma_f32_16x16x4_f32), so the cost of strict precision is on record
-        spoofsv_amd.set_precision("fp32")
-        f1, f2 = Trainer("text2mel", args.batch, dev, rank, world, use_graph), Trainer("ssrn", args.batch, dev, rank, world, use_graph)
-        f1.prepare(); f2.prepare()
-        fp = timed([f1, f2], 5, 1)
-        cfg.update({"fp32_exact_ms_per_step": round(fp * 1e3, 3), "fp32_exact_value": round(frames_per_step / fp, 1)})
-        del f1, f2
+    if world == 1 and not args.no_fp32:
+        # the same step in the other arithmetic modes, beside the headline and never inside `value`: exact fp32 MFMA
+        # (v_mfma_f32_16x16x4_f32: what strict fp32 fma chains cost) and, opt-in for users who accept ~2^-16 products, split-bf16
+        for other, key in (("fp32", "fp32_exact"), ("bf16x3", "fast_bf16x3"), ("f16x2", "f16x2")):
+            if other == args.precision:
+                continue
+            spoofsv_amd.set_precision(other)
+            f1, f2 = Trainer("text2mel", args.batch, dev, rank, world, use_graph), Trainer("ssrn", args.batch, dev, rank, world, use_graph)
+            f1.prepare(); f2.prepare()
+            fp = timed([f1, f2], 10, 2)
+            cfg.update({key + "_ms_per_step": round(fp * 1e3, 3), key + "_value": round(frames_per_step / fp, 1)})
+            del f1, f2
+            torch.cuda.empty_cache()
         spoofsv_amd.set_precision(args.precision)
-        torch.cuda.empty_cache()
     if rank == 0:
-        res["roofline"] = kernel_roofline(dev)
+        if not args.no_roofline:
+            res["roofline"] = kernel_roofline(dev)
         if world == 1 and not args.no_ge2e:
             # BASELINE config 5 on the same line (flat scalars); `python bench.py --ge2e` prints the full record
             g = ge2e_config5()
             cfg.update({"ge2e_utt_per_s": g["value"], "ge2e_ms": g["ms"], "ge2e_tflops": g["tflops"], "ge2e_rel_err_vs_oracle": g["rel_err_vs_cpu_oracle"],
+                        "ge2e_roofline_frac": round(g["tflops"] / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),       # split-bf16 LSTM products: 3 MFMAs per product
                         "ge2e_train_iteration_ms": g["train_iteration"]["ms"], "ge2e_cpu_utt_per_s": g["cpu_baseline"]["value"],
                         "ge2e_cpu_cores": g["cpu_baseline"]["cores"]})
+        bad = None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             cfg["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+            # Parity of the configuration that was just timed: the oracle ran the SAME model (seed 1234) on the SAME batch
+            # (seed 0 = rank 0's); its loss terms at optimizer iterations 0 (initial weights) and 1 (after one forward +
+            # backward + Adam step) against the ones the captured, batched-weight-gradient step produced.
+            if args.batch == B_PER_GPU:
+                ref = res["cpu_baseline"].pop("first_losses")
+                for kind in ("text2mel", "ssrn"):
+                    for it in range(2):
+                        e = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(first[kind][it], ref[kind][it]))
+                        cfg["loss_rel_err_vs_oracle_%s_iter%d" % (kind, it)] = float("%.3g" % e)
+                        if not e < 1e-4:
+                            bad = (kind, it, first[kind][it], ref[kind][it])
         print(json.dumps(res), flush=True)
+        if bad is not None:
+            raise SystemExit("bench: losses differ from the CPU oracle's by more than 1e-4: %r" % (bad,))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -50,16 +50,27 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
 // split-fp16 (ssv_common.h, "split-fp16"): hi = fp16(v s), lo = fp16(v s - hi); s is a power of two, so v s is exact and
 // v s - hi is an exact fp32 number: the only roundings are the two conversions.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// Written with v_fma_mix{lo,hi}_f16 (fp32 x fp32 + {0, -fp16} -> fp16 half of a register): 16 VALU instructions per 8
+// elements, the scale included.  From the plain C++ form (kept below for the host pass) hipcc builds 4 v_pk_mul_f32 + 4
+// v_cvt_pk_f16_f32 + 8 v_cvt_f32_f16 + 4 v_pk_fma_f32 + 4 v_cvt_pk_f16_f32 = 24, against 20 for the bf16 split -- measured
+// as +5..7 % on every GEMM kernel of the step.  Bit-identical results (checked on the device, signed zeros aside).
+__device__ __forceinline__ void split2h(float a, float b, float s, unsigned& h, unsigned& l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // s: the (wave-uniform) scale, in a scalar register -- one constant-bus operand per instruction, no VGPR for it
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a), "s"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(b), "s"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "s"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "s"(s), "v"(h));
+#else
+  (void)a; (void)b; (void)s; h = l = 0;
+#endif
+}
 __device__ __forceinline__ void split8h(const float (&v)[8], float s, uint4& hi, uint4& lo) {
-  f16x8 h, l;
+  unsigned h[4], l[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const _Float16 t = (_Float16)(v[i] * s);
-    h[i] = t;
-    l[i] = (_Float16)__builtin_fmaf(v[i], s, -(float)t);
-  }
-  hi = __builtin_bit_cast(uint4, h);
-  lo = __builtin_bit_cast(uint4, l);
+  for (int i = 0; i < 4; ++i) split2h(v[2 * i], v[2 * i + 1], s, h[i], l[i]);
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 template <int F16>
 __device__ __forceinline__ void split8s(const float (&v)[8], float s, uint4& hi, uint4& lo) {
@@ -236,8 +247,9 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 // (L2-resident, pre-split, fragment-shaped 16-byte loads) into MFMA operand registers, one K chunk ahead (two register
 // sets, the chunk loop is unrolled by two).  Only the input tile, which all four waves share, is staged in LDS -- this
 // removes 2/3 of the LDS writes and 1/4 of the LDS reads of a version that staged both operands.
+// (third waves per SIMD for the small k = 1 tile: 168 VGPRs in the split-bf16 form, 174 in the split-fp16 one without the bound -- +22 % time)
 template <int KT, int WM, int NT, int EPI, int F16>
-__global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
+__global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 3 : 2) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   static_assert(!(EPI && F16), "the LSTM epilogue runs on the split-bf16 arithmetic");
   constexpr int BM = 64 * WM, BN = 16 * NT;
   constexpr int HALO = (KT == 1) ? 0 : 54;
@@ -336,9 +348,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
   float xs = 1.f, us = 1.f;
   auto scales = [&]() {
     if constexpr (F16) {
-      float inv;
-      ssv_pow2_scale(ssv_list_max<4>(p.x_amax + (long)b * p.x_amax_bs, p.x_namax, amax_sm), xs, inv);
-      us = inv * *p.a_inv;
+      float sc, inv;
+      ssv_pow2_scale(ssv_list_max<4>(p.x_amax + (long)b * p.x_amax_bs, p.x_namax, amax_sm), sc, inv);
+      xs = ssv_uniform(sc);
+      us = ssv_uniform(inv * *p.a_inv);
     }
   };
   auto prefetchX = [&](int ch) {
@@ -581,8 +594,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf3_kernel(const GemmNNB p, co
 // weight tile, so both operands are staged in LDS once per workgroup and the L2 bytes per MAC drop by ~2x (128 x 336 tile:
 // 16 B/clk/CU at the full MFMA rate).  Same LDS image layout [k-group][row][8 x bf16] (conflict-free b128 reads), same
 // "issue raw loads, mask at commit" staging and hoisted addressing as above.
+// (two 8-wave workgroups per CU = 4 waves per SIMD need <= 128 VGPRs: the split-bf16 form of the 128 x 192 tile has 122, the split-fp16 one 134
+// without the bound -- +42 % time; the second __launch_bounds__ argument is waves per SIMD in HIP)
 template <int KT, int WM, int NT, int NWN, int F16>
-__global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
+__global__ __launch_bounds__(256 * NWN, NWN == 2 ? 4 : 1) void gemm_nn_bf3w_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int T = 256 * NWN;
   constexpr int BM = 64 * WM, BN = 16 * NT * NWN;
   constexpr int HALO = (KT == 1) ? 0 : 54;
@@ -701,9 +716,10 @@ __global__ __launch_bounds__(256 * NWN) void gemm_nn_bf3w_kernel(const GemmNNB p
 
   prefetch(0);
   if constexpr (F16) {
-    float inv;
-    ssv_pow2_scale(ssv_list_max<4 * NWN>(p.x_amax + (long)b * p.x_amax_bs, p.x_namax, amax_sm), xs, inv);
-    us = inv * *p.a_inv;
+    float sc, inv;
+    ssv_pow2_scale(ssv_list_max<4 * NWN>(p.x_amax + (long)b * p.x_amax_bs, p.x_namax, amax_sm), sc, inv);
+    xs = ssv_uniform(sc);
+    us = ssv_uniform(inv * *p.a_inv);
   }
   for (int ch = 0; ch < nchunks; ++ch) {
     __syncthreads();
@@ -914,10 +930,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   float as = 1.f, xs = 1.f, us = 1.f;
   auto scales = [&]() {
     if constexpr (F16) {
-      float ia, ix;
-      ssv_pow2_scale(ssv_list_max<4>(a_amax, a_namax, amax_sm), as, ia);
-      ssv_pow2_scale(ssv_list_max<4>(x_amax, x_namax, amax_sm + 4), xs, ix);
-      us = ia * ix;
+      float sa, sx, ia, ix;
+      ssv_pow2_scale(ssv_list_max<4>(a_amax, a_namax, amax_sm), sa, ia);
+      ssv_pow2_scale(ssv_list_max<4>(x_amax, x_namax, amax_sm + 4), sx, ix);
+      as = ssv_uniform(sa); xs = ssv_uniform(sx);
+      us = ssv_uniform(ia * ix);
     }
   };
   const int mt = bxx % mtiles, ct = bxx / mtiles;

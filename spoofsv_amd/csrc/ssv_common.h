@@ -142,6 +142,8 @@ __device__ __forceinline__ void ssv_pow2_scale(float amax, float& scale, float& 
   scale = __uint_as_float((unsigned)(268 - E) << 23);
   inv = __uint_as_float((unsigned)(E - 14) << 23);
 }
+// a value every lane of the wave holds (hipcc cannot prove it after an LDS round trip) -> a scalar register
+__device__ __forceinline__ float ssv_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 // maximum of a per-thread value over the workgroup (NW waves); sm: NW floats of LDS nobody else uses around the call
 template <int NW>
 __device__ __forceinline__ float ssv_wg_max(float v, float* sm) {

@@ -543,6 +543,7 @@ class TrainStep:
         self.static = [b.clone() for b in batch] if (graph and batch is not None) else None
         self.batch = self.static if self.static is not None else batch
         self.out = self.att = None
+        self.loss_log = None          # a list: receives the loss terms of every EAGERLY executed iteration (warm-up; not replays)
         seg = ddp is not None and ddp.arena is not None
         self.cuts = Cuts(ddp.cut_names if seg else [])
         self._segs = None
@@ -584,6 +585,8 @@ class TrainStep:
             self.out = (l1.detach(), bd.detach())
             segs = backward_segments(self.cuts, [seed(l1 + bd)], None, self.ddp, self.defer)
         self._segs = segs
+        if self.loss_log is not None and not torch.cuda.is_current_stream_capturing():
+            self.loss_log.append(torch.stack([o.reshape(()) for o in self.out]).clone())
         segs[0]()
 
     def _adam(self):

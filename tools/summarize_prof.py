@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output (kernel_stats.csv, optional FETCH_SIZE / WRITE_SIZE counter passes) into a short text table."""
 import csv, glob, sys, collections
-def stats(path, top=25):
+def stats(path, top=60):
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     out = ["%7s %7s %11s  %s" % ("time%", "calls", "avg_us", "kernel")]
