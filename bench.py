@@ -74,12 +74,14 @@ class Trainer:
         self.model.to(dev).train()
         self.opt = train.FusedAdam(self.model.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
         self.ddp = None
-        if world > 1 or os.environ.get("SSV_FORCE_SEGMENTED") == "1":      # the second form: rehearse the N > 1 launch structure on one GPU
+        if world > 1 or os.environ.get("SSV_FORCE_SEGMENTED") == "1" or os.environ.get("SSV_FORCE_COLLECTIVES") == "1":
+            # the second and third form rehearse the N > 1 launch structure on one GPU (the third with RCCL really called)
             self.ddp = train.DataParallelRanks(model=self.model)
             self.ddp.broadcast_parameters(0)
         self.opt.refresh_resident_weights()
         self.stepper = train.TrainStep(kind, self.model, self.opt, list(data), gaw, self.ddp, graph=use_graph,
                                        defer_wgrad=os.environ.get("SSV_DEFER_WGRAD", "1") != "0")
+        self.stepper.loss_log = []         # loss terms of the eager warm-up iterations 0, 1: checked against the oracle's
 
     def prepare(self):
         self.stepper.prepare()
@@ -90,6 +92,10 @@ class Trainer:
     @property
     def loss(self):
         return float(sum(self.stepper.out))
+
+    def first_losses(self):
+        """Loss terms of optimizer iterations 0 and 1 (initial weights; after one Adam step) as lists of floats."""
+        return [[float(v) for v in t.cpu()] for t in self.stepper.loss_log[:2]]
 
 
 def adversarial_cycle_ms(kind, batch, dev, world=1, cycles=3):
@@ -244,17 +250,20 @@ def kernel_roofline(dev):
     flops = 2.0 * B * L * (2 * C) * C * k
     bytes_alg = 4.0 * (B * C * L + B * 2 * C * L + 2 * C * C * k + 2 * C)
     ach = flops / (ms * 1e-3) / 1e12
-    split = _lib.lib().ssv_set_precision(1) == 1      # read the mode (set_precision returns the previous one) ...
-    _lib.lib().ssv_set_precision(1 if split else 0)   # ... and restore it
-    # split-bf16 mode executes 3 bf16 MFMAs per algorithmic fp32 product: the roof for ALGORITHMIC flops is peak/3
+    mode = _lib.precision()                           # 0 exact fp32, 1 split-bf16, 2 split-fp16
+    split = mode >= 1
+    # both split modes execute 3 sixteen-bit MFMAs (bf16 or fp16: same dense peak) per algorithmic fp32 product: the roof for
+    # ALGORITHMIC flops is peak/3
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-    name = "gemm_nn_bf3_kernel<3,1,7,0> (split-bf16 MFMA, 3 bf16 MFMAs per fp32 product)" if split else "gemm_nn_kernel<KT=3> (fp32 MFMA)"
+    name = {2: "gemm_nn_bf3_kernel<3,1,7,0,1> (split-fp16 MFMA: fp16 hi+lo of power-of-two scaled operands, 3 fp16 MFMAs per fp32 product)",
+            1: "gemm_nn_bf3_kernel<3,1,7,0,0> (split-bf16 MFMA, 3 bf16 MFMAs per fp32 product)", 0: "gemm_nn_kernel<KT=3> (fp32 MFMA)"}[mode]
+    tmpl = "1" if mode == 2 else "0"
     # the same measurement for the step's most expensive single launch (SSRN highwayConv C=512, L=1300: 130.9 GFLOP)
     # and for the weight gradient of the headline shape (kernel + slab reduction), so the line shows the range, not one point
     others = []
-    for label, fn, (b_, c_, l_) in (("Conv1d fwd C=512->1024 L=1300 (gemm_nn_bf3_kernel<3,2,7,0>)", time_conv_fwd, (32, 512, 1300)),
-                                     ("Conv1d weight gradient C=256->512 L=325 (gemm_nt_bf3_kernel<3,2,4> + reduce_slabs_perm)", time_conv_dw, (32, 256, 325)),
-                                     ("Conv1d weight gradient C=512->1024 L=1300 (gemm_nt_bf3_kernel<3,2,4> + reduce_slabs_perm)", time_conv_dw, (32, 512, 1300))):
+    for label, fn, (b_, c_, l_) in (("Conv1d fwd C=512->1024 L=1300 (gemm_nn_bf3_kernel<3,2,7,0,%s>)" % tmpl, time_conv_fwd, (32, 512, 1300)),
+                                     ("Conv1d weight gradient C=256->512 L=325 (gemm_nt_bf3_kernel<3,2,4,%s> + reduce_slabs_perm)" % tmpl, time_conv_dw, (32, 256, 325)),
+                                     ("Conv1d weight gradient C=512->1024 L=1300 (gemm_nt_bf3_kernel<3,2,4,%s> + reduce_slabs_perm)" % tmpl, time_conv_dw, (32, 512, 1300))):
         m_ = fn(b_, c_, l_, k, 4 if l_ > 1000 else 20)
         f_ = 2.0 * b_ * l_ * (2 * c_) * c_ * k
         a_ = f_ / (m_ * 1e-3) / 1e12
@@ -287,14 +296,14 @@ def kernel_roofline(dev):
                    "algorithmic_tflops_if_three_products": round(flops / (3 * lus) / 1e6, 1)}
     return {"bound": "mfma", "kernel": name + ", dilated Conv1d fwd B=32 C=256->512 L=325",
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "peak_note": "bf16 dense 2500 TFLOP/s / 3" if split else "fp32-input MFMA dense",
+            "peak_note": ("fp16 dense 2500 TFLOP/s / 3 (three fp16 MFMAs per fp32 product)" if mode == 2 else "bf16 dense 2500 TFLOP/s / 3") if split else "fp32-input MFMA dense",
             "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
             "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4),
-            **pmc_traffic(split),
+            **pmc_traffic(mode),
             "others": others, "library_reference": lib_ref}
 
 
-def pmc_traffic(split):
+def pmc_traffic(mode):
     """``roofline.traffic``: HBM bytes per launch of the headline kernel from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate
     rocprofv3 --pmc passes, gfx950 corrections of MI355X_MICROARCH.md applied).  Counters cannot be collected by the run that
     prints the line, so the figure is read from ``profiles/traffic.json``, which records the sha256 of the kernel sources it was
@@ -302,7 +311,7 @@ def pmc_traffic(split):
     import hashlib
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        rec = json.load(open(path))["bf16x3" if split else "fp32"]
+        rec = json.load(open(path))[{0: "fp32", 1: "bf16x3", 2: "f16x2"}[mode]]
     except Exception as e:
         return {"traffic": None, "traffic_source": "no PMC record (%s)" % type(e).__name__}
     h = hashlib.sha256()
@@ -447,13 +456,27 @@ def main():
     local = local % max(ndev, 1)          # rehearsal on fewer GPUs than ranks (SSV_DIST_BACKEND=gloo); identity on a full node
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_coll = os.environ.get("SSV_FORCE_COLLECTIVES") == "1"     # one rank, every collective really issued (RCCL rehearsal, see train.DataParallelRanks)
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("SSV_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # librccl prints a version banner on STDOUT when its communicator comes up; the contract is ONE JSON line there, so the
+        # file descriptor points at stderr until the communicator exists (created eagerly: device_id + a first collective)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     from spoofsv_amd import _lib
     _lib.lib()
 
@@ -501,6 +524,9 @@ def main():
     if not (loss_t2m == loss_t2m and loss_ssrn == loss_ssrn):
         raise SystemExit("non-finite loss in the benchmark step")
     ddp_note = "none"
+    if t2m.ddp is not None and world == 1:
+        ddp_note = ("single-GPU rehearsal of the N > 1 step: gradient arena, backward in %d+%d segments (hipGraphs)%s"
+                    % (t2m.ddp.n_buckets, ssr.ddp.n_buckets, ", one RCCL all-reduce per bucket (world size 1) launched between the replays" if t2m.ddp.collectives else ""))
     if world > 1:
         ddp_note = ("gradient arena, backward in %d+%d segments (hipGraphs), one RCCL all-reduce per bucket launched between the replays"
                     % (t2m.ddp.n_buckets, ssr.ddp.n_buckets))
@@ -571,7 +597,7 @@ def main():
         print(json.dumps(res), flush=True)
         if bad is not None:
             raise SystemExit("bench: losses differ from the CPU oracle's by more than 1e-4: %r" % (bad,))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -28,6 +28,13 @@ def _entry(t):
         # parameter was moved: the slot is stale
         _SLOTS.pop(t.data_ptr(), None)
         return None
+    g = param.grad
+    if g is not None and g.data_ptr() == arena.flat.data_ptr() + 4 * e[1]:
+        # The slot already HOLDS a gradient of this parameter (a second use of the parameter in one backward, or a backward
+        # without zero_grad(set_to_none=True) before it).  A kernel writing there again would clobber what p.grad aliases and
+        # autograd would then add the slot to itself.  Hand out no slot: the operator allocates a fresh tensor and autograd
+        # accumulates it into p.grad -- i.e. into the arena -- in place.
+        return None
     return arena, e[1], e[2]
 
 

@@ -52,11 +52,19 @@ def _distributed(cfg):
     rank = int(os.environ.get("RANK", "0"))
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
-    if world > 1:
+    if world > 1 or os.environ.get("SSV_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("SSV_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        # bind the rank's GPU FIRST and tell the process group which device it serves: RCCL then creates its communicator
+        # on that device eagerly instead of guessing from the first collective (device_count() does not initialise HIP)
         ndev = torch.cuda.device_count()
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(ndev, 1))
+        local = int(os.environ.get("LOCAL_RANK", rank)) % max(ndev, 1)
+        torch.cuda.set_device(local)
+        backend = os.environ.get("SSV_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         return rank, world
     if cfg.get("MULTI_GPU") and torch.cuda.device_count() > 1:
         raise RuntimeError("spoofsv_amd: MULTI_GPU=true needs one process per GPU: launch with `python -m torch.distributed.run "
@@ -76,9 +84,14 @@ def _pad_to_global(sp, world):
     import torch.distributed as dist
     if world == 1:
         return sp
-    dims = torch.tensor([sp["data_0"].shape[-1], sp["data_1"].shape[-1]], dtype=torch.int64, device=sp["data_0"].device)
+    # The two integers travel as a HOST tensor when the back end can reduce one (gloo), else through the device: either way the
+    # result is needed on the host to size the padding -- batches come from the prefetch thread as host tensors, so this is
+    # the loader's synchronisation, not the training stream's (the captured step never passes through here).
+    on_host = dist.get_backend() != "nccl"
+    dims = torch.tensor([sp["data_0"].shape[-1], sp["data_1"].shape[-1]], dtype=torch.int64,
+                        device="cpu" if on_host else torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(dims, op=dist.ReduceOp.MAX)
-    T, N = int(dims[0]), int(dims[1])
+    T, N = (int(v) for v in dims.tolist())
     out = dict(sp)
     pad = lambda t, n: torch.nn.functional.pad(t, (0, n - t.shape[-1])) if t.shape[-1] < n else t
     out["data_0"] = pad(sp["data_0"], T)
@@ -155,9 +168,13 @@ class CorpusSource:
         self.epoch += 1
         per = self.B * self.world
         for i in range(len(self)):
-            idx = order[i * per + self.rank * self.B:i * per + (self.rank + 1) * self.B]
-            if len(idx) == 0:
-                continue
+            if self.world > 1:
+                # Data parallel: every rank must run the SAME number of iterations (each one ends in collectives) on FULL, equal
+                # shards (gradients are averaged with 1/world; the penalty coefficients are drawn for B * world samples), so the
+                # ragged last global batch wraps around to the head of this epoch's order instead of leaving some ranks short.
+                idx = order[np.arange(i * per + self.rank * self.B, i * per + (self.rank + 1) * self.B) % n]
+            else:
+                idx = order[i * per:(i + 1) * per]                     # one process: the reference's partial last batch (drop_last=False)
             items = [self._item(int(k)) for k in idx]
             yield {key: (torch.stack([it[key] for it in items], 0) if key == "data_2" else self._pad_stack(items, key)) for key in items[0]}
 
@@ -559,6 +576,10 @@ def _adversarial_train_stepped(train_step, cfg, dev, model, disc, src, gaw, save
         if ck is None:
             ddp_syn.broadcast_parameters(0)
             ddp_disc.broadcast_parameters(0)
+        # The critics' dropout masks are Philox(seed = torch.cuda.initial_seed(), device-side call counter, element): without a
+        # per-rank seed every rank would draw the SAME masks for its different shard, where the reference draws an independent
+        # mask per sample of the global batch (models/discriminator.py:27-36).  Must precede the capture: the seed is frozen in it.
+        torch.cuda.manual_seed(int(cfg.get("SEED", 0)) + 7919 * (rank + 1))
     graph = bool(cfg.get("CAPTURE_GRAPHS")) and not src.source.files and src.source.corpus is None
     w_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
     w_disc = {k: v.detach().clone() for k, v in disc.state_dict().items()}

@@ -137,7 +137,12 @@ class DeferredWgrad:
         self.cursor = 0
 
     @staticmethod
-    def accepts(B, Cin, Cout, L, k, nblk):
+    def accepts(B, Cin, Cout, L, k, nblk, params=()):
+        """``params``: the parameters whose gradients the job would deliver late.  A deferred gradient is handed to autograd
+        BEFORE it is computed, which is only sound while autograd adopts the tensor as ``p.grad`` as it is: not when it would
+        add it to an existing ``.grad`` or record the addition (create_graph) -- then the immediate path is taken."""
+        if torch.is_grad_enabled() or any(p is not None and p.grad is not None for p in params):
+            return False
         return nblk <= 768 and bool(_lib.lib().ssv_conv1d_bwd_weight_multi_ok(B, Cin, Cout, L, k))
 
     def add(self, dy, dy_bs, x, x_bs, dw, part, pg, k, dilation, causal, n2, nblk, dy_amax=None, x_amax=None):
@@ -236,7 +241,7 @@ class HighwayConvFn(torch.autograd.Function):
         bias = ctx.bias_ref
         pg = gradarena.grad_block((g1, b1, g2, b2, bias), 6, C, x.device) if bias is not None else torch.empty((6, C), dtype=_F32, device=x.device)
         nblk = _lib.query("ssv_ln_partial_rows", B, L)
-        if _DEFER is not None and _DEFER.accepts(B, C, 2 * C, L, k, nblk):
+        if _DEFER is not None and _DEFER.accepts(B, C, 2 * C, L, k, nblk, (w, g1, b1, g2, b2, bias)):
             # LayerNorm / gate backward + data gradient now; the weight gradient joins the other layers of this shape at flush
             dh = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
             part = torch.empty((nblk, 6 * C), dtype=_F32, device=x.device)
@@ -344,7 +349,7 @@ class PointwiseConvLnActFn(torch.autograd.Function):
         dw = gradarena.grad_like(w)
         ds = torch.empty((B, Cout, 1), dtype=_F32, device=x.device) if ctx.has_s else None
         nblk = _lib.query("ssv_ln_partial_rows", B, L)
-        if _DEFER is not None and _DEFER.accepts(B, Cin, Cout, L, 1, nblk):
+        if _DEFER is not None and _DEFER.accepts(B, Cin, Cout, L, 1, nblk, (w, gamma, beta, ctx.bias_ref)):
             dpre = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
             part = torch.empty((nblk, 3 * Cout), dtype=_F32, device=x.device)
             f16 = _f16()

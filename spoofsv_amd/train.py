@@ -11,6 +11,7 @@ What each piece replaces in the reference:
   DataParallelRanks      nn.DataParallel (train/ordinary.py:165-173) -> one rank per GPU, RCCL all-reduce
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -221,6 +222,11 @@ class DataParallelRanks:
     def __init__(self, params=None, bucket_mb=64, group=None, model=None, segmented=True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # Collectives are issued when there is somebody to talk to -- or, with SSV_FORCE_COLLECTIVES=1 and an initialised
+        # process group of ONE rank, regardless: every all-reduce / broadcast of the multi-GPU step then really goes through the
+        # back end (RCCL on one MI355X) with results that cannot change, which is how the launch structure of the N > 1 step
+        # (asynchronous collectives between hipGraph replays) is rehearsed on a single GPU (tests/test_gpu_ddp.py).
+        self.collectives = self.world > 1 or (dist.is_initialized() and os.environ.get("SSV_FORCE_COLLECTIVES") == "1")
         self.grad_scale = 1.0 / self.world
         self.bucket_elems = max(1, int(bucket_mb * 1024 * 1024 // 4))
         self._flat = None
@@ -245,7 +251,7 @@ class DataParallelRanks:
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank `src`'s weights (what DataParallel's replicate does)."""
-        if self.world == 1:
+        if not self.collectives:
             return
         with torch.no_grad():
             for p in self.params:
@@ -263,7 +269,7 @@ class DataParallelRanks:
     def start_bucket(self, i):
         """Backward has produced every gradient of bucket ``i`` (enqueued on the current stream): start the bucket's
         all-reduce (asynchronous: RCCL runs it on its own stream behind an event on the current one)."""
-        if self.world > 1:
+        if self.collectives:
             self._works.append(dist.all_reduce(self.arena.bucket(i), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -309,7 +315,7 @@ class DataParallelRanks:
 
     def exchange(self):
         """All-reduce (sum) the packed buckets; asynchronous, ``finish`` waits."""
-        if self.world > 1:
+        if self.collectives:
             for flat in self._flat:
                 self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -333,7 +339,7 @@ class DataParallelRanks:
     @torch.no_grad()
     def all_reduce_grads(self, grads=None):
         """Average gradients over ranks after a complete backward."""
-        if self.world == 1:
+        if not self.collectives:
             return
         if self.arena is not None:
             for i in range(self.n_buckets):
@@ -354,7 +360,7 @@ class DataParallelRanks:
     def all_reduce_mean(self, *scalars):
         """Average loss scalars over ranks (global-batch semantics for the adaptive critic weight,
         train/adversarial_wasserstein_gp.py:290)."""
-        if self.world == 1:
+        if not self.collectives:
             return scalars
         v = torch.stack([s.detach().reshape(()) for s in scalars])
         dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
@@ -364,7 +370,7 @@ class DataParallelRanks:
     @torch.no_grad()
     def all_reduce_mean_(self, vec):
         """In-place variant on a persistent device vector (the form used between captured hipGraphs)."""
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
             vec.mul_(1.0 / self.world)
         return vec
@@ -545,6 +551,11 @@ class TrainStep:
         self.out = self.att = None
         self.loss_log = None          # a list: receives the loss terms of every EAGERLY executed iteration (warm-up; not replays)
         seg = ddp is not None and ddp.arena is not None
+        if graph and ddp is not None and not seg:
+            # A replayed backward writes the gradient tensors of the CAPTURE; the packed exchange reads the Python-level p.grad,
+            # which after a capture points at its own flat buckets (or at nothing): the replay would exchange stale data.
+            raise ValueError("TrainStep(graph=True) needs an arena DataParallelRanks(model=...); a packed DataParallelRanks(params) "
+                             "only works with graph=False")
         self.cuts = Cuts(ddp.cut_names if seg else [])
         self._segs = None
         nseg = len(self.cuts.groups) + 1
@@ -662,6 +673,9 @@ class AdversarialGraphStep:
         self._coeff_gen = torch.Generator().manual_seed(int(coeff_seed))
         self.scalars = torch.zeros(4, device=dev)                      # (l1, bd, att, disc), averaged over ranks on G iterations
         seg = ddp_syn is not None and ddp_syn.arena is not None
+        if graph and ddp_syn is not None and not seg:
+            raise ValueError("AdversarialGraphStep(graph=True) needs an arena ddp_syn = DataParallelRanks(model=...) for the generator "
+                             "(see TrainStep); the critic's ddp_disc stays a packed DataParallelRanks(params)")
         self.cuts = Cuts(ddp_syn.cut_names if seg else [])
         self._segs = None
         # ---- generator iteration

@@ -342,3 +342,102 @@ def test_deferred_batched_weight_gradients_match_the_immediate_step(kind, graph,
                 assert g is not None and float((p.grad - g).abs().max()) <= 2e-6 * float(p.grad.abs().max()) + 1e-12, k
     for (k, p), q in zip(a.state_dict().items(), b.state_dict().values()):
         assert float((p - q).abs().max()) < 1e-6, k
+
+
+# ---- RCCL itself, on the one GPU there is: a process group of ONE rank with every collective really issued ------------------
+def _rccl_world1(rank, world, port, q, what):
+    """Child process: the process group is built BEFORE the first GPU call (device_count() does not initialise HIP), with the
+    device it serves, as bench.py and harness._distributed do."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SSV_FORCE_COLLECTIVES="1")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from spoofsv_amd import train
+    issued = {"all_reduce": 0, "broadcast": 0}
+    real_ar, real_bc = dist.all_reduce, dist.broadcast
+
+    def count_ar(*a, **k):
+        issued["all_reduce"] += 1
+        return real_ar(*a, **k)
+
+    def count_bc(*a, **k):
+        issued["broadcast"] += 1
+        return real_bc(*a, **k)
+    dist.all_reduce, dist.broadcast = count_ar, count_bc
+    out = {}
+    if what == "train":
+        for kind in ("text2mel", "ssrn"):
+            if kind == "text2mel":
+                a, b = _melsyn(), _melsyn()
+                batch = list(train.synthetic_text2mel_batch(4, N=40, T=64, seed=3, device=DEV))
+                gaw = train.guided_attention_mat(40, 64, device=DEV)
+            else:
+                a, b = _ssrn(), _ssrn()
+                batch = list(train.synthetic_ssrn_batch(4, T=40, out_bins=65, seed=3, device=DEV))
+                gaw = None
+            oa = train.FusedAdam(a.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+            ob = train.FusedAdam(b.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+            oa.refresh_resident_weights(); ob.refresh_resident_weights()
+            plain = train.TrainStep(kind, a, oa, batch, gaw, None, graph=False)
+            ddp = train.DataParallelRanks(model=b)
+            assert ddp.world == 1 and ddp.collectives
+            ddp.broadcast_parameters(0)
+            ob.refresh_resident_weights()
+            seg = train.TrainStep(kind, b, ob, batch, gaw, ddp, graph=True, defer_wgrad=True).prepare()
+            b.load_state_dict(a.state_dict())
+            for st in ob.state.values():
+                st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+            ob._step_dev.zero_()
+            ob.refresh_resident_weights()
+            n0 = issued["all_reduce"]
+            for it in range(3):
+                la, lb = plain(), seg()
+                assert [float(x) for x in la] == [float(y) for y in lb], (kind, it)
+            torch.cuda.synchronize()
+            out[kind] = dict(per_step=(issued["all_reduce"] - n0) / 3, buckets=ddp.n_buckets,
+                             worst=max(float((p - q_).abs().max()) for p, q_ in zip(a.state_dict().values(), b.state_dict().values())))
+    else:
+        for kind in ("text2mel", "ssrn"):
+            m0, d0 = _adv_build(kind)
+            m1, d1 = _adv_build(kind)
+            batch, gaw = _adv_batch(kind, 4)
+            ref = _adv_run(kind, m0, d0, batch, gaw, None, None, graph=False)
+            ddp_syn, ddp_disc = train.DataParallelRanks(model=m1), train.DataParallelRanks(list(d1.parameters()))
+            n0 = issued["all_reduce"]
+            got = _adv_run(kind, m1, d1, batch, gaw, ddp_syn, ddp_disc, graph=True)
+            out[kind] = dict(all_reduces=issued["all_reduce"] - n0, g_out=(ref[0], got[0]), d_out=(ref[2], got[2]),
+                             worst=max(float(np.abs(ref[4][k] - got[4][k]).max()) for k in ref[4]))
+    q.put((0, out, issued))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_train_step_with_every_collective_issued():
+    """The launch structure of the N > 1 step on the hardware there is: process group "nccl" (= RCCL) of one rank,
+    SSV_FORCE_COLLECTIVES=1, so the parameter broadcast and EVERY bucket's asynchronous all-reduce really run through RCCL --
+    between the replays of the backward segments' hipGraphs, on RCCL's own stream behind an event, Adam's graph waiting for
+    the last one.  A sum over one rank changes nothing, so losses must equal the plain eager step's exactly, step after step
+    (the batched weight gradients differ from the immediate ones in summation order only: weights within 1e-6).
+    train/ordinary.py:165-173 is what this replaces."""
+    (_, out, issued), = _spawn(_rccl_world1, ("train",), world=1)
+    assert issued["broadcast"] > 0
+    for kind, buckets in (("text2mel", 5), ("ssrn", 3)):
+        assert out[kind]["buckets"] == buckets and out[kind]["per_step"] == buckets, out[kind]      # one all-reduce per bucket per replayed step
+        assert out[kind]["worst"] < 1e-6, out[kind]
+
+
+def test_rccl_world_size_one_adversarial_iterations_with_every_collective_issued():
+    """Same for the WGAN-GP iterations (train/adversarial_wasserstein_gp.py:183-196,290,300): the all-reduce of the four loss
+    scalars between the forward graph and the backward graphs of a G iteration, the generator's bucket all-reduces, and the
+    critic's packed all-reduce between the two graphs of a D iteration, all through RCCL; results equal to the captured
+    single-process iterations."""
+    (_, out, issued), = _spawn(_rccl_world1, ("adv",), world=1)
+    for kind, buckets in (("text2mel", 5), ("ssrn", 3)):
+        r = out[kind]
+        assert r["all_reduces"] >= 2 * (buckets + 2), r          # 2 x (scalars + buckets) for G, 2 x packed for D, plus the warm-up iterations
+        for a, b in zip(r["g_out"][0], r["g_out"][1]):
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), r["g_out"]
+        for a, b in zip(r["d_out"][0], r["d_out"][1]):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), r["d_out"]
+        assert r["worst"] < 1e-5, r

@@ -298,6 +298,10 @@ def test_corpus_source_collates_like_the_reference(tmp_path):
     r0 = list(harness.BatchSource(cfg, "train_ssrn", 2, spec, mode="validate", rank=0, world=2))
     r1 = list(harness.BatchSource(cfg, "train_ssrn", 2, spec, mode="validate", rank=1, world=2))
     assert len(r0) == 2 and r0[0]["data_0"].shape[-1] == 10 and r1[0]["data_0"].shape[-1] == 16
+    # 5 utterances, global batch 2 x 2: the ragged last global batch wraps around, so both ranks run the same number of
+    # iterations on full shards (a rank that stopped early would leave the others waiting in an all-reduce)
+    assert len(r1) == 2 and all(b["data_0"].shape[0] == 2 for b in r0 + r1)
+    assert torch.equal(r0[1]["data_0"][1, :, :7], b0["data_0"][0, :, :7])          # rank 0's second item of the last batch = utterance 0 again
 
 
 # ---- data parallel: gradient arena, segmented backward with per-bucket all-reduce -------------------------------
@@ -353,6 +357,15 @@ def test_grad_arena_layout_views_and_adopt():
     for n, p in net.named_parameters():
         assert p.grad.data_ptr() == ar.slot(p).data_ptr()
         assert torch.equal(p.grad, torch.zeros_like(p) if n == "a.bias" else want[n])
+    # a slot that already holds p.grad is not handed out again: a second gradient of the parameter in one backward (or a
+    # backward without zero_grad(set_to_none=True)) must be ACCUMULATED by autograd, not written over what p.grad aliases
+    assert gradarena.view(net.a.weight) is None and gradarena.block((net.b.weight, net.b.bias), 9, 8) is None
+    assert gradarena.grad_like(net.a.weight).data_ptr() != ar.slot(net.a.weight).data_ptr()
+    before = net.c.weight.grad.clone()
+    torch.nn.functional.mse_loss(net(x), y).backward()                # no zero_grad: accumulates into the arena in place
+    assert net.c.weight.grad.data_ptr() == ar.slot(net.c.weight).data_ptr() and torch.allclose(net.c.weight.grad, 2 * before)
+    net.a.weight.grad = None
+    assert gradarena.view(net.a.weight) is not None                   # free again after zero_grad(set_to_none=True)
     ar.release()
     assert gradarena.view(net.a.weight) is None
 
