@@ -28,6 +28,9 @@
 #define SSV_ABL 0      // tuning builds only (WRONG results), weight-gradient kernel: 1 = without its MFMAs, 2 = dH fragments not split (raw bits
                        // re-used as operands), 4 = input tile not split before the LDS write, 6 = both, 8 = epilogue never executed
 #endif
+#ifndef SSV_F16_ABL
+#define SSV_F16_ABL 0  // tuning builds only (results are WRONG), split-fp16 kernels: 1 = fixed scales (no scale-list read / reduction in the prologue),
+#endif                 // 2 = the bf16 MFMA instruction on the fp16 operand bits (same issue pattern, other multiplier array)
 #ifndef SSV_NN_ABL
 #define SSV_NN_ABL 0   // tuning builds only (results are WRONG), bit mask on gemm_nn_bf3_kernel: 1 = no barrier in the chunk loop,
 #endif                 // 2 = no split / LDS write of the input tile, 4 = no input loads, 8 = no weight re-loads, 16 = one LDS fragment
@@ -79,7 +82,7 @@ __device__ __forceinline__ void split8s(const float (&v)[8], float s, uint4& hi,
 // one 16x16x32 MFMA on 16-byte operand fragments: bf16 or fp16 inputs, fp32 accumulate
 template <int F16>
 __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c) {
-  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  if constexpr (F16 && !(SSV_F16_ABL & 2)) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -262,7 +265,6 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
   constexpr int IMG = 2 * X_SLOTS, EPI_U4 = 4 * 16 * (BN + 4) / 4;
   constexpr int LDS_U4 = 2 * IMG > EPI_U4 ? 2 * IMG : EPI_U4;
   __shared__ uint4 lds_all[LDS_U4];
-  __shared__ float amax_sm[4];
   uint4 (*lds)[IMG] = reinterpret_cast<uint4 (*)[IMG]>(lds_all);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -348,10 +350,19 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
   float xs = 1.f, us = 1.f;
   auto scales = [&]() {
     if constexpr (F16) {
+#if SSV_F16_ABL & 1            // tuning builds only (WRONG results): no scale list read, no reduction
+      xs = 1024.f; us = 1.f / 1024.f;
+#elif SSV_F16_ABL & 4          // ... one scalar load of the list's first entry, no reduction
       float sc, inv;
-      ssv_pow2_scale(ssv_list_max<4>(p.x_amax + (long)b * p.x_amax_bs, p.x_namax, amax_sm), sc, inv);
+      ssv_pow2_scale(p.x_amax[(long)b * p.x_amax_bs], sc, inv);
       xs = ssv_uniform(sc);
       us = ssv_uniform(inv * *p.a_inv);
+#else
+      float sc, inv;
+      ssv_pow2_scale(ssv_wave_list_max(p.x_amax + (long)b * p.x_amax_bs, p.x_namax), sc, inv);
+      xs = ssv_uniform(sc);
+      us = ssv_uniform(inv * *p.a_inv);
+#endif
     }
   };
   auto prefetchX = [&](int ch) {
@@ -605,7 +616,6 @@ __global__ __launch_bounds__(256 * NWN, NWN == 2 ? 4 : 1) void gemm_nn_bf3w_kern
   constexpr int A_SLOTS = KT * 4 * BM, X_SLOTS = 4 * WX;
   constexpr int NA = (A_SLOTS + T - 1) / T, NX = (X_SLOTS + T - 1) / T;
   __shared__ uint4 lds[2 * A_SLOTS + 2 * X_SLOTS];
-  __shared__ float amax_sm[4 * NWN];
   uint4* Ah = lds;
   uint4* Al = lds + A_SLOTS;
   uint4* Xh = lds + 2 * A_SLOTS;
@@ -717,7 +727,7 @@ __global__ __launch_bounds__(256 * NWN, NWN == 2 ? 4 : 1) void gemm_nn_bf3w_kern
   prefetch(0);
   if constexpr (F16) {
     float sc, inv;
-    ssv_pow2_scale(ssv_list_max<4 * NWN>(p.x_amax + (long)b * p.x_amax_bs, p.x_namax, amax_sm), sc, inv);
+    ssv_pow2_scale(ssv_wave_list_max(p.x_amax + (long)b * p.x_amax_bs, p.x_namax), sc, inv);
     xs = ssv_uniform(sc);
     us = ssv_uniform(inv * *p.a_inv);
   }
@@ -930,11 +940,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   float as = 1.f, xs = 1.f, us = 1.f;
   auto scales = [&]() {
     if constexpr (F16) {
+#if SSV_F16_ABL & 1
+      as = xs = 1024.f; us = 1.f / (1024.f * 1024.f);
+#elif SSV_F16_ABL & 4
       float sa, sx, ia, ix;
-      ssv_pow2_scale(ssv_list_max<4>(a_amax, a_namax, amax_sm), sa, ia);
+      ssv_pow2_scale(a_amax[0], sa, ia);
+      ssv_pow2_scale(x_amax[0], sx, ix);
+      as = ssv_uniform(sa); xs = ssv_uniform(sx);
+      us = ssv_uniform(ia * ix);
+#else
+      float sa, sx, ia, ix;
+      ssv_pow2_scale(ssv_list_max<4>(a_amax, a_namax, amax_sm), sa, ia);       // long lists (B * tiles entries): shared among the waves
       ssv_pow2_scale(ssv_list_max<4>(x_amax, x_namax, amax_sm + 4), sx, ix);
       as = ssv_uniform(sa); xs = ssv_uniform(sx);
       us = ssv_uniform(ia * ix);
+#endif
     }
   };
   const int mt = bxx % mtiles, ct = bxx / mtiles;

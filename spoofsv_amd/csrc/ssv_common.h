@@ -156,6 +156,24 @@ __device__ __forceinline__ float ssv_wg_max(float v, float* sm) {
   for (int i = 1; i < NW; ++i) r = fmaxf(r, sm[i]);
   return r;
 }
+template <int CTRL> __device__ __forceinline__ float ssv_dpp_mov(float v);
+// maximum of the n non-negative floats at p, computed by EVERY wave on its own (no LDS, no barrier: a GEMM prologue cannot
+// afford a workgroup round trip per tile -- measured 3-4 % of the large conv kernels): each lane takes entries lane, lane + 64,
+// ..., a DPP butterfly inside the rows of 16 lanes, then the four row results through scalar registers.  Returns a scalar.
+template <int CTRL>
+__device__ __forceinline__ float ssv_dpp_max(float v) { return fmaxf(v, ssv_dpp_mov<CTRL>(v)); }
+__device__ __forceinline__ float ssv_wave_list_max(const float* __restrict__ p, int n) {
+  float v = 0.f;
+  for (int i = threadIdx.x & 63; i < n; i += 64) v = fmaxf(v, p[i]);
+  v = ssv_dpp_max<0xB1>(v);      // quad_perm [1,0,3,2]
+  v = ssv_dpp_max<0x4E>(v);      // quad_perm [2,3,0,1]
+  v = ssv_dpp_max<0x141>(v);     // row_half_mirror
+  v = ssv_dpp_max<0x140>(v);     // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 // maximum of the n floats at p (every thread of an NW-wave workgroup gets it)
 template <int NW>
 __device__ __forceinline__ float ssv_list_max(const float* __restrict__ p, int n, float* sm) {
