@@ -824,6 +824,8 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
       return (g.M % 128 == 0) ? launch_nnbw<KT, 2, 6, 2>(g, st, smin, span) : launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
   }
   static const int nts[] = {7, 6, 4, 2};
+  // (round 3: 64 x 176 and 64 x 192 tiles -- 22 % less L2 -> CU operand traffic per launch at C = 256, L = 325 -- were forced per
+  //  shape inside the step with SSV_NNB_FORCE, tools/sweep_force.sh: every one of ten shapes +0.03..+0.2 ms; instantiations removed)
   int wm = 2, nt = 7;
   bool forced = false;
   if (const char* e = ssv_tuning(SSV_T_NNB_TILE)) {
