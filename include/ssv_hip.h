@@ -45,12 +45,12 @@ const char* ssv_last_error(void); /* thread-local, valid until the next failing 
  * Operand scales (mode 2).  A kernel that reads an fp32 tensor as an MFMA operand needs max |x| BEFORE it starts.  The
  * convention: a "scale list" of x (B, C, L) is `namax` floats per batch item, items consecutive, whose maximum per item
  * is max |x(b)| -- partial maxima, in any partition.  The LayerNorm / gate kernels write such a list for their output as
- * a by-product (ssv_amax_rows(L) entries per item: one per 16-column tile), ssv_absmax computes one for any tensor, and
+ * a by-product (ssv_amax_rows(L) entries per item: one per kernel tile, unused ones zeroed), ssv_absmax computes one for any tensor, and
  * every entry below that takes `*_amax, *_namax` arguments accepts NULL, 0: it then computes the list itself in its
  * workspace (one extra small launch).  Outside mode 2 the arguments are ignored (amax outputs are still written). */
 int ssv_set_precision(int mode);
 int ssv_get_precision(void);
-int ssv_amax_rows(int L);         /* entries per batch item of the lists the LayerNorm / gate kernels write: ceil(L / 16) */
+int ssv_amax_rows(int L);         /* entries per batch item of the lists the LayerNorm / gate kernels write: 4 * ceil(L / 64) */
 /* amax[b * namax + i] = max |x| over the i-th of namax equal pieces of item b (n dense floats at x + b * x_bs). */
 int ssv_absmax(const float* x, long x_bs, int B, long n, float* amax, int namax, ssv_stream_t stream);
 /* Tuning knobs (SSV_NNB_TILE, SSV_NT_Z, SSV_LN_GROUPS, ... -- tile / slab overrides used by tools/sweep_*.py) are read

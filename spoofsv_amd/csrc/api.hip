@@ -33,7 +33,7 @@ int ssv_precision() {
   return g_precision;
 }
 static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_Z", "SSV_NT_FORCE", "SSV_LSTM_SEQUENTIAL", "SSV_NNB_WIDE", "SSV_NNB_TILE",
-                                                       "SSV_NNB_FORCE", "SSV_NT_PLAN", "SSV_NN_TILE", "SSV_LN_GROUPS"};
+                                                       "SSV_NNB_FORCE", "SSV_NT_PLAN", "SSV_NN_TILE", "SSV_LN_GROUPS", "SSV_LN_NOSTREAM"};
 static char g_knob_val[SSV_T_COUNT][512];
 static const char* g_knob[SSV_T_COUNT];
 static int g_knobs_loaded = 0;
@@ -65,6 +65,8 @@ extern "C" const char* ssv_last_error(void) { return g_err; }
 int ssv_launch_ln_gate_fwd(const float*, long, const float*, long, const float*, const float*, const float*, const float*, float*, long, float*, int, int, int, hipStream_t, float* = nullptr);
 int ssv_launch_ln_gate_bwd(const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*, const float*, float*, float*, long, float*, float*, int, int, int, hipStream_t, float* = nullptr);
 int ssv_ln_gate_bwd_nblk(int B, int L);
+int ssv_launch_ln_gate_fwd_stream(const float* H, const float* X, long x_bs, const float* colstats, const float* g1, const float* b1, const float* g2, const float* b2,
+                                  float* Y, long y_bs, float* stats, float* amax, int B, int C, int L, hipStream_t st);
 int ssv_launch_ln_bwd2(const float*, long, const float*, long, const float*, long, const float*, const float*, float*, long, float*, long, float*, float*, int, int, int, hipStream_t);
 int ssv_reduce_partial_rows(const float* part, float* out, int n, int nblk, hipStream_t st);
 int ssv_launch_ln_gate_bwd2(const float*, const float*, long, const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*,
@@ -146,7 +148,7 @@ static int amax_of(const float* x, long x_bs, int B, long n_item, const float* g
   out->p = fb; out->n = npb;
   return 0;
 }
-extern "C" int ssv_amax_rows(int L) { return ssv_cdiv(L, 16); }
+extern "C" int ssv_amax_rows(int L) { return ssv_amax_rows_(L); }
 extern "C" int ssv_absmax(const float* x, long x_bs, int B, long n, float* amax, int namax, ssv_stream_t stream) {
   SSV_CHECK(x && amax && B > 0 && B <= 65535 && n > 0 && namax > 0 && namax <= 65535, SSV_BAD_SHAPE, "absmax: bad argument");
   return ssv_launch_absmax(x, x_bs, B, n, amax, namax, (hipStream_t)stream);
@@ -166,6 +168,7 @@ static GemmNNB nnb_zero() {
   g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0;
   g.gates_out = nullptr;
   g.f16 = 0; g.a_inv = nullptr; g.x_amax = nullptr; g.x_namax = 0; g.x_amax_bs = 0;
+  g.colstats = nullptr;
   return g;
 }
 
@@ -176,7 +179,8 @@ static GemmNNB nnb_zero() {
 static inline size_t conv_aux_bytes() { return SSV_F16_AUX_BYTES + AMAX_FB_BYTES; }
 static int conv_nn(const float* x, long x_bs, const float* w, const void* packed, long w_sm, long w_sk, const float* bias, const float* bias_b,
                    const float* r, long r_bs, float* y, long y_bs, int B, int K, int M, int L, int k, const int* shift,
-                   bool bf3, void* ws, hipStream_t st, const float* a_inv = nullptr, const float* xa_given = nullptr, int xa_n = 0, size_t ws_main = 0) {
+                   bool bf3, void* ws, hipStream_t st, const float* a_inv = nullptr, const float* xa_given = nullptr, int xa_n = 0, size_t ws_main = 0,
+                   float* colstats = nullptr) {
   if (bf3) {
     const int Kpad = pad32(K);
     const unsigned short* hi = (const unsigned short*)(packed ? packed : ws);
@@ -193,6 +197,7 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
       SSV_TRY(amax_of(x, x_bs, B, (long)K * L, xa_given, xa_n, aux ? aux + SSV_F16_AUX_FLOATS : nullptr, &xa, st));
       g.f16 = 1; g.a_inv = a_inv; g.x_amax = xa.p; g.x_namax = xa.n; g.x_amax_bs = xa.n;
     }
+    g.colstats = colstats;
     g.Ahi = hi; g.Alo = lo; g.Kpad = Kpad;
     g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
     g.C = y; g.scb = y_bs; g.scm = L;
@@ -416,14 +421,29 @@ extern "C" int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* 
 }
 
 // ---- highwayConv ---------------------------------------------------------------------------------------
+// Column statistics of h come out of the conv kernel's epilogue (64-row groups) when the split-MFMA kernel runs and the two
+// halves are whole groups; the LayerNorm / gate forward is then a streaming kernel without reductions (norm.hip).
+static inline bool hw_colstats(int B, int C, int L) { return use_bf3(B, L, C, 2 * C) && C % 64 == 0 && C <= 512 && !ssv_tuning(SSV_T_LN_NOSTREAM); }
+static inline size_t hw_colstats_bytes(int B, int C, int L) { return align256((size_t)B * (2 * C / 64) * L * 2 * sizeof(float)); }
 extern "C" size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k) {
-  (void)B; (void)L;
-  return ssv_conv1d_fwd_workspace(C, 2 * C, k);
+  return ssv_conv1d_fwd_workspace(C, 2 * C, k) + (hw_colstats(B, C, L) ? hw_colstats_bytes(B, C, L) : 0);
 }
 extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
                                       const float* g1, const float* b1, const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
                                       float* y_amax, int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w && g1 && b1 && g2 && b2 && h && y, SSV_BAD_SHAPE, "highway_conv1d_fwd: null argument");
+  SSV_CHECK(B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_conv1d_fwd: bad shape B=%d C=%d L=%d", B, C, L);
+  if (hw_colstats(B, C, L)) {
+    const size_t conv_ws = ssv_conv1d_fwd_workspace(C, 2 * C, k);
+    SSV_CHECK(ws && ws_bytes >= conv_ws + hw_colstats_bytes(B, C, L), SSV_BAD_SHAPE, "highway_conv1d_fwd: workspace too small");
+    SSV_CHECK(x_bs >= (long)C * L && y_bs >= (long)C * L, SSV_BAD_SHAPE, "highway_conv1d_fwd: batch stride smaller than C*L");
+    float* cs = (float*)((char*)ws + conv_ws);
+    int shift[3];
+    SSV_TRY(conv_shifts(k, dilation, causal, shift));
+    SSV_TRY(conv_nn(x, x_bs, w, w_packed, (long)C * k, k, bias, nullptr, nullptr, 0, h, (long)2 * C * L, B, C, 2 * C, L, k, shift, true, ws, (hipStream_t)stream,
+                    packed_inv(w_packed, 2 * C, C, k, 0), x_amax, x_namax, 2 * split_bytes(2 * C, C, k), cs));
+    return ssv_launch_ln_gate_fwd_stream(h, x, x_bs, cs, g1, b1, g2, b2, y, y_bs, stats, y_amax, B, C, L, (hipStream_t)stream);
+  }
   SSV_TRY(ssv_conv1d_fwd(x, x_bs, x_amax, x_namax, w, w_packed, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
   return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream, y_amax);
 }
@@ -437,7 +457,7 @@ static PwWs pw_ws(int B, int Cin, int Cout, int L) {
   s.dpre = 0;
   s.part = s.dpre + align256((size_t)B * Cout * L * sizeof(float));
   s.amax = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * Cout * sizeof(float));
-  s.wt = s.amax + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * sizeof(float));     // max |dpre| per LayerNorm tile (split-fp16 scales)
+  s.wt = s.amax + align256((size_t)B * ssv_amax_rows_(L) * sizeof(float));     // max |dpre| per LayerNorm tile (split-fp16 scales)
   s.slabs = s.wt + ssv_conv1d_bwd_data_workspace(Cin, Cout, 1);
   s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, 1);
   return s;
@@ -455,7 +475,7 @@ extern "C" int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const 
   float* dpre = (float*)(base + s.dpre);
   const long pbs = (long)Cout * L;
   float* da = use_f16() ? (float*)(base + s.amax) : nullptr;
-  const int dn = ssv_cdiv(L, 16);
+  const int dn = ssv_amax_rows_(L);
   SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, (float*)(base + s.part), nullptr, B, Cout, L, act, (hipStream_t)stream, da));
   if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, da, dn, w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, base + s.wt, s.slabs - s.wt, stream));
   if (ds) SSV_TRY(ssv_rowsum(dpre, pbs, ds, B, Cout, L, stream));               // gradient of the broadcast (B, Cout, 1) term
@@ -507,7 +527,7 @@ static HwWs hw_ws(int B, int C, int L, int k) {
   s.dh = 0;
   s.part = s.dh + align256((size_t)B * 2 * C * L * sizeof(float));
   s.amax = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float));
-  s.wt = s.amax + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * sizeof(float));      // max |dH| per LayerNorm tile (split-fp16 scales)
+  s.wt = s.amax + align256((size_t)B * ssv_amax_rows_(L) * sizeof(float));      // max |dH| per LayerNorm tile (split-fp16 scales)
   s.slabs = s.wt + ssv_conv1d_bwd_data_workspace(C, 2 * C, k);
   s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, C, 2 * C, k);
   return s;
@@ -527,7 +547,7 @@ extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* 
   // gate + both LayerNorms backward: dH (B,2C,L), the residual-path gradient dy*(1-g) into dx, parameter partials
   // (its partial rows are summed at the end, by the launch that also sums the weight-gradient slabs)
   float* da = use_f16() ? (float*)(base + s.amax) : nullptr;
-  const int dn = ssv_cdiv(L, 16);
+  const int dn = ssv_amax_rows_(L);
   SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dH, dx, dx_bs, (float*)(base + s.part), nullptr, B, C, L, (hipStream_t)stream, da));
   // dx += conv^T(dH)
   SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, da, dn, w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
@@ -544,7 +564,7 @@ extern "C" int ssv_highway_conv1d_bwd_data(const float* dy, long dy_bs, const fl
   SSV_CHECK(dy && x && w && g1 && b1 && g2 && b2 && h && stats && dx && dh && part, SSV_BAD_SHAPE, "highway_conv1d_bwd_data: null argument");
   SSV_CHECK(B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_conv1d_bwd_data: bad shape B=%d C=%d L=%d", B, C, L);
   SSV_TRY(ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dx, dx_bs, part, nullptr, B, C, L, (hipStream_t)stream, dh_amax));
-  return ssv_conv1d_bwd_data(dh, (long)2 * C * L, dh_amax, ssv_cdiv(L, 16), w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream);
+  return ssv_conv1d_bwd_data(dh, (long)2 * C * L, dh_amax, ssv_amax_rows_(L), w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream);
 }
 extern "C" size_t ssv_pointwise_conv_ln_act_bwd_data_workspace(int B, int Cin, int Cout, int L) { (void)B; (void)L; return ssv_conv1d_bwd_data_workspace(Cin, Cout, 1); }
 extern "C" int ssv_pointwise_conv_ln_act_bwd_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* gamma, const float* beta,
@@ -554,7 +574,7 @@ extern "C" int ssv_pointwise_conv_ln_act_bwd_data(const float* dy, long dy_bs, c
   SSV_CHECK(B > 0 && B <= 65535 && Cin > 0 && Cout > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd_data: bad shape");
   const long pbs = (long)Cout * L;
   SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, part, nullptr, B, Cout, L, act, (hipStream_t)stream, dpre_amax));
-  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, dpre_amax, ssv_cdiv(L, 16), w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, ws, ws_bytes, stream));
+  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, dpre_amax, ssv_amax_rows_(L), w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, ws, ws_bytes, stream));
   if (ds) SSV_TRY(ssv_rowsum(dpre, pbs, ds, B, Cout, L, stream));
   return 0;
 }

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
   // two images of the staged input tile: the MFMAs of chunk c read image c & 1 while chunk c+1 is split into the other
   // one -- one barrier per chunk, and the split (VALU) runs under the MFMAs instead of between two barriers
   // (the epilogue re-uses the memory to turn the accumulator tiles into row-contiguous stores: 4 waves x 16 rows x (BN + 4))
-  constexpr int IMG = 2 * X_SLOTS, EPI_U4 = 4 * 16 * (BN + 4) / 4;
+  // (+ 4 * WM * BN (mean, M2) pairs behind the parked tiles when the caller wants the output's column statistics)
+  constexpr int IMG = 2 * X_SLOTS, EPI_U4 = (4 * 16 * (BN + 4) + 4 * WM * BN * 2) / 4;
   constexpr int LDS_U4 = 2 * IMG > EPI_U4 ? 2 * IMG : EPI_U4;
   __shared__ uint4 lds_all[LDS_U4];
   uint4 (*lds)[IMG] = reinterpret_cast<uint4 (*)[IMG]>(lds_all);
@@ -555,6 +556,25 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
         for (int t = 0; t < NT; ++t) stage[(kq * 4 + r) * LDW + t * 16 + nq] = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add;
       }
       // the block is private to the wave: no workgroup barrier, the LDS operations of one wave complete in order
+      if (p.colstats) {
+        // column statistics of this 16-row block: a lane reads ITS column of the parked block (consecutive lanes, consecutive
+        // words: conflict-free), two passes over 16 values in registers
+        float* cst = reinterpret_cast<float*>(lds_all) + 4 * 16 * LDW + (wave * WM + i) * BN * 2;
+#pragma unroll
+        for (int c0 = 0; c0 < BN; c0 += 64) {
+          const int c = c0 + lane;
+          if (c < BN) {
+            float v[16], sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v[r] = stage[r * LDW + c]; sum += v[r]; }
+            const float mean = sum * (1.f / 16.f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; m2 += d * d; }
+            cst[2 * c] = mean; cst[2 * c + 1] = m2;
+          }
+        }
+      }
 #pragma unroll
       for (int it = 0; it < NT; ++it) {
         const int e = lane + 64 * it;                           // 16-byte vector index in the 16 x BN block
@@ -573,6 +593,23 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
               if (gn + q < p.N) dst[q] = v[q] + (Rb ? Rb[(long)gm * p.srm + gn + q] : 0.f);
           }
         }
+      }
+    }
+    if (p.colstats) {
+      // four 16-row blocks -> one 64-row group (Chan's merge of equal counts), WM groups per tile
+      __syncthreads();
+      const float* cst = reinterpret_cast<const float*>(lds_all) + 4 * 16 * LDW;
+      for (int e = tid; e < WM * BN; e += 256) {
+        const int grp = e / BN, c = e % BN, gn = n0 + c;
+        if (gn >= p.N) continue;
+        float mu[4], mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { mu[q] = cst[((grp * 4 + q) * BN + c) * 2]; mean += mu[q]; m2 += cst[((grp * 4 + q) * BN + c) * 2 + 1]; }
+        mean *= 0.25f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float d = mu[q] - mean; m2 += 16.f * d * d; }
+        float* dst = p.colstats + (((long)b * (p.M >> 6) + (m0 >> 6) + grp) * p.N + gn) * 2;
+        dst[0] = mean; dst[1] = m2;
       }
     }
     return;
@@ -608,7 +645,7 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
 // (two 8-wave workgroups per CU = 4 waves per SIMD need <= 128 VGPRs: the split-bf16 form of the 128 x 192 tile has 122, the split-fp16 one 134
 // without the bound -- +42 % time; the second __launch_bounds__ argument is waves per SIMD in HIP)
 template <int KT, int WM, int NT, int NWN, int F16>
-__global__ __launch_bounds__(256 * NWN, NWN == 2 ? 4 : 1) void gemm_nn_bf3w_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
+__global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm_nn_bf3w_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int T = 256 * NWN;
   constexpr int BM = 64 * WM, BN = 16 * NT * NWN;
   constexpr int HALO = (KT == 1) ? 0 : 54;
@@ -808,7 +845,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   {
     int wm = 0, nt = 0, nwn = 0;
     const char* e = ssv_tuning(SSV_T_NNB_WIDE);
-    if (e && g.sxn == 1 && g.scn == 1 && sscanf(e, "%d,%d,%d", &wm, &nt, &nwn) == 3) {
+    if (e && g.sxn == 1 && g.scn == 1 && !g.colstats && sscanf(e, "%d,%d,%d", &wm, &nt, &nwn) == 3) {
 #define SSV_W(A_, C_, D_) if (wm == A_ && nt == C_ && nwn == D_) return launch_nnbw<KT, A_, C_, D_>(g, st, smin, span)
       SSV_W(2, 7, 3); SSV_W(1, 7, 3); SSV_W(2, 7, 2); SSV_W(2, 6, 2); SSV_W(1, 6, 2); SSV_W(2, 4, 4); SSV_W(2, 7, 4);
 #undef SSV_W
@@ -819,7 +856,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
     // when M leaves a nearly empty last row tile (M = 513), where the 16-wave 128 x 448 tile loses less (tools/sweep_wide.py)
     // ... and only when the 128 x 192 tiling still gives every CU a workgroup: a single long utterance (the vocoder's DFT
     // at B = 1: 1026 x 1300 x 1024) is 27-56 wide tiles, a fifth of the chip; the cost model below then picks small tiles.
-    if (KT == 1 && !e && !g.epi && !g.perm_h && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256 &&
+    if (KT == 1 && !e && !g.epi && !g.perm_h && !g.colstats && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256 &&
         (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 192) * g.B >= 256)
       return (g.M % 128 == 0) ? launch_nnbw<KT, 2, 6, 2>(g, st, smin, span) : launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
   }
@@ -890,6 +927,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   const int span = smax - smin;
   SSV_CHECK(span <= 54, SSV_UNSUPPORTED, "gemm_nn_bf3: dilation halo %d exceeds 54", span);
   SSV_CHECK(!g.f16 || (!g.epi && g.a_inv && g.x_amax && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales and no LSTM epilogue");
+  SSV_CHECK(!g.colstats || (g.M % 64 == 0 && g.scn == 1 && !g.epi && !g.perm_h), SSV_BAD_SHAPE, "gemm_nn_bf3: column statistics need M %% 64 == 0 and a plain epilogue");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
 }
 

@@ -129,8 +129,102 @@ __global__ __launch_bounds__(16 * G) void ln_gate_fwd_kernel(
   // split-fp16 operand scale of the NEXT convolution: this tile's max |y| (one entry per workgroup, ssv_amax_rows(L) per item)
   if (amax) {
     am = ssv_wg_max<G / 4>(am, amx);
-    if (threadIdx.x == 0) amax[(long)b * gridDim.x + bx] = am;
+    if (threadIdx.x == 0) {
+      const int na = ssv_amax_rows_(L);            // list length: >= the tiles of this kernel; the last tile zeroes the rest
+      amax[(long)b * na + bx] = am;
+      if (bx == (int)gridDim.x - 1) for (int e = gridDim.x; e < na; ++e) amax[(long)b * na + e] = 0.f;
+    }
   }
+}
+
+// The same forward with the column statistics ALREADY known: the conv kernel that produced H left, per 64-row group and
+// column, the mean and the sum of squared deviations (GemmNNB::colstats).  Without a reduction the channels can be cut freely:
+// a workgroup owns 64 columns x a QUARTER of the channels of one batch item (4x the workgroups of a whole-column tile: at
+// L = 186 a 64-column tile alone gives 96 workgroups for 256 CUs, and the kernel ran no faster than the reducing one).  128 threads first merge the C / 64 groups of each half
+// (Chan, equal counts) into mean / rstd, then all 256 threads stream -- thread (cq, g) takes columns 4 cq .. 4 cq + 3 of
+// channels c0 + g, c0 + g + 16, ... as 16-byte accesses (256 contiguous bytes of a row per 16 lanes instead of 64 with the
+// 16-column tiles above), nothing is kept in registers across channels.
+typedef float f4ln __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void ln_gate_fwd_stream_kernel(
+    const float* __restrict__ H, const float* __restrict__ X, long x_bs, const float* __restrict__ cst,
+    const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
+    float* __restrict__ Y, long y_bs, float* __restrict__ stats, float* __restrict__ amax, int namax, int C, int L) {
+  __shared__ float st[2][64][2];
+  __shared__ float amx[4];
+  int bxq, by;
+  xcd_tile(bxq, by);
+  const int bx = bxq >> 2, quarter = bxq & 3;               // the four channel quarters of a column tile are neighbours (same XCD)
+  const int tid = threadIdx.x, b = by, t0 = bx * 64;
+  if (tid < 128) {
+    const int half = tid >> 6, col = tid & 63, t = t0 + col;
+    if (t < L) {
+      const int P = C >> 6, MG = 2 * P;
+      const float* __restrict__ q = cst + (((long)b * MG + half * P) * L + t) * 2;
+      float mu[8], mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { mu[i] = 0.f; if (i < P) { mu[i] = q[(long)i * L * 2]; mean += mu[i]; m2 += q[(long)i * L * 2 + 1]; } }
+      mean /= (float)P;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (i < P) { const float d = mu[i] - mean; m2 += 64.f * d * d; }
+      const float r = rsqrtf(m2 / (float)C + LN_EPS);
+      st[half][col][0] = mean; st[half][col][1] = r;
+      if (stats && quarter == 0) { float* sb = stats + (long)b * 4 * L + (long)(2 * half) * L + t; sb[0] = mean; sb[L] = r; }
+    }
+  }
+  __syncthreads();
+  const int cq = tid & 15, g = tid >> 4, t = t0 + 4 * cq;
+  float am = 0.f;
+  if (t < L) {
+    float mu1[4], r1[4], mu2[4], r2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu1[j] = st[0][4 * cq + j][0]; r1[j] = st[0][4 * cq + j][1]; mu2[j] = st[1][4 * cq + j][0]; r2[j] = st[1][4 * cq + j][1]; }
+    const float* __restrict__ H1 = H + (long)b * 2 * C * L + t;
+    const float* __restrict__ H2 = H1 + (long)C * L;
+    const float* __restrict__ Xb = X + (long)b * x_bs + t;
+    float* __restrict__ Yb = Y + (long)b * y_bs + t;
+    const bool full = t + 3 < L;
+    const int cq4 = C >> 2, c0 = quarter * cq4;
+#pragma unroll 4
+    for (int c = c0 + g; c < c0 + cq4; c += 16) {
+      const unsigned o = (unsigned)c * (unsigned)L;
+      const float ga1 = g1[c], be1 = b1[c], ga2 = g2[c], be2 = b2[c];
+      float h1[4], h2[4], xv[4], y[4];
+      if (full) {
+        const f4ln a = *reinterpret_cast<const f4ln*>(H1 + o), d = *reinterpret_cast<const f4ln*>(H2 + o), e = *reinterpret_cast<const f4ln*>(Xb + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h1[j] = a[j]; h2[j] = d[j]; xv[j] = e[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const bool v = t + j < L; h1[j] = v ? H1[o + j] : 0.f; h2[j] = v ? H2[o + j] : 0.f; xv[j] = v ? Xb[o + j] : 0.f; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float n1 = (h1[j] - mu1[j]) * r1[j] * ga1 + be1;
+        const float n2 = (h2[j] - mu2[j]) * r2[j] * ga2 + be2;
+        const float s = sigmoidf_(n1);
+        y[j] = s * n2 + (1.f - s) * xv[j];
+      }
+      if (full) {
+        *reinterpret_cast<f4ln*>(Yb + o) = (f4ln){y[0], y[1], y[2], y[3]};
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (t + j < L) { Yb[o + j] = y[j]; am = fmaxf(am, fabsf(y[j])); }
+      }
+    }
+  }
+  if (amax) {                                    // this workgroup's max |y| for the next conv's operand scale: entry 4 * tile + quarter
+    am = ssv_wg_max<4>(am, amx);                 // of the item's list (ssv_amax_rows(L) = 4 per 64 columns)
+    if (tid == 0) amax[(long)b * namax + bxq] = am;
+  }
+}
+int ssv_launch_ln_gate_fwd_stream(const float* H, const float* X, long x_bs, const float* colstats, const float* g1, const float* b1, const float* g2,
+                                  const float* b2, float* Y, long y_bs, float* stats, float* amax, int B, int C, int L, hipStream_t st) {
+  if (C % 64 != 0 || C > 512) return ssv_fail(SSV_UNSUPPORTED, "streaming highway gate: %d channels (multiples of 64 up to 512)", C);
+  if ((long)2 * C * L >= (1L << 31)) return ssv_fail(SSV_UNSUPPORTED, "LayerNorm: one batch item exceeds 2^31 elements");
+  hipLaunchKernelGGL(ln_gate_fwd_stream_kernel, dim3(4 * ssv_cdiv(L, 64), B), dim3(256), 0, st, H, X, x_bs, colstats, g1, b1, g2, b2, Y, y_bs, stats, amax,
+                     ssv_amax_rows_(L), C, L);
+  return ssv_check_launch("ln_gate_fwd_stream");
 }
 
 // part layout: [block][6][C] = dgamma1, dbeta1, dgamma2, dbeta2, dbiasH1, dbiasH2
@@ -206,7 +300,11 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
   }
   if (amax) {                                    // max |dH| of this tile: operand scale of the two conv gradients (split-fp16)
     am = ssv_wg_max<G / 4>(am, amx);
-    if (threadIdx.x == 0) amax[(long)b * gridDim.x + bx] = am;
+    if (threadIdx.x == 0) {
+      const int na = ssv_amax_rows_(L);            // list length: >= the tiles of this kernel; the last tile zeroes the rest
+      amax[(long)b * na + bx] = am;
+      if (bx == (int)gridDim.x - 1) for (int e = gridDim.x; e < na; ++e) amax[(long)b * na + e] = 0.f;
+    }
   }
 }
 
@@ -259,7 +357,11 @@ __global__ __launch_bounds__(16 * G) void ln_act_fwd_kernel(
   }
   if (amax) {                                    // see ln_gate_fwd_kernel
     am = ssv_wg_max<G / 4>(am, amx);
-    if (threadIdx.x == 0) amax[(long)b * gridDim.x + bx] = am;
+    if (threadIdx.x == 0) {
+      const int na = ssv_amax_rows_(L);            // list length: >= the tiles of this kernel; the last tile zeroes the rest
+      amax[(long)b * na + bx] = am;
+      if (bx == (int)gridDim.x - 1) for (int e = gridDim.x; e < na; ++e) amax[(long)b * na + e] = 0.f;
+    }
   }
 }
 
@@ -322,7 +424,11 @@ __global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
   }
   if (amax) {                                    // see ln_gate_bwd_kernel
     am = ssv_wg_max<G / 4>(am, amx);
-    if (threadIdx.x == 0) amax[(long)b * gridDim.x + bx] = am;
+    if (threadIdx.x == 0) {
+      const int na = ssv_amax_rows_(L);            // list length: >= the tiles of this kernel; the last tile zeroes the rest
+      amax[(long)b * na + bx] = am;
+      if (bx == (int)gridDim.x - 1) for (int e = gridDim.x; e < na; ++e) amax[(long)b * na + e] = 0.f;
+    }
   }
 }
 

@@ -82,6 +82,11 @@ struct GemmNNB {
   // hi / lo of A * 2^ea and *a_inv = 2^-ea (written by the pack kernels); X is scaled by 2^ex while it is split, with ex from
   // the maximum of the x_namax partial maxima |X| at x_amax + b * x_amax_bs (x_amax_bs = 0: one list for every batch item).
   int f16; const float* a_inv; const float* x_amax; int x_namax; long x_amax_bs;
+  // Column statistics of the OUTPUT for the LayerNorm that follows (highwayConv: the reduction over channels runs across the
+  // GEMM's M axis, i.e. across workgroups; this makes the LayerNorm / gate forward a reduction-free streaming kernel):
+  // colstats[((b * (M / 64) + m / 64) * N + n) * 2 + {0, 1}] = mean and sum of squared deviations of C(b, 64-row group, n)
+  // over the group's 64 rows, bias included.  Needs M % 64 == 0, unit column stride, no LSTM epilogue.  Null: not wanted.
+  float* colstats;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
@@ -102,7 +107,7 @@ int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA, 2 = split
 // Tuning knobs from the environment (SSV_NT_Z, SSV_NNB_TILE, ...): read ONCE at first use -- a launch must not cost
 // half a dozen getenv() scans of the environment block -- and again only when a tuning script calls ssv_reload_tuning().
 enum { SSV_T_NT_Z, SSV_T_NT_FORCE, SSV_T_LSTM_SEQUENTIAL, SSV_T_NNB_WIDE, SSV_T_NNB_TILE, SSV_T_NNB_FORCE, SSV_T_NT_PLAN, SSV_T_NN_TILE,
-       SSV_T_LN_GROUPS, SSV_T_COUNT };
+       SSV_T_LN_GROUPS, SSV_T_LN_NOSTREAM, SSV_T_COUNT };
 const char* ssv_tuning(int knob);          // value of the knob or nullptr
 int ssv_pack_job_blocks(const ssv_pack_job& j);           // workgroups one job of ssv_conv_pack_multi takes
 int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, float* amax_ws, hipStream_t st);   // amax_ws != null: split-fp16 planes
@@ -117,6 +122,10 @@ int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hip
 int ssv_launch_fill(float* p, float v, long n, hipStream_t st);
 
 static inline int ssv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// entries per batch item of the scale lists the LayerNorm / gate kernels write (include/ssv_hip.h, ssv_amax_rows): the 16-column
+// kernels fill one per tile and zero the rest, the streaming forward (64 columns x 4 channel quarters per tile) fills four per tile
+// (eight per tile with 64-channel chunks was measured: the kernel gains 2 %, every consumer's longer list costs more: +0.09 ms a step)
+__host__ __device__ static inline int ssv_amax_rows_(int L) { return 4 * ((L + 63) / 64); }
 
 // ---- XCD-aware workgroup order ----------------------------------------------------------------
 // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8, x fastest), each with a private 4 MB L2.  In launch

@@ -71,9 +71,15 @@ def _f16():
     return _lib.precision() == 2
 
 
+_AMAX_ROWS = {}
+
+
 def _amax_out(B, L, device):
-    """Buffer for the scale list a LayerNorm / gate kernel writes for its (B, C, L) output."""
-    return torch.empty((B, (L + 15) // 16), dtype=_F32, device=device)
+    """Buffer for the scale list a LayerNorm / gate kernel writes for its (B, C, L) output (``ssv_amax_rows(L)`` per item)."""
+    n = _AMAX_ROWS.get(L)
+    if n is None:
+        n = _AMAX_ROWS[L] = int(_lib.lib().ssv_amax_rows(L))
+    return torch.empty((B, n), dtype=_F32, device=device)
 
 
 def _tag(y, amax):
