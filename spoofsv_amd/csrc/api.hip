@@ -50,6 +50,33 @@ const char* ssv_tuning(int knob) {
   return g_knob[knob];
 }
 extern "C" void ssv_reload_tuning(void) { load_knobs(); }
+// ---- shape log (see ssv_common.h) ---------------------------------------------------------------
+#include <mutex>
+#include <string>
+#include <map>
+static int g_shape_log = -1;
+static std::mutex g_shape_mu;
+static std::map<std::string, long>* g_shape_seen = nullptr;      // line -> host-side launches (eager and capture passes; replays do not come here)
+static void shape_log_flush() {
+  std::lock_guard<std::mutex> lk(g_shape_mu);
+  if (!g_shape_seen) return;
+  if (FILE* f = fopen(getenv("SSV_SHAPE_LOG"), "w")) {
+    for (const auto& kv : *g_shape_seen) fprintf(f, "%s\t%ld\n", kv.first.c_str(), kv.second);
+    fclose(f);
+  }
+}
+bool ssv_shape_log_on() {
+  if (g_shape_log < 0) { const char* e = getenv("SSV_SHAPE_LOG"); g_shape_log = (e && *e) ? 1 : 0; if (g_shape_log) atexit(shape_log_flush); }
+  return g_shape_log == 1;
+}
+void ssv_shape_log(const char* kernel, dim3 grid, dim3 block, double flops, double bytes, const char* note) {
+  if (!ssv_shape_log_on()) return;
+  char line[768];
+  snprintf(line, sizeof line, "%s\t%ux%ux%u\t%.6g\t%.6g\t%s", kernel, grid.x * block.x, grid.y * block.y, grid.z * block.z, flops, bytes, note ? note : "");
+  std::lock_guard<std::mutex> lk(g_shape_mu);
+  if (!g_shape_seen) g_shape_seen = new std::map<std::string, long>();
+  ++(*g_shape_seen)[line];
+}
 extern "C" int ssv_set_precision(int mode) {
   const int prev = ssv_precision();
   g_precision = mode <= 0 ? 0 : (mode == 1 ? 1 : 2);

@@ -821,6 +821,13 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
 template <int KT, int WM, int NT, int NWN>
 static int launch_nnbw(const GemmNNB& g, hipStream_t st, int smin, int span) {
   const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT * NWN);
+  if (ssv_shape_log_on()) {
+    char nm[96], note[96];
+    snprintf(nm, sizeof nm, "gemm_nn_bf3w_kernel<%d, %d, %d, %d, %d>", KT, WM, NT, NWN, g.f16);
+    snprintf(note, sizeof note, "B=%d M=%d N=%d K=%d k=%d", g.B, g.M, g.N, g.Kc, KT);
+    ssv_shape_log(nm, dim3(mtiles * ntiles, g.B), dim3(256 * NWN), 2.0 * g.B * g.M * g.N * g.Kc * KT,
+                  4.0 * ((double)g.B * g.Kc * g.N + (double)g.B * g.M * g.N + (double)g.M * g.Kc * KT), note);
+  }
   if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3w_kernel<KT, WM, NT, NWN, 1>), dim3(mtiles * ntiles, g.B), dim3(256 * NWN), 0, st, g, mtiles, smin, span);
   else hipLaunchKernelGGL((gemm_nn_bf3w_kernel<KT, WM, NT, NWN, 0>), dim3(mtiles * ntiles, g.B), dim3(256 * NWN), 0, st, g, mtiles, smin, span);
   return ssv_check_launch("gemm_nn_bf3w");
@@ -834,6 +841,13 @@ static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
       hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 1, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
       return ssv_check_launch("gemm_nn_bf3_lstm");
     }
+  }
+  if (ssv_shape_log_on()) {
+    char nm[96], note[96];
+    snprintf(nm, sizeof nm, "gemm_nn_bf3_kernel<%d, %d, %d, 0, %d>", KT, WM, NT, g.f16);
+    snprintf(note, sizeof note, "B=%d M=%d N=%d K=%d k=%d%s", g.B, g.M, g.N, g.Kc, KT, g.colstats ? " +colstats" : "");
+    ssv_shape_log(nm, dim3(mtiles * ntiles, g.B), dim3(256), 2.0 * g.B * g.M * g.N * g.Kc * KT,
+                  4.0 * ((double)g.B * g.Kc * g.N + (double)g.B * g.M * g.N * (g.R ? 2 : 1) + (double)g.M * g.Kc * KT), note);
   }
   if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0, 1>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
   else hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
@@ -1291,6 +1305,14 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
   SSV_CHECK(nz <= 65535, SSV_UNSUPPORTED, "gemm_nt_bf3: %d slabs exceed grid.z", nz);
   const dim3 grid(mtiles * ssv_cdiv(g.Nc, 16 * ntc), 1, nz);
   SSV_CHECK(!g.f16 || g.jobs || (g.a_amax && g.x_amax && g.a_namax > 0 && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_nt_bf3: split-fp16 needs both operand scales");
+  if (ssv_shape_log_on()) {
+    char nm[96], note[96];
+    const int nj = g.jobs ? g.njobs : 1;
+    snprintf(nm, sizeof nm, "gemm_nt_bf3_kernel<%d, %d, %d, %d>", g.KT, wm, ntc, g.f16);
+    snprintf(note, sizeof note, "jobs=%d B=%d M=%d Nc=%d L=%d k=%d Z=%d", nj, g.B, g.M, g.Nc, g.La, g.KT, g.Z);
+    ssv_shape_log(nm, grid, dim3(256), 2.0 * nj * g.B * g.M * g.Nc * g.La * g.KT,
+                  4.0 * nj * ((double)g.B * g.M * g.La + (double)g.B * g.Nc * g.Lx + (double)g.Z * g.M * g.Nc * g.KT), note);
+  }
 #define SSV_NT(K_, A_, C_) if (g.KT == K_ && wm == A_ && ntc == C_) { \
     if (g.f16) hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_, 1>), grid, dim3(256), 0, st, g, mtiles); \
     else hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_, 0>), grid, dim3(256), 0, st, g, mtiles); \

@@ -222,6 +222,11 @@ int ssv_launch_ln_gate_fwd_stream(const float* H, const float* X, long x_bs, con
                                   const float* b2, float* Y, long y_bs, float* stats, float* amax, int B, int C, int L, hipStream_t st) {
   if (C % 64 != 0 || C > 512) return ssv_fail(SSV_UNSUPPORTED, "streaming highway gate: %d channels (multiples of 64 up to 512)", C);
   if ((long)2 * C * L >= (1L << 31)) return ssv_fail(SSV_UNSUPPORTED, "LayerNorm: one batch item exceeds 2^31 elements");
+  if (ssv_shape_log_on()) {
+    char note[64];
+    snprintf(note, sizeof note, "B=%d C=%d L=%d", B, C, L);
+    ssv_shape_log("ln_gate_fwd_stream_kernel", dim3(4 * ssv_cdiv(L, 64), B), dim3(256), 0.0, 16.0 * B * C * L, note);
+  }
   hipLaunchKernelGGL(ln_gate_fwd_stream_kernel, dim3(4 * ssv_cdiv(L, 64), B), dim3(256), 0, st, H, X, x_bs, colstats, g1, b1, g2, b2, Y, y_bs, stats, amax,
                      ssv_amax_rows_(L), C, L);
   return ssv_check_launch("ln_gate_fwd_stream");
@@ -678,12 +683,19 @@ int ssv_reduce_partial_rows(const float* part, float* out, int n, int nblk, hipS
 // faster on 32 groups (half the registers per thread: 224 -> ~130 VGPRs in the gate backward, so twice the waves per CU);
 // the 513-channel backward is fastest on 64 groups (113 -> 92 us at L = 1300), its forward on 16.
 // SSV_LN_GROUPS forces G (tuning aid).
+static void ln_log(const char* name, int cpt, int g, dim3 grid, double bytes_per_elem, int B, int C, int L) {
+  if (!ssv_shape_log_on()) return;
+  char nm[96], note[64];
+  snprintf(nm, sizeof nm, "%s<%d, %d>", name, cpt, g);
+  snprintf(note, sizeof note, "B=%d C=%d L=%d", B, C, L);
+  ssv_shape_log(nm, grid, dim3(16 * g), 0.0, bytes_per_elem * B * C * L, note);
+}
 static int ln_groups(int C, bool bwd) {
   if (const char* e = ssv_tuning(SSV_T_LN_GROUPS)) { const int g = atoi(e); if (g == 16 || g == 32 || g == 64) return g; }
   if (C > 512) return bwd ? 64 : 16;
   return C > 256 ? 32 : 16;
 }
-#define LN_CASE(G_, N_) if (_g == G_ && _cpt <= N_) { CALL(N_, G_); } else
+#define LN_CASE(G_, N_) if (_g == G_ && _cpt <= N_) { ln_log(LN_NAME, N_, G_, grid, LN_BYTES, B, C, L); CALL(N_, G_); } else
 #define LN_DISPATCH(BWD, C, L, CALL)                                    \
   do {                                                                  \
     const int _g = ln_groups(C, BWD);                                   \
@@ -699,10 +711,14 @@ int ssv_launch_ln_gate_fwd(const float* H, long h_bs, const float* X, long x_bs,
                            const float* g2, const float* b2, float* Y, long y_bs, float* stats, int B, int C, int L,
                            hipStream_t st, float* amax) {
   dim3 grid(ssv_cdiv(L, 16), B);
+#define LN_NAME "ln_gate_fwd_kernel"
+#define LN_BYTES 16.0
 #define CALL(N, G) hipLaunchKernelGGL((ln_gate_fwd_kernel<N, G>), grid, dim3(16 * G), 0, st, H, h_bs, X, x_bs, g1, b1, g2, b2, Y, y_bs, stats, amax, C, L)
   if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
   LN_DISPATCH(false, C, L, CALL);
 #undef CALL
+#undef LN_NAME
+#undef LN_BYTES
   return ssv_check_launch("ln_gate_fwd");
 }
 
@@ -712,10 +728,14 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
                            const float* g1, const float* b1, const float* g2, const float* b2, float* dH, float* dXres,
                            long dx_bs, float* part, float* pgrads /* [6][C] */, int B, int C, int L, hipStream_t st, float* amax) {
   dim3 grid(ssv_cdiv(L, 16), B);
+#define LN_NAME "ln_gate_bwd_kernel"
+#define LN_BYTES 28.0
 #define CALL(N, G) hipLaunchKernelGGL((ln_gate_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L)
   if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
   LN_DISPATCH(true, C, L, CALL);
 #undef CALL
+#undef LN_NAME
+#undef LN_BYTES
   SSV_TRY(ssv_check_launch("ln_gate_bwd"));
   if (!pgrads) return 0;        // the caller sums the partial rows itself (fused with the weight-gradient slab sum)
   return reduce_partials(part, pgrads, 6 * C, (int)(grid.x * grid.y), st);
@@ -724,9 +744,13 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
 int ssv_launch_ln_act_fwd(const float* X, long x_bs, const float* gam, const float* bet, float* Y, long y_bs, float* stats,
                           int B, int C, int L, int act, hipStream_t st, float* amax) {
   dim3 grid(ssv_cdiv(L, 16), B);
+#define LN_NAME "ln_act_fwd_kernel"
+#define LN_BYTES 8.0
 #define CALL(N, G) hipLaunchKernelGGL((ln_act_fwd_kernel<N, G>), grid, dim3(16 * G), 0, st, X, x_bs, gam, bet, Y, y_bs, stats, amax, C, L, act)
   LN_DISPATCH(false, C, L, CALL);
 #undef CALL
+#undef LN_NAME
+#undef LN_BYTES
   return ssv_check_launch("ln_act_fwd");
 }
 
@@ -734,9 +758,13 @@ int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs
                           const float* bet, float* dX, long dx_bs, float* part, float* pgrads /* [3][C] */, int B, int C,
                           int L, int act, hipStream_t st, float* amax) {
   dim3 grid(ssv_cdiv(L, 16), B);
+#define LN_NAME "ln_act_bwd_kernel"
+#define LN_BYTES 12.0
 #define CALL(N, G) hipLaunchKernelGGL((ln_act_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, amax, C, L, act)
   LN_DISPATCH(true, C, L, CALL);
 #undef CALL
+#undef LN_NAME
+#undef LN_BYTES
   SSV_TRY(ssv_check_launch("ln_act_bwd"));
   if (!pgrads) return 0;        // the caller sums the partial rows itself (fused with the weight-gradient slab sum)
   return reduce_partials(part, pgrads, 3 * C, (int)(grid.x * grid.y), st);

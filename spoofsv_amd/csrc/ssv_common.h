@@ -122,6 +122,11 @@ int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hip
 int ssv_launch_fill(float* p, float v, long n, hipStream_t st);
 
 static inline int ssv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// Profiling aid (env SSV_SHAPE_LOG=<file>): every distinct (kernel, grid) a launcher issues is appended once as
+//   kernel-name \t gridX x gridY x gridZ (in threads, as rocprofv3 prints it) \t algorithmic FLOP \t algorithmic HBM bytes \t note
+// so that tools/summarize_prof.py can put "achieved / roof" beside each row of a kernel trace.  Off (one predictable branch) otherwise.
+bool ssv_shape_log_on();
+void ssv_shape_log(const char* kernel, dim3 grid, dim3 block, double flops, double bytes, const char* note);
 // entries per batch item of the scale lists the LayerNorm / gate kernels write (include/ssv_hip.h, ssv_amax_rows): the 16-column
 // kernels fill one per tile and zero the rest, the streaming forward (64 columns x 4 channel quarters per tile) fills four per tile
 // (eight per tile with 64-channel chunks was measured: the kernel gains 2 %, every consumer's longer list costs more: +0.09 ms a step)
