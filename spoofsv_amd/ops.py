@@ -418,18 +418,26 @@ class Conv1dFn(torch.autograd.Function):
 # bilinear in (x, w), so its three kernels -- forward, data gradient, weight gradient -- are closed under differentiation:
 # each is an autograd Function whose backward is written with the other two, which makes the op differentiable to any
 # order on the HIP kernels alone.  The bias gradient is a plain torch sum (already differentiable).
+# Split-fp16 operand scales (``*_amax``: the tensor's scale list or None): every tensor that enters these Functions as a GEMM
+# operand has its list computed ONCE (``_dd_amax``: the producer's tag or one ssv_absmax launch) and handed to every product that
+# reads it -- x serves the forward and the weight gradient, dy both gradients -- instead of one fallback launch per product.
+def _dd_amax(t):
+    return amax_of(t) if (t is not None and _f16() and _bf3_shape(t)) else None
+
+
 class ConvFwdDD(torch.autograd.Function):
     """y = conv1d(x, w) + bias, kernel 1 or 3, "same" or causal zero padding (the bias is added by the kernel's epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, k, dilation, causal):
+    def forward(ctx, x, w, bias, k, dilation, causal, x_amax=None):
         x, xbs = _act3(x, "conv input")
         w = _c(w)
         bias = _c(bias) if bias is not None else None
         B, Cin, L = x.shape
         y = torch.empty((B, w.shape[0], L), dtype=_F32, device=x.device)
-        _conv_fwd(x, xbs, w, bias, None, y, w.shape[0] * L, k, dilation, causal)
+        _conv_fwd(x, xbs, w, bias, None, y, w.shape[0] * L, k, dilation, causal, x_amax)
         ctx.save_for_backward(x, w)
+        ctx.x_amax = x_amax
         ctx.cfg = (k, dilation, causal, bias is not None)
         return y
 
@@ -437,10 +445,11 @@ class ConvFwdDD(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         k, dilation, causal, has_bias = ctx.cfg
-        dx = ConvBwdDataDD.apply(dy, w, x.shape[1], k, dilation, causal) if ctx.needs_input_grad[0] else None
-        dw = ConvBwdWeightDD.apply(dy, x, k, dilation, causal) if ctx.needs_input_grad[1] else None
+        dya = _dd_amax(dy)
+        dx = ConvBwdDataDD.apply(dy, w, x.shape[1], k, dilation, causal, dya) if ctx.needs_input_grad[0] else None
+        dw = ConvBwdWeightDD.apply(dy, x, k, dilation, causal, dya, ctx.x_amax) if ctx.needs_input_grad[1] else None
         db = BiasGradFn.apply(dy) if (has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class BiasGradFn(torch.autograd.Function):
@@ -465,11 +474,12 @@ class ConvBwdDataDD(torch.autograd.Function):
     """dx = conv1d_transpose(dy, w): linear in dy and in w."""
 
     @staticmethod
-    def forward(ctx, dy, w, Cin, k, dilation, causal):
+    def forward(ctx, dy, w, Cin, k, dilation, causal, dy_amax=None):
         dy, dybs = _act3(dy, "grad")
         w = _c(w)
-        dx = _conv_bwd_data(dy, dybs, w, Cin, dy.shape[2], k, dilation, causal)
+        dx = _conv_bwd_data(dy, dybs, w, Cin, dy.shape[2], k, dilation, causal, dy_amax)
         ctx.save_for_backward(dy, w)
+        ctx.dy_amax = dy_amax
         ctx.cfg = (k, dilation, causal)
         return dx
 
@@ -477,20 +487,22 @@ class ConvBwdDataDD(torch.autograd.Function):
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
         k, dilation, causal = ctx.cfg
-        g_dy = ConvFwdDD.apply(ddx, w, None, k, dilation, causal) if ctx.needs_input_grad[0] else None
-        g_w = ConvBwdWeightDD.apply(dy, ddx, k, dilation, causal) if ctx.needs_input_grad[1] else None
-        return g_dy, g_w, None, None, None, None
+        xa = _dd_amax(ddx)
+        g_dy = ConvFwdDD.apply(ddx, w, None, k, dilation, causal, xa) if ctx.needs_input_grad[0] else None
+        g_w = ConvBwdWeightDD.apply(dy, ddx, k, dilation, causal, ctx.dy_amax, xa) if ctx.needs_input_grad[1] else None
+        return g_dy, g_w, None, None, None, None, None
 
 
 class ConvBwdWeightDD(torch.autograd.Function):
     """dw = sum_{b,t} dy x: linear in dy and in x."""
 
     @staticmethod
-    def forward(ctx, dy, x, k, dilation, causal):
+    def forward(ctx, dy, x, k, dilation, causal, dy_amax=None, x_amax=None):
         dy, dybs = _act3(dy, "grad")
         x, xbs = _act3(x, "conv input")
-        dw = _conv_bwd_weight(dy, dybs, x, xbs, (dy.shape[1], x.shape[1], k), k, dilation, causal)
+        dw = _conv_bwd_weight(dy, dybs, x, xbs, (dy.shape[1], x.shape[1], k), k, dilation, causal, dy_amax=dy_amax, x_amax=x_amax)
         ctx.save_for_backward(dy, x)
+        ctx.amax = (dy_amax, x_amax)
         ctx.cfg = (k, dilation, causal)
         return dw
 
@@ -498,14 +510,14 @@ class ConvBwdWeightDD(torch.autograd.Function):
     def backward(ctx, ddw):
         dy, x = ctx.saved_tensors
         k, dilation, causal = ctx.cfg
-        g_dy = ConvFwdDD.apply(x, ddw, None, k, dilation, causal) if ctx.needs_input_grad[0] else None
-        g_x = ConvBwdDataDD.apply(dy, ddw, x.shape[1], k, dilation, causal) if ctx.needs_input_grad[1] else None
-        return g_dy, g_x, None, None, None
+        g_dy = ConvFwdDD.apply(x, ddw, None, k, dilation, causal, ctx.amax[1]) if ctx.needs_input_grad[0] else None
+        g_x = ConvBwdDataDD.apply(dy, ddw, x.shape[1], k, dilation, causal, ctx.amax[0]) if ctx.needs_input_grad[1] else None
+        return g_dy, g_x, None, None, None, None, None
 
 
 def conv1d_dd(x, w, bias=None, k=1, dilation=1, causal=False):
     """Conv1d (kernel 1 or 3) differentiable to any order on the HIP kernels; the bias is added in the kernel's epilogue."""
-    return ConvFwdDD.apply(x, w, bias, k, dilation, bool(causal))
+    return ConvFwdDD.apply(x, w, bias, k, dilation, bool(causal), _dd_amax(x))
 
 
 # ------------------------------------------------------------------------------------------- critics: dropout / leaky-ReLU / pooling / penalty
@@ -624,7 +636,14 @@ def act_dropout(x, slope=1.0, p=0.0):
     """dropout(leaky_relu(x, slope), p); slope = 1 and p = 0 is the identity."""
     if slope == 1.0 and p == 0.0:
         return x
-    return ActDropoutFn.apply(x, slope, p)
+    y = ActDropoutFn.apply(x, slope, p)
+    h = getattr(x, "_ssv_amax", None)
+    if h is not None and h[1] == x._version and 0.0 <= slope <= 1.0 and p <= 0.25:
+        # |leaky_relu(x)| <= |x| and the keep mask scales by 1 / (1 - p) <= 4/3: x's scale list bounds y within the factor-of-two
+        # headroom the split-fp16 scaling leaves (max |x| 2^e < 2^15 against fp16's 65504), so the convolution that reads y
+        # needs no ssv_absmax launch of its own
+        _tag(y, h[0])
+    return y
 
 
 def avg_pool1d(x, k):
@@ -652,7 +671,7 @@ class ChannelLnDD(torch.autograd.Function):
     """y = LayerNorm over channels of a (B, C, T) tensor (no activation), any use up to second order."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta):
+    def forward(ctx, x, gamma, beta, y_amax=None):
         x, xbs = _act3(x, "LayerNorm input")
         B, C, L = x.shape
         gamma, beta = _c(gamma), _c(beta)
@@ -660,14 +679,14 @@ class ChannelLnDD(torch.autograd.Function):
         stats = torch.empty((B, 2, L), dtype=_F32, device=x.device)
         nb = _lib.query("ssv_channel_ln_act_fwd_workspace", B, C, L)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_channel_ln_act_fwd", _p(x), xbs, _p(gamma), _p(beta), _p(y), C * L, None, _p(stats), B, C, L, 0, _p(ws), nb, _stream())
+        _lib.call("ssv_channel_ln_act_fwd", _p(x), xbs, _p(gamma), _p(beta), _p(y), C * L, _p(y_amax), _p(stats), B, C, L, 0, _p(ws), nb, _stream())
         ctx.save_for_backward(x, gamma, beta, stats)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, gamma, beta, stats = ctx.saved_tensors
-        return ChannelLnBwdDD.apply(gy, x, gamma, beta, stats)
+        return ChannelLnBwdDD.apply(gy, x, gamma, beta, stats) + (None,)
 
 
 class ChannelLnBwdDD(torch.autograd.Function):
@@ -710,7 +729,7 @@ class HighwayGateDD(torch.autograd.Function):
     """y = sigmoid(LN1(h[:, :C])) * LN2(h[:, C:]) + (1 - sigmoid(LN1(h[:, :C]))) * x, any use up to second order."""
 
     @staticmethod
-    def forward(ctx, h, x, g1, b1, g2, b2):
+    def forward(ctx, h, x, g1, b1, g2, b2, y_amax=None):
         x, xbs = _act3(x, "gate input")
         B, C, L = x.shape
         h = _dev(h).float().contiguous()
@@ -719,13 +738,13 @@ class HighwayGateDD(torch.autograd.Function):
         g1, b1, g2, b2 = map(_c, (g1, b1, g2, b2))
         y = torch.empty((B, C, L), dtype=_F32, device=x.device)
         stats = torch.empty((B, 4, L), dtype=_F32, device=x.device)
-        _lib.call("ssv_highway_gate_fwd", _p(h), _p(x), xbs, _p(g1), _p(b1), _p(g2), _p(b2), _p(stats), _p(y), C * L, None, B, C, L, _stream())
+        _lib.call("ssv_highway_gate_fwd", _p(h), _p(x), xbs, _p(g1), _p(b1), _p(g2), _p(b2), _p(stats), _p(y), C * L, _p(y_amax), B, C, L, _stream())
         ctx.save_for_backward(h, x, g1, b1, g2, b2, stats)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        return HighwayGateBwdDD.apply(gy, *ctx.saved_tensors)
+        return HighwayGateBwdDD.apply(gy, *ctx.saved_tensors) + (None,)
 
 
 class HighwayGateBwdDD(torch.autograd.Function):
@@ -769,11 +788,17 @@ class HighwayGateBwdDD(torch.autograd.Function):
 
 
 def channel_ln_dd(x, gamma, beta):
-    return ChannelLnDD.apply(x, gamma, beta)
+    if not (_f16() and _bf3_shape(x)):
+        return ChannelLnDD.apply(x, gamma, beta)
+    ya = _amax_out(x.shape[0], x.shape[2], x.device)
+    return _tag(ChannelLnDD.apply(x, gamma, beta, ya), ya)
 
 
 def highway_gate_dd(h, x, g1, b1, g2, b2):
-    return HighwayGateDD.apply(h, x, g1, b1, g2, b2)
+    if not (_f16() and _bf3_shape(x)):
+        return HighwayGateDD.apply(h, x, g1, b1, g2, b2)
+    ya = _amax_out(x.shape[0], x.shape[2], x.device)
+    return _tag(HighwayGateDD.apply(h, x, g1, b1, g2, b2, ya), ya)
 
 
 # ------------------------------------------------------------------------------------------- embedding

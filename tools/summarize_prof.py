@@ -135,8 +135,31 @@ def busy_share(path):
     busy += ce - cs
     span = rows[-1][1] - rows[0][0]
     aten = [r for r in rows if "at::native" in r[2]]
-    return ("\nwhole trace: %d kernels over %.3f ms, device busy %.1f %%; torch element-wise / reduction kernels (at::native::*): %d launches, %.2f %% of kernel time"
-            % (len(rows), span / 1e6, 100 * busy / span, len(aten), 100 * sum(e - s for s, e, _ in aten) / max(1.0, sum(e - s for s, e, _ in rows))))
+    out = ("\nwhole trace: %d kernels over %.3f ms, device busy %.1f %%; torch element-wise / reduction kernels (at::native::*): %d launches, %.2f %% of kernel time"
+           % (len(rows), span / 1e6, 100 * busy / span, len(aten), 100 * sum(e - s for s, e, _ in aten) / max(1.0, sum(e - s for s, e, _ in rows))))
+    # the replayed part: from the last host-side gap of more than 2 ms (warm-up / capture end there) to the end of the trace
+    i = len(rows) - 1
+    hi = rows[i][0]
+    while i > 0:
+        prev_end = max(r[1] for r in rows[max(0, i - 64):i])
+        if rows[i][0] - prev_end > 2e6:
+            break
+        i -= 1
+    tail = rows[i:]
+    if len(tail) > 100:
+        b2, cs, ce = 0.0, tail[0][0], tail[0][1]
+        for s_, e_, _ in tail[1:]:
+            if s_ > ce:
+                b2 += ce - cs
+                cs, ce = s_, e_
+            else:
+                ce = max(ce, e_)
+        b2 += ce - cs
+        sp2 = max(r[1] for r in tail) - tail[0][0]
+        at2 = [r for r in tail if "at::native" in r[2]]
+        out += ("\nreplayed part (after the last host-side gap > 2 ms): %d kernels over %.3f ms, device busy %.1f %%, idle %.2f us per kernel; at::native::* %d launches, %.2f %% of its kernel time"
+                % (len(tail), sp2 / 1e6, 100 * b2 / sp2, (sp2 - b2) / len(tail) / 1e3, len(at2), 100 * sum(e - s for s, e, _ in at2) / max(1.0, sum(e - s for s, e, _ in tail))))
+    return out
 
 
 def counters(path, name):
