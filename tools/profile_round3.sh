@@ -21,3 +21,7 @@ rm -rf /tmp/p_adv
 (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_adv -- python3 $R/tools/bench_adversarial.py > $O/adv.json 2> $O/adv.err) || echo "adv rc=$?"
 python3 $R/tools/summarize_prof.py /tmp/p_adv > $O/adversarial.txt 2>> $O/summarize.err
 head -30 $O/bench_f16x2.txt
+# the headline kernel alone, for roofline.traffic
+for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/p_h$c; (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p_h$c -- python3 $R/tools/pmc_headline.py > /dev/null 2> $O/headline_$c.err) || echo "headline $c rc=$?"; done
+python3 $R/tools/pmc_headline.py --json /tmp/p_hFETCH_SIZE /tmp/p_hWRITE_SIZE > $O/traffic_f16x2.json 2>> $O/summarize.err
+cat $O/traffic_f16x2.json
