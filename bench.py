@@ -181,7 +181,10 @@ def kernel_roofline(dev):
         wp = resident.lookup(w)
         nb = _lib.query("ssv_conv1d_fwd_workspace", C, 2 * C, k)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        run = lambda i: _lib.call("ssv_conv1d_fwd", P(xs[i]), C * L, P(xa[i]), na, P(w), wp, P(bias), None, P(ys[i]), 2 * C * L, B, C, 2 * C, L, k, 1, 1,
+        # exactly the launch the training step makes for this layer: with the column statistics of the output the streaming
+        # LayerNorm / gate kernel reads (highwayConv forward, C % 64 == 0), outside the exact-fp32 mode
+        cs = torch.empty(B * (2 * C // 64) * L * 2, device=dev) if _lib.precision() >= 1 else None
+        run = lambda i: _lib.call("ssv_conv1d_fwd", P(xs[i]), C * L, P(xa[i]), na, P(w), wp, P(bias), None, P(ys[i]), 2 * C * L, P(cs), B, C, 2 * C, L, k, 1, 1,
                                   P(ws), nb, st)
         for i in range(nset):
             run(i)

@@ -67,8 +67,12 @@ void ssv_reload_tuning(void);
  * ssv_conv_pack_multi (see "Resident pre-split weights" below) -- then the call skips its own weight split.  The
  * caller vouches that the planes are current for w. */
 size_t ssv_conv1d_fwd_workspace(int Cin, int Cout, int k);   /* holds the pre-split weights */
+/* y_colstats (may be NULL; split-MFMA modes, Cout % 64 == 0, dense y): per batch item, 64-row group of output channels and
+ * column, the mean and the sum of squared deviations of y over the group's 64 channels, (B, Cout/64, L, 2) floats -- the
+ * channel-axis LayerNorm that follows merges the groups instead of reducing over y again (ssv_highway_conv1d_fwd does). */
 int ssv_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
-                   const float* bias_b, float* y, long y_bs, int B, int Cin, int Cout, int L, int k, int dilation, int causal,
+                   const float* bias_b, float* y, long y_bs, float* y_colstats,
+                   int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                    void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* dx = conv1d_transpose(dy, w) [+ dx_add if non-NULL, same layout as dx]; ws holds w transposed. */
 size_t ssv_conv1d_bwd_data_workspace(int Cin, int Cout, int k);

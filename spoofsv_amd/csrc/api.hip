@@ -257,7 +257,7 @@ static const float* packed_inv(const void* w_packed, int Cout, int Cin, int k, i
 }
 extern "C" size_t ssv_conv1d_fwd_workspace(int Cin, int Cout, int k) { return 2 * split_bytes(Cout, Cin, k) + conv_aux_bytes(); }
 extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
-                              const float* bias_b, float* y, long y_bs,
+                              const float* bias_b, float* y, long y_bs, float* y_colstats,
                               int B, int Cin, int Cout, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes,
                               ssv_stream_t stream) {
   SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_fwd: bad argument B=%d Cin=%d Cout=%d L=%d", B, Cin, Cout, L);
@@ -267,8 +267,10 @@ extern "C" int ssv_conv1d_fwd(const float* x, long x_bs, const float* x_amax, in
   const bool bf3 = use_bf3(B, L, Cin, Cout);
   if (bf3 && (!w_packed || (use_f16() && !x_amax)))
     SSV_CHECK(ws && ws_bytes >= ssv_conv1d_fwd_workspace(Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_fwd: workspace too small");
+  SSV_CHECK(!y_colstats || (bf3 && Cout % 64 == 0 && y_bs == (long)Cout * L), SSV_UNSUPPORTED,
+            "conv1d_fwd: column statistics need a split-MFMA mode, Cout %% 64 == 0 and a dense output (Cout=%d)", Cout);
   return conv_nn(x, x_bs, w, w_packed, (long)Cin * k, k, bias, bias_b, nullptr, 0, y, y_bs, B, Cin, Cout, L, k, shift, bf3, ws, (hipStream_t)stream,
-                 packed_inv(w_packed, Cout, Cin, k, 0), x_amax, x_namax, 2 * split_bytes(Cout, Cin, k));
+                 packed_inv(w_packed, Cout, Cin, k, 0), x_amax, x_namax, 2 * split_bytes(Cout, Cin, k), y_colstats);
 }
 
 static size_t bwd_data_main(int Cin, int Cout, int k) {
@@ -471,7 +473,7 @@ extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_
                     packed_inv(w_packed, 2 * C, C, k, 0), x_amax, x_namax, 2 * split_bytes(2 * C, C, k), cs));
     return ssv_launch_ln_gate_fwd_stream(h, x, x_bs, cs, g1, b1, g2, b2, y, y_bs, stats, y_amax, B, C, L, (hipStream_t)stream);
   }
-  SSV_TRY(ssv_conv1d_fwd(x, x_bs, x_amax, x_namax, w, w_packed, bias, nullptr, h, (long)2 * C * L, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
+  SSV_TRY(ssv_conv1d_fwd(x, x_bs, x_amax, x_namax, w, w_packed, bias, nullptr, h, (long)2 * C * L, nullptr, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
   return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream, y_amax);
 }
 

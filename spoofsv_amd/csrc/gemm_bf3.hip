@@ -556,25 +556,6 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
         for (int t = 0; t < NT; ++t) stage[(kq * 4 + r) * LDW + t * 16 + nq] = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add;
       }
       // the block is private to the wave: no workgroup barrier, the LDS operations of one wave complete in order
-      if (p.colstats) {
-        // column statistics of this 16-row block: a lane reads ITS column of the parked block (consecutive lanes, consecutive
-        // words: conflict-free), two passes over 16 values in registers
-        float* cst = reinterpret_cast<float*>(lds_all) + 4 * 16 * LDW + (wave * WM + i) * BN * 2;
-#pragma unroll
-        for (int c0 = 0; c0 < BN; c0 += 64) {
-          const int c = c0 + lane;
-          if (c < BN) {
-            float v[16], sum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { v[r] = stage[r * LDW + c]; sum += v[r]; }
-            const float mean = sum * (1.f / 16.f);
-            float m2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; m2 += d * d; }
-            cst[2 * c] = mean; cst[2 * c + 1] = m2;
-          }
-        }
-      }
 #pragma unroll
       for (int it = 0; it < NT; ++it) {
         const int e = lane + 64 * it;                           // 16-byte vector index in the 16 x BN block
@@ -591,6 +572,26 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               if (gn + q < p.N) dst[q] = v[q] + (Rb ? Rb[(long)gm * p.srm + gn + q] : 0.f);
+          }
+        }
+      }
+      if (p.colstats) {
+        // (after the row stores: they are asynchronous and the kernel cannot end before they drain, so they go first)
+        // column statistics of this 16-row block: a lane reads ITS column of the parked block (consecutive lanes, consecutive
+        // words: conflict-free), two passes over 16 values in registers
+        float* cst = reinterpret_cast<float*>(lds_all) + 4 * 16 * LDW + (wave * WM + i) * BN * 2;
+#pragma unroll
+        for (int c0 = 0; c0 < BN; c0 += 64) {
+          const int c = c0 + lane;
+          if (c < BN) {
+            float v[16], sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v[r] = stage[r * LDW + c]; sum += v[r]; }
+            const float mean = sum * (1.f / 16.f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; m2 += d * d; }
+            cst[2 * c] = mean; cst[2 * c + 1] = m2;
           }
         }
       }
@@ -941,7 +942,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   const int span = smax - smin;
   SSV_CHECK(span <= 54, SSV_UNSUPPORTED, "gemm_nn_bf3: dilation halo %d exceeds 54", span);
   SSV_CHECK(!g.f16 || (!g.epi && g.a_inv && g.x_amax && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales and no LSTM epilogue");
-  SSV_CHECK(!g.colstats || (g.M % 64 == 0 && g.scn == 1 && !g.epi && !g.perm_h), SSV_BAD_SHAPE, "gemm_nn_bf3: column statistics need M %% 64 == 0 and a plain epilogue");
+  SSV_CHECK(!g.colstats || (g.M % 64 == 0 && g.scn == 1 && !g.epi && !g.perm_h && !g.R), SSV_BAD_SHAPE, "gemm_nn_bf3: column statistics need M %% 64 == 0 and a plain epilogue");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
 }
 

@@ -273,7 +273,7 @@ def _conv_fwd(x, xbs, w, bias, bias_b, y, ybs, k, dilation, causal, x_amax=None)
     B, Cin, L = x.shape
     nb = _lib.query("ssv_conv1d_fwd_workspace", Cin, w.shape[0], k)
     ws = _ws(nb, x.device)
-    _lib.call("ssv_conv1d_fwd", _p(x), xbs, *_an(x_amax), _p(w), resident.lookup(w), _p(bias), _p(bias_b), _p(y), ybs, B, Cin, w.shape[0], L,
+    _lib.call("ssv_conv1d_fwd", _p(x), xbs, *_an(x_amax), _p(w), resident.lookup(w), _p(bias), _p(bias_b), _p(y), ybs, None, B, Cin, w.shape[0], L,
               k, dilation, int(causal), _p(ws), nb, _stream())
 
 

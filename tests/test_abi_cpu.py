@@ -60,13 +60,13 @@ def test_bad_arguments_fail_before_the_device():
     null = ctypes.c_void_p(0)
     one = ctypes.c_void_p(16)           # non-null dummy, never dereferenced: the checks come first
     # empty problem -> -1
-    rc = L.ssv_conv1d_fwd(one, 0, null, 0, one, null, null, null, one, 0, 0, 4, 4, 8, 3, 1, 0, null, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 0, null, 0, one, null, null, null, one, 0, null, 0, 4, 4, 8, 3, 1, 0, null, 0, null)
     assert rc == -1 and b"conv1d_fwd" in L.ssv_last_error()
     # unsupported kernel size -> -2
-    rc = L.ssv_conv1d_fwd(one, 64, null, 0, one, null, null, null, one, 64, 1, 4, 4, 16, 5, 1, 0, null, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 64, null, 0, one, null, null, null, one, 64, null, 1, 4, 4, 16, 5, 1, 0, null, 0, null)
     assert rc == -2 and b"kernel_size" in L.ssv_last_error()
     # dilation halo beyond the staged tile -> -2
-    rc = L.ssv_conv1d_fwd(one, 64, null, 0, one, null, null, null, one, 64, 1, 4, 4, 16, 3, 28, 0, null, 0, null)
+    rc = L.ssv_conv1d_fwd(one, 64, null, 0, one, null, null, null, one, 64, null, 1, 4, 4, 16, 3, 28, 0, null, 0, null)
     assert rc == -2
     # workspace too small -> -1
     rc = L.ssv_conv1d_bwd_data(one, 64, null, 0, one, null, null, one, 64, 1, 4, 4, 16, 3, 1, 0, one, 8, null)
