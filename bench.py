@@ -204,7 +204,7 @@ def kernel_roofline(dev):
         dys = [torch.randn(B, 2 * C, L, device=dev) for _ in range(nset)]
         xa, dya = amax(xs), amax(dys)
         dw = torch.empty(2 * C, C, k, device=dev)
-        nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, C, 2 * C, k)
+        nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, C, 2 * C, L, k)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         run = lambda i: _lib.call("ssv_conv1d_bwd_weight", P(dys[i]), 2 * C * L, P(dya[i]), na, P(xs[i]), C * L, P(xa[i]), na, P(dw), B, C, 2 * C, L, k, 1, 1,
                                   P(ws), nb, st)
@@ -236,7 +236,7 @@ def kernel_roofline(dev):
             if f16:
                 t.dy_amax, t.x_amax, t.dy_namax, t.x_namax = dya_.data_ptr(), xa_.data_ptr(), dya_.numel(), xa_.numel()
         tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
-        nb = L_.query("ssv_conv1d_bwd_weight_multi_workspace", njobs, B, C, 2 * C, k)
+        nb = L_.query("ssv_conv1d_bwd_weight_multi_workspace", njobs, B, C, 2 * C, L, k)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         run = lambda: L_.call("ssv_conv1d_bwd_weight_multi", P(tdev), njobs, 2 * C * L, C * L, B, C, 2 * C, L, k, 0, 0, P(ws), nb, st)
         run(); run()

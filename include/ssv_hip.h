@@ -82,7 +82,7 @@ int ssv_conv1d_bwd_data(const float* dy, long dy_bs, const float* dy_amax, int d
                         void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* dw(o,c,j) = sum_{b,t} dy(b,o,t) x(b,c,t+(j-j0)*dilation); split over the batch into slabs, summed
  * in a fixed order (bitwise reproducible). */
-size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int k);
+size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int L, int k);
 int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* dy_amax, int dy_namax, const float* x, long x_bs, const float* x_amax, int x_namax,
                           float* dw, int B, int Cin, int Cout, int L, int k, int dilation, int causal,
                           void* ws, size_t ws_bytes, ssv_stream_t stream);
@@ -140,8 +140,8 @@ typedef struct {
 } ssv_wgrad_job;
 int ssv_conv_shifts(int k, int dilation, int causal, int* shift3);
 int ssv_conv1d_bwd_weight_multi_ok(int B, int Cin, int Cout, int L, int k);
-int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int Cout, int k);          /* the Z the entry will use */
-size_t ssv_conv1d_bwd_weight_multi_workspace(int njobs, int B, int Cin, int Cout, int k);
+int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int Cout, int L, int k);   /* the Z the entry will use */
+size_t ssv_conv1d_bwd_weight_multi_workspace(int njobs, int B, int Cin, int Cout, int L, int k);
 int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int njobs, long dy_bs, long x_bs, int B, int Cin, int Cout, int L, int k,
                                 int n2, int nblk, void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* highwayConv backward without the weight gradient: dx, plus dh (B,2C,L) dense and part (ssv_ln_partial_rows(B,L), 6C) for the job. */

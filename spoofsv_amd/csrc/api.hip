@@ -33,7 +33,7 @@ int ssv_precision() {
   return g_precision;
 }
 static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_Z", "SSV_NT_FORCE", "SSV_LSTM_SEQUENTIAL", "SSV_NNB_WIDE", "SSV_NNB_TILE",
-                                                       "SSV_NNB_FORCE", "SSV_NT_PLAN", "SSV_NN_TILE", "SSV_LN_GROUPS", "SSV_LN_NOSTREAM"};
+                                                       "SSV_NNB_FORCE", "SSV_NT_PLAN", "SSV_NN_TILE", "SSV_LN_GROUPS", "SSV_LN_NOSTREAM", "SSV_NT_OLDZ"};
 static char g_knob_val[SSV_T_COUNT][512];
 static const char* g_knob[SSV_T_COUNT];
 static int g_knobs_loaded = 0;
@@ -327,11 +327,34 @@ extern "C" int ssv_conv_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int 
   return ssv_launch_pack_multi(jobs_dev, njobs, nblocks, f16 ? (float*)ws : nullptr, (hipStream_t)stream);
 }
 
-// Number of batch slabs the weight gradient is split into: enough workgroups to fill the chip (2 per CU), no more --
-// every slab is an extra copy of the output written and read back.  SSV_NT_Z forces a count (tuning aid).
-static int dw_splits(int B, int M, int Nc, int k) {
+// Number of batch slabs Z a weight-gradient launch is cut into (njobs layers x output tiles x Z workgroups, each reducing over
+// ceil(B / Z) batch items).  The launch lasts  rounds x (items per workgroup) x (time per item)  +  Z x (slab write + read back),
+// rounds = ceil(workgroups / co-resident slots): the slots are few (2 workgroups per CU for the 128 x 64 x 3 tile = 512), so the
+// count is a matter of wave quantisation -- 640 workgroups take TWO rounds of which the second runs a quarter full (the ten
+// C = 512 / L = 186 layers of the text encoder with Z = 1: 905 us; Z = 4 -> 2,560 workgroups, 5 full rounds of 8 items: 660 us by
+// this model).  Round 2 aimed at "about 512 workgroups" whatever the remainder.  L = 0: length unknown (325 assumed).
+static int nt_slabs(long tiles_all, int njobs, int B, int L, int kt, int M, int Nc) {
+  int wm, ntc;
+  ssv_nt_bf3_tile(kt, M, Nc, &wm, &ntc);
+  const int per_cu = ssv_nt_bf3_wg_per_cu(kt, wm, ntc);
+  const long slots = 256L * per_cu;
+  if (L <= 0) L = 325;
+  // per workgroup and batch item: 2 x (64 wm) x (16 ntc) x kt x L flop at ~0.55 TFLOP/s per resident workgroup (2 per CU; scaled
+  // when more fit); per slab and job: the output written and read back at ~4 TB/s
+  const double t_item = 2.0 * 64 * wm * 16 * ntc * kt * L / (0.55e12 * 2.0 / per_cu);
+  const double t_slab = 8.0 * (double)M * Nc * kt / 4e12 * njobs;
+  int best = 1;
+  double best_t = 1e30;
+  for (int z = 1; z <= B && z <= 64; ++z) {
+    const long rounds = (tiles_all * z + slots - 1) / slots;
+    const double t = (double)rounds * ssv_cdiv(B, z) * t_item + (z > 1 ? z * t_slab : 0.0);
+    if (t < best_t * 0.98) { best_t = t; best = z; }          // ties and near-ties: the smaller count
+  }
+  return best;
+}
+static int dw_splits(int B, int M, int Nc, int k, int L = 0) {
   const int tiles = ssv_nt_bf3_tiles(k == 3 ? 3 : 1, M, Nc);
-  int z = ssv_cdiv(ssv_nt_bf3_target(k == 3 ? 3 : 1, M, Nc), tiles);
+  int z = ssv_tuning(SSV_T_NT_OLDZ) ? ssv_cdiv(ssv_nt_bf3_target(k == 3 ? 3 : 1, M, Nc), tiles) : nt_slabs(tiles, 1, B, L, k == 3 ? 3 : 1, M, Nc);
   if (const char* e = ssv_tuning(SSV_T_NT_Z)) { const int v = atoi(e); if (v > 0) z = v; }
   if (const char* e = ssv_tuning(SSV_T_NT_FORCE)) {      // "M:Nc:k=Z;..." -- one shape's slab count inside a whole step (tools/sweep_step_tiles.py)
     char key[48];
@@ -343,8 +366,8 @@ static int dw_splits(int B, int M, int Nc, int k) {
   if (z < 1) z = 1;
   return z;
 }
-static size_t bwd_weight_main(int B, int Cin, int Cout, int k) { return align256((size_t)dw_splits(B, Cout, Cin, k) * Cout * Cin * k * sizeof(float)); }
-extern "C" size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int k) { return bwd_weight_main(B, Cin, Cout, k) + 2 * AMAX_FB_BYTES; }
+static size_t bwd_weight_main(int B, int Cin, int Cout, int L, int k) { return align256((size_t)dw_splits(B, Cout, Cin, k, L) * Cout * Cin * k * sizeof(float)); }
+extern "C" size_t ssv_conv1d_bwd_weight_workspace(int B, int Cin, int Cout, int L, int k) { return bwd_weight_main(B, Cin, Cout, L, k) + 2 * AMAX_FB_BYTES; }
 // part / pgrads / n2 / nblk: partial rows of another reduction (the LayerNorm / bias gradients of the same layer) summed by the
 // SAME launch that sums the weight-gradient slabs (highwayConv backward); part == nullptr: weight gradient only.
 // dy_amax / x_amax (n entries per batch item each): the operands' scale lists for the split-fp16 arithmetic, or null (computed here).
@@ -361,11 +384,11 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
                                   int causal, void* ws, size_t ws_bytes, ssv_stream_t stream, const float* part, float* pgrads, int n2, int nblk,
                                   const float* dy_amax, int dy_namax, const float* x_amax, int x_namax) {
   SSV_CHECK(dy && x && dw && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_weight: bad argument");
-  SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_bwd_weight: workspace too small");
+  SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, L, k), SSV_BAD_SHAPE, "conv1d_bwd_weight: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   GemmNT g = nt_zero();
   SSV_TRY(conv_shifts(k, dilation, causal, g.shift));
-  const int Z = dw_splits(B, Cout, Cin, k);
+  const int Z = dw_splits(B, Cout, Cin, k, L);
   const long n = (long)Cout * Cin * k;
   g.A = dy; g.sab = dy_bs; g.sam = L; g.La = L;
   g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
@@ -374,7 +397,7 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
   if (ssv_precision() >= 1 && (long)B * L >= 256 && ssv_nt_bf3_fits(g)) {
     if (use_f16()) {
-      float* fb = (float*)((char*)ws + bwd_weight_main(B, Cin, Cout, k));
+      float* fb = (float*)((char*)ws + bwd_weight_main(B, Cin, Cout, L, k));
       AmaxList la, lx;
       SSV_TRY(amax_of(dy, dy_bs, B, (long)Cout * L, dy_amax, dy_namax, fb, &la, st));
       SSV_TRY(amax_of(x, x_bs, B, (long)Cin * L, x_amax, x_namax, fb + SSV_AMAX_FB_FLOATS, &lx, st));
@@ -399,25 +422,26 @@ extern "C" int ssv_conv1d_bwd_weight_multi_ok(int B, int Cin, int Cout, int L, i
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = 1; g.bstep = 1;
   return ssv_nt_bf3_fits(g) ? 1 : 0;
 }
-extern "C" int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int Cout, int k) {
+extern "C" int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int Cout, int L, int k) {
   const int kt = k == 3 ? 3 : 1;
-  const long tiles = (long)ssv_nt_bf3_tiles(kt, Cout, Cin) * (njobs > 0 ? njobs : 1);
-  int z = ssv_cdiv(ssv_nt_bf3_target(kt, Cout, Cin), tiles);
+  if (njobs < 1) njobs = 1;
+  const long tiles = (long)ssv_nt_bf3_tiles(kt, Cout, Cin) * njobs;
+  int z = ssv_tuning(SSV_T_NT_OLDZ) ? ssv_cdiv(ssv_nt_bf3_target(kt, Cout, Cin), tiles) : nt_slabs(tiles, njobs, B, L, kt, Cout, Cin);
   if (z > B) z = B;
   if (z < 1) z = 1;
   return z;
 }
-extern "C" size_t ssv_conv1d_bwd_weight_multi_workspace(int njobs, int B, int Cin, int Cout, int k) {
-  return align256((size_t)njobs * ssv_conv1d_bwd_weight_multi_splits(njobs, B, Cin, Cout, k) * Cout * Cin * k * sizeof(float));
+extern "C" size_t ssv_conv1d_bwd_weight_multi_workspace(int njobs, int B, int Cin, int Cout, int L, int k) {
+  return align256((size_t)njobs * ssv_conv1d_bwd_weight_multi_splits(njobs, B, Cin, Cout, L, k) * Cout * Cin * k * sizeof(float));
 }
 extern "C" int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int njobs, long dy_bs, long x_bs, int B, int Cin, int Cout, int L, int k,
                                            int n2, int nblk, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(jobs_dev && njobs > 0 && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_weight_multi: bad argument");
   SSV_CHECK(ssv_conv1d_bwd_weight_multi_ok(B, Cin, Cout, L, k), SSV_UNSUPPORTED, "conv1d_bwd_weight_multi: shape or arithmetic mode not supported");
   SSV_CHECK(n2 == 0 || nblk <= 768, SSV_UNSUPPORTED, "conv1d_bwd_weight_multi: %d partial rows (max 768)", nblk);
-  SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_weight_multi_workspace(njobs, B, Cin, Cout, k), SSV_BAD_SHAPE, "conv1d_bwd_weight_multi: workspace too small");
+  SSV_CHECK(ws && ws_bytes >= ssv_conv1d_bwd_weight_multi_workspace(njobs, B, Cin, Cout, L, k), SSV_BAD_SHAPE, "conv1d_bwd_weight_multi: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int Z = ssv_conv1d_bwd_weight_multi_splits(njobs, B, Cin, Cout, k);
+  const int Z = ssv_conv1d_bwd_weight_multi_splits(njobs, B, Cin, Cout, L, k);
   const long n = (long)Cout * Cin * k;
   GemmNT g = nt_zero();
   g.A = nullptr; g.sab = dy_bs; g.sam = L; g.La = L;
@@ -488,7 +512,7 @@ static PwWs pw_ws(int B, int Cin, int Cout, int L) {
   s.amax = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * Cout * sizeof(float));
   s.wt = s.amax + align256((size_t)B * ssv_amax_rows_(L) * sizeof(float));     // max |dpre| per LayerNorm tile (split-fp16 scales)
   s.slabs = s.wt + ssv_conv1d_bwd_data_workspace(Cin, Cout, 1);
-  s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, 1);
+  s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, Cin, Cout, L, 1);
   return s;
 }
 extern "C" size_t ssv_pointwise_conv_ln_act_bwd_workspace(int B, int Cin, int Cout, int L) { return pw_ws(B, Cin, Cout, L).total; }
@@ -558,7 +582,7 @@ static HwWs hw_ws(int B, int C, int L, int k) {
   s.amax = s.part + align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 6 * C * sizeof(float));
   s.wt = s.amax + align256((size_t)B * ssv_amax_rows_(L) * sizeof(float));      // max |dH| per LayerNorm tile (split-fp16 scales)
   s.slabs = s.wt + ssv_conv1d_bwd_data_workspace(C, 2 * C, k);
-  s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, C, 2 * C, k);
+  s.total = s.slabs + ssv_conv1d_bwd_weight_workspace(B, C, 2 * C, L, k);
   return s;
 }
 extern "C" size_t ssv_highway_conv1d_bwd_workspace(int B, int C, int L, int k) { return hw_ws(B, C, L, k).total; }

@@ -1275,6 +1275,14 @@ void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
   else if ((long)M * Nc >= (1L << 18)) { *wm = 2; *ntc = 6; }
   else { *wm = 1; *ntc = 4; }
 }
+// co-resident workgroups per CU (4 waves each, one per SIMD): 512 / VGPRs of the instantiation, as compiled for gfx950
+// (tools/kernel_regs.py: <3,2,4> 238-243, <3,2,2> 163-168, <3,1,4> 156-159, <3,1,2> 105-108, <1,2,6> 212-217, <1,2,4> 172-177,
+// <1,2,2> 131-136, <1,1,6> 153-157, <1,1,4> 121-125, <1,1,2> 89-92; the two 32 KB LDS buffers allow 4)
+int ssv_nt_bf3_wg_per_cu(int KT, int wm, int ntc) {
+  if (KT == 3) return wm == 2 ? (ntc >= 4 ? 2 : 3) : (ntc >= 4 ? 3 : 4);
+  if (wm == 2) return ntc >= 4 ? 2 : 3;
+  return ntc >= 6 ? 3 : 4;
+}
 // workgroups to aim for when choosing the number of batch slabs
 int ssv_nt_bf3_target(int KT, int M, int Nc) {
   int wm, ntc;

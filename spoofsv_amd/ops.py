@@ -199,7 +199,7 @@ class DeferredWgrad:
             if not torch.cuda.is_current_stream_capturing():
                 slot[2] = torch.cuda.Event()
                 slot[2].record()
-            nb = _lib.query("ssv_conv1d_bwd_weight_multi_workspace", n, B, Cin, Cout, k)
+            nb = _lib.query("ssv_conv1d_bwd_weight_multi_workspace", n, B, Cin, Cout, L, k)
             ws = _ws(nb, dev)
             _lib.call("ssv_conv1d_bwd_weight_multi", _p(slot[1]), n, dy_bs, x_bs, B, Cin, Cout, L, k, n2, nblk, _p(ws), nb, _stream())
         self.jobs = {}
@@ -291,7 +291,7 @@ def _conv_bwd_weight(dy, dybs, x, xbs, wshape, k=1, dilation=1, causal=0, out=No
     B, Cin, L = x.shape
     Cout = wshape[0]
     dw = out if out is not None else torch.empty(wshape, dtype=_F32, device=x.device)
-    nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, Cin, Cout, k)
+    nb = _lib.query("ssv_conv1d_bwd_weight_workspace", B, Cin, Cout, L, k)
     ws = _ws(nb, x.device)
     _lib.call("ssv_conv1d_bwd_weight", _p(dy), dybs, *_an(dy_amax), _p(x), xbs, *_an(x_amax), _p(dw), B, Cin, Cout, L, k, dilation, int(causal),
               _p(ws), nb, _stream())
