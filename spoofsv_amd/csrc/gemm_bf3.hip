@@ -26,7 +26,8 @@
 #include "ssv_common.h"
 #ifndef SSV_ABL
 #define SSV_ABL 0      // tuning builds only (WRONG results), weight-gradient kernel: 1 = without its MFMAs, 2 = dH fragments not split (raw bits
-                       // re-used as operands), 4 = input tile not split before the LDS write, 6 = both, 8 = epilogue never executed
+                       // re-used as operands), 4 = input tile not split before the LDS write, 6 = both, 8 = epilogue never executed,
+                       // 16 / 32 = every input tile / dH chunk loaded from one fixed place (L1 hits: what do the operand loads cost?)
 #endif
 #ifndef SSV_F16_ABL
 #define SSV_F16_ABL 0  // tuning builds only (results are WRONG), split-fp16 kernels: 1 = fixed scales (no scale-list read / reduction in the prologue),
@@ -251,8 +252,18 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 // sets, the chunk loop is unrolled by two).  Only the input tile, which all four waves share, is staged in LDS -- this
 // removes 2/3 of the LDS writes and 1/4 of the LDS reads of a version that staged both operands.
 // (third waves per SIMD for the small k = 1 tile: 168 VGPRs in the split-bf16 form, 174 in the split-fp16 one without the bound -- +22 % time)
+#ifndef SSV_NN_FD
+#define SSV_NN_FD 1         // LDS fragment blocks read ahead of the MFMAs (see tap())
+#endif
+#ifndef SSV_NN_STEADY3
+#define SSV_NN_STEADY3 1
+#endif
+// waves per SIMD the register allocation must leave room for
+#ifndef SSV_NNB_WAVES
+#define SSV_NNB_WAVES(KT, WM, NT, EPI) ((KT) == 1 && (WM) == 2 && (NT) == 4 && (EPI) == 0 ? 3 : 2)
+#endif
 template <int KT, int WM, int NT, int EPI, int F16>
-__global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 3 : 2) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
+__global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   static_assert(!(EPI && F16), "the LSTM epilogue runs on the split-bf16 arithmetic");
   constexpr int BM = 64 * WM, BN = 16 * NT;
   constexpr int HALO = (KT == 1) ? 0 : 54;
@@ -413,14 +424,25 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
 #pragma unroll
   for (int j = 0; j < KT; ++j) offj[j] = p.shift[j] - smin;
 
+  // The input fragments of column block t + FD are read from LDS before the MFMAs of block t are issued (2 reads, 3 WM MFMAs per
+  // block): hipcc on its own issues a block's reads right in front of its MFMAs and parks the wave for the LDS latency NT times per tap.
+  constexpr int FD = (SSV_NN_FD < NT) ? SSV_NN_FD : NT - 1;
   auto tap = [&](int set, int j, int ch) {
     const uint4* Xh = lds[ch & 1];
     const uint4* Xl = lds[ch & 1] + X_SLOTS;
+    uint4 fb[FD + 1][2];
+    auto frag = [&](int t, uint4 (&f)[2]) __attribute__((always_inline)) {
+      const int xs_ = (SSV_NN_ABL & 16) ? (kq * WX + nq) : (kq * WX + t * 16 + nq + offj[j]);
+      f[0] = Xh[xs_]; f[1] = Xl[xs_];
+    };
+#pragma unroll
+    for (int t = 0; t < FD; ++t) frag(t, fb[t]);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int xs_ = (SSV_NN_ABL & 16) ? (kq * WX + nq) : (kq * WX + t * 16 + nq + offj[j]);
-      const uint4 bh = Xh[xs_];
-      const uint4 bl = Xl[xs_];
+      if (t + FD < NT) frag(t + FD, fb[(t + FD) % (FD + 1)]);
+      if (FD > 0) __builtin_amdgcn_sched_barrier(0);                          // or the scheduler sinks the reads back to their use
+      const uint4 bh = fb[t % (FD + 1)][0];
+      const uint4 bl = fb[t % (FD + 1)][1];
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         acc[i][t] = mma16<F16>(Al_[set][j][i], bh, acc[i][t]);
@@ -432,6 +454,12 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
 
   // Prologue: chunk 0 staged, chunk 1 in flight.  Chunk c: MFMAs on image c & 1 (weight fragments of chunk c+1 re-loaded
   // tap by tap behind them), then chunk c+1 is split into the other image and the loads of chunk c+2 are issued.
+  // The loop comes in two forms: STEADY, for the chunks whose every load / commit is known to be due, has no "is there a chunk
+  // c + 2" tests -- not for the branches: hipcc's s_waitcnt bookkeeping merges over all paths, and with the prefetch under a test it
+  // waited for vmcnt(0) in front of each chunk's first MFMA, i.e. for the input loads issued a few hundred cycles earlier (one
+  // exposed L2 round trip per chunk; the weight-gradient kernel has the full story at its STEADY).  The last chunks run the tested form.
+  using ST_ = std::integral_constant<bool, true>;
+  using TL_ = std::integral_constant<bool, false>;
   if constexpr (KT == 1) {
     if (nchunks > 0) {
       loadA(0, 0, 0);
@@ -441,19 +469,25 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
       if (nchunks > 1) { prefetchX(1); loadA(1, 0, 1); }
     }
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ch += 2) {
+    auto pair = [&](auto steady, int ch) __attribute__((always_inline)) -> bool {
+      constexpr bool ST = decltype(steady)::value;
       tap(0, 0, ch);
-      if (ch + 1 >= nchunks) break;
+      if (!ST && ch + 1 >= nchunks) return false;
       commitX(ch + 1);
-      if (ch + 2 < nchunks) { prefetchX(ch + 2); loadA(0, 0, ch + 2); }
+      if (ST || ch + 2 < nchunks) { prefetchX(ch + 2); loadA(0, 0, ch + 2); }
       __syncthreads();
       tap(1, 0, ch + 1);
-      if (ch + 2 < nchunks) {
+      if (ST || ch + 2 < nchunks) {
         commitX(ch + 2);
-        if (ch + 3 < nchunks) { prefetchX(ch + 3); loadA(1, 0, ch + 3); }
+        if (ST || ch + 3 < nchunks) { prefetchX(ch + 3); loadA(1, 0, ch + 3); }
       }
       __syncthreads();
-    }
+      return true;
+    };
+    int ch = 0;
+    for (; ch + 3 < nchunks; ch += 2) pair(ST_{}, ch);
+    for (; ch < nchunks; ch += 2)
+      if (!pair(TL_{}, ch)) break;
   } else {
 #pragma unroll
     for (int j = 0; j < KT; ++j) loadA(0, j, 0);
@@ -462,8 +496,9 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
     commitX(0);
     if (nchunks > 1) prefetchX(1);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const bool more = ch + 1 < nchunks;
+    auto chunk = [&](auto steady, int ch) __attribute__((always_inline)) {
+      constexpr bool ST = decltype(steady)::value;
+      const bool more = ST || ch + 1 < nchunks;
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
         tap(0, j, ch);
@@ -472,9 +507,20 @@ __global__ __launch_bounds__(256, (KT == 1 && WM == 2 && NT == 4 && EPI == 0) ? 
       }
       if (more) {
         if (!(SSV_NN_ABL & 2)) commitX(ch + 1);
-        if (!(SSV_NN_ABL & 4) && ch + 2 < nchunks) prefetchX(ch + 2);
+        if (!(SSV_NN_ABL & 4) && (ST || ch + 2 < nchunks)) prefetchX(ch + 2);
       }
       if (!(SSV_NN_ABL & 1)) __syncthreads();
+    };
+    int ch = 0;
+    // (the steady form holds more values live: 140 -> 190 VGPRs for the 64 x 112 tile, whose hot launches are 768 workgroups and need
+    // three per CU to run in one round -- +20 % on it; the 64 x 96 tile's launches are 512 workgroups and gain 7 % from it)
+    constexpr bool STEADY3 = SSV_NN_STEADY3 && (WM == 2 || NT == 6);
+    for (; STEADY3 && ch + 2 < nchunks; ++ch) {
+      chunk(ST_{}, ch);
+      if ((SSV_NN_ABL & 64) && p.M > 0) break;
+    }
+    for (; ch < nchunks; ++ch) {
+      chunk(TL_{}, ch);
       if ((SSV_NN_ABL & 64) && p.M > 0) break;
     }
   }
@@ -957,6 +1003,18 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
 //     16 staging registers instead of 48 (staging all taps at once put the 128 x 64 x 3 tile at 256 VGPRs with spills,
 //     and every scratch reload waits for vmcnt(0), i.e. for the whole prefetch in flight).
 // Loads are issued raw, one step (input) or one chunk (A) ahead, with no branch in the prefetch (see load8/fix8).
+// Tuning builds only (-DSSV_NT_STAMP): wave 0 of workgroup 0 records s_memtime at six points of every step from step 24 on
+// (8 steps); read back with ssv_debug_nt_stamps().  Results are unaffected.
+#ifdef SSV_NT_STAMP
+__device__ unsigned long long ssv_nt_stamps[64];
+#define NT_STAMP(k) do { if (stamp_on && (unsigned)(stamp_s - 24) < 8u) ssv_nt_stamps[(stamp_s - 24) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int ssv_debug_nt_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssv_nt_stamps), sizeof(ssv_nt_stamps)); }
+#else
+#define NT_STAMP(k) do {} while (0)
+#endif
+#ifndef SSV_NT_FD
+#define SSV_NT_FD 1         // LDS fragment groups read ahead of the MFMAs (see the step loop)
+#endif
 template <int KT, int WM, int NTC, int F16>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
   constexpr int KB = 64, KG = KB / 8, KS = KB / 32;         // time steps per chunk, k-groups, MFMA k-steps
@@ -986,10 +1044,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   if (p.jobs) {
     const int job = z / p.Z;
     z -= job * p.Z;
-    const ssv_wgrad_job jb = p.jobs[job];
-    Ap = jb.dy; Xp = jb.x; Cp = p.C + (long)job * p.Z * p.scz;
-    shj[0] = jb.shift[0]; shj[1] = jb.shift[1]; shj[2] = jb.shift[2];
-    a_amax = jb.dy_amax; x_amax = jb.x_amax; a_namax = jb.dy_namax; x_namax = jb.x_namax;
+    // member by member: a by-value copy of the entry reaches the pointers through integer loads, and hipcc then knows nothing of
+    // their address space -- every operand load of this kernel was a flat_load (see ssv_global)
+    const ssv_wgrad_job* __restrict__ jb = p.jobs + job;
+    Ap = ssv_global(jb->dy); Xp = ssv_global(jb->x); Cp = p.C + (long)job * p.Z * p.scz;
+    shj[0] = jb->shift[0]; shj[1] = jb->shift[1]; shj[2] = jb->shift[2];
+    a_amax = ssv_global(jb->dy_amax); x_amax = ssv_global(jb->x_amax); a_namax = jb->dy_namax; x_namax = jb->x_namax;
   }
   // split-fp16: one power-of-two scale per operand tensor (the reduction runs over the batch), undone in the epilogue
   float as = 1.f, xs = 1.f, us = 1.f;
@@ -1025,8 +1085,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
       for (int q = 0; q < NTC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float ra[WM][KS][8], rx[2][NX][8];   // rx: two sets, the tile of step s travels in set s & 1
-  int ma[WM][KS], mx[2][NX];           // edge windows only: validity bits (low 8) | offset clamp distance << 8
+  float ra[WM][KS][8], rx[NX][8];      // raw loads in flight: the next chunk's dH windows, the tile of step s + 2
+  int ma[WM][KS], mx[NX];              // edge windows only: validity bits (low 8) | offset clamp distance << 8
   uint4 ah[WM][KS], al[WM][KS];
 
   // A window = 8 consecutive time steps of one row, at any alignment.  Element offsets are 32-bit (the launcher checks
@@ -1052,17 +1112,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 
   auto load8 = [&](const float* __restrict__ base, int off, float (&v)[8]) {
     // uniform base + zero-extended 32-bit BYTE offset (operands span < 2^30 elements): the saddr form of global_load
-    const char* __restrict__ q = reinterpret_cast<const char*>(base) + ((unsigned)off << 2);
-    const f4u a = *reinterpret_cast<const f4u*>(q);
-    const f4u c = *reinterpret_cast<const f4u*>(q + 16);
+    // address space spelled out: with operand pointers that may come from a job table hipcc emitted flat_load here (see ssv_global)
+    typedef __attribute__((address_space(1))) const char gchar;
+    typedef __attribute__((address_space(1))) const f4u gf4u;
+    gchar* q = (gchar*)reinterpret_cast<const char*>(base) + ((unsigned)off << 2);
+    const f4u a = *(gf4u*)q;
+    const f4u c = *(gf4u*)(q + 16);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
   };
-  auto load8_edge = [&](const float* __restrict__ base, int off, int span, int t, int len, bool row_ok, float (&v)[8]) -> int {
+  // Interior and edge windows are loaded by the SAME instructions (the offset clamped by one v_med3 either way): with the loads
+  // under an interior / edge branch, hipcc's waitcnt bookkeeping differed between the two paths and it drained vmcnt to 0 in front
+  // of the edge path's loads.  Only the mask (VALU) is edge-only.
+  auto load8c = [&](const float* __restrict__ base, int off, int span, float (&v)[8]) -> int {
     const int oc = min(max(off, 0), span);
     load8(base, oc, v);
+    return off - oc;
+  };
+  auto edge_meta = [&](int d, int t, int len, bool row_ok) -> int {
     const int sl = min(max(-t, 0), 8), sh = min(max(t + 8 - len, 0), 8);
     const int m = row_ok ? (int)((0xFFu << sl) & (0xFFu >> sh) & 0xFFu) : 0;
-    return m | ((off - oc) << 8);
+    return m | (d << 8);
   };
   auto split_edge = [&](const float (&raw)[8], int meta, float sc, uint4& h, uint4& l) {
     float v[8];
@@ -1099,19 +1168,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   auto x_edge = [&](int t0, int j) __attribute__((always_inline)) -> bool { return !(rows_in_c && t0 + shj[j] >= 0 && t0 + KB + shj[j] <= p.Lx); };
 
   auto loadA = [&](int b, int t0) __attribute__((always_inline)) {                                         // -> ra (/ ma)
-    const int base = b * (int)p.sab + t0;
-    if (!a_edge(t0)) {
+    const int base = (SSV_ABL & 32) ? z * (int)p.sab : b * (int)p.sab + t0;         // (tuning build: the same chunk again and again -- L1 hits)
+    int dd[WM][KS];
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) load8(Ap, base + arow[i] + s2 * 32, ra[i][s2]);
-    } else {
+      for (int s2 = 0; s2 < KS; ++s2) dd[i][s2] = load8c(Ap, base + arow[i] + s2 * 32, a_span, ra[i][s2]);
+    if (a_edge(t0)) {
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const bool ok = m0 + wave * WM * 16 + i * 16 + nq < p.M;
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2)
-          ma[i][s2] = load8_edge(Ap, base + arow[i] + s2 * 32, a_span, t0 + s2 * 32 + 8 * kq, p.La, ok, ra[i][s2]);
+        for (int s2 = 0; s2 < KS; ++s2) ma[i][s2] = edge_meta(dd[i][s2], t0 + s2 * 32 + 8 * kq, p.La, ok);
       }
     }
   };
@@ -1131,22 +1199,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
         for (int s2 = 0; s2 < KS; ++s2) split_edge(ra[i][s2], ma[i][s2], as, ah[i][s2], al[i][s2]);
     }
   };
-  auto loadX = [&](auto set, int b, int t0, int j) __attribute__((always_inline)) {                        // -> rx[set] (/ mx[set])
-    constexpr int S = decltype(set)::value;
-    const int base = b * (int)p.sxb + t0 + shj[j];
-    if (!x_edge(t0, j)) {
+  auto loadX = [&](int b, int t0, int j) __attribute__((always_inline)) {                                  // -> rx (/ mx)
+    const int base = (SSV_ABL & 16) ? z * (int)p.sxb + 64 : b * (int)p.sxb + t0 + shj[j];   // (tuning build: the same tile again and again)
+    int dd[NX];
 #pragma unroll
-      for (int r = 0; r < NX; ++r) load8(Xp, base + xrow[r], rx[S][r]);
-    } else {
+    for (int r = 0; r < NX; ++r) dd[r] = load8c(Xp, base + xrow[r], x_span, rx[r]);
+    if (x_edge(t0, j)) {
 #pragma unroll
       for (int r = 0; r < NX; ++r) {
         const int f = tid + 256 * r;
-        mx[S][r] = load8_edge(Xp, base + xrow[r], x_span, t0 + shj[j] + 8 * (f % KG), p.Lx, c0 + f / KG < p.Nc, rx[S][r]);
+        mx[r] = edge_meta(dd[r], t0 + shj[j] + 8 * (f % KG), p.Lx, c0 + f / KG < p.Nc);
       }
     }
   };
-  auto commitX = [&](auto set, int t0, int j) __attribute__((always_inline)) {                             // rx[set] -> LDS buffer `set`
-    constexpr int S = decltype(set)::value;
+  auto commitX = [&](auto buf, int t0, int j) __attribute__((always_inline)) {                             // rx -> LDS buffer `buf`
+    constexpr int S = decltype(buf)::value;
     uint4* Xh = lds[S];
     uint4* Xl = lds[S] + X_SLOTS;
     const bool edge = x_edge(t0, j);
@@ -1155,9 +1222,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       const int f = tid + 256 * r;
       const int kg = f % KG, c = f / KG;
       uint4 h, l;
-      if (SSV_ABL & 4) { h = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[S][r][0])); l = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[S][r][4])); }
-      else if (!edge) split8s<F16>(rx[S][r], xs, h, l);
-      else split_edge(rx[S][r], mx[S][r], xs, h, l);
+      if (SSV_ABL & 4) { h = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[r][0])); l = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[r][4])); }
+      else if (!edge) split8s<F16>(rx[r], xs, h, l);
+      else split_edge(rx[r], mx[r], xs, h, l);
       Xh[kg * NCH + (c ^ kg)] = h; Xl[kg * NCH + (c ^ kg)] = l;          // XOR swizzle, see the slot comment above
     }
   };
@@ -1165,53 +1232,84 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   using P1 = std::integral_constant<int, 1>;
   const int steps = total * KT;
 
-  // One chunk = KT steps (tap fastest); step s = n*KT + j uses LDS buffer and staging set s & 1.  In step s:
-  //   MFMAs of step s on buffer s&1  |  tile s+1 (loaded two steps ago) is split into buffer (s+1)&1  |  the loads of
-  //   tile s+3 are issued into the set just freed  ->  a tile's loads have two steps (~100 MFMAs per wave) to land.
-  auto chunk = [&](auto par, int n) __attribute__((always_inline)) {
+  // One chunk = KT steps (tap fastest); step s = n*KT + j uses LDS buffer s & 1.  In step s:
+  //   MFMAs of step s on buffer s&1  |  tile s+1 (loaded a step ago) is split into buffer (s+1)&1  |  the loads of tile s+2
+  //   are issued into the registers just freed  ->  a tile's loads have a barrier and a step's MFMAs (~2,000 cycles) to land.
+  // (Round 2 kept two register sets and issued tile s+3: 16 more VGPRs, and hipcc's vmcnt(0) in front of every batch -- see
+  // STEADY below -- made it wait for tile s+2 anyway.)
+  // STEADY = every commit and load of the chunk is known to be due (no "is there a step s + 3" tests).  Not for the branches
+  // saved: hipcc's s_waitcnt placement merges its bookkeeping over all paths, and the path that skips a commit leaves that
+  // tile's loads "possibly in flight" -- it then drained vmcnt to 0 in front of EVERY batch of loads (their address registers
+  // reuse the tile's), so each batch waited for the previous one to land: four exposed L2 round trips per chunk, 7,000 of a
+  // chunk's 10,000 cycles by s_memtime stamps.  The last chunks run the tested form.
+  auto chunk = [&](auto steady, auto par, int n) __attribute__((always_inline)) {
+    constexpr bool STEADY = decltype(steady)::value;
     constexpr int PAR = decltype(par)::value;                               // parity of this chunk's first step
-    const bool more = n + 1 < total;
+    const bool more = STEADY || n + 1 < total;
+#ifdef SSV_NT_STAMP
+    const bool stamp_on = blockIdx.x == 0 && blockIdx.z == 0 && tid == 0;
+#endif
     if (more) loadA(cb[1], ct0[1]);                                         // lands during this chunk's KT steps
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
       const int q_ = (PAR + j) & 1;
+#ifdef SSV_NT_STAMP
+      const int stamp_s = n * KT + j;
+#endif
+      NT_STAMP(0);
       const uint4* Xh = lds[q_];
       const uint4* Xl = lds[q_] + X_SLOTS;
+      // The input fragments of group g + FD are read from LDS BEFORE the MFMAs of group g are issued (a group = one 16-channel
+      // block of one k-step: 2 reads, 3 WM MFMAs).  Left to itself hipcc issues a group's reads right in front of its MFMAs and
+      // parks the wave on lgkmcnt for the LDS latency eight times per step -- a third of the wave's cycles by the SQ counters.
+      constexpr int G = KS * NTC;
+      uint4 fb[SSV_NT_FD + 1][2];
+      auto frag = [&](int g, uint4 (&f)[2]) __attribute__((always_inline)) {
+        const int kg = (g / NTC) * 4 + kq;
+        const int xs_ = kg * NCH + (((g % NTC) * 16 + nq) ^ kg);
+        f[0] = Xh[xs_]; f[1] = Xl[xs_];
+      };
 #pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) {
-        if (s2 > 0 && ct0[0] + 32 * s2 >= p.La) continue;                  // ragged last chunk: this k-step lies past the row end (A is zero there)
-        const int kg = s2 * 4 + kq;
+      for (int g = 0; g < SSV_NT_FD; ++g) frag(g, fb[g]);
 #pragma unroll
-        for (int q = 0; q < NTC; ++q) {
-          const int xs_ = kg * NCH + ((q * 16 + nq) ^ kg);
-          const uint4 bh = Xh[xs_];
-          const uint4 bl = Xl[xs_];
+      for (int g = 0; g < G; ++g) {
+        if (g + SSV_NT_FD < G) frag(g + SSV_NT_FD, fb[(g + SSV_NT_FD) % (SSV_NT_FD + 1)]);
+        __builtin_amdgcn_sched_barrier(0);                                   // or the scheduler sinks the reads back to their use
+        const int s2 = g / NTC, q = g % NTC;
+        if (s2 > 0 && q == 0 && ct0[0] + 32 * s2 >= p.La) break;           // ragged last chunk: the k-steps from here on lie past the row end (A is zero there)
+        const uint4 bh = fb[g % (SSV_NT_FD + 1)][0];
+        const uint4 bl = fb[g % (SSV_NT_FD + 1)][1];
 #pragma unroll
-          for (int i = 0; i < WM; ++i) {
-            const uint4 a_h = ah[i][s2];
-            const uint4 a_l = al[i][s2];
+        for (int i = 0; i < WM; ++i) {
+          const uint4 a_h = ah[i][s2];
+          const uint4 a_l = al[i][s2];
 #if (SSV_ABL & 1)
-            acc[i][j][q][0] += __builtin_bit_cast(float, a_l.x ^ bh.x ^ a_h.y ^ bl.y);
+          acc[i][j][q][0] += __builtin_bit_cast(float, a_l.x ^ bh.x ^ a_h.y ^ bl.y);
 #else
-            acc[i][j][q] = mma16<F16>(a_l, bh, acc[i][j][q]);
-            acc[i][j][q] = mma16<F16>(a_h, bl, acc[i][j][q]);
-            acc[i][j][q] = mma16<F16>(a_h, bh, acc[i][j][q]);
+          acc[i][j][q] = mma16<F16>(a_l, bh, acc[i][j][q]);
+          acc[i][j][q] = mma16<F16>(a_h, bl, acc[i][j][q]);
+          acc[i][j][q] = mma16<F16>(a_h, bh, acc[i][j][q]);
 #endif
-          }
         }
       }
+      NT_STAMP(1);
       const int c1 = (j + 1) / KT, j1 = (j + 1) % KT;                       // step s+1: chunk n + c1, tap j1
-      const int c3 = (j + 3) / KT, j3 = (j + 3) % KT;                       // step s+3
+      const int c2 = (j + 2) / KT, j2 = (j + 2) % KT;                       // step s+2
       const int s = n * KT + j;
-      if (((PAR + j) & 1) == 0) {
-        if (s + 1 < steps) commitX(P1{}, ct0[c1], j1);
-        if (s + 3 < steps) loadX(P1{}, cb[c3], ct0[c3], j3);
-      } else {
-        if (s + 1 < steps) commitX(P0{}, ct0[c1], j1);
-        if (s + 3 < steps) loadX(P0{}, cb[c3], ct0[c3], j3);
+#ifdef SSV_NT_STAMP
+      asm volatile("" : "+v"(rx[NX - 1][7]));        // the tile's last load has landed
+      NT_STAMP(6);
+#endif
+      if (STEADY || s + 1 < steps) {
+        if (((PAR + j) & 1) == 0) commitX(P1{}, ct0[c1], j1); else commitX(P0{}, ct0[c1], j1);
       }
+      NT_STAMP(2);
+      if (STEADY || s + 2 < steps) loadX(cb[c2], ct0[c2], j2);
+      NT_STAMP(3);
       if (j == KT - 1 && more) splitA(ct0[1]);
+      NT_STAMP(4);
       __syncthreads();
+      NT_STAMP(5);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { cb[k] = cb[k + 1]; ct0[k] = ct0[k + 1]; }
@@ -1219,22 +1317,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   };
 
   if (total > 0) {
-    // prologue: A of chunk 0 split, tile 0 staged, tiles 1 and 2 in flight
+    // prologue: A of chunk 0 split, tile 0 staged, tile 1 in flight
     loadA(cb[0], ct0[0]);
-    loadX(P0{}, cb[0], ct0[0], 0);
-    if (steps > 1) loadX(P1{}, cb[1 / KT], ct0[1 / KT], 1 % KT);
+    loadX(cb[0], ct0[0], 0);
     scales();
     splitA(ct0[0]);
     commitX(P0{}, ct0[0], 0);
-    if (steps > 2) loadX(P0{}, cb[2 / KT], ct0[2 / KT], 2 % KT);
+    if (steps > 1) loadX(cb[1 / KT], ct0[1 / KT], 1 % KT);
     __syncthreads();
-    if constexpr ((KT & 1) == 0) {
-      for (int n = 0; n < total; ++n) chunk(P0{}, n);
-    } else {
-      for (int n = 0; n < total; n += 2) {
-        chunk(P0{}, n);
-        if (n + 1 < total) chunk(P1{}, n + 1);
-      }
+    using ST = std::integral_constant<bool, true>;
+    using TL = std::integral_constant<bool, false>;
+    const int nfull = (steps - 2) / KT;                 // chunks n < nfull have all their steps' s + 2 < steps
+    static_assert((KT & 1) == 1, "chunk parities alternate");
+    int n = 0;
+    for (; n + 1 < nfull; n += 2) {
+      chunk(ST{}, P0{}, n);
+      chunk(ST{}, P1{}, n + 1);
+    }
+    for (; n < total; n += 2) {
+      chunk(TL{}, P0{}, n);
+      if (n + 1 < total) chunk(TL{}, P1{}, n + 1);
     }
   }
 
@@ -1276,12 +1378,12 @@ void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
   else { *wm = 1; *ntc = 4; }
 }
 // co-resident workgroups per CU (4 waves each, one per SIMD): 512 / VGPRs of the instantiation, as compiled for gfx950
-// (tools/kernel_regs.py: <3,2,4> 238-243, <3,2,2> 163-168, <3,1,4> 156-159, <3,1,2> 105-108, <1,2,6> 212-217, <1,2,4> 172-177,
-// <1,2,2> 131-136, <1,1,6> 153-157, <1,1,4> 121-125, <1,1,2> 89-92; the two 32 KB LDS buffers allow 4)
+// (-Rpass-analysis=kernel-resource-usage: <3,2,4> 238, <3,2,2> 165, <3,1,4> 154, <3,1,2> 108, <1,2,6> 208, <1,2,4> 166, <1,2,2> 136,
+// <1,1,6> 148, <1,1,4> 122, <1,1,2> 92; the two LDS buffers of the largest tile (32 KB) allow 4)
 int ssv_nt_bf3_wg_per_cu(int KT, int wm, int ntc) {
   if (KT == 3) return wm == 2 ? (ntc >= 4 ? 2 : 3) : (ntc >= 4 ? 3 : 4);
-  if (wm == 2) return ntc >= 4 ? 2 : 3;
-  return ntc >= 6 ? 3 : 4;
+  if (wm == 2) return ntc >= 6 ? 2 : 3;
+  return ntc >= 6 ? 3 : (ntc >= 4 ? 4 : 5);
 }
 // workgroups to aim for when choosing the number of batch slabs
 int ssv_nt_bf3_target(int KT, int M, int Nc) {

@@ -159,6 +159,12 @@ __device__ __forceinline__ void ssv_pow2_scale(float amax, float& scale, float& 
   inv = __uint_as_float((unsigned)(E - 14) << 23);
 }
 // a value every lane of the wave holds (hipcc cannot prove it after an LDS round trip) -> a scalar register
+// A pointer READ FROM MEMORY (a job table) is a generic pointer to hipcc: it emits flat_load / flat_store, which count on vmcnt AND
+// lgkmcnt and return out of order, so every wait on them -- and every wait on an LDS read issued after them -- becomes
+// vmcnt(0) lgkmcnt(0): no load stays in flight across a use.  Kernel arguments are known to be global; this says so for the rest.
+template <class T> __device__ __forceinline__ T* ssv_global(T* p) {
+  return (T*)(__attribute__((address_space(1))) T*)p;
+}
 __device__ __forceinline__ float ssv_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 // maximum of a per-thread value over the workgroup (NW waves); sm: NW floats of LDS nobody else uses around the call
 template <int NW>

@@ -12,6 +12,8 @@ What each piece replaces in the reference:
 """
 import ctypes
 import os
+import contextlib
+import gc
 
 import numpy as np
 import torch
@@ -41,6 +43,23 @@ def guided_attention_mat(max_text_len, max_frame_num, device=None, g=0.2):
 # --------------------------------------------------------------------------------------------- Adam
 _CHUNK = 32768
 
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a stream capture is in progress.  A collection can start at any allocation, in any thread
+    (autograd's backward thread included), and finalise objects of EARLIER captures -- a CUDAGraph and its private pool kept alive by a
+    reference cycle -- whose destructors free device memory: not allowed during a capture, and an error thrown in a destructor
+    aborts the process (seen once in the GPU suite: 'Fatal Python error: Aborted ... Garbage-collecting' inside a backward
+    under capture).  Collect first, then hold the collector off until the capture has ended."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (no weight decay / amsgrad, as the reference uses it), all parameters
@@ -510,7 +529,7 @@ class PhasedStep:
             g = torch.cuda.CUDAGraph()
             # thread_local: only THIS thread's calls are checked against the capture; the communication back end's helper
             # threads (see above) may touch the device while a later iteration's capture is in progress
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            with _no_gc(), torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 for _, f in self.phases[i:j]:
                     f()
             plan.append(g.replay)
