@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void reduce_pair_multi_kernel(const ssv_wgrad_
     return;
   }
   if (!jb.part) return;
-  const float* __restrict__ part = jb.part;
+  const __attribute__((address_space(1))) float* __restrict__ part = (const __attribute__((address_space(1))) float*)jb.part;   // (table pointer: see ssv_global)
   const int li = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int i = ((int)blockIdx.x - nA) * 32 + li;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -381,12 +381,33 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const ssv_adam_chunk* _
   // 16-byte accesses when the four pointers allow it (28 B/param of pure streaming: this kernel is HBM-bound)
   if ((((uintptr_t)ch.p | (uintptr_t)ch.g | (uintptr_t)ch.m | (uintptr_t)ch.v) & 15) == 0) {
     const long n4 = ch.n >> 2;
-    float4* __restrict__ p4 = (float4*)ch.p; const float4* __restrict__ g4 = (const float4*)ch.g;
-    float4* __restrict__ m4 = (float4*)ch.m; float4* __restrict__ v4 = (float4*)ch.v;
-    for (long i = threadIdx.x; i < n4; i += 256) {
-      float4 p = p4[i], m = m4[i], v = v4[i];
-      const float4 g = g4[i];
-      upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+    // The pointers come from the chunk table, i.e. from memory: spelled out as global, or hipcc emits flat_load / flat_store
+    // (see ssv_global in ssv_common.h).  Two elements per thread in flight: eight 16-byte loads before the first use.
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    auto upd4 = [&](vf4& p, const vf4 g, vf4& m, vf4& v) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float pp = p[k], mm = m[k], vv = v[k];
+        upd(pp, g[k], mm, vv);
+        p[k] = pp; m[k] = mm; v[k] = vv;
+      }
+    };
+    typedef __attribute__((address_space(1))) vf4 gf4;
+    gf4* __restrict__ p4 = (gf4*)ch.p; const gf4* __restrict__ g4 = (const gf4*)ch.g;
+    gf4* __restrict__ m4 = (gf4*)ch.m; gf4* __restrict__ v4 = (gf4*)ch.v;
+    long i = threadIdx.x;
+    for (; i + 256 < n4; i += 512) {
+      vf4 p = p4[i], m = m4[i], v = v4[i], q = p4[i + 256], n = m4[i + 256], w = v4[i + 256];
+      const vf4 g = g4[i], h = g4[i + 256];
+      upd4(p, g, m, v);
+      upd4(q, h, n, w);
+      p4[i] = p; m4[i] = m; v4[i] = v;
+      p4[i + 256] = q; m4[i + 256] = n; v4[i + 256] = w;
+    }
+    for (; i < n4; i += 256) {
+      vf4 p = p4[i], m = m4[i], v = v4[i];
+      const vf4 g = g4[i];
+      upd4(p, g, m, v);
       p4[i] = p; m4[i] = m; v4[i] = v;
     }
     i0 = n4 << 2;
