@@ -303,6 +303,9 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 #ifndef SSV_NN_FD
 #define SSV_NN_FD 1         // LDS fragment blocks read ahead of the MFMAs (see tap())
 #endif
+#ifndef SSV_NN_FD_BIG
+#define SSV_NN_FD_BIG 1     // ... of the 128-row k = 3 tiles
+#endif
 #ifndef SSV_NN_STEADY3
 #define SSV_NN_STEADY3 1
 #endif
@@ -377,14 +380,13 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   unsigned arowb[WM];
 #pragma unroll
   for (int i = 0; i < WM; ++i) arowb[i] = (unsigned)(arow[i] * 2);
+  const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(p.Ahi + (long)b * p.sab), rsAl = ssv_buf(p.Alo + (long)b * p.sab);   // (see ssv_buf)
   auto loadA = [&](int set, int j, int ch) {
-    const long ub = ((long)b * p.sab + j * aplane + (long)ch * 512) * 2;                                  // wave-uniform
-    const char* __restrict__ hb = reinterpret_cast<const char*>(p.Ahi) + ub;
-    const char* __restrict__ lb = reinterpret_cast<const char*>(p.Alo) + ub;
+    const unsigned ub = (unsigned)((j * aplane + (long)ch * 512) * 2);                                  // wave-uniform byte offset
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-      Ah_[set][j][i] = *reinterpret_cast<const uint4*>(hb + arowb[i]);
-      Al_[set][j][i] = *reinterpret_cast<const uint4*>(lb + arowb[i]);
+      Ah_[set][j][i] = ssv_buf_u4(rsAh, arowb[i], ub);
+      Al_[set][j][i] = ssv_buf_u4(rsAl, arowb[i], ub);
     }
   };
   // Input staging, two halves.  prefetchX only ISSUES loads (raw values, addresses clamped into the batch item so every
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   //   [Xb + (ch*32 + i)*L]  (wave-uniform, scalar ALU)  +  [8*kg*L + column]  (per thread, computed once),
   // and the column mask is computed once; only a ragged last chunk (Kc % 32 != 0) needs per-channel clamps and masks.
   const int Lrow = (int)p.sxc;
+  const __amdgpu_buffer_rsrc_t rsX = ssv_buf(Xb), rsX2 = ssv_buf(X2b ? X2b : Xb);        // (see ssv_buf)
   unsigned voff[NX], voffb[NX];
   bool cvs[NX];
 #pragma unroll
@@ -403,8 +406,8 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     const int gcol = n0 + smin + col;
     cvs[r] = e < X_SLOTS && col < W && gcol >= 0 && gcol < p.Lx;
     voff[r] = (unsigned)((e < X_SLOTS ? 8 * kg : 0) * Lrow + min(max(gcol, 0), p.Lx - 1) * p.sxn);
-    voffb[r] = voff[r] * 4u;           // BYTE offset: a zero-extended 32-bit VGPR offset off a uniform base is the saddr form of
-  }                                    // global_load (no 64-bit VALU address per load, no VGPR pair per address)
+    voffb[r] = voff[r] * 4u;           // BYTE offset of the buffer load (a row's offset is added as its scalar operand)
+  }
   const bool ragged = (p.Kc & 31) != 0;
   // split-fp16: xs = 2^ex scales the input while it is split, us = 2^-(ea + ex) the accumulators in the epilogue
   float xs = 1.f, us = 1.f;
@@ -427,11 +430,12 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   };
   auto prefetchX = [&](int ch) {
     if (!ragged || ch + 1 < nchunks) {
+      const bool seg2 = EPI == 1 && X2b && ch >= p.xsplit;                       // (LSTM: the h_{t-1} segment of K)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const char* __restrict__ rowp = (const char*)(((EPI == 1 && X2b && ch >= p.xsplit) ? X2b : Xb) + (long)(ch * 32 + i) * Lrow);     // uniform
+        const unsigned so = (unsigned)((ch * 32 + i) * Lrow) * 4u;              // uniform row offset: scalar arithmetic
 #pragma unroll
-        for (int r = 0; r < NX; ++r) rx[r][i] = *reinterpret_cast<const float*>(rowp + voffb[r]);
+        for (int r = 0; r < NX; ++r) rx[r][i] = (EPI == 1 && seg2) ? ssv_buf_f32(rsX2, voffb[r], so) : ssv_buf_f32(rsX, voffb[r], so);
       }
     } else {                                                                   // last, partial chunk: clamp channels
 #pragma unroll
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
         const int kg = (e < X_SLOTS) ? e / WX : 0;
         const unsigned colo = voff[r] - (unsigned)(8 * kg * Lrow);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rx[r][i] = Xb[(long)min(ch * 32 + 8 * kg + i, p.Kc - 1) * Lrow + colo];
+        for (int i = 0; i < 8; ++i) rx[r][i] = ssv_buf_f32(rsX, ((unsigned)min(ch * 32 + 8 * kg + i, p.Kc - 1) * (unsigned)Lrow + colo) * 4u, 0u);
       }
     }
   };
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
 
   // The input fragments of column block t + FD are read from LDS before the MFMAs of block t are issued (2 reads, 3 WM MFMAs per
   // block): hipcc on its own issues a block's reads right in front of its MFMAs and parks the wave for the LDS latency NT times per tap.
-  constexpr int FD = (SSV_NN_FD < NT) ? SSV_NN_FD : NT - 1;
+  constexpr int FD = (KT == 3 && WM == 2 && NT >= 6) ? SSV_NN_FD_BIG : (SSV_NN_FD < NT) ? SSV_NN_FD : NT - 1;
   auto tap = [&](int set, int j, int ch) {
     const uint4* Xh = lds[ch & 1];
     const uint4* Xl = lds[ch & 1] + X_SLOTS;
@@ -800,19 +804,23 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
   const bool ragged = (p.Kc & 31) != 0;
   float xs = 1.f, us = 1.f;           // split-fp16 scales, see gemm_nn_bf3_kernel
 
+  // buffer loads (see ssv_buf): per-thread byte offsets fixed for the kernel, the chunk / row offset a scalar operand
+  const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(p.Ahi), rsAl = ssv_buf(p.Alo), rsX = ssv_buf(Xb);
+  unsigned aoffb[NA];
+#pragma unroll
+  for (int r = 0; r < NA; ++r) aoffb[r] = (unsigned)(a_off(r) * 2);
   auto prefetch = [&](int ch) {
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
-      const long o = a_off(r) + ch * 512;
-      rah[r] = *reinterpret_cast<const uint4*>(p.Ahi + o);
-      ral[r] = *reinterpret_cast<const uint4*>(p.Alo + o);
+      rah[r] = ssv_buf_u4(rsAh, aoffb[r], (unsigned)ch * 1024u);
+      ral[r] = ssv_buf_u4(rsAl, aoffb[r], (unsigned)ch * 1024u);
     }
     if (!ragged || ch + 1 < nchunks) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const char* __restrict__ rowp = reinterpret_cast<const char*>(Xb + (long)(ch * 32 + i) * Lrow);     // wave-uniform
+        const unsigned so = (unsigned)((ch * 32 + i) * Lrow) * 4u;                                     // wave-uniform row offset
 #pragma unroll
-        for (int r = 0; r < NX; ++r) rx[r][i] = *reinterpret_cast<const float*>(rowp + voff[r] * 4u);      // saddr form (see gemm_nn_bf3_kernel)
+        for (int r = 0; r < NX; ++r) rx[r][i] = ssv_buf_f32(rsX, voff[r] * 4u, so);
       }
     } else {
 #pragma unroll
@@ -821,7 +829,7 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
         const int kg = (e < X_SLOTS) ? e / WX : 0;
         const unsigned colo = voff[r] - (unsigned)(8 * kg * Lrow);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rx[r][i] = Xb[(long)min(ch * 32 + 8 * kg + i, p.Kc - 1) * Lrow + colo];
+        for (int i = 0; i < 8; ++i) rx[r][i] = ssv_buf_f32(rsX, ((unsigned)min(ch * 32 + 8 * kg + i, p.Kc - 1) * (unsigned)Lrow + colo) * 4u, 0u);
       }
     }
   };
@@ -1035,6 +1043,9 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   for (int j = 1; j < g.KT; ++j) { smin = g.shift[j] < smin ? g.shift[j] : smin; smax = g.shift[j] > smax ? g.shift[j] : smax; }
   const int span = smax - smin;
   SSV_CHECK(span <= 54, SSV_UNSUPPORTED, "gemm_nn_bf3: dilation halo %d exceeds 54", span);
+  // the kernels address one batch item's input rows and the weight planes with 32-bit byte offsets (buffer loads)
+  SSV_CHECK(((long)g.Kpad * g.sxc + (long)g.Lx * (g.sxn > 0 ? g.sxn : 1)) * 4 < (1L << 31) && (long)g.KT * ((g.M + 15) / 16) * (g.Kpad / 32) * 1024 < (1L << 31),
+            SSV_UNSUPPORTED, "gemm_nn_bf3: a batch item's input or the weight planes span 2 GiB or more");
   SSV_CHECK(!g.f16 || (!g.epi && g.a_inv && g.x_amax && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales and no LSTM epilogue");
   SSV_CHECK(!g.colstats || (g.M % 64 == 0 && g.scn == 1 && !g.epi && !g.perm_h && !g.R), SSV_BAD_SHAPE, "gemm_nn_bf3: column statistics need M %% 64 == 0 and a plain epilogue");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);

@@ -159,6 +159,20 @@ __device__ __forceinline__ void ssv_pow2_scale(float amax, float& scale, float& 
   inv = __uint_as_float((unsigned)(E - 14) << 23);
 }
 // a value every lane of the wave holds (hipcc cannot prove it after an LDS round trip) -> a scalar register
+// Buffer loads: uniform 128-bit resource (base address in SGPRs) + 32-bit VGPR byte offset + 32-bit SGPR byte offset.  Used where a
+// loop loads many streams off one base: with plain pointers hipcc's strength reduction keeps a 64-bit VGPR pointer PER STREAM
+// (24 input-row streams of the conv kernel = 48 VGPRs and 48 VALU adds per chunk); here a stream costs nothing -- its row offset is
+// scalar arithmetic.  num_records = 2^32 - 1: no range check is relied on, callers clamp as before.
+typedef unsigned ssv_u32x4g __attribute__((vector_size(16)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ssv_buf(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float ssv_buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ uint4 ssv_buf_u4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
 // A pointer READ FROM MEMORY (a job table) is a generic pointer to hipcc: it emits flat_load / flat_store, which count on vmcnt AND
 // lgkmcnt and return out of order, so every wait on them -- and every wait on an LDS read issued after them -- becomes
 // vmcnt(0) lgkmcnt(0): no load stays in flight across a use.  Kernel arguments are known to be global; this says so for the rest.
