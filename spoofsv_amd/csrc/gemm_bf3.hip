@@ -303,6 +303,13 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 #ifndef SSV_NN_FD
 #define SSV_NN_FD 1         // LDS fragment blocks read ahead of the MFMAs (see tap())
 #endif
+#ifndef SSV_NN_XBUF
+#define SSV_NN_XBUF(KT, WM, NT) (!((KT) == 3 && (NT) == 6))   // input rows by buffer loads (ssv_buf) or through pointers: in-step, per tile -- the k = 1
+                                                             // tiles are 5-12 % faster with buffer loads, the 96-column k = 3 tiles 4-6 % with pointers, the rest equal
+#endif
+#ifndef SSV_NN_ABUF
+#define SSV_NN_ABUF(KT, WM, NT) 1                             // weight fragments: buffer loads everywhere (equal or 1-3 % faster)
+#endif
 #ifndef SSV_NN_FD_BIG
 #define SSV_NN_FD_BIG 1     // ... of the 128-row k = 3 tiles
 #endif
@@ -383,10 +390,20 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(p.Ahi + (long)b * p.sab), rsAl = ssv_buf(p.Alo + (long)b * p.sab);   // (see ssv_buf)
   auto loadA = [&](int set, int j, int ch) {
     const unsigned ub = (unsigned)((j * aplane + (long)ch * 512) * 2);                                  // wave-uniform byte offset
+    if constexpr (SSV_NN_ABUF(KT, WM, NT)) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      Ah_[set][j][i] = ssv_buf_u4(rsAh, arowb[i], ub);
-      Al_[set][j][i] = ssv_buf_u4(rsAl, arowb[i], ub);
+      for (int i = 0; i < WM; ++i) {
+        Ah_[set][j][i] = ssv_buf_u4(rsAh, arowb[i], ub);
+        Al_[set][j][i] = ssv_buf_u4(rsAl, arowb[i], ub);
+      }
+    } else {
+      const char* __restrict__ hb = reinterpret_cast<const char*>(p.Ahi + (long)b * p.sab) + ub;
+      const char* __restrict__ lb = reinterpret_cast<const char*>(p.Alo + (long)b * p.sab) + ub;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        Ah_[set][j][i] = *reinterpret_cast<const uint4*>(hb + arowb[i]);
+        Al_[set][j][i] = *reinterpret_cast<const uint4*>(lb + arowb[i]);
+      }
     }
   };
   // Input staging, two halves.  prefetchX only ISSUES loads (raw values, addresses clamped into the batch item so every
@@ -433,9 +450,15 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
       const bool seg2 = EPI == 1 && X2b && ch >= p.xsplit;                       // (LSTM: the h_{t-1} segment of K)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const unsigned so = (unsigned)((ch * 32 + i) * Lrow) * 4u;              // uniform row offset: scalar arithmetic
+        if constexpr (SSV_NN_XBUF(KT, WM, NT)) {
+          const unsigned so = (unsigned)((ch * 32 + i) * Lrow) * 4u;              // uniform row offset: scalar arithmetic
 #pragma unroll
-        for (int r = 0; r < NX; ++r) rx[r][i] = (EPI == 1 && seg2) ? ssv_buf_f32(rsX2, voffb[r], so) : ssv_buf_f32(rsX, voffb[r], so);
+          for (int r = 0; r < NX; ++r) rx[r][i] = (EPI == 1 && seg2) ? ssv_buf_f32(rsX2, voffb[r], so) : ssv_buf_f32(rsX, voffb[r], so);
+        } else {
+          const char* __restrict__ rowp = (const char*)((seg2 ? X2b : Xb) + (long)(ch * 32 + i) * Lrow);     // uniform
+#pragma unroll
+          for (int r = 0; r < NX; ++r) rx[r][i] = *reinterpret_cast<const float*>(rowp + voffb[r]);
+        }
       }
     } else {                                                                   // last, partial chunk: clamp channels
 #pragma unroll
@@ -566,7 +589,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     int ch = 0;
     // (the steady form holds more values live: 140 -> 190 VGPRs for the 64 x 112 tile, whose hot launches are 768 workgroups and need
     // three per CU to run in one round -- +20 % on it; the 64 x 96 tile's launches are 512 workgroups and gain 7 % from it)
-    constexpr bool STEADY3 = SSV_NN_STEADY3 && (WM == 2 || NT == 6);
+    constexpr bool STEADY3 = SSV_NN_STEADY3 != 0;
     for (; STEADY3 && ch + 2 < nchunks; ++ch) {
       chunk(ST_{}, ch);
       if ((SSV_NN_ABL & 64) && p.M > 0) break;
