@@ -1098,7 +1098,7 @@ extern "C" int ssv_debug_nt_stamps(unsigned long long* out) { return (int)hipMem
 #define SSV_NT_FD 1         // LDS fragment groups read ahead of the MFMAs (see the step loop)
 #endif
 template <int KT, int WM, int NTC, int F16>
-__global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
   constexpr int KB = 64, KG = KB / 8, KS = KB / 32;         // time steps per chunk, k-groups, MFMA k-steps
   constexpr int NCH = 16 * NTC;
   constexpr int X_SLOTS = KG * NCH;                         // 16-byte slots of one tap's tile (multiple of 256)
@@ -1446,9 +1446,8 @@ __global__ __launch_bounds__(256, WM == 4 ? 1 : 2) void gemm_nt_bf3_kernel(const
 void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
   int a = 0, c = 0;
   if (const char* e = ssv_tuning(SSV_T_NT_PLAN)) {
-    if (sscanf(e, "%d,%d", &a, &c) == 2 && (a == 1 || a == 2 || a == 4) && (c == 2 || c == 4 || c == 6)) {
+    if (sscanf(e, "%d,%d", &a, &c) == 2 && (a == 1 || a == 2) && (c == 2 || c == 4 || c == 6)) {
       if (KT == 3 && c == 6) c = 4;
-      if (a == 4 && !(KT == 3 && c == 4)) a = 2;
       *wm = a; *ntc = c;
       return;
     }
@@ -1464,7 +1463,6 @@ void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
 // (-Rpass-analysis=kernel-resource-usage: <3,2,4> 238, <3,2,2> 165, <3,1,4> 154, <3,1,2> 108, <1,2,6> 208, <1,2,4> 166, <1,2,2> 136,
 // <1,1,6> 148, <1,1,4> 122, <1,1,2> 92; the two LDS buffers of the largest tile (32 KB) allow 4)
 int ssv_nt_bf3_wg_per_cu(int KT, int wm, int ntc) {
-  if (wm == 4) return 1;
   if (KT == 3) return wm == 2 ? (ntc >= 4 ? 2 : 3) : (ntc >= 4 ? 3 : 4);
   if (wm == 2) return ntc >= 6 ? 2 : 3;
   return ntc >= 6 ? 3 : (ntc >= 4 ? 4 : 5);
@@ -1512,7 +1510,7 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
     if (g.f16) hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_, 1>), grid, dim3(256), 0, st, g, mtiles); \
     else hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_, 0>), grid, dim3(256), 0, st, g, mtiles); \
     return ssv_check_launch("gemm_nt_bf3"); }
-  SSV_NT(3, 4, 4) SSV_NT(3, 2, 4) SSV_NT(3, 2, 2) SSV_NT(3, 1, 4) SSV_NT(3, 1, 2)
+  SSV_NT(3, 2, 4) SSV_NT(3, 2, 2) SSV_NT(3, 1, 4) SSV_NT(3, 1, 2)
   SSV_NT(1, 2, 6) SSV_NT(1, 2, 4) SSV_NT(1, 2, 2) SSV_NT(1, 1, 6) SSV_NT(1, 1, 4) SSV_NT(1, 1, 2)
 #undef SSV_NT
   return ssv_fail(SSV_UNSUPPORTED, "gemm_nt_bf3: no tile %d,%d for kernel size %d", wm, ntc, g.KT);
