@@ -231,6 +231,9 @@ size_t ssv_deconv1d_k2s2_fwd_workspace(int Cin, int Cout);   /* pre-split weight
 int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const float* bias, float* y, long y_bs,
                           int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout);
+/* dw may be NULL: the weight gradient is then left to the caller -- dw[:, :, j] is the k = 1 conv weight gradient of
+ * (dy' = x, x' = dy[:, :, j::2]) and runs on the split-precision kernel through ssv_conv1d_bwd_weight once dy is de-interleaved,
+ * which the stride-2 operand of this entry's own product (an exact-fp32 MFMA kernel) cannot; spoofsv_amd/ops.py does so. */
 int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* dy_amax, int dy_namax, const float* x, long x_bs, const float* w,
                           float* dx, long dx_bs, float* dw, float* dbias,
                           int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);

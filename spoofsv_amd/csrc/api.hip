@@ -772,7 +772,7 @@ extern "C" size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout) {
 }
 extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* dy_amax, int dy_namax, const float* x, long x_bs, const float* w, float* dx, long dx_bs,
                                      float* dw, float* dbias, int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
-  SSV_CHECK(dy && x && w && dx && dw && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "deconv1d_k2s2_bwd: bad argument");
+  SSV_CHECK(dy && x && w && dx && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "deconv1d_k2s2_bwd: bad argument");      // dw may be NULL: see the header
   SSV_CHECK(ws && ws_bytes >= ssv_deconv1d_k2s2_bwd_workspace(B, Cin, Cout), SSV_BAD_SHAPE, "deconv1d_k2s2_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int Z = deconv_splits(B, Cin, Cout);
@@ -810,6 +810,7 @@ extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* d
       g.M = Cin; g.N = L; g.Kc = Cout; g.B = B;
       SSV_TRY(ssv_launch_gemm_nn(g, st));
     }
+    if (!dw) continue;
     GemmNT t = nt_zero();                      // dw[c,o,j] = sum_{b,t} x(b,c,t) dy(b,o,2t+j)
     t.A = x; t.sab = x_bs; t.sam = L; t.La = L;
     t.X = dy + j; t.sxb = dy_bs; t.sxc = (long)2 * L; t.sxn = 2; t.Lx = L;
@@ -817,7 +818,7 @@ extern "C" int ssv_deconv1d_k2s2_bwd(const float* dy, long dy_bs, const float* d
     t.M = Cin; t.Nc = Cout; t.B = B; t.Z = Z; t.bstep = Z;
     SSV_TRY(ssv_launch_gemm_nt(t, st));
   }
-  if (Z > 1) SSV_TRY(ssv_launch_reduce_slabs(slabs, dw, n, Z, n, st));
+  if (dw && Z > 1) SSV_TRY(ssv_launch_reduce_slabs(slabs, dw, n, Z, n, st));
   if (dbias) {
     SSV_TRY(ssv_rowsum(dy, dy_bs, rs, B, Cout, 2 * L, stream));
     SSV_TRY(ssv_launch_reduce_slabs(rs, dbias, Cout, B, Cout, st));

@@ -955,8 +955,20 @@ class DeconvK2S2Fn(torch.autograd.Function):
         db = gradarena.grad_like(ctx.bias_ref)
         nb = _lib.query("ssv_deconv1d_k2s2_bwd_workspace", B, Cin, Cout)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, None, 0, _p(x), xbs, _p(w), _p(dx), Cin * L, _p(dw), _p(db),
+        # Weight gradient: dw[c, o, j] = sum_{b,t} x(b,c,t) dy(b,o,2t+j).  The entry's own product reads dy with stride 2, which only the
+        # exact-fp32 MFMA kernel takes (60 us per tap at C = 256, L = 650).  De-interleaved (one copy kernel), each tap is the k = 1 conv
+        # weight gradient of (dy' = x, x' = dy_j) and runs on the split-precision kernel; the entry is then told to skip dw.
+        split = _lib.precision() >= 1 and B * L >= 256 and L >= 8 and dybs == Cout * 2 * L
+        dy_am = amax_of(dy) if split else None
+        _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, *_an(dy_am), _p(x), xbs, _p(w), _p(dx), Cin * L, None if split else _p(dw), _p(db),
                   B, Cin, Cout, L, _p(ws), nb, _stream())
+        if split:
+            dyj = dy.view(B, Cout, L, 2).permute(3, 0, 1, 2).contiguous()            # (2, B, Cout, L)
+            x_am = amax_of(x)
+            dwj = torch.empty((2, Cin, Cout), dtype=_F32, device=x.device)
+            for j in range(2):
+                _conv_bwd_weight(x, xbs, dyj[j], Cout * L, (Cin, Cout, 1), 1, 1, 0, dwj[j].view(Cin, Cout, 1), x_am, dy_am)
+            dw.copy_(dwj.permute(1, 2, 0))
         return dx, dw, db, None
 
 
