@@ -160,9 +160,15 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_stream_kernel(
     if (t < L) {
       const int P = C >> 6, MG = 2 * P;
       const float* __restrict__ q = cst + (((long)b * MG + half * P) * L + t) * 2;
+      // all (mean, M2) pairs of the column loaded before the first is used: clamped index, no branch around a load (with the loads
+      // under `i < P` hipcc issued them one by one, each behind a wait for the one before: P dependent round trips at the head of a 12-us kernel)
+      typedef float f2ln __attribute__((ext_vector_type(2), aligned(8)));
+      f2ln pr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pr[i] = *reinterpret_cast<const f2ln*>(q + (long)min(i, P - 1) * L * 2);
       float mu[8], mean = 0.f, m2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { mu[i] = 0.f; if (i < P) { mu[i] = q[(long)i * L * 2]; mean += mu[i]; m2 += q[(long)i * L * 2 + 1]; } }
+      for (int i = 0; i < 8; ++i) { mu[i] = i < P ? pr[i].x : 0.f; mean += mu[i]; m2 += i < P ? pr[i].y : 0.f; }
       mean /= (float)P;
 #pragma unroll
       for (int i = 0; i < 8; ++i) if (i < P) { const float d = mu[i] - mean; m2 += 64.f * d * d; }
