@@ -192,7 +192,12 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x
   const int b = row / C, c = row % C;
   const float* p = x + (long)b * x_bs + (long)c * L;
   float s = 0.f;
-  for (int t = lane; t < L; t += 64) s += p[t];
+  int t = lane;
+  for (; t + 192 < L; t += 256) {                    // four loads in flight (one at a time, each behind a wait, as a plain loop); same order of adds
+    const float v0 = p[t], v1 = p[t + 64], v2 = p[t + 128], v3 = p[t + 192];
+    s += v0; s += v1; s += v2; s += v3;
+  }
+  for (; t < L; t += 64) s += p[t];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) out[row] = s;
