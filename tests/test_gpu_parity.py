@@ -439,6 +439,43 @@ def test_ge2e_backward_midsize_vs_oracle():
         assert rel_err(p.grad, sd[k].grad) < 2e-3, (k, rel_err(p.grad, sd[k].grad))
 
 
+@pytest.mark.parametrize("B,C,L", [(32, 256, 325), (3, 64, 37), (2, 24, 9)])
+def test_deconv_k2s2_forward_backward_vs_float64_and_both_weight_gradient_routes(B, C, L, precision):
+    """upsampling.deconv (models/TTSModel.py:309,314 = nn.ConvTranspose1d(C, C, 2, stride=2)) against torch's float64 conv_transpose1d
+    on the CPU: y, dx, dw, db.  In the split modes ops.py computes dw as two k = 1 conv weight gradients on de-interleaved dy and tells
+    ssv_deconv1d_k2s2_bwd to skip it (dw = NULL); the entry's own stride-2 product is checked beside it through the ABI."""
+    from spoofsv_amd import ops, _lib
+    torch.manual_seed(B + C + L)
+    x0, w0, b0 = torch.randn(B, C, L), torch.randn(C, C, 2) * 0.05, torch.randn(C) * 0.1
+    g0 = torch.randn(B, C, 2 * L) * 1e-3
+    xr, wr, br = [v.double().requires_grad_(True) for v in (x0, w0, b0)]
+    yr = torch.nn.functional.conv_transpose1d(xr, wr, br, stride=2)
+    yr.backward(g0.double())
+    xg, wg, bg = [v.clone().to(DEV).requires_grad_(True) for v in (x0, w0, b0)]
+    y = ops.deconv1d_k2s2(xg, wg, bg)
+    y.backward(g0.to(DEV))
+    assert rel_l2(y, yr) < FWD_TOL
+    for a, r, n in ((xg.grad, xr.grad, "dx"), (wg.grad, wr.grad, "dw"), (bg.grad, br.grad, "db")):
+        assert rel_l2(a, r) < BWD_TOL, (n, rel_l2(a, r))
+    # the entry's own weight gradient (dw given) and its dx with dw = NULL
+    dy = g0.to(DEV).contiguous()
+    xd, wd = x0.to(DEV).contiguous(), w0.to(DEV).contiguous()
+    nb = _lib.query("ssv_deconv1d_k2s2_bwd_workspace", B, C, C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    p = lambda t_: t_.data_ptr()
+    outs = []
+    for with_dw in (True, False):
+        dx = torch.empty(B, C, L, device=DEV)
+        dw = torch.full((C, C, 2), float("nan"), device=DEV)
+        db = torch.empty(C, device=DEV)
+        _lib.call("ssv_deconv1d_k2s2_bwd", p(dy), C * 2 * L, None, 0, p(xd), C * L, p(wd), p(dx), C * L, p(dw) if with_dw else None, p(db),
+                  B, C, C, L, p(ws), nb, torch.cuda.current_stream().cuda_stream)
+        outs.append((dx, dw, db))
+    assert rel_l2(outs[0][1], wr.grad) < BWD_TOL
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.isnan(outs[1][1]).all()                      # dw = NULL: nothing written
+
+
 @pytest.mark.parametrize("k,d", [(1, 1), (3, 1), (3, 3)])
 def test_conv1d_dd_second_order_vs_torch(k, d):
     """ops.conv1d_dd (forward / data-gradient / weight-gradient Functions that differentiate into each other) against
