@@ -80,6 +80,28 @@ template <int F16>
 __device__ __forceinline__ void split8s(const float (&v)[8], float s, uint4& hi, uint4& lo) {
   if constexpr (F16) split8h(v, s, hi, lo); else split8(v, hi, lo);
 }
+// one PAIR of elements -> one packed dword of the hi plane and one of the lo plane
+template <int F16>
+__device__ __forceinline__ void split_pair(float a, float b, float s, unsigned& h, unsigned& l) {
+  if constexpr (F16) split2h(a, b, s, h, l);
+  else {
+    const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+    const __bf16 la = (__bf16)(a - (float)ha), lb = (__bf16)(b - (float)hb);
+    h = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+    l = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
+  }
+}
+// The weight-gradient kernel's order of the 8 time steps of a window inside a fragment: dword q holds steps (q, q + 4).  Any order is
+// right as long as both operands use it; this one lets a window loaded as two 4-dword tuples be split IN PLACE, pair by pair
+// (dword q of the first tuple and dword q of the second go in, dword q of hi and dword q of lo come out).
+template <int F16>
+__device__ __forceinline__ void split8p(const float (&v)[8], float s, uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split_pair<F16>(v[q], v[q + 4], s, h[q], l[q]);
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
 // one 16x16x32 MFMA on 16-byte operand fragments: bf16 or fp16 inputs, fp32 accumulate
 template <int F16>
 __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c) {
@@ -1167,9 +1189,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
       for (int q = 0; q < NTC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float ra[WM][KS][8], rx[NX][8];      // raw loads in flight: the next chunk's dH windows, the tile of step s + 2
-  int ma[WM][KS], mx[NX];              // edge windows only: validity bits (low 8) | offset clamp distance << 8
-  uint4 ah[WM][KS], al[WM][KS];
+  float rx[NX][8];                     // raw loads in flight: the tile of step s + 2
+  int mx[NX];                          // edge windows only: validity bits (low 8) | offset clamp distance << 8
+  // dH fragments: two sets of (hi, lo) register tuples; set n & 1 is chunk n's.  The next chunk's windows are LOADED into the other
+  // set (a window's two 16-byte loads = its two tuples) and split there in place, dword by dword (split8p's order of the time steps):
+  // no staging registers.  (The split of the next set woven behind the MFMAs of a chunk's last tap -- one half-rate split instruction
+  // hides behind a 16x16x32 MFMA of the same wave, tools/probe/mfma_valu.hip -- was built on this layout and measured: no change
+  // in-step, 268.5 vs 268.3 us; with two waves on a SIMD the other wave's MFMAs already fill those slots.)  dH needs no masks and no clamps:
+  //   * it is read by BUFFER loads whose range is the tensor (per-dword range check: what lies past the end reads 0; its offsets are
+  //     never negative), so a window may run past its row -- into the next row's values, or into zeros;
+  //   * time steps at or past the row length meet an input tile that is zero there (x_edge / the mask of the input include t < La).
+  //   (A NaN or Inf at the head of the NEXT row would so reach this row's sums as NaN; with masks it stayed in its own row.)
+  uint4 AH[2][WM][KS], AL[2][WM][KS];
 
   // A window = 8 consecutive time steps of one row, at any alignment.  Element offsets are 32-bit (the launcher checks
   // that both tensors span < 2^30 elements): a per-thread row offset, fixed for the whole kernel, plus a wave-uniform
@@ -1180,11 +1211,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   //     bits are applied when the values are split, a step later.  Masking at load time makes hipcc branch around each
   //     load and wait for it.  Only a window that would leave the TENSOR (head of its first row, tail of its last) has
   //     its offset clamped; the clamp distance travels with the mask and the split shifts the values back into place.
-  const int a_span = (int)((long)(p.B - 1) * p.sab + (long)(p.M - 1) * p.sam + p.La) - 8;     // last legal window start
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ap), 0,
+      (int)(((long)(p.B - 1) * p.sab + (long)(p.M - 1) * p.sam + p.La) * 4), 0x00020000);
   const int x_span = (int)((long)(p.B - 1) * p.sxb + (long)(p.Nc - 1) * p.sxc + p.Lx) - 8;
   int arow[WM], xrow[NX];
 #pragma unroll
-  for (int i = 0; i < WM; ++i) arow[i] = min(m0 + wave * WM * 16 + i * 16 + nq, p.M - 1) * (int)p.sam + 8 * kq;
+  for (int i = 0; i < WM; ++i) arow[i] = (min(m0 + wave * WM * 16 + i * 16 + nq, p.M - 1) * (int)p.sam + 8 * kq) * 4;     // BYTE offset of the buffer loads
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
     const int f = tid + 256 * r;
@@ -1210,8 +1242,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     load8(base, oc, v);
     return off - oc;
   };
-  auto edge_meta = [&](int d, int t, int len, bool row_ok) -> int {
-    const int sl = min(max(-t, 0), 8), sh = min(max(t + 8 - len, 0), 8);
+  auto edge_meta = [&](int d, int t, int len, bool row_ok, int over2 = 0) -> int {     // over2: elements cut off the window's end by a second limit
+    const int sl = min(max(-t, 0), 8), sh = max(min(max(t + 8 - len, 0), 8), min(max(over2, 0), 8));
     const int m = row_ok ? (int)((0xFFu << sl) & (0xFFu >> sh) & 0xFFu) : 0;
     return m | (d << 8);
   };
@@ -1232,7 +1264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = ((meta >> i) & 1) ? v[i] : 0.f;
-    split8s<F16>(v, sc, h, l);
+    split8p<F16>(v, sc, h, l);
   };
 
   // chunk cursors (wave-uniform): batch item and first time step of chunks n .. n+3
@@ -1246,40 +1278,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   };
 #pragma unroll
   for (int k = 1; k < 4; ++k) next_chunk(cb[k - 1], ct0[k - 1], cb[k], ct0[k]);
-  auto a_edge = [&](int t0) __attribute__((always_inline)) -> bool { return !(rows_in_m && t0 + KB <= p.La); };
-  auto x_edge = [&](int t0, int j) __attribute__((always_inline)) -> bool { return !(rows_in_c && t0 + shj[j] >= 0 && t0 + KB + shj[j] <= p.Lx); };
+  auto x_edge = [&](int t0, int j) __attribute__((always_inline)) -> bool {
+    return !(rows_in_c && t0 + shj[j] >= 0 && t0 + KB + shj[j] <= p.Lx && t0 + KB <= p.La);       // (the last: dH is not masked, see AH / AL)
+  };
 
-  auto loadA = [&](int b, int t0) __attribute__((always_inline)) {                                         // -> ra (/ ma)
-    const int base = (SSV_ABL & 32) ? z * (int)p.sab : b * (int)p.sab + t0;         // (tuning build: the same chunk again and again -- L1 hits)
-    int dd[WM][KS];
+  auto loadA = [&](auto set, int b, int t0) __attribute__((always_inline)) {                               // -> AH / AL[set], raw
+    constexpr int SET = decltype(set)::value;
+    const unsigned so = (unsigned)((SSV_ABL & 32) ? z * (int)p.sab : b * (int)p.sab + t0) * 4u;   // uniform; (tuning build: the same chunk again and again)
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) dd[i][s2] = load8c(Ap, base + arow[i] + s2 * 32, a_span, ra[i][s2]);
-    if (a_edge(t0)) {
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const bool ok = m0 + wave * WM * 16 + i * 16 + nq < p.M;
-#pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) ma[i][s2] = edge_meta(dd[i][s2], t0 + s2 * 32 + 8 * kq, p.La, ok);
+      for (int s2 = 0; s2 < KS; ++s2) {
+        AH[SET][i][s2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, arow[i] + s2 * 128, (int)so, 0));
+        AL[SET][i][s2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, arow[i] + s2 * 128 + 16, (int)so, 0));
       }
-    }
   };
-  auto splitA = [&](int t0) __attribute__((always_inline)) {
-    if (!a_edge(t0)) {
+  auto raw8 = [&](const uint4& t0_, const uint4& t1_, float (&v)[8]) __attribute__((always_inline)) {
+    v[0] = __builtin_bit_cast(float, t0_.x); v[1] = __builtin_bit_cast(float, t0_.y); v[2] = __builtin_bit_cast(float, t0_.z); v[3] = __builtin_bit_cast(float, t0_.w);
+    v[4] = __builtin_bit_cast(float, t1_.x); v[5] = __builtin_bit_cast(float, t1_.y); v[6] = __builtin_bit_cast(float, t1_.z); v[7] = __builtin_bit_cast(float, t1_.w);
+  };
+  auto splitA = [&](auto set) __attribute__((always_inline)) {                                             // AH / AL[set]: raw -> (hi, lo), in place
+    constexpr int SET = decltype(set)::value;
+    if (SSV_ABL & 2) return;
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) {
-          if (SSV_ABL & 2) { ah[i][s2] = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&ra[i][s2][0])); al[i][s2] = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&ra[i][s2][4])); }
-          else split8s<F16>(ra[i][s2], as, ah[i][s2], al[i][s2]);
-        }
-    } else {
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) split_edge(ra[i][s2], ma[i][s2], as, ah[i][s2], al[i][s2]);
-    }
+      for (int s2 = 0; s2 < KS; ++s2) {
+        float v[8];
+        raw8(AH[SET][i][s2], AL[SET][i][s2], v);
+        split8p<F16>(v, as, AH[SET][i][s2], AL[SET][i][s2]);
+      }
   };
   auto loadX = [&](int b, int t0, int j) __attribute__((always_inline)) {                                  // -> rx (/ mx)
     const int base = (SSV_ABL & 16) ? z * (int)p.sxb + 64 : b * (int)p.sxb + t0 + shj[j];   // (tuning build: the same tile again and again)
@@ -1290,7 +1318,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
       for (int r = 0; r < NX; ++r) {
         const int f = tid + 256 * r;
-        mx[r] = edge_meta(dd[r], t0 + shj[j] + 8 * (f % KG), p.Lx, c0 + f / KG < p.Nc);
+        mx[r] = edge_meta(dd[r], t0 + shj[j] + 8 * (f % KG), p.Lx, c0 + f / KG < p.Nc, t0 + 8 * (f % KG) + 8 - p.La);
       }
     }
   };
@@ -1305,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       const int kg = f % KG, c = f / KG;
       uint4 h, l;
       if (SSV_ABL & 4) { h = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[r][0])); l = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[r][4])); }
-      else if (!edge) split8s<F16>(rx[r], xs, h, l);
+      else if (!edge) split8p<F16>(rx[r], xs, h, l);
       else split_edge(rx[r], mx[r], xs, h, l);
       Xh[kg * NCH + (c ^ kg)] = h; Xl[kg * NCH + (c ^ kg)] = l;          // XOR swizzle, see the slot comment above
     }
@@ -1331,7 +1359,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #ifdef SSV_NT_STAMP
     const bool stamp_on = blockIdx.x == 0 && blockIdx.z == 0 && tid == 0;
 #endif
-    if (more) loadA(cb[1], ct0[1]);                                         // lands during this chunk's KT steps
+    using CUR = std::integral_constant<int, PAR>;                           // this chunk's dH set (n & 1 = the parity of its first step: KT is odd)
+    using NXT = std::integral_constant<int, PAR ^ 1>;
+    if (more) loadA(NXT{}, cb[1], ct0[1]);                                  // lands during this chunk's first steps
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
       const int q_ = (PAR + j) & 1;
@@ -1358,13 +1388,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
         if (g + SSV_NT_FD < G) frag(g + SSV_NT_FD, fb[(g + SSV_NT_FD) % (SSV_NT_FD + 1)]);
         __builtin_amdgcn_sched_barrier(0);                                   // or the scheduler sinks the reads back to their use
         const int s2 = g / NTC, q = g % NTC;
-        if (s2 > 0 && q == 0 && ct0[0] + 32 * s2 >= p.La) break;           // ragged last chunk: the k-steps from here on lie past the row end (A is zero there)
+        if (s2 > 0 && q == 0 && ct0[0] + 32 * s2 >= p.La) break;           // ragged last chunk: the k-steps from here on lie past the row end (the input tile is zero there)
         const uint4 bh = fb[g % (SSV_NT_FD + 1)][0];
         const uint4 bl = fb[g % (SSV_NT_FD + 1)][1];
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-          const uint4 a_h = ah[i][s2];
-          const uint4 a_l = al[i][s2];
+          const uint4 a_h = AH[CUR::value][i][s2];
+          const uint4 a_l = AL[CUR::value][i][s2];
 #if (SSV_ABL & 1)
           acc[i][j][q][0] += __builtin_bit_cast(float, a_l.x ^ bh.x ^ a_h.y ^ bl.y);
 #else
@@ -1388,7 +1418,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       NT_STAMP(2);
       if (STEADY || s + 2 < steps) loadX(cb[c2], ct0[c2], j2);
       NT_STAMP(3);
-      if (j == KT - 1 && more) splitA(ct0[1]);
+      if (j == KT - 1 && more) splitA(NXT{});
       NT_STAMP(4);
       __syncthreads();
       NT_STAMP(5);
@@ -1400,10 +1430,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 
   if (total > 0) {
     // prologue: A of chunk 0 split, tile 0 staged, tile 1 in flight
-    loadA(cb[0], ct0[0]);
+    loadA(P0{}, cb[0], ct0[0]);
     loadX(cb[0], ct0[0], 0);
     scales();
-    splitA(ct0[0]);
+    splitA(P0{});
     commitX(P0{}, ct0[0], 0);
     if (steps > 1) loadX(cb[1 / KT], ct0[1 / KT], 1 % KT);
     __syncthreads();
@@ -1460,10 +1490,10 @@ void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
   else { *wm = 1; *ntc = 4; }
 }
 // co-resident workgroups per CU (4 waves each, one per SIMD): 512 / VGPRs of the instantiation, as compiled for gfx950
-// (-Rpass-analysis=kernel-resource-usage: <3,2,4> 238, <3,2,2> 165, <3,1,4> 154, <3,1,2> 108, <1,2,6> 208, <1,2,4> 166, <1,2,2> 136,
-// <1,1,6> 148, <1,1,4> 122, <1,1,2> 92; the two LDS buffers of the largest tile (32 KB) allow 4)
+// (-Rpass-analysis=kernel-resource-usage: <3,2,4> 236, <3,2,2> 174, <3,1,4> 156, <3,1,2> 110, <1,2,6> 208, <1,2,4> 168, <1,2,2> 134,
+// <1,1,6> 148, <1,1,4> 120, <1,1,2> 94; the two LDS buffers of the largest tile (32 KB) allow 4)
 int ssv_nt_bf3_wg_per_cu(int KT, int wm, int ntc) {
-  if (KT == 3) return wm == 2 ? (ntc >= 4 ? 2 : 3) : (ntc >= 4 ? 3 : 4);
+  if (KT == 3) return wm == 2 ? 2 : (ntc >= 4 ? 3 : 4);
   if (wm == 2) return ntc >= 6 ? 2 : 3;
   return ntc >= 6 ? 3 : (ntc >= 4 ? 4 : 5);
 }
