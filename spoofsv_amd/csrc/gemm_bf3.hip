@@ -1100,13 +1100,14 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
 //   C(z,m,c,j) = sum_{b = z, z+bstep, ..} sum_t A(b,m,t) * X(b,c,t+shift[j]);  rows contiguous in t for both operands.
 // The reduction runs over time, so a tap's dilation shift is a misaligned shift along k: every tap needs its own staged
 // copy of the input rows.  The kernel therefore steps over (batch item, 64-step chunk, tap), tap fastest:
-//   * the waves split M, so a wave's A rows (dL/dH) are private: its fragments go global -> registers (two 16-byte loads
-//     per 8 time steps), are split there once per chunk and reused by the KT taps -- A never touches LDS;
+//   * the waves split M, so a wave's A rows (dL/dH) are private: its fragments go global -> registers (two 16-byte buffer
+//     loads per 8 time steps = the window's two fragment tuples), are split there in place once per chunk and reused by the
+//     KT taps -- A never touches LDS (see AH / AL in the kernel);
 //   * per step only ONE tap's input tile (16*NTC channels x 64 steps) is split and staged, into one of two LDS buffers:
 //     the step's MFMAs read buffer s while the next step's tile is written to buffer s^1 -- one barrier per step, and
 //     16 staging registers instead of 48 (staging all taps at once put the 128 x 64 x 3 tile at 256 VGPRs with spills,
 //     and every scratch reload waits for vmcnt(0), i.e. for the whole prefetch in flight).
-// Loads are issued raw, one step (input) or one chunk (A) ahead, with no branch in the prefetch (see load8/fix8).
+// Loads are issued raw, one step (input) or one chunk (A) ahead, with no branch in the prefetch (see load8c / split_edge).
 // Tuning builds only (-DSSV_NT_STAMP): wave 0 of workgroup 0 records s_memtime at six points of every step from step 24 on
 // (8 steps); read back with ssv_debug_nt_stamps().  Results are unaffected.
 #ifdef SSV_NT_STAMP
