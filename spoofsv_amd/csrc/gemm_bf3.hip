@@ -325,6 +325,20 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 #ifndef SSV_NN_FD
 #define SSV_NN_FD 1         // LDS fragment blocks read ahead of the MFMAs (see tap())
 #endif
+// Tuning builds only (-DSSV_NN_STAMP): thread 0 of workgroup (0, 0) records s_memtime at five points of every K chunk; ssv_debug_nn_stamps().
+#ifdef SSV_NN_STAMP
+#ifndef SSV_NN_STAMP_WG
+#define SSV_NN_STAMP_WG 0
+#endif
+__device__ unsigned long long ssv_nn_stamps[128];
+#define NN_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (unsigned)ch < 15u) ssv_nn_stamps[ch * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define NN_STAMP_AT(slot) do { if ((SSV_NN_STAMP_WG ? (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) : (blockIdx.x == 0 && blockIdx.y == 0)) && threadIdx.x == 0) \
+    ssv_nn_stamps[120 + (slot)] = __builtin_readcyclecounter(); } while (0)       /* SSV_NN_STAMP_WG=1: the launch's last workgroup instead of its first */
+extern "C" int ssv_debug_nn_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssv_nn_stamps), sizeof(ssv_nn_stamps)); }
+#else
+#define NN_STAMP(k) do {} while (0)
+#define NN_STAMP_AT(slot) do {} while (0)
+#endif
 #ifndef SSV_NN_XBUF
 #define SSV_NN_XBUF(KT, WM, NT) (!((KT) == 3 && (NT) == 6))   // input rows by buffer loads (ssv_buf) or through pointers: in-step, per tile -- the k = 1
                                                              // tiles are 5-12 % faster with buffer loads, the 96-column k = 3 tiles 4-6 % with pointers, the rest equal
@@ -557,6 +571,10 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   // exposed L2 round trip per chunk; the weight-gradient kernel has the full story at its STEADY).  The last chunks run the tested form.
   using ST_ = std::integral_constant<bool, true>;
   using TL_ = std::integral_constant<bool, false>;
+  NN_STAMP_AT(0);
+#ifdef SSV_NN_STAMP
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ssv_nn_stamps[127] = __builtin_readcyclecounter();     // the first workgroup's entry, for the ramp
+#endif
   if constexpr (KT == 1) {
     if (nchunks > 0) {
       loadA(0, 0, 0);
@@ -593,20 +611,26 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     commitX(0);
     if (nchunks > 1) prefetchX(1);
     __syncthreads();
+    NN_STAMP_AT(1);
     auto chunk = [&](auto steady, int ch) __attribute__((always_inline)) {
       constexpr bool ST = decltype(steady)::value;
       const bool more = ST || ch + 1 < nchunks;
+      NN_STAMP(0);
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
         tap(0, j, ch);
         __builtin_amdgcn_sched_barrier(0);      // keep the re-load behind this tap's MFMAs, and later taps' LDS reads behind it
         if (!(SSV_NN_ABL & 8) && more) loadA(0, j, ch + 1);
       }
+      NN_STAMP(1);
       if (more) {
         if (!(SSV_NN_ABL & 2)) commitX(ch + 1);
+        NN_STAMP(2);
         if (!(SSV_NN_ABL & 4) && (ST || ch + 2 < nchunks)) prefetchX(ch + 2);
       }
+      NN_STAMP(3);
       if (!(SSV_NN_ABL & 1)) __syncthreads();
+      NN_STAMP(4);
     };
     int ch = 0;
     // (the steady form holds more values live: 140 -> 190 VGPRs for the 64 x 112 tile, whose hot launches are 768 workgroups and need
@@ -622,6 +646,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     }
   }
 
+  NN_STAMP_AT(2);
   float* __restrict__ Cb = p.C + (long)b * p.scb;
   const float* __restrict__ Rb = p.R ? p.R + (long)b * p.srb : nullptr;
   if constexpr (EPI == 1) {
@@ -756,6 +781,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
         dst[0] = mean; dst[1] = m2;
       }
     }
+    NN_STAMP_AT(3);
     return;
   }
 #pragma unroll
