@@ -331,6 +331,9 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 #define SSV_NN_STAMP_WG 0
 #endif
 __device__ unsigned long long ssv_nn_stamps[128];
+__device__ unsigned long long ssv_nn_rt[4096];        // s_memrealtime (100 MHz, one clock for the device) at entry / exit of the first 2048 workgroups
+extern "C" int ssv_debug_nn_realtime(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssv_nn_rt), sizeof(ssv_nn_rt)); }
+#define NN_RT(which) do { const unsigned w_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && w_ < 2048u) ssv_nn_rt[2 * w_ + (which)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define NN_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (unsigned)ch < 15u) ssv_nn_stamps[ch * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #define NN_STAMP_AT(slot) do { if ((SSV_NN_STAMP_WG ? (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) : (blockIdx.x == 0 && blockIdx.y == 0)) && threadIdx.x == 0) \
     ssv_nn_stamps[120 + (slot)] = __builtin_readcyclecounter(); } while (0)       /* SSV_NN_STAMP_WG=1: the launch's last workgroup instead of its first */
@@ -338,6 +341,7 @@ extern "C" int ssv_debug_nn_stamps(unsigned long long* out) { return (int)hipMem
 #else
 #define NN_STAMP(k) do {} while (0)
 #define NN_STAMP_AT(slot) do {} while (0)
+#define NN_RT(which) do {} while (0)
 #endif
 #ifndef SSV_NN_XBUF
 #define SSV_NN_XBUF(KT, WM, NT) (!((KT) == 3 && (NT) == 6))   // input rows by buffer loads (ssv_buf) or through pointers: in-step, per tile -- the k = 1
@@ -572,6 +576,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   using ST_ = std::integral_constant<bool, true>;
   using TL_ = std::integral_constant<bool, false>;
   NN_STAMP_AT(0);
+  NN_RT(0);
 #ifdef SSV_NN_STAMP
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ssv_nn_stamps[127] = __builtin_readcyclecounter();     // the first workgroup's entry, for the ramp
 #endif
@@ -782,6 +787,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
       }
     }
     NN_STAMP_AT(3);
+    NN_RT(1);
     return;
   }
 #pragma unroll

@@ -23,6 +23,20 @@ for (Cin, Cout, L, k, d) in ((256, 512, 325, 3, 3), (512, 1024, 186, 3, 3), (512
         print("  chunk %2d: taps %5d | commit %5d | issue loads %5d | barrier %5d | total %5d (+%d)" % (
             ch, t[1] - t[0], t[2] - t[1] if t[2] else 0, (t[3] - t[2]) if t[2] else t[3] - t[1], t[4] - t[3], t[4] - t[0], (t[0] - prev) if prev else 0))
         prev = t[4]
+    rt = (ctypes.c_ulonglong * 4096)()
+    _lib.lib().ssv_debug_nn_realtime(rt)
+    nwg = min(2048, B * ((Cout + 63) // 64) * ((L + 111) // 112))
+    ent = sorted(rt[2 * i] for i in range(nwg) if rt[2 * i]); ext = sorted(rt[2 * i + 1] for i in range(nwg) if rt[2 * i + 1])
+    if ent and ext:
+        t0_ = ent[0]
+        q = lambda v, f: (v[int(f * (len(v) - 1))] - t0_) / 100.0
+        print("  s_memrealtime, us after the first entry (%d workgroups): entries median %.1f, 90 %% %.1f, last %.1f | exits first %.1f, median %.1f, last %.1f" % (
+            len(ent), q(ent, .5), q(ent, .9), q(ent, 1), q(ext, 0), q(ext, .5), q(ext, 1)))
+        import statistics  # noqa
+        for lo_ in range(0, nwg, 256):
+            seg = [(rt[2 * i + 1] - t0_) / 100.0 for i in range(lo_, min(lo_ + 256, nwg)) if rt[2 * i + 1]]
+            dur = [(rt[2 * i + 1] - rt[2 * i]) / 100.0 for i in range(lo_, min(lo_ + 256, nwg)) if rt[2 * i + 1]]
+            print("    workgroups %4d-%4d: exit median %.1f us (min %.1f, max %.1f), duration median %.1f" % (lo_, lo_ + len(seg) - 1, statistics.median(seg), min(seg), max(seg), statistics.median(dur)))
     a = [buf[120 + i] for i in range(4)]
     print("  workgroup %s: entry -> first chunk ready %d | chunk loop %d | epilogue (stores issued) %d cycles; entry %d cycles after workgroup (0, 0)'s" % (
         os.environ.get("NN_WG", "0"), a[1] - a[0], a[2] - a[1], a[3] - a[2], a[0] - buf[127]))
