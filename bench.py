@@ -322,7 +322,7 @@ def pmc_traffic(mode):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     if h.hexdigest()[:16] != rec["sources_sha16"]:
         return {"traffic": None, "traffic_source": "stale: %s changed since the PMC pass %s" % (", ".join(rec["sources"]), rec["profile"])}
-    return {"traffic": rec["traffic_bytes"], "traffic_source": "%s (sources sha %s); %s" % (rec["profile"], rec["sources_sha16"], rec["note"])}
+    return {"traffic": rec["traffic_bytes"], "traffic_corrected": rec.get("traffic_bytes_corrected"), "traffic_source": "%s (sources sha %s); %s" % (rec["profile"], rec["sources_sha16"], rec["note"])}
 
 
 def cpu_baseline():
@@ -445,17 +445,67 @@ def ge2e_config5():
             "cpu_baseline": {"value": round(44 / tc, 1), "unit": "utterances/s", "cores": cores, "sample": "44 utterances x 120 frames"}}
 
 
+def launch_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: become N ranks.  The parent starts N children of this very script with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what ``torch.distributed.run`` would set), relays rank 0's stdout (the ONE JSON
+    line), sends the other ranks' stdout to stderr, and exits non-zero as soon as any child does (ending the others by their exact
+    PIDs).  It makes NO GPU call itself -- nothing here initialises HIP -- so it is a plain process manager; the reference turns
+    multi-GPU on from inside one process (`MULTI_GPU`, train/adversarial_wasserstein_gp.py:183-196), here it is one process per GPU."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, SSV_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            c = p.poll()
+            if c is not None:
+                live.remove(p)
+                if c != 0:
+                    rc = c if c > 0 else 1
+    for p in live:                      # a rank failed: the others would wait in a collective for ever
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
 def main():
     args = parse()
     if args.ge2e:
         print(json.dumps(ge2e_config5()))
         return
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # the line says "n_gpus": the number of ranks that really ran must be the number that was asked for
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d: launch %d ranks (python bench.py --gpus %d starts them itself, or "
+                         "python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d)" % (args.gpus, world, args.gpus, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
+    if world > ndev and os.environ.get("SSV_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit("bench: %d ranks but %d GPU(s) visible: RCCL needs one GPU per rank (SSV_DIST_BACKEND=gloo rehearses the "
+                         "launch structure with several ranks on one GPU)" % (world, ndev))
     local = local % max(ndev, 1)          # rehearsal on fewer GPUs than ranks (SSV_DIST_BACKEND=gloo); identity on a full node
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -480,6 +530,8 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit("bench: process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
     from spoofsv_amd import _lib
     _lib.lib()
 
@@ -534,7 +586,8 @@ def main():
         ddp_note = ("gradient arena, backward in %d+%d segments (hipGraphs), one RCCL all-reduce per bucket launched between the replays"
                     % (t2m.ddp.n_buckets, ssr.ddp.n_buckets))
     res = {"metric": "mel-frames/sec (Text2Mel+SSRN train)", "value": round(frames_per_step / per_step, 1), "unit": "mel-frames/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 3),
+           "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0),
+           "dist_backend": (dist.get_backend() if dist.is_initialized() else "none"), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": dtype_note, "data": "synthetic",
            "config": {"workload": "train_text2mel + train_ssrn (train/ordinary.py step: fwd, l1+bin-div+guided-att losses, bwd, Adam), "

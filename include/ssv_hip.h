@@ -53,9 +53,6 @@ int ssv_get_precision(void);
 int ssv_amax_rows(int L);         /* entries per batch item of the lists the LayerNorm / gate kernels write: 4 * ceil(L / 64) */
 /* amax[b * namax + i] = max |x| over the i-th of namax equal pieces of item b (n dense floats at x + b * x_bs). */
 int ssv_absmax(const float* x, long x_bs, int B, long n, float* amax, int namax, ssv_stream_t stream);
-/* Tuning knobs (SSV_NNB_TILE, SSV_NT_Z, SSV_LN_GROUPS, ... -- tile / slab overrides used by tools/sweep_*.py) are read
- * from the environment once, at first use; a tuning script that changes them inside one process calls this to re-read. */
-void ssv_reload_tuning(void);
 
 /* ---- Conv1d (stride 1, kernel 1 or 3, dilated, "same" or causal zero padding) -------------------
  * Replaces nn.Conv1d as used at models/TTSModel.py:59,78 (highway), :115-117, :154-158, :203-214,

@@ -28,7 +28,14 @@ static int g_precision = -1;
 int ssv_precision() {
   if (g_precision < 0) {
     const char* e = getenv("SSV_PRECISION");
-    g_precision = (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) ? 0 : (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? 1 : 2;
+    if (!e || !*e || !strcmp(e, "f16x2") || !strcmp(e, "2")) g_precision = 2;
+    else if (!strcmp(e, "fp32") || !strcmp(e, "0")) g_precision = 0;
+    else if (!strcmp(e, "bf16x3") || !strcmp(e, "1")) g_precision = 1;
+    else {
+      // a typo must not silently select another arithmetic than the one asked for
+      fprintf(stderr, "libssv_hip: SSV_PRECISION=%s is not one of fp32|0, bf16x3|1, f16x2|2: using the default f16x2\n", e);
+      g_precision = 2;
+    }
   }
   return g_precision;
 }
@@ -55,18 +62,20 @@ extern "C" void ssv_reload_tuning(void) { load_knobs(); }
 #include <string>
 #include <map>
 static int g_shape_log = -1;
+static std::string g_shape_path;                                 // cached when the log is enabled: the environment may change before exit
 static std::mutex g_shape_mu;
 static std::map<std::string, long>* g_shape_seen = nullptr;      // line -> host-side launches (eager and capture passes; replays do not come here)
 static void shape_log_flush() {
   std::lock_guard<std::mutex> lk(g_shape_mu);
   if (!g_shape_seen) return;
-  if (FILE* f = fopen(getenv("SSV_SHAPE_LOG"), "w")) {
+  if (g_shape_path.empty()) return;
+  if (FILE* f = fopen(g_shape_path.c_str(), "w")) {
     for (const auto& kv : *g_shape_seen) fprintf(f, "%s\t%ld\n", kv.first.c_str(), kv.second);
     fclose(f);
   }
 }
 bool ssv_shape_log_on() {
-  if (g_shape_log < 0) { const char* e = getenv("SSV_SHAPE_LOG"); g_shape_log = (e && *e) ? 1 : 0; if (g_shape_log) atexit(shape_log_flush); }
+  if (g_shape_log < 0) { const char* e = getenv("SSV_SHAPE_LOG"); g_shape_log = (e && *e) ? 1 : 0; if (g_shape_log) { g_shape_path = e; atexit(shape_log_flush); } }
   return g_shape_log == 1;
 }
 void ssv_shape_log(const char* kernel, dim3 grid, dim3 block, double flops, double bytes, const char* note) {

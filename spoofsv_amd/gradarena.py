@@ -30,38 +30,57 @@ def _entry(t):
         return None
     g = param.grad
     if g is not None and g.data_ptr() == arena.flat.data_ptr() + 4 * e[1]:
-        # The slot already HOLDS a gradient of this parameter (a second use of the parameter in one backward, or a backward
-        # without zero_grad(set_to_none=True) before it).  A kernel writing there again would clobber what p.grad aliases and
-        # autograd would then add the slot to itself.  Hand out no slot: the operator allocates a fresh tensor and autograd
-        # accumulates it into p.grad -- i.e. into the arena -- in place.
+        # The slot already HOLDS a gradient of this parameter (a backward without zero_grad(set_to_none=True) before it).  A
+        # kernel writing there again would clobber what p.grad aliases and autograd would then add the slot to itself.  Hand
+        # out no slot: the operator allocates a fresh tensor and autograd accumulates it into p.grad -- i.e. into the arena.
+        return None
+    if e[1] in arena.claimed:
+        # The slot was handed to another user of this parameter EARLIER IN THE SAME BACKWARD: autograd's AccumulateGrad runs only
+        # after all users of a leaf have delivered, so p.grad is still None and the test above cannot see it.  The mark is set
+        # by view() / block() and cleared by the parameter's post-accumulate hook.  Same answer: no slot, autograd sums.
         return None
     return arena, e[1], e[2]
 
 
-def view(w):
-    """The arena slot of parameter ``w`` (looked up by address and shape) as a tensor of ``w``'s shape, or None."""
+def view(w, claim=True):
+    """The arena slot of parameter ``w`` (looked up by address and shape) as a tensor of ``w``'s shape, or None.  ``claim``: the
+    caller is a backward operator about to write the gradient there (the slot is not handed out again before autograd has
+    accumulated it); False only looks."""
     e = _entry(w)
     if e is None:
         return None
     arena, off, n = e
+    if claim:
+        arena.claimed.add(off)
     return arena.flat[off:off + n].view(w.shape)
 
 
-def block(params, rows, cols):
+def claimed(w):
+    """True when ``w`` has an arena slot that a backward operator already took in the backward in progress."""
+    e = _SLOTS.get(w.data_ptr())
+    arena = e[0]() if e is not None else None
+    return arena is not None and e[1] in arena.claimed
+
+
+def block(params, rows, cols, claim=True):
     """One ``(rows, cols)`` view covering the slots of ``params`` when they are adjacent in this order and fill it exactly,
-    else None."""
+    else None.  ``claim`` as in ``view``."""
     first = _entry(params[0])
     if first is None:
         return None
     arena, off0, _ = first
     off = off0
+    offs = []
     for p in params:
         e = _entry(p)
         if e is None or e[0] is not arena or e[1] != off:
             return None
+        offs.append(off)
         off += e[2]
     if off - off0 != rows * cols:
         return None
+    if claim:
+        arena.claimed.update(offs)
     return arena.flat[off0:off].view(rows, cols)
 
 
@@ -79,6 +98,8 @@ class GradArena:
     def __init__(self, plan, device=None, align=4):
         self.names, self.ranges, self.slots = [], [], {}
         self.params = []
+        self.claimed = set()       # offsets of slots handed to a backward operator and not yet accumulated by autograd
+        self._hooks = []
         off = 0
         seen = set()
         for name, groups in plan:
@@ -103,8 +124,14 @@ class GradArena:
         for p in self.params:
             o, n = self.slots[id(p)]
             _SLOTS[p.data_ptr()] = (ref, o, n, weakref.ref(p))
+            if p.requires_grad:
+                # AccumulateGrad has run for p (all of its users in this backward have delivered): its slot may be handed out again
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, o=o, r=ref: r() is not None and r().claimed.discard(o)))
 
     def release(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
         for p in self.params:
             e = _SLOTS.get(p.data_ptr())
             if e is not None and e[0]() is self:
@@ -141,4 +168,5 @@ class GradArena:
                 dst.copy_(g)
                 p.grad = dst
                 moved += 1
+            self.claimed.discard(o)        # (a backward that never reached AccumulateGrad must not leave the slot marked)
         return moved

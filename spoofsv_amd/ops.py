@@ -128,6 +128,7 @@ class DeferredWgrad:
         self.jobs = {}
         self.slots = []                # [pinned uint8 table, device table, event after the last eager copy]
         self.cursor = 0
+        self.pending = set()           # addresses of the parameters whose gradient is queued and not yet flushed
 
     def __enter__(self):
         global _DEFER
@@ -149,7 +150,18 @@ class DeferredWgrad:
         add it to an existing ``.grad`` or record the addition (create_graph) -- then the immediate path is taken."""
         if torch.is_grad_enabled() or any(p is not None and p.grad is not None for p in params):
             return False
-        return nblk <= 768 and bool(_lib.lib().ssv_conv1d_bwd_weight_multi_ok(B, Cin, Cout, L, k))
+        ok = nblk <= 768 and bool(_lib.lib().ssv_conv1d_bwd_weight_multi_ok(B, Cin, Cout, L, k))
+        if _DEFER is not None:
+            # A parameter used twice in one backward: p.grad is still None at its second use (AccumulateGrad runs after all users),
+            # and autograd would ADD the first, not yet computed, deferred gradient to the second.  Nothing in the models here
+            # shares a parameter; refuse loudly instead of computing a wrong sum.
+            ptrs = [p.data_ptr() for p in params if p is not None]
+            if any(q in _DEFER.pending for q in ptrs):
+                raise RuntimeError("DeferredWgrad: a parameter is used by two operators of one backward pass; deferred (batched) "
+                                   "weight gradients cannot be summed by autograd -- build the step with defer_wgrad=False")
+            if ok:
+                _DEFER.pending.update(ptrs)
+        return ok
 
     def add(self, dy, dy_bs, x, x_bs, dw, part, pg, k, dilation, causal, n2, nblk, dy_amax=None, x_amax=None):
         B, Cin, L = x.shape
@@ -203,6 +215,7 @@ class DeferredWgrad:
             ws = _ws(nb, dev)
             _lib.call("ssv_conv1d_bwd_weight_multi", _p(slot[1]), n, dy_bs, x_bs, B, Cin, Cout, L, k, n2, nblk, _p(ws), nb, _stream())
         self.jobs = {}
+        self.pending.clear()
 
 
 _DEFER = None
@@ -402,7 +415,7 @@ class Conv1dFn(torch.autograd.Function):
         dy, dybs = _act3(dy, "grad")
         B, Cin, L = x.shape
         Cout = w.shape[0]
-        dy_amax = amax_of(dy) if _f16() else None
+        dy_amax = amax_of(dy) if (_f16() and _bf3_shape(dy)) else None       # (the L = 1 speaker-code convs take the fp32 kernel)
         dx = _conv_bwd_data(dy, dybs, w, Cin, L, k, dilation, causal, dy_amax) if need_dx else None
         dw = _conv_bwd_weight(dy, dybs, x, xbs, tuple(w.shape), k, dilation, causal, out=gradarena.view(w), dy_amax=dy_amax, x_amax=ctx.x_amax)
         db = None
@@ -959,12 +972,13 @@ class DeconvK2S2Fn(torch.autograd.Function):
         # exact-fp32 MFMA kernel takes (60 us per tap at C = 256, L = 650).  De-interleaved (one copy kernel), each tap is the k = 1 conv
         # weight gradient of (dy' = x, x' = dy_j) and runs on the split-precision kernel; the entry is then told to skip dw.
         split = _lib.precision() >= 1 and B * L >= 256 and L >= 8 and dybs == Cout * 2 * L
-        dy_am = amax_of(dy) if split else None
+        f16 = _f16()                      # the scale lists are read in the split-fp16 mode only
+        dy_am = amax_of(dy) if (split and f16) else None
         _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, *_an(dy_am), _p(x), xbs, _p(w), _p(dx), Cin * L, None if split else _p(dw), _p(db),
                   B, Cin, Cout, L, _p(ws), nb, _stream())
         if split:
             dyj = dy.view(B, Cout, L, 2).permute(3, 0, 1, 2).contiguous()            # (2, B, Cout, L)
-            x_am = amax_of(x)
+            x_am = amax_of(x) if f16 else None
             dwj = torch.empty((2, Cin, Cout), dtype=_F32, device=x.device)
             for j in range(2):
                 _conv_bwd_weight(x, xbs, dyj[j], Cout * L, (Cin, Cout, 1), 1, 1, 0, dwj[j].view(Cin, Cout, 1), x_am, dy_am)

@@ -30,9 +30,11 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()                      # raises if a declared symbol is missing
     assert L.ssv_version() == 2
     assert L.ssv_arch() == b"gfx950"
+    # the default arithmetic is split-fp16 (2) unless SSV_PRECISION names another mode (strictly parsed: a typo falls back to 2 with a warning)
+    default = {"fp32": 0, "0": 0, "bf16x3": 1, "1": 1}.get(os.environ.get("SSV_PRECISION", ""), 2)
     prev = L.ssv_set_precision(0)
-    assert prev == 2 and L.ssv_get_precision() == 0          # split-fp16 is the default arithmetic
-    assert L.ssv_set_precision(prev) == 0 and L.ssv_get_precision() == 2
+    assert prev == default and L.ssv_get_precision() == 0
+    assert L.ssv_set_precision(prev) == 0 and L.ssv_get_precision() == default
     assert L.ssv_amax_rows(325) == 24 and L.ssv_amax_rows(1300) == 84
     raw = ctypes.CDLL(_lib.LIBPATH)
     for name in _lib.parse_header():

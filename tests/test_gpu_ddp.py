@@ -441,3 +441,27 @@ def test_rccl_world_size_one_adversarial_iterations_with_every_collective_issued
         for a, b in zip(r["d_out"][0], r["d_out"][1]):
             assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), r["d_out"]
         assert r["worst"] < 1e-5, r
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself_and_reports_them():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent (no GPU call) starts two ranks, here sharing the
+    one GPU over gloo (SSV_DIST_BACKEND=gloo); rank 0's single JSON line says n_gpus = 2 and counts both ranks' frames.  With RCCL
+    the same command needs two GPUs and says so.  train/adversarial_wasserstein_gp.py:183-196 (MULTI_GPU) is what this replaces."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+            "--no-cpu-baseline", "--no-adversarial", "--no-fp32", "--no-ge2e", "--no-roofline"]
+    r = subprocess.run(args, env=dict(env, SSV_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"] == "dp2"
+    assert rec["dist_backend"] == "gloo" and rec["rccl_ranks"] == 0
+    assert abs(rec["value"] - 2 * 4 * 325 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "one GPU per rank" in r.stderr and r.stdout.strip() == ""

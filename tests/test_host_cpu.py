@@ -341,13 +341,13 @@ def test_grad_arena_layout_views_and_adopt():
     for (a0, a1), (b0, b1) in zip(ar.ranges, ar.ranges[1:]):
         assert a1 == b0 and a0 % 64 == 0                               # buckets are contiguous, 256-byte aligned ranges
     for p in net.parameters():
-        v = gradarena.view(p)
+        v = gradarena.view(p, claim=False)
         assert v is not None and v.shape == p.shape and v.data_ptr() == ar.slot(p).data_ptr()
         assert (v.data_ptr() - ar.flat.data_ptr()) % 16 == 0           # every group starts 16-byte aligned
-    blk = gradarena.block((net.b.weight, net.b.bias), 9, 8)            # adjacent slots of one group: one (rows, C) block
-    assert blk is not None and blk.data_ptr() == gradarena.view(net.b.weight).data_ptr()
+    blk = gradarena.block((net.b.weight, net.b.bias), 9, 8, claim=False)            # adjacent slots of one group: one (rows, C) block
+    assert blk is not None and blk.data_ptr() == gradarena.view(net.b.weight, claim=False).data_ptr()
     assert gradarena.block((net.b.bias, net.b.weight), 9, 8) is None and gradarena.block((net.a.weight, net.a.bias), 8, 8) is None
-    assert gradarena.view(net.a.weight.unsqueeze(-1)).shape == (8, 6, 1)          # nn.Linear weight used as a 1x1 conv
+    assert gradarena.view(net.a.weight.unsqueeze(-1), claim=False).shape == (8, 6, 1)          # nn.Linear weight used as a 1x1 conv
     assert gradarena.view(torch.zeros(8, 6)) is None
     # gradients produced outside the arena are copied in; missing ones become zero slots
     torch.nn.functional.mse_loss(net(x), y).backward()
@@ -365,9 +365,49 @@ def test_grad_arena_layout_views_and_adopt():
     torch.nn.functional.mse_loss(net(x), y).backward()                # no zero_grad: accumulates into the arena in place
     assert net.c.weight.grad.data_ptr() == ar.slot(net.c.weight).data_ptr() and torch.allclose(net.c.weight.grad, 2 * before)
     net.a.weight.grad = None
-    assert gradarena.view(net.a.weight) is not None                   # free again after zero_grad(set_to_none=True)
+    assert gradarena.view(net.a.weight, claim=False) is not None      # free again after zero_grad(set_to_none=True)
     ar.release()
     assert gradarena.view(net.a.weight) is None
+
+
+class _TwiceFn(torch.autograd.Function):
+    """y = x * w with the parameter gradient written where the gradient arena says (as the fused operators of ops.py do)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x * w
+
+    @staticmethod
+    def backward(ctx, dy):
+        from spoofsv_amd import gradarena
+        x, w = ctx.saved_tensors
+        dw = gradarena.grad_like(w)
+        dw.copy_(dy * x)
+        return dy * w, dw
+
+
+def test_grad_arena_parameter_used_twice_in_one_backward_is_summed_not_overwritten():
+    """A leaf's AccumulateGrad runs only after ALL its users have delivered, so p.grad is still None when the second user asks
+    for a slot: the arena must remember that the slot is taken (claimed) until autograd has accumulated, or both users write
+    the same memory and autograd adds the slot to itself (2*g2 instead of g1 + g2)."""
+    from spoofsv_amd import gradarena
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(6))
+    x1, x2 = torch.randn(6), torch.randn(6)
+    ar = gradarena.GradArena([("only", [[w]])])
+    for it in range(2):                       # the claim is released by the post-accumulate hook: the second iteration gets the slot again
+        w.grad = None
+        (_TwiceFn.apply(x1, w).sum() + 3.0 * _TwiceFn.apply(x2, w).sum()).backward()
+        assert torch.allclose(w.grad, x1 + 3.0 * x2), (it, w.grad, x1 + 3.0 * x2)
+        assert not ar.claimed
+        ar.adopt()
+        assert w.grad.data_ptr() == ar.slot(w).data_ptr() and torch.allclose(w.grad, x1 + 3.0 * x2)
+    # single use: the kernel's destination IS the slot and autograd adopts it without a copy
+    w.grad = None
+    _TwiceFn.apply(x1, w).sum().backward()
+    assert w.grad.data_ptr() == ar.slot(w).data_ptr() and torch.allclose(w.grad, x1)
+    ar.release()
 
 
 def _segmented_iteration(net, x, y, ddp):
@@ -548,3 +588,31 @@ def test_ragged_rank_batches_are_padded_to_the_global_longest_item_gloo_world2()
         assert shapes == {"data_0": (3, 80, 20), "data_1": (3, 1, 12), "data_2": (3, 200, 1), "data_3": (3, 513, 80)}, (rank, shapes)
         T, N = (20, 9) if rank == 0 else (14, 12)
         assert s0 == 3 * 80 * T and s1 == 3 * N and s3 == 3 * 513 * 4 * T        # padding is zeros ('P' = id 0 for the text)
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_refuses_a_world_size_that_is_not_the_gpus_asked_for():
+    """`--gpus N` is what the line reports as n_gpus: a launch with another WORLD_SIZE exits non-zero before any GPU call
+    (the reference turns multi-GPU on with one flag, train/adversarial_wasserstein_gp.py:183-196)."""
+    r = _run_bench(["--gpus", "8"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks_and_propagates_their_failure():
+    """`python bench.py --gpus 2` with no WORLD_SIZE becomes two ranks (children of a parent that never touches the GPU).  On this
+    GPU-less host every rank stops at its own "needs a ROCm GPU" check: two such messages, one per rank, and the parent's exit
+    code is non-zero with nothing on stdout."""
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: the launched ranks would run the benchmark (covered by tests/test_gpu_ddp.py)")
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert r.stderr.count("needs a ROCm GPU") == 2, r.stderr

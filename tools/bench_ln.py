@@ -27,14 +27,14 @@ for (B, C, L) in [(32, 512, 186), (32, 256, 325), (32, 256, 650), (32, 256, 1300
     for G in os.environ.get("BENCH_LN_GROUPS", "16,32,64").split(","):      # "auto" = the library's own choice
         if G == "auto": os.environ.pop("SSV_LN_GROUPS", None)
         else: os.environ["SSV_LN_GROUPS"] = G
-        _lib.lib().ssv_reload_tuning()
-        f = lambda: _lib.call("ssv_channel_ln_act_fwd", P(x), C * L, P(g), P(b), P(y), C * L, P(stats), B, C, L, 1, None, 0, st)
+        ctypes.CDLL(_lib.LIBPATH).ssv_reload_tuning()        # exported for tuning scripts, not part of include/ssv_hip.h
+        f = lambda: _lib.call("ssv_channel_ln_act_fwd", P(x), C * L, P(g), P(b), P(y), C * L, None, P(stats), B, C, L, 1, None, 0, st)
         bw = lambda: _lib.call("ssv_channel_ln_act_bwd", P(dy), C * L, P(x), C * L, P(stats), P(g), P(b), P(dx), C * L, P(pg), B, C, L, 1, P(ws), nb, st)
         tf, tb = timeit(f), timeit(bw)
         line += "  G%s act f %.1f (%.2f) b %.1f (%.2f)" % (G, tf, 2 * n / tf / 1e6, tb, 3 * n / tb / 1e6)
         if C <= 512:
             gb = lambda: _lib.call("ssv_highway_gate_bwd", P(dy), C * L, P(x), C * L, P(g), P(b), P(g), P(b), P(h), P(stats), P(dh), P(dx), C * L, P(pg), B, C, L, P(wg), ng, st)
-            gf = lambda: _lib.call("ssv_highway_gate_fwd", P(h), P(x), C * L, P(g), P(b), P(g), P(b), P(stats), P(y), C * L, B, C, L, st)
+            gf = lambda: _lib.call("ssv_highway_gate_fwd", P(h), P(x), C * L, P(g), P(b), P(g), P(b), P(stats), P(y), C * L, None, B, C, L, st)
             tg, tgf = timeit(gb), timeit(gf)
             line += " gate-f %.1f (%.2f) gate-b %.1f (%.2f)" % (tgf, 4 * n / tgf / 1e6, tg, 7 * n / tg / 1e6)
     print(line, flush=True)

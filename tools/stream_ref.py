@@ -25,7 +25,7 @@ for (B, C, L) in [(32, 256, 325), (32, 512, 186), (32, 256, 1300), (32, 512, 130
         g = torch.rand(C, device=dev) + 0.5; b = torch.randn(C, device=dev)
         n = B * C * L * 4
         t_ref = timeit(lambda i: torch.addcmul(x[i], h[i][:, :C], h[i][:, C:], out=y[i]), nset)
-        t_gate = timeit(lambda i: _lib.call("ssv_highway_gate_fwd", P(h[i]), P(x[i]), C * L, P(g), P(b), P(g), P(b), P(stats), P(y[i]), C * L, B, C, L, st), nset)
+        t_gate = timeit(lambda i: _lib.call("ssv_highway_gate_fwd", P(h[i]), P(x[i]), C * L, P(g), P(b), P(g), P(b), P(stats), P(y[i]), C * L, None, B, C, L, st), nset)
         print("B%d C%d L%d %-40s addcmul %6.1f us = %.2f TB/s | highway gate fwd %6.1f us = %.2f TB/s" % (B, C, L, label, t_ref, 4 * n / t_ref / 1e6, t_gate, 4 * n / t_gate / 1e6), flush=True)
         del x, h, y
         torch.cuda.empty_cache()
