@@ -152,6 +152,94 @@ def adversarial_cycle_ms(kind, batch, dev, world=1, cycles=3):
     return dt / (6 * cycles) * 1e3
 
 
+ADV_MASK_SEED = 99
+
+
+def _adv_build(kind):
+    """Generator + critic of the adversarial parity check, on the CPU: seed 1234, generator first (the construction order of
+    ``adversarial_cycle_ms``), ``init_weights`` on both."""
+    from spoofsv_amd import train
+    from spoofsv_amd.critic import linDisc, melDisc
+    from spoofsv_amd.tts import SSRN, melSyn
+    torch.manual_seed(1234)
+    if kind == "text2mel":
+        model, disc = melSyn(34, True, 200, 128, 80, 256), melDisc(80, 128)
+    else:
+        model, disc = SSRN(80, 513, 256), linDisc(513, 128)
+    model.apply(train.init_weights); disc.apply(train.init_weights)
+    return model, disc
+
+
+def _adv_masks(kind, batch, n_calls):
+    """The keep masks (already scaled by 1 / 0.95, what nn.Dropout multiplies by) of ``n_calls`` critic calls: three per call, at the
+    critic's three dropout sites (models/discriminator.py:26,31 and the dropout highwayConv), drawn from one seeded CPU generator."""
+    g = torch.Generator().manual_seed(ADV_MASK_SEED)
+    T, pool = (T_MEL, 4) if kind == "text2mel" else (4 * T_MEL, 8)
+    shapes = [(batch, 128, T), (batch, 128, T), (batch, 64, T // pool)]
+    return [(torch.rand(sh, generator=g) >= 0.05).float() / 0.95 for _ in range(n_calls) for sh in shapes]
+
+
+def adversarial_first_g_iterations(kind, batch, dev):
+    """Loss terms (l1, bin-div, [att,] disc) of generator iterations 0 and 1 of the WGAN-GP trainer at the workload's batch, eagerly, with
+    the critic's dropout masks INJECTED (``critic.injected_dropout_masks``) so the CPU oracle can apply the same ones: iteration 0 checks
+    generator + critic forward, iteration 1 the generator's gradient THROUGH the critic, the adaptive weight and Adam
+    (train/adversarial_wasserstein_gp.py:278-297, :329-343)."""
+    from spoofsv_amd import critic, train
+    model, disc = _adv_build(kind)
+    gaw = None
+    if kind == "text2mel":
+        data = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=0, device=dev)
+        gaw = train.guided_attention_mat(186, 325, device=dev)
+    else:
+        data = train.synthetic_ssrn_batch(batch, T_MEL, seed=0, device=dev)
+    model.to(dev).train(); disc.to(dev).train()
+    og = train.FusedAdam(model.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+    od = train.FusedAdam(disc.parameters(), 2e-4, (0.5, 0.9), 1e-6, capturable=True)
+    og.refresh_resident_weights()
+    stepper = train.AdversarialGraphStep(kind, model, disc, og, od, data, gaw, 10.0, None, None, graph=False)
+    masks = [m.to(dev) for m in _adv_masks(kind, batch, 2)]
+    out = []
+    with critic.injected_dropout_masks(masks):
+        for _ in range(2):
+            l1, bd, la, ld, _tot = stepper.g_step()
+            out.append([float(l1), float(bd)] + ([float(la)] if kind == "text2mel" else []) + [float(ld)])
+    del stepper, og, od, model, disc
+    torch.cuda.empty_cache()
+    return out
+
+
+def adversarial_first_g_iterations_oracle(kind, batch):
+    """The same two generator iterations on the CPU oracles (oracle/tts_oracle.py + oracle/critic_oracle.py, same masks, torch's Adam)."""
+    from oracle import critic_oracle as CO
+    from oracle import tts_oracle as TO
+    from spoofsv_amd import train
+    model, disc = _adv_build(kind)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    dsd = {k: v.detach().clone() for k, v in disc.state_dict().items()}
+    opt = torch.optim.Adam(list(sd.values()), 2e-4, (0.5, 0.9), 1e-6)
+    if kind == "text2mel":
+        mel, text, spk = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=0)
+        gaw = train.guided_attention_mat(186, 325)
+    else:
+        mel, lin = train.synthetic_ssrn_batch(batch, T_MEL, seed=0)
+    masks = _adv_masks(kind, batch, 2)
+    out = []
+    for it in range(2):
+        opt.zero_grad()
+        if kind == "text2mel":
+            Y, A = TO.melsyn_train(train.shift_right(mel), text, spk, sd)
+            terms = list(TO.text2mel_losses(Y, A, mel, gaw))
+        else:
+            Y = TO.ssrn(mel, sd)
+            terms = list(TO.ssrn_losses(Y, lin))
+        ld = torch.mean(-CO.critic(Y, dsd, "mel" if kind == "text2mel" else "lin", masks=masks[3 * it:3 * it + 3]))
+        base = sum(terms)
+        (base + (float(base.detach()) / abs(float(ld.detach()))) * ld).backward()        # adversarial_wasserstein_gp.py:290 / :338
+        opt.step()
+        out.append([float(t.detach()) for t in terms] + [float(ld.detach())])
+    return out
+
+
 def kernel_roofline(dev):
     """Average duration of the dominant kernel -- the k=3 dilated Conv1d implicit GEMM (gemm_nn_bf3_kernel / gemm_nn_kernel)
     at its most frequent launch shape in the step: highwayConv C=256 (M=2C=512), L=325, B=32 -- timed with HIP events
@@ -487,7 +575,9 @@ def launch_ranks(n):
 def main():
     args = parse()
     if args.ge2e:
-        print(json.dumps(ge2e_config5()))
+        import spoofsv_amd
+        spoofsv_amd.set_precision(args.precision)
+        print(json.dumps(dict(ge2e_config5(), arithmetic=args.precision)))
         return
     if args.gpus < 1:
         raise SystemExit("bench: --gpus must be >= 1")
@@ -611,6 +701,9 @@ def main():
                     "adversarial_note": "ms per iteration averaged over 1 G : 5 D cycles (RATIO=5), WGAN-GP critics on twice-differentiable HIP kernels, "
                                         "hipGraph replay" + ("; data parallel: global adaptive weight, bucketed generator all-reduce, packed critic all-reduce" if world > 1 else "")})
         torch.cuda.empty_cache()
+    adv_first = None
+    if world == 1 and not args.no_adversarial and not args.no_cpu_baseline and args.batch == B_PER_GPU:
+        adv_first = {k: adversarial_first_g_iterations(k, args.batch, dev) for k in ("text2mel", "ssrn")}
     if world == 1 and not args.no_fp32:
         # the same step in the other arithmetic modes, beside the headline and never inside `value`: exact fp32 MFMA
         # (v_mfma_f32_16x16x4_f32: what strict fp32 fma chains cost) and, opt-in for users who accept ~2^-16 products, split-bf16
@@ -632,7 +725,8 @@ def main():
             # BASELINE config 5 on the same line (flat scalars); `python bench.py --ge2e` prints the full record
             g = ge2e_config5()
             cfg.update({"ge2e_utt_per_s": g["value"], "ge2e_ms": g["ms"], "ge2e_tflops": g["tflops"], "ge2e_rel_err_vs_oracle": g["rel_err_vs_cpu_oracle"],
-                        "ge2e_roofline_frac": round(g["tflops"] / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),       # split-bf16 LSTM products: 3 MFMAs per product
+                        "ge2e_roofline_frac": round(g["tflops"] / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),       # split-fp16 (or split-bf16) LSTM products: 3 MFMAs per product
+                        "ge2e_arithmetic": "LSTM products in the %s mode" % args.precision,
                         "ge2e_train_iteration_ms": g["train_iteration"]["ms"], "ge2e_cpu_utt_per_s": g["cpu_baseline"]["value"],
                         "ge2e_cpu_cores": g["cpu_baseline"]["cores"]})
         bad = None
@@ -650,6 +744,20 @@ def main():
                         cfg["loss_rel_err_vs_oracle_%s_iter%d" % (kind, it)] = float("%.3g" % e)
                         if not e < 1e-4:
                             bad = (kind, it, first[kind][it], ref[kind][it])
+            # ... and of the ADVERSARIAL trainer (BASELINE config 3 at its own batch): generator iterations 0 and 1 with the critic's
+            # dropout masks injected on both sides -- forward of generator and critic, then the gradient through the critic with the
+            # adaptive weight and one Adam step
+            if adv_first is not None:
+                for kind in ("text2mel", "ssrn"):
+                    ref = adversarial_first_g_iterations_oracle(kind, args.batch)
+                    worst = 0.0
+                    for it in range(2):
+                        e = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(adv_first[kind][it], ref[it]))
+                        cfg["loss_rel_err_vs_oracle_adv_%s_iter%d" % (kind, it)] = float("%.3g" % e)
+                        worst = max(worst, e)
+                    cfg["loss_rel_err_vs_oracle_adv_%s" % kind] = float("%.3g" % worst)
+                    if not worst < 1e-4:
+                        bad = ("adversarial " + kind, adv_first[kind], ref)
         print(json.dumps(res), flush=True)
         if bad is not None:
             raise SystemExit("bench: losses differ from the CPU oracle's by more than 1e-4: %r" % (bad,))

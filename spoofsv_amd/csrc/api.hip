@@ -8,6 +8,7 @@
 #include <string.h>
 #include "ssv_common.h"
 #include "../../include/ssv_hip.h"
+#define SSV_HIP(expr) do { hipError_t _he = (expr); if (_he != hipSuccess) { ssv_fail(0, "%s: %s", #expr, hipGetErrorString(_he)); return -(int)_he; } } while (0)
 
 // ---- error state ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -205,6 +206,8 @@ static GemmNNB nnb_zero() {
   g.gates_out = nullptr;
   g.f16 = 0; g.a_inv = nullptr; g.x_amax = nullptr; g.x_namax = 0; g.x_amax_bs = 0;
   g.colstats = nullptr;
+  g.gate_cnt = nullptr; g.gate_g1 = g.gate_b1 = g.gate_g2 = g.gate_b2 = nullptr;
+  g.gate_y = nullptr; g.gate_ybs = 0; g.gate_stats = nullptr; g.gate_amax = nullptr; g.gate_namax = 0;
   return g;
 }
 
@@ -216,7 +219,7 @@ static inline size_t conv_aux_bytes() { return SSV_F16_AUX_BYTES + AMAX_FB_BYTES
 static int conv_nn(const float* x, long x_bs, const float* w, const void* packed, long w_sm, long w_sk, const float* bias, const float* bias_b,
                    const float* r, long r_bs, float* y, long y_bs, int B, int K, int M, int L, int k, const int* shift,
                    bool bf3, void* ws, hipStream_t st, const float* a_inv = nullptr, const float* xa_given = nullptr, int xa_n = 0, size_t ws_main = 0,
-                   float* colstats = nullptr) {
+                   float* colstats = nullptr, const GemmNNB* gate = nullptr) {
   if (bf3) {
     const int Kpad = pad32(K);
     const unsigned short* hi = (const unsigned short*)(packed ? packed : ws);
@@ -234,6 +237,10 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
       g.f16 = 1; g.a_inv = a_inv; g.x_amax = xa.p; g.x_namax = xa.n; g.x_amax_bs = xa.n;
     }
     g.colstats = colstats;
+    if (gate) {           // fused highway gate: see GemmNNB::gate_cnt
+      g.gate_cnt = gate->gate_cnt; g.gate_g1 = gate->gate_g1; g.gate_b1 = gate->gate_b1; g.gate_g2 = gate->gate_g2; g.gate_b2 = gate->gate_b2;
+      g.gate_y = gate->gate_y; g.gate_ybs = gate->gate_ybs; g.gate_stats = gate->gate_stats; g.gate_amax = gate->gate_amax; g.gate_namax = gate->gate_namax;
+    }
     g.Ahi = hi; g.Alo = lo; g.Kpad = Kpad;
     g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
     g.C = y; g.scb = y_bs; g.scm = L;
@@ -487,8 +494,10 @@ extern "C" int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* 
 // halves are whole groups; the LayerNorm / gate forward is then a streaming kernel without reductions (norm.hip).
 static inline bool hw_colstats(int B, int C, int L) { return use_bf3(B, L, C, 2 * C) && C % 64 == 0 && C <= 512 && !ssv_tuning(SSV_T_LN_NOSTREAM); }
 static inline size_t hw_colstats_bytes(int B, int C, int L) { return align256((size_t)B * (2 * C / 64) * L * 2 * sizeof(float)); }
+static inline size_t hw_cnt_bytes(int B, int L) { return align256((size_t)B * ssv_cdiv(L, 32) * sizeof(unsigned)); }
+static inline bool hw_fuse_gate() { static const int on = getenv("SSV_FUSE_GATE") ? atoi(getenv("SSV_FUSE_GATE")) : 0; return on != 0; }
 extern "C" size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k) {
-  return ssv_conv1d_fwd_workspace(C, 2 * C, k) + (hw_colstats(B, C, L) ? hw_colstats_bytes(B, C, L) : 0);
+  return ssv_conv1d_fwd_workspace(C, 2 * C, k) + (hw_colstats(B, C, L) ? hw_colstats_bytes(B, C, L) + hw_cnt_bytes(B, L) : 0);
 }
 extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
                                       const float* g1, const float* b1, const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
@@ -497,11 +506,21 @@ extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_
   SSV_CHECK(B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_conv1d_fwd: bad shape B=%d C=%d L=%d", B, C, L);
   if (hw_colstats(B, C, L)) {
     const size_t conv_ws = ssv_conv1d_fwd_workspace(C, 2 * C, k);
-    SSV_CHECK(ws && ws_bytes >= conv_ws + hw_colstats_bytes(B, C, L), SSV_BAD_SHAPE, "highway_conv1d_fwd: workspace too small");
+    SSV_CHECK(ws && ws_bytes >= conv_ws + hw_colstats_bytes(B, C, L) + hw_cnt_bytes(B, L), SSV_BAD_SHAPE, "highway_conv1d_fwd: workspace too small");
     SSV_CHECK(x_bs >= (long)C * L && y_bs >= (long)C * L, SSV_BAD_SHAPE, "highway_conv1d_fwd: batch stride smaller than C*L");
     float* cs = (float*)((char*)ws + conv_ws);
     int shift[3];
     SSV_TRY(conv_shifts(k, dilation, causal, shift));
+    if (hw_fuse_gate() && C % 64 == 0 && (!y_amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 32))) {
+      // EXPERIMENT (SSV_FUSE_GATE=1): the gate runs in the conv kernel's epilogue, by the last workgroup to finish each column tile
+      GemmNNB gt = nnb_zero();
+      gt.gate_cnt = (unsigned*)((char*)cs + hw_colstats_bytes(B, C, L));
+      SSV_HIP(hipMemsetAsync(gt.gate_cnt, 0, hw_cnt_bytes(B, L), (hipStream_t)stream));
+      gt.gate_g1 = g1; gt.gate_b1 = b1; gt.gate_g2 = g2; gt.gate_b2 = b2;
+      gt.gate_y = y; gt.gate_ybs = y_bs; gt.gate_stats = stats; gt.gate_amax = y_amax; gt.gate_namax = ssv_amax_rows_(L);
+      return conv_nn(x, x_bs, w, w_packed, (long)C * k, k, bias, nullptr, nullptr, 0, h, (long)2 * C * L, B, C, 2 * C, L, k, shift, true, ws, (hipStream_t)stream,
+                     packed_inv(w_packed, 2 * C, C, k, 0), x_amax, x_namax, 2 * split_bytes(2 * C, C, k), cs, &gt);
+    }
     SSV_TRY(conv_nn(x, x_bs, w, w_packed, (long)C * k, k, bias, nullptr, nullptr, 0, h, (long)2 * C * L, B, C, 2 * C, L, k, shift, true, ws, (hipStream_t)stream,
                     packed_inv(w_packed, 2 * C, C, k, 0), x_amax, x_namax, 2 * split_bytes(2 * C, C, k), cs));
     return ssv_launch_ln_gate_fwd_stream(h, x, x_bs, cs, g1, b1, g2, b2, y, y_bs, stats, y_amax, B, C, L, (hipStream_t)stream);
@@ -863,9 +882,12 @@ static int lstm_gemm_f32(const float* A, const float* X, long sxb, float* C, lon
   g.M = M; g.N = Bn; g.Kc = K; g.B = nb;
   return ssv_launch_gemm_nn(g, st);
 }
-#define SSV_HIP(expr) do { hipError_t _he = (expr); if (_he != hipSuccess) { ssv_fail(0, "%s: %s", #expr, hipGetErrorString(_he)); return -(int)_he; } } while (0)
 // Wavefront (split-bf16) layout: h of every layer lives in a 2-frame ring, weights of layer l >= 1 are [W_ih | W_hh] side by side.
-struct LstmWave { size_t xt, xp, out, c, bias, ih0, hh0, comb, comb_stride, total; };
+struct LstmWave { size_t xt, xp, out, c, bias, ih0, hh0, comb, comb_stride, aux, total; };
+// split-fp16 scales of the wavefront (floats at `aux`): [0, 64) partial maxima over ALL weight matrices (one scale for every layer: a
+// launch batches layers over grid.y and has one epilogue factor), [64] its inverse scale, [65] = 1.0: the activations' one-entry
+// list (|h| = |o tanh c| < 1, so their scale is the constant 2^14), [128, 192) partial maxima of the input frames (layer 0's projection)
+#define LSTM_AUX_FLOATS 192
 static LstmWave lstm_wave_ws(int Bn, int T, int F, int H, int layers) {
   LstmWave s;
   s.xt = 0;
@@ -877,7 +899,8 @@ static LstmWave lstm_wave_ws(int Bn, int T, int F, int H, int layers) {
   s.hh0 = s.ih0 + 2 * split_bytes(4 * H, F, 1);
   s.comb = s.hh0 + 2 * split_bytes(4 * H, H, 1);
   s.comb_stride = 2 * split_bytes(4 * H, 2 * H, 1);
-  s.total = s.comb + (size_t)(layers > 1 ? layers - 1 : 0) * s.comb_stride;
+  s.aux = s.comb + (size_t)(layers > 1 ? layers - 1 : 0) * s.comb_stride;
+  s.total = s.aux + align256(LSTM_AUX_FLOATS * sizeof(float));
   return s;
 }
 static bool lstm_wave_ok(int Bn, int H) { return Bn >= 64 && H >= 32 && H % 32 == 0; }
@@ -911,14 +934,32 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   unsigned short* ih0_lo = (unsigned short*)(base + s.ih0 + split_bytes(4 * H, F, 1));
   unsigned short* hh0_hi = (unsigned short*)(base + s.hh0);
   unsigned short* hh0_lo = (unsigned short*)(base + s.hh0 + split_bytes(4 * H, H, 1));
-  SSV_TRY(ssv_launch_pack_split(w_ih[0], ih0_hi, ih0_lo, 4 * H, F, pad32(F), 1, F, 1, 1, H, st));
-  SSV_TRY(ssv_launch_pack_split(w_hh[0], hh0_hi, hh0_lo, 4 * H, H, H, 1, H, 1, 1, H, st));
+  // Arithmetic of the products: split-fp16 in the default mode (the reference's nn.LSTM computes in fp32,
+  // GE2E/speech_embedder_net.py:19,28), split-bf16 when that mode is selected.
+  const bool f16 = use_f16() && 2 * layers <= 64;
+  float* aux = (float*)(base + s.aux);
+  if (f16) {
+    const int npb = 64 / (2 * layers);                            // partial maxima per weight matrix
+    SSV_HIP(hipMemsetAsync(aux, 0, LSTM_AUX_FLOATS * sizeof(float), st));
+    for (int l = 0; l < layers; ++l) {
+      SSV_TRY(ssv_launch_absmax(w_ih[l], 0, 1, (long)4 * H * (l == 0 ? F : H), aux + (2 * l) * npb, npb, st));
+      SSV_TRY(ssv_launch_absmax(w_hh[l], 0, 1, (long)4 * H * H, aux + (2 * l + 1) * npb, npb, st));
+    }
+    SSV_TRY(ssv_launch_fill(aux + 65, 1.f, 1, st));
+    SSV_TRY(ssv_launch_absmax(xt, 0, 1, (long)T * F * Bn, aux + 128, 64, st));
+  }
+  auto pack = [&](const float* w, unsigned short* hi, unsigned short* lo, int K, int Kpad, int nch_total, int ch_off) -> int {
+    if (f16) return ssv_launch_pack_split_f16_list(w, hi, lo, 4 * H, K, Kpad, 1, K, 1, 1, H, aux, 64, aux + 64, st, nch_total, ch_off);
+    return ssv_launch_pack_split(w, hi, lo, 4 * H, K, Kpad, 1, K, 1, 1, H, st, nch_total, ch_off);
+  };
+  SSV_TRY(pack(w_ih[0], ih0_hi, ih0_lo, F, pad32(F), 0, 0));
+  SSV_TRY(pack(w_hh[0], hh0_hi, hh0_lo, H, H, 0, 0));
   const int hch = H / 32;
   for (int l = 1; l < layers; ++l) {
     unsigned short* hi = (unsigned short*)(base + s.comb + (size_t)(l - 1) * s.comb_stride);
     unsigned short* lo = (unsigned short*)((char*)hi + split_bytes(4 * H, 2 * H, 1));
-    SSV_TRY(ssv_launch_pack_split(w_ih[l], hi, lo, 4 * H, H, H, 1, H, 1, 1, H, st, 2 * hch, 0));
-    SSV_TRY(ssv_launch_pack_split(w_hh[l], hi, lo, 4 * H, H, H, 1, H, 1, 1, H, st, 2 * hch, hch));
+    SSV_TRY(pack(w_ih[l], hi, lo, H, H, 2 * hch, 0));
+    SSV_TRY(pack(w_hh[l], hi, lo, H, H, 2 * hch, hch));
   }
   // layer 0's input projection for every frame at once (biases are left to the cell): xp[t] = W_ih x_t
   {
@@ -927,11 +968,13 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
     g.X = xt; g.sxb = (long)F * Bn; g.sxc = Bn; g.Lx = Bn;
     g.C = xp; g.scb = (long)4 * H * Bn; g.scm = Bn;
     g.M = 4 * H; g.N = Bn; g.B = T; g.perm_h = H;
+    if (f16) { g.f16 = 1; g.a_inv = aux + 64; g.x_amax = aux + 128; g.x_namax = 64; g.x_amax_bs = 0; }
     SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
   }
   GemmNNB g = nnb_zero();
   g.sxc = Bn; g.Lx = Bn; g.scm = Bn; g.srm = Bn;
   g.M = 4 * H; g.N = Bn; g.perm_h = H; g.epi = 1; g.cstate = cbuf;
+  if (f16) { g.f16 = 1; g.a_inv = aux + 64; g.x_amax = aux + 65; g.x_namax = 1; g.x_amax_bs = 0; }
   g.lstm_out = out; g.lstm_D = D; g.sbb = (long)8 * H; g.gates_out = keep_gates;
   g.X = out; g.C = out;                        // placeholders: the kernel derives X, X2 and C from (layer, frame)
   for (int step = 0; step < T + layers - 1; ++step) {

@@ -160,15 +160,17 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
   hi[d] = h;
   lo[d] = (__bf16)(v - (float)h);
 }
-// split-fp16 planes of ONE dense weight: same element map; the scale comes from the 64 partial maxima at aux (written by
-// absmax_kernel just before), the inverse scale goes to aux[64] for the GEMM's epilogue.
+// split-fp16 planes of one dense weight: same element map (perm_h / nch_total / ch_off as in pack_split_kernel); the scale comes from
+// the `nlist` partial maxima at `list` (written by absmax_kernel just before -- of this weight alone, or of every weight that shares
+// the scale), the inverse scale goes to *inv_out for the GEMM's epilogue.
 __global__ __launch_bounds__(256) void pack_split_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                             int M, int K, int Kpad, int KT, long sm, long sk, long sj, float* __restrict__ aux) {
+                                                             int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h,
+                                                             int nch_total, int ch_off, const float* __restrict__ list, int nlist, float* __restrict__ inv_out) {
   __shared__ float smx[4];
   float sc, inv;
-  ssv_pow2_scale(ssv_list_max<4>(aux, 64, smx), sc, inv);
+  ssv_pow2_scale(ssv_list_max<4>(list, nlist, smx), sc, inv);
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) aux[64] = inv;
+  if (i == 0) *inv_out = inv;
   const int MB = (M + 15) >> 4, NCH = Kpad >> 5;
   const long n = (long)KT * MB * NCH * 512;
   if (i >= n) return;
@@ -176,17 +178,25 @@ __global__ __launch_bounds__(256) void pack_split_f16_kernel(const float* __rest
   const long blk = i >> 9;
   const int ch = (int)(blk % NCH), mb = (int)((blk / NCH) % MB), j = (int)(blk / ((long)NCH * MB));
   const int m = mb * 16 + r16, k = ch * 32 + kg * 8 + e;
-  const float v = (m < M && k < K) ? w[(long)m * sm + (long)k * sk + (long)j * sj] : 0.f;
+  const int ms = perm_h ? (m & 3) * perm_h + (m >> 2) : m;       // LSTM: gate-interleaved output rows
+  const float v = (m < M && k < K) ? w[(long)ms * sm + (long)k * sk + (long)j * sj] : 0.f;
   const _Float16 h = (_Float16)(v * sc);
-  hi[i] = h;
-  lo[i] = (_Float16)__builtin_fmaf(v, sc, -(float)h);
+  const long d = ((((long)j * MB + mb) * nch_total + ch + ch_off) << 9) + (i & 511);
+  hi[d] = h;
+  lo[d] = (_Float16)__builtin_fmaf(v, sc, -(float)h);
+}
+int ssv_launch_pack_split_f16_list(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h,
+                                   const float* list, int nlist, float* inv_out, hipStream_t st, int nch_total, int ch_off) {
+  const long n = (long)KT * ((M + 15) / 16 * 16) * Kpad;
+  if (nch_total <= 0) { nch_total = Kpad / 32; ch_off = 0; }
+  hipLaunchKernelGGL(pack_split_f16_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, (_Float16*)hi, (_Float16*)lo, M, K, Kpad, KT, sm, sk, sj, perm_h,
+                     nch_total, ch_off, list, nlist, inv_out);
+  return ssv_check_launch("pack_split_f16");
 }
 int ssv_launch_pack_split_f16(const float* w, long w_elems, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, float* aux,
                               hipStream_t st) {
   SSV_TRY(ssv_launch_absmax(w, 0, 1, w_elems, aux, 64, st));
-  const long n = (long)KT * ((M + 15) / 16 * 16) * Kpad;
-  hipLaunchKernelGGL(pack_split_f16_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, w, (_Float16*)hi, (_Float16*)lo, M, K, Kpad, KT, sm, sk, sj, aux);
-  return ssv_check_launch("pack_split_f16");
+  return ssv_launch_pack_split_f16_list(w, hi, lo, M, K, Kpad, KT, sm, sk, sj, 0, aux, 64, aux + 64, st, 0, 0);
 }
 int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h, hipStream_t st,
                           int nch_total, int ch_off) {
@@ -316,6 +326,85 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
   return ssv_check_launch("pack_multi");
 }
 
+// ---- highway gate of one column tile (fused into the conv that produced h: see GemmNNB::gate_cnt) ------------------------------------
+// Same arithmetic, in the same order, as ln_gate_fwd_stream_kernel (norm.hip): the C / 64 (mean, M2) partials of each half merged per
+// column (Chan, equal counts), then y = sigmoid(LN1(h1)) LN2(h2) + (1 - sigmoid(LN1(h1))) x streamed as 16-byte accesses.
+// sm: 4 * BN + 4 floats of LDS nobody else uses.  Called by ALL 256 threads of the last workgroup to finish a column tile.
+typedef float f4g __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2g __attribute__((ext_vector_type(2), aligned(8)));
+template <int BN>
+__device__ __forceinline__ void highway_gate_tile(const GemmNNB& p, const int b, const int ntile, const int n0, float* sm) {
+  const int tid = threadIdx.x;
+  const int C = p.M >> 1, L = p.N, P = C >> 6, MG = 2 * P;
+  for (int e = tid; e < 2 * BN; e += 256) {
+    const int half = e / BN, col = e % BN, t = n0 + col;
+    float mean = 0.f, r = 0.f;
+    if (t < L) {
+      const float* q = p.colstats + (((long)b * MG + half * P) * L + t) * 2;
+      f2g pr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pr[i] = *reinterpret_cast<const f2g*>(q + (long)min(i, P - 1) * L * 2);
+      float mu[8], m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { mu[i] = i < P ? pr[i].x : 0.f; mean += mu[i]; m2 += i < P ? pr[i].y : 0.f; }
+      mean /= (float)P;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (i < P) { const float d = mu[i] - mean; m2 += 64.f * d * d; }
+      r = rsqrtf(m2 / (float)C + 1e-5f);
+      if (p.gate_stats) { float* sb = p.gate_stats + (long)b * 4 * L + (long)(2 * half) * L + t; sb[0] = mean; sb[L] = r; }
+    }
+    sm[e * 2] = mean; sm[e * 2 + 1] = r;
+  }
+  __syncthreads();
+  const float* H1 = p.C + (long)b * p.scb + n0;
+  const float* H2 = H1 + (long)C * L;
+  const float* Xb = p.X + (long)b * p.sxb + n0;
+  float* Yb = p.gate_y + (long)b * p.gate_ybs + n0;
+  constexpr int Q = BN / 4;                       // 4-column groups per channel row of the tile
+  float am = 0.f;
+#pragma unroll 2
+  for (int e = tid; e < C * Q; e += 256) {
+    const int c = e / Q, q4 = (e % Q) * 4;
+    if (n0 + q4 >= L) continue;
+    const unsigned o = (unsigned)c * (unsigned)L + (unsigned)q4;
+    const float ga1 = p.gate_g1[c], be1 = p.gate_b1[c], ga2 = p.gate_g2[c], be2 = p.gate_b2[c];
+    float h1[4], h2[4], xv[4], y[4];
+    const bool full = n0 + q4 + 3 < L;
+    if (full) {
+      const f4g a = *reinterpret_cast<const f4g*>(H1 + o), d = *reinterpret_cast<const f4g*>(H2 + o), x4 = *reinterpret_cast<const f4g*>(Xb + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { h1[j] = a[j]; h2[j] = d[j]; xv[j] = x4[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const bool v = n0 + q4 + j < L; h1[j] = v ? H1[o + j] : 0.f; h2[j] = v ? H2[o + j] : 0.f; xv[j] = v ? Xb[o + j] : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mu1 = sm[(q4 + j) * 2], r1 = sm[(q4 + j) * 2 + 1], mu2 = sm[(BN + q4 + j) * 2], r2 = sm[(BN + q4 + j) * 2 + 1];
+      const float n1 = (h1[j] - mu1) * r1 * ga1 + be1;
+      const float n2 = (h2[j] - mu2) * r2 * ga2 + be2;
+      const float sg = 1.f / (1.f + __expf(-n1));
+      y[j] = sg * n2 + (1.f - sg) * xv[j];
+    }
+    if (full) {
+      *reinterpret_cast<f4g*>(Yb + o) = (f4g){y[0], y[1], y[2], y[3]};
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (n0 + q4 + j < L) { Yb[o + j] = y[j]; am = fmaxf(am, fabsf(y[j])); }
+    }
+  }
+  if (p.gate_amax) {
+    am = ssv_wg_max<4>(am, sm + 4 * BN);
+    if (tid == 0) {
+      float* al = p.gate_amax + (long)b * p.gate_namax;
+      al[ntile] = am;
+      const int ntiles = (L + BN - 1) / BN;
+      if (ntile == ntiles - 1) for (int e = ntiles; e < p.gate_namax; ++e) al[e] = 0.f;
+    }
+  }
+}
+
 // ---- NN ---------------------------------------------------------------------------------------------------------------
 // Waves split the M axis, so a weight row is only ever used by ONE wave: weight fragments go straight from global memory
 // (L2-resident, pre-split, fragment-shaped 16-byte loads) into MFMA operand registers, one K chunk ahead (two register
@@ -362,7 +451,6 @@ extern "C" int ssv_debug_nn_stamps(unsigned long long* out) { return (int)hipMem
 #endif
 template <int KT, int WM, int NT, int EPI, int F16>
 __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
-  static_assert(!(EPI && F16), "the LSTM epilogue runs on the split-bf16 arithmetic");
   constexpr int BM = 64 * WM, BN = 16 * NT;
   constexpr int HALO = (KT == 1) ? 0 : 54;
   constexpr int WX = ((BN + HALO + 15) / 16) * 16;         // staged columns, plane = WX*16 B = multiple of 256 B
@@ -690,7 +778,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
         if (gn >= p.N) continue;
         float gte[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gte[r] = acc[i][t][r] + add[r] + (Rb ? Rb[(long)(row0 + r) * p.srm + gn] : 0.f);
+        for (int r = 0; r < 4; ++r) gte[r] = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add[r] + (Rb ? Rb[(long)(row0 + r) * p.srm + gn] : 0.f);
         const float gi = 1.f / (1.f + expf(-gte[0])), gf = 1.f / (1.f + expf(-gte[1]));
         const float gg = tanhf(gte[2]), go = 1.f / (1.f + expf(-gte[3]));
         const long ci = (long)u * p.N + gn;
@@ -784,6 +872,27 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
         for (int q = 0; q < 4; ++q) { const float d = mu[q] - mean; m2 += 16.f * d * d; }
         float* dst = p.colstats + (((long)b * (p.M >> 6) + (m0 >> 6) + grp) * p.N + gn) * 2;
         dst[0] = mean; dst[1] = m2;
+      }
+      if (p.gate_cnt) {
+        // Fused highway gate (GemmNNB::gate_cnt).  Release: every thread's h rows and column partials are visible device-wide
+        // before the counter moves; the workgroup that finds mtiles - 1 earlier arrivals acquires and runs the tile's gate.
+        __threadfence();
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(lds_all);
+        if (tid == 0) {
+          unsigned* cnt = p.gate_cnt + (long)b * (gridDim.x / mtiles) + ntile;
+          const unsigned old = atomicAdd(cnt, 1u);
+          const int last = old == (unsigned)mtiles - 1u;
+          if (last) atomicExch(cnt, 0u);                  // self-resetting: zero again for the next launch (capture-safe, no memset node)
+          *flag = last;
+        }
+        __syncthreads();
+        const int last = *flag;
+        __syncthreads();
+        if (last) {
+          __threadfence();
+          highway_gate_tile<BN>(p, b, ntile, n0, reinterpret_cast<float*>(lds_all));
+        }
       }
     }
     NN_STAMP_AT(3);
@@ -1018,7 +1127,8 @@ static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT);
   if constexpr (KT == 1) {
     if (g.epi == 1) {
-      hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 1, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+      if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 1, 1>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+      else hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 1, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
       return ssv_check_launch("gemm_nn_bf3_lstm");
     }
   }
@@ -1123,8 +1233,11 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   // the kernels address one batch item's input rows and the weight planes with 32-bit byte offsets (buffer loads)
   SSV_CHECK(((long)g.Kpad * g.sxc + (long)g.Lx * (g.sxn > 0 ? g.sxn : 1)) * 4 < (1L << 31) && (long)g.KT * ((g.M + 15) / 16) * (g.Kpad / 32) * 1024 < (1L << 31),
             SSV_UNSUPPORTED, "gemm_nn_bf3: a batch item's input or the weight planes span 2 GiB or more");
-  SSV_CHECK(!g.f16 || (!g.epi && g.a_inv && g.x_amax && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales and no LSTM epilogue");
+  SSV_CHECK(!g.f16 || (g.a_inv && g.x_amax && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales");
   SSV_CHECK(!g.colstats || (g.M % 64 == 0 && g.scn == 1 && !g.epi && !g.perm_h && !g.R), SSV_BAD_SHAPE, "gemm_nn_bf3: column statistics need M %% 64 == 0 and a plain epilogue");
+  SSV_CHECK(!g.gate_cnt || (g.colstats && g.M % 128 == 0 && g.M <= 1024 && g.sxn == 1 && g.sxc == g.N && g.Kc == g.M / 2 && g.gate_g1 && g.gate_b1 && g.gate_g2 && g.gate_b2 && g.gate_y &&
+                            (!g.gate_amax || g.gate_namax >= ssv_cdiv(g.N, 32))),
+            SSV_BAD_SHAPE, "gemm_nn_bf3: the fused highway gate needs column statistics, M = 2 Kc <= 1024 and a dense input");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
 }
 

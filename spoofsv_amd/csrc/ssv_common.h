@@ -78,7 +78,8 @@ struct GemmNNB {
   // training (gates_out != null, lstm_D = number of frames): the activated gates i, f, g, o are saved as
   // gates_out[layer][frame][gate*H + u][N] (torch row order) and cstate is [layer][frame][H][N] (c_{t-1} read, c_t written)
   float* gates_out;
-  // split-fp16 arithmetic (f16 = 1, see "split-fp16" below; conv products only, not the LSTM epilogue): the planes hold fp16
+  // split-fp16 arithmetic (f16 = 1, see "split-fp16" below; with the LSTM epilogue one weight scale serves all layers of a launch and
+  // the activations, |h| < 1, take the fixed scale 2^14 from a one-entry list holding 1.0): the planes hold fp16
   // hi / lo of A * 2^ea and *a_inv = 2^-ea (written by the pack kernels); X is scaled by 2^ex while it is split, with ex from
   // the maximum of the x_namax partial maxima |X| at x_amax + b * x_amax_bs (x_amax_bs = 0: one list for every batch item).
   int f16; const float* a_inv; const float* x_amax; int x_namax; long x_amax_bs;
@@ -87,6 +88,14 @@ struct GemmNNB {
   // colstats[((b * (M / 64) + m / 64) * N + n) * 2 + {0, 1}] = mean and sum of squared deviations of C(b, 64-row group, n)
   // over the group's 64 rows, bias included.  Needs M % 64 == 0, unit column stride, no LSTM epilogue.  Null: not wanted.
   float* colstats;
+  // Fused highway gate (highwayConv forward, models/TTSModel.py:78-83; needs colstats): C = h (B, 2C, L) is the conv output.  Every
+  // workgroup releases its rows and column partials, bumps gate_cnt[b * column tiles + column tile]; the LAST arriver of a column
+  // tile (its row tiles are neighbours in the XCD order: one L2) runs both LayerNorms and the gate for that tile -- y = s n2 + (1 - s) x
+  // with x = this GEMM's own input X (unit column stride, sxc = L) -- and resets the counter.  gate_cnt: caller-owned, zero before the
+  // FIRST launch only.  gate_amax: one max |y| per column tile, the rest of the item's gate_namax entries zeroed.  Null: off.
+  unsigned* gate_cnt;
+  const float* gate_g1; const float* gate_b1; const float* gate_g2; const float* gate_b2;
+  float* gate_y; long gate_ybs; float* gate_stats; float* gate_amax; int gate_namax;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
@@ -97,6 +106,9 @@ int ssv_launch_pack_split(const float* w, void* hi, void* lo, int M, int K, int 
                           int nch_total = 0, int ch_off = 0);
 // split-fp16 planes of one dense weight (w_elems floats at w): partial maxima -> aux[0..63], 2^-ea -> aux[64]; then the planes
 int ssv_launch_pack_split_f16(const float* w, long w_elems, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, float* aux, hipStream_t st);
+// ... with the scale taken from a list the caller filled (several weights sharing one scale; LSTM row order / side-by-side planes as in ssv_launch_pack_split)
+int ssv_launch_pack_split_f16_list(const float* w, void* hi, void* lo, int M, int K, int Kpad, int KT, long sm, long sk, long sj, int perm_h,
+                                   const float* list, int nlist, float* inv_out, hipStream_t st, int nch_total = 0, int ch_off = 0);
 #define SSV_F16_AUX_FLOATS 128          // floats of aux the call above needs (64 partial maxima, the inverse scale, padding)
 #define SSV_AMAX_FALLBACK 64            // partial maxima an internally computed |x| list has (one list for the whole tensor)
 // partial maxima of |x| for B items of n dense floats each (item stride x_bs): out[b * npb + i], i < npb

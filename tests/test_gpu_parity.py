@@ -316,7 +316,7 @@ def test_ge2e_embedder_golden():
     m.load_state_dict(sub(g, "sd/"))
     m = m.to(DEV).eval()
     e = m(t(g["x"], DEV))
-    assert rel_err(e, t(g["e"])) < 1e-4, rel_err(e, t(g["e"]))
+    assert rel_err(e, t(g["e"])) < FWD_TOL, rel_err(e, t(g["e"]))      # split-fp16 is held to the exact-fp32 bar
 
 
 def test_ge2e_embedder_midsize_vs_oracle():
@@ -327,7 +327,7 @@ def test_ge2e_embedder_midsize_vs_oracle():
     with torch.no_grad():
         eo = GO.speech_embedder(x, m.state_dict())
     eg = m.to(DEV).eval()(x.to(DEV))
-    assert rel_err(eg, eo) < 1e-4, rel_err(eg, eo)
+    assert rel_err(eg, eo) < FWD_TOL, rel_err(eg, eo)
 
 
 def test_ge2e_embedder_full_width_production_tiles_vs_oracle(precision):
@@ -345,7 +345,10 @@ def test_ge2e_embedder_full_width_production_tiles_vs_oracle(precision):
     with torch.no_grad():
         eo = GO.speech_embedder(x, m.state_dict())
     eg = m.to(DEV).eval()(x.to(DEV))
-    tol = 2e-5 if precision == "fp32" else 1e-4
+    # the LSTM products run in the mode's arithmetic: split-fp16 (default; weights share one power-of-two scale, |h| < 1 takes 2^14) is held
+    # to the exact-fp32 bar, split-bf16 to its own
+    tol = 1e-4 if precision == "bf16x3" else 2e-5
+    print("GE2E embedder 768 x 704 utterances, %s: max-norm %.2e, rel L2 %.2e" % (precision, rel_err(eg, eo), rel_l2(eg, eo)))
     assert rel_err(eg, eo) < tol and rel_l2(eg, eo) < tol, (rel_err(eg, eo), rel_l2(eg, eo))
 
 
@@ -662,13 +665,17 @@ def _check_grads_on_hip_sides(o, m, sides, precision, what):
         if n:
             assert float(pre[d].abs().max()) < _KINK_NOISE[precision] * rms, ("kink", i, n, float(pre[d].abs().max()), rms)
     exact = o["grads64"] if flips == 0 else _oracle_pass(o, torch.float64, force=sides)[2]
-    bad, worst = {}, 0.0
+    bad, worst, worst_free = {}, 0.0, 0.0
     for k, p in m.named_parameters():
         e_hip = rel_l2(p.grad, exact[k])
         worst = max(worst, e_hip)
+        worst_free = max(worst_free, rel_l2(p.grad, o["grads64"][k]))     # against the float64 oracle on ITS OWN sides (nothing forced)
         if e_hip > _GRAD_ALLOWANCE[precision]:
             bad[k] = e_hip
-    print("%s %s: %d kink sides (ReLU / L1) differ from float64 (all at noise level), worst gradient rel L2 %.2e" % (what, precision, flips, worst))
+    # both distances are reported: the asserted one (float64 held on the HIP path's kink sides) and the un-forced one, so that a growth in
+    # the number of flips -- or in what a flip costs -- shows in the log even while the forced comparison stays green
+    print("%s %s: %d kink sides (ReLU / L1) differ from float64 (all at noise level); worst gradient rel L2 %.2e on the HIP path's sides, "
+          "%.2e against the un-forced float64 oracle" % (what, precision, flips, worst, worst_free))
     assert not bad, (worst, flips, bad)
     big = sorted(((p.numel(), k) for k, p in m.named_parameters()), reverse=True)[:6]
     for _, k in big:        # element-wise: every entry within 5 % (split-bf16: 20 %) of itself, or of 5 % of the tensor's RMS for entries near zero
