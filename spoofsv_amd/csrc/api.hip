@@ -206,8 +206,6 @@ static GemmNNB nnb_zero() {
   g.gates_out = nullptr;
   g.f16 = 0; g.a_inv = nullptr; g.x_amax = nullptr; g.x_namax = 0; g.x_amax_bs = 0;
   g.colstats = nullptr;
-  g.gate_cnt = nullptr; g.gate_g1 = g.gate_b1 = g.gate_g2 = g.gate_b2 = nullptr;
-  g.gate_y = nullptr; g.gate_ybs = 0; g.gate_stats = nullptr; g.gate_amax = nullptr; g.gate_namax = 0;
   return g;
 }
 
@@ -219,7 +217,7 @@ static inline size_t conv_aux_bytes() { return SSV_F16_AUX_BYTES + AMAX_FB_BYTES
 static int conv_nn(const float* x, long x_bs, const float* w, const void* packed, long w_sm, long w_sk, const float* bias, const float* bias_b,
                    const float* r, long r_bs, float* y, long y_bs, int B, int K, int M, int L, int k, const int* shift,
                    bool bf3, void* ws, hipStream_t st, const float* a_inv = nullptr, const float* xa_given = nullptr, int xa_n = 0, size_t ws_main = 0,
-                   float* colstats = nullptr, const GemmNNB* gate = nullptr) {
+                   float* colstats = nullptr) {
   if (bf3) {
     const int Kpad = pad32(K);
     const unsigned short* hi = (const unsigned short*)(packed ? packed : ws);
@@ -237,10 +235,6 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
       g.f16 = 1; g.a_inv = a_inv; g.x_amax = xa.p; g.x_namax = xa.n; g.x_amax_bs = xa.n;
     }
     g.colstats = colstats;
-    if (gate) {           // fused highway gate: see GemmNNB::gate_cnt
-      g.gate_cnt = gate->gate_cnt; g.gate_g1 = gate->gate_g1; g.gate_b1 = gate->gate_b1; g.gate_g2 = gate->gate_g2; g.gate_b2 = gate->gate_b2;
-      g.gate_y = gate->gate_y; g.gate_ybs = gate->gate_ybs; g.gate_stats = gate->gate_stats; g.gate_amax = gate->gate_amax; g.gate_namax = gate->gate_namax;
-    }
     g.Ahi = hi; g.Alo = lo; g.Kpad = Kpad;
     g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
     g.C = y; g.scb = y_bs; g.scm = L;
@@ -494,10 +488,8 @@ extern "C" int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* 
 // halves are whole groups; the LayerNorm / gate forward is then a streaming kernel without reductions (norm.hip).
 static inline bool hw_colstats(int B, int C, int L) { return use_bf3(B, L, C, 2 * C) && C % 64 == 0 && C <= 512 && !ssv_tuning(SSV_T_LN_NOSTREAM); }
 static inline size_t hw_colstats_bytes(int B, int C, int L) { return align256((size_t)B * (2 * C / 64) * L * 2 * sizeof(float)); }
-static inline size_t hw_cnt_bytes(int B, int L) { return align256((size_t)B * ssv_cdiv(L, 32) * sizeof(unsigned)); }
-static inline bool hw_fuse_gate() { static const int on = getenv("SSV_FUSE_GATE") ? atoi(getenv("SSV_FUSE_GATE")) : 0; return on != 0; }
 extern "C" size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k) {
-  return ssv_conv1d_fwd_workspace(C, 2 * C, k) + (hw_colstats(B, C, L) ? hw_colstats_bytes(B, C, L) + hw_cnt_bytes(B, L) : 0);
+  return ssv_conv1d_fwd_workspace(C, 2 * C, k) + (hw_colstats(B, C, L) ? hw_colstats_bytes(B, C, L) : 0);
 }
 extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
                                       const float* g1, const float* b1, const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
@@ -506,21 +498,11 @@ extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_
   SSV_CHECK(B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_conv1d_fwd: bad shape B=%d C=%d L=%d", B, C, L);
   if (hw_colstats(B, C, L)) {
     const size_t conv_ws = ssv_conv1d_fwd_workspace(C, 2 * C, k);
-    SSV_CHECK(ws && ws_bytes >= conv_ws + hw_colstats_bytes(B, C, L) + hw_cnt_bytes(B, L), SSV_BAD_SHAPE, "highway_conv1d_fwd: workspace too small");
+    SSV_CHECK(ws && ws_bytes >= conv_ws + hw_colstats_bytes(B, C, L), SSV_BAD_SHAPE, "highway_conv1d_fwd: workspace too small");
     SSV_CHECK(x_bs >= (long)C * L && y_bs >= (long)C * L, SSV_BAD_SHAPE, "highway_conv1d_fwd: batch stride smaller than C*L");
     float* cs = (float*)((char*)ws + conv_ws);
     int shift[3];
     SSV_TRY(conv_shifts(k, dilation, causal, shift));
-    if (hw_fuse_gate() && C % 64 == 0 && (!y_amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 32))) {
-      // EXPERIMENT (SSV_FUSE_GATE=1): the gate runs in the conv kernel's epilogue, by the last workgroup to finish each column tile
-      GemmNNB gt = nnb_zero();
-      gt.gate_cnt = (unsigned*)((char*)cs + hw_colstats_bytes(B, C, L));
-      SSV_HIP(hipMemsetAsync(gt.gate_cnt, 0, hw_cnt_bytes(B, L), (hipStream_t)stream));
-      gt.gate_g1 = g1; gt.gate_b1 = b1; gt.gate_g2 = g2; gt.gate_b2 = b2;
-      gt.gate_y = y; gt.gate_ybs = y_bs; gt.gate_stats = stats; gt.gate_amax = y_amax; gt.gate_namax = ssv_amax_rows_(L);
-      return conv_nn(x, x_bs, w, w_packed, (long)C * k, k, bias, nullptr, nullptr, 0, h, (long)2 * C * L, B, C, 2 * C, L, k, shift, true, ws, (hipStream_t)stream,
-                     packed_inv(w_packed, 2 * C, C, k, 0), x_amax, x_namax, 2 * split_bytes(2 * C, C, k), cs, &gt);
-    }
     SSV_TRY(conv_nn(x, x_bs, w, w_packed, (long)C * k, k, bias, nullptr, nullptr, 0, h, (long)2 * C * L, B, C, 2 * C, L, k, shift, true, ws, (hipStream_t)stream,
                     packed_inv(w_packed, 2 * C, C, k, 0), x_amax, x_namax, 2 * split_bytes(2 * C, C, k), cs));
     return ssv_launch_ln_gate_fwd_stream(h, x, x_bs, cs, g1, b1, g2, b2, y, y_bs, stats, y_amax, B, C, L, (hipStream_t)stream);
@@ -885,8 +867,8 @@ static int lstm_gemm_f32(const float* A, const float* X, long sxb, float* C, lon
 // Wavefront (split-bf16) layout: h of every layer lives in a 2-frame ring, weights of layer l >= 1 are [W_ih | W_hh] side by side.
 struct LstmWave { size_t xt, xp, out, c, bias, ih0, hh0, comb, comb_stride, aux, total; };
 // split-fp16 scales of the wavefront (floats at `aux`): [0, 64) partial maxima over ALL weight matrices (one scale for every layer: a
-// launch batches layers over grid.y and has one epilogue factor), [64] its inverse scale, [65] = 1.0: the activations' one-entry
-// list (|h| = |o tanh c| < 1, so their scale is the constant 2^14), [128, 192) partial maxima of the input frames (layer 0's projection)
+// launch batches layers over grid.y and has one epilogue factor), [64] its inverse scale, [128, 192) partial maxima of the input frames
+// (layer 0's projection).  The recurrent activations need no list: |h| = |o tanh c| < 1, their scale is the constant 2^14 (x_namax = 0).
 #define LSTM_AUX_FLOATS 192
 static LstmWave lstm_wave_ws(int Bn, int T, int F, int H, int layers) {
   LstmWave s;
@@ -945,7 +927,6 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
       SSV_TRY(ssv_launch_absmax(w_ih[l], 0, 1, (long)4 * H * (l == 0 ? F : H), aux + (2 * l) * npb, npb, st));
       SSV_TRY(ssv_launch_absmax(w_hh[l], 0, 1, (long)4 * H * H, aux + (2 * l + 1) * npb, npb, st));
     }
-    SSV_TRY(ssv_launch_fill(aux + 65, 1.f, 1, st));
     SSV_TRY(ssv_launch_absmax(xt, 0, 1, (long)T * F * Bn, aux + 128, 64, st));
   }
   auto pack = [&](const float* w, unsigned short* hi, unsigned short* lo, int K, int Kpad, int nch_total, int ch_off) -> int {
@@ -974,7 +955,7 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   GemmNNB g = nnb_zero();
   g.sxc = Bn; g.Lx = Bn; g.scm = Bn; g.srm = Bn;
   g.M = 4 * H; g.N = Bn; g.perm_h = H; g.epi = 1; g.cstate = cbuf;
-  if (f16) { g.f16 = 1; g.a_inv = aux + 64; g.x_amax = aux + 65; g.x_namax = 1; g.x_amax_bs = 0; }
+  if (f16) { g.f16 = 1; g.a_inv = aux + 64; g.x_amax = nullptr; g.x_namax = 0; g.x_amax_bs = 0; }     // activations: |h| < 1, the fixed scale 2^14
   g.lstm_out = out; g.lstm_D = D; g.sbb = (long)8 * H; g.gates_out = keep_gates;
   g.X = out; g.C = out;                        // placeholders: the kernel derives X, X2 and C from (layer, frame)
   for (int step = 0; step < T + layers - 1; ++step) {

@@ -24,19 +24,6 @@
 #include <string.h>
 #include <stdio.h>
 #include "ssv_common.h"
-#ifndef SSV_ABL
-#define SSV_ABL 0      // tuning builds only (WRONG results), weight-gradient kernel: 1 = without its MFMAs, 2 = dH fragments not split (raw bits
-                       // re-used as operands), 4 = input tile not split before the LDS write, 6 = both, 8 = epilogue never executed,
-                       // 16 / 32 = every input tile / dH chunk loaded from one fixed place (L1 hits: what do the operand loads cost?)
-#endif
-#ifndef SSV_F16_ABL
-#define SSV_F16_ABL 0  // tuning builds only (results are WRONG), split-fp16 kernels: 1 = fixed scales (no scale-list read / reduction in the prologue),
-#endif                 // 2 = the bf16 MFMA instruction on the fp16 operand bits (same issue pattern, other multiplier array)
-#ifndef SSV_NN_ABL
-#define SSV_NN_ABL 0   // tuning builds only (results are WRONG), bit mask on gemm_nn_bf3_kernel: 1 = no barrier in the chunk loop,
-#endif                 // 2 = no split / LDS write of the input tile, 4 = no input loads, 8 = no weight re-loads, 16 = one LDS fragment
-                       // address for all reads, 32 = epilogue stores never executed, 64 = a single K chunk (prologue + epilogue only)
-
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned 16-byte load
 
@@ -61,6 +48,10 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 __device__ __forceinline__ void split2h(float a, float b, float s, unsigned& h, unsigned& l) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // s: the (wave-uniform) scale, in a scalar register -- one constant-bus operand per instruction, no VGPR for it
+  // (Round 4, measured in-step, no kernel moved by more than the run-to-run 1-2 %: (i) scale by v_pk_mul_f32, hi by v_cvt_pk_f16_f32, lo by two
+  //  v_fma_mix -- 2 full-rate + 2 half-rate instructions per pair instead of these 4 half-rate ones (tools/probe/valu_rate.hip: 5 vs 9-11
+  //  cycles), bit-identical; (ii) the slot's validity folded into a per-thread scale, sparing the select per element.  The split is not
+  //  what these kernels wait for.)
   asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a), "s"(s));
   asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(b), "s"(s));
   asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "s"(s), "v"(h));
@@ -105,7 +96,7 @@ __device__ __forceinline__ void split8p(const float (&v)[8], float s, uint4& hi,
 // one 16x16x32 MFMA on 16-byte operand fragments: bf16 or fp16 inputs, fp32 accumulate
 template <int F16>
 __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c) {
-  if constexpr (F16 && !(SSV_F16_ABL & 2)) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -326,85 +317,6 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
   return ssv_check_launch("pack_multi");
 }
 
-// ---- highway gate of one column tile (fused into the conv that produced h: see GemmNNB::gate_cnt) ------------------------------------
-// Same arithmetic, in the same order, as ln_gate_fwd_stream_kernel (norm.hip): the C / 64 (mean, M2) partials of each half merged per
-// column (Chan, equal counts), then y = sigmoid(LN1(h1)) LN2(h2) + (1 - sigmoid(LN1(h1))) x streamed as 16-byte accesses.
-// sm: 4 * BN + 4 floats of LDS nobody else uses.  Called by ALL 256 threads of the last workgroup to finish a column tile.
-typedef float f4g __attribute__((ext_vector_type(4), aligned(4)));
-typedef float f2g __attribute__((ext_vector_type(2), aligned(8)));
-template <int BN>
-__device__ __forceinline__ void highway_gate_tile(const GemmNNB& p, const int b, const int ntile, const int n0, float* sm) {
-  const int tid = threadIdx.x;
-  const int C = p.M >> 1, L = p.N, P = C >> 6, MG = 2 * P;
-  for (int e = tid; e < 2 * BN; e += 256) {
-    const int half = e / BN, col = e % BN, t = n0 + col;
-    float mean = 0.f, r = 0.f;
-    if (t < L) {
-      const float* q = p.colstats + (((long)b * MG + half * P) * L + t) * 2;
-      f2g pr[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) pr[i] = *reinterpret_cast<const f2g*>(q + (long)min(i, P - 1) * L * 2);
-      float mu[8], m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { mu[i] = i < P ? pr[i].x : 0.f; mean += mu[i]; m2 += i < P ? pr[i].y : 0.f; }
-      mean /= (float)P;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) if (i < P) { const float d = mu[i] - mean; m2 += 64.f * d * d; }
-      r = rsqrtf(m2 / (float)C + 1e-5f);
-      if (p.gate_stats) { float* sb = p.gate_stats + (long)b * 4 * L + (long)(2 * half) * L + t; sb[0] = mean; sb[L] = r; }
-    }
-    sm[e * 2] = mean; sm[e * 2 + 1] = r;
-  }
-  __syncthreads();
-  const float* H1 = p.C + (long)b * p.scb + n0;
-  const float* H2 = H1 + (long)C * L;
-  const float* Xb = p.X + (long)b * p.sxb + n0;
-  float* Yb = p.gate_y + (long)b * p.gate_ybs + n0;
-  constexpr int Q = BN / 4;                       // 4-column groups per channel row of the tile
-  float am = 0.f;
-#pragma unroll 2
-  for (int e = tid; e < C * Q; e += 256) {
-    const int c = e / Q, q4 = (e % Q) * 4;
-    if (n0 + q4 >= L) continue;
-    const unsigned o = (unsigned)c * (unsigned)L + (unsigned)q4;
-    const float ga1 = p.gate_g1[c], be1 = p.gate_b1[c], ga2 = p.gate_g2[c], be2 = p.gate_b2[c];
-    float h1[4], h2[4], xv[4], y[4];
-    const bool full = n0 + q4 + 3 < L;
-    if (full) {
-      const f4g a = *reinterpret_cast<const f4g*>(H1 + o), d = *reinterpret_cast<const f4g*>(H2 + o), x4 = *reinterpret_cast<const f4g*>(Xb + o);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { h1[j] = a[j]; h2[j] = d[j]; xv[j] = x4[j]; }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const bool v = n0 + q4 + j < L; h1[j] = v ? H1[o + j] : 0.f; h2[j] = v ? H2[o + j] : 0.f; xv[j] = v ? Xb[o + j] : 0.f; }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float mu1 = sm[(q4 + j) * 2], r1 = sm[(q4 + j) * 2 + 1], mu2 = sm[(BN + q4 + j) * 2], r2 = sm[(BN + q4 + j) * 2 + 1];
-      const float n1 = (h1[j] - mu1) * r1 * ga1 + be1;
-      const float n2 = (h2[j] - mu2) * r2 * ga2 + be2;
-      const float sg = 1.f / (1.f + __expf(-n1));
-      y[j] = sg * n2 + (1.f - sg) * xv[j];
-    }
-    if (full) {
-      *reinterpret_cast<f4g*>(Yb + o) = (f4g){y[0], y[1], y[2], y[3]};
-      am = fmaxf(fmaxf(am, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (n0 + q4 + j < L) { Yb[o + j] = y[j]; am = fmaxf(am, fabsf(y[j])); }
-    }
-  }
-  if (p.gate_amax) {
-    am = ssv_wg_max<4>(am, sm + 4 * BN);
-    if (tid == 0) {
-      float* al = p.gate_amax + (long)b * p.gate_namax;
-      al[ntile] = am;
-      const int ntiles = (L + BN - 1) / BN;
-      if (ntile == ntiles - 1) for (int e = ntiles; e < p.gate_namax; ++e) al[e] = 0.f;
-    }
-  }
-}
-
 // ---- NN ---------------------------------------------------------------------------------------------------------------
 // Waves split the M axis, so a weight row is only ever used by ONE wave: weight fragments go straight from global memory
 // (L2-resident, pre-split, fragment-shaped 16-byte loads) into MFMA operand registers, one K chunk ahead (two register
@@ -554,23 +466,20 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     voffb[r] = voff[r] * 4u;           // BYTE offset of the buffer load (a row's offset is added as its scalar operand)
   }
   const bool ragged = (p.Kc & 31) != 0;
-  // split-fp16: xs = 2^ex scales the input while it is split, us = 2^-(ea + ex) the accumulators in the epilogue
-  float xs = 1.f, us = 1.f;
+  // split-fp16: xs = 2^ex scales the input while it is split, us = 2^-(ea + ex) the accumulators in the epilogue.  The weights'
+  // inverse scale is requested here (a scalar load) and first USED in the epilogue: nothing in the prologue waits for it.  The input's
+  // scale is needed before the first split; x_namax == 0 (the LSTM products: |h| < 1 by construction) means the constant 2^14, no list.
+  float xs = 1.f, xinv = 1.f, ainv = 1.f;
+  if constexpr (F16) ainv = *p.a_inv;
   auto scales = [&]() {
     if constexpr (F16) {
-#if SSV_F16_ABL & 1            // tuning builds only (WRONG results): no scale list read, no reduction
-      xs = 1024.f; us = 1.f / 1024.f;
-#elif SSV_F16_ABL & 4          // ... one scalar load of the list's first entry, no reduction
-      float sc, inv;
-      ssv_pow2_scale(p.x_amax[(long)b * p.x_amax_bs], sc, inv);
-      xs = ssv_uniform(sc);
-      us = ssv_uniform(inv * *p.a_inv);
-#else
-      float sc, inv;
-      ssv_pow2_scale(ssv_wave_list_max(p.x_amax + (long)b * p.x_amax_bs, p.x_namax), sc, inv);
-      xs = ssv_uniform(sc);
-      us = ssv_uniform(inv * *p.a_inv);
-#endif
+      if (p.x_namax == 0) { xs = 16384.f; xinv = 1.f / 16384.f; }
+      else {
+        float sc, inv;
+        ssv_pow2_scale(ssv_wave_list_max(p.x_amax + (long)b * p.x_amax_bs, p.x_namax), sc, inv);
+        xs = ssv_uniform(sc);
+        xinv = ssv_uniform(inv);
+      }
     }
   };
   auto prefetchX = [&](int ch) {
@@ -635,7 +544,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     const uint4* Xl = lds[ch & 1] + X_SLOTS;
     uint4 fb[FD + 1][2];
     auto frag = [&](int t, uint4 (&f)[2]) __attribute__((always_inline)) {
-      const int xs_ = (SSV_NN_ABL & 16) ? (kq * WX + nq) : (kq * WX + t * 16 + nq + offj[j]);
+      const int xs_ = kq * WX + t * 16 + nq + offj[j];
       f[0] = Xh[xs_]; f[1] = Xl[xs_];
     };
 #pragma unroll
@@ -713,33 +622,28 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
       for (int j = 0; j < KT; ++j) {
         tap(0, j, ch);
         __builtin_amdgcn_sched_barrier(0);      // keep the re-load behind this tap's MFMAs, and later taps' LDS reads behind it
-        if (!(SSV_NN_ABL & 8) && more) loadA(0, j, ch + 1);
+        if (more) loadA(0, j, ch + 1);
       }
       NN_STAMP(1);
       if (more) {
-        if (!(SSV_NN_ABL & 2)) commitX(ch + 1);
+        commitX(ch + 1);
         NN_STAMP(2);
-        if (!(SSV_NN_ABL & 4) && (ST || ch + 2 < nchunks)) prefetchX(ch + 2);
+        if (ST || ch + 2 < nchunks) prefetchX(ch + 2);
       }
       NN_STAMP(3);
-      if (!(SSV_NN_ABL & 1)) __syncthreads();
+      __syncthreads();
       NN_STAMP(4);
     };
     int ch = 0;
     // (the steady form holds more values live: 140 -> 190 VGPRs for the 64 x 112 tile, whose hot launches are 768 workgroups and need
     // three per CU to run in one round -- +20 % on it; the 64 x 96 tile's launches are 512 workgroups and gain 7 % from it)
     constexpr bool STEADY3 = SSV_NN_STEADY3 != 0;
-    for (; STEADY3 && ch + 2 < nchunks; ++ch) {
-      chunk(ST_{}, ch);
-      if ((SSV_NN_ABL & 64) && p.M > 0) break;
-    }
-    for (; ch < nchunks; ++ch) {
-      chunk(TL_{}, ch);
-      if ((SSV_NN_ABL & 64) && p.M > 0) break;
-    }
+    for (; STEADY3 && ch + 2 < nchunks; ++ch) chunk(ST_{}, ch);
+    for (; ch < nchunks; ++ch) chunk(TL_{}, ch);
   }
 
   NN_STAMP_AT(2);
+  const float us = F16 ? ssv_uniform(xinv * ainv) : 1.f;
   float* __restrict__ Cb = p.C + (long)b * p.scb;
   const float* __restrict__ Rb = p.R ? p.R + (long)b * p.srb : nullptr;
   if constexpr (EPI == 1) {
@@ -793,8 +697,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     }
     return;
   }
-  if ((SSV_NN_ABL & 32) && p.M > 0) return;
-  if (p.scn == 1 && !(SSV_NN_ABL & 128)) {
+  if (p.scn == 1) {
     // Row-contiguous stores.  An MFMA accumulator holds 4 rows x 1 column per lane, so storing it directly writes 64-byte
     // pieces of 4 different rows per instruction (measured: the epilogue was 7.3 of 36.6 us at C = 256, L = 325).  The tile
     // goes through LDS instead (free after the K loop): every wave parks its 16 x BN block row-major and reads it back as
@@ -872,27 +775,6 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
         for (int q = 0; q < 4; ++q) { const float d = mu[q] - mean; m2 += 16.f * d * d; }
         float* dst = p.colstats + (((long)b * (p.M >> 6) + (m0 >> 6) + grp) * p.N + gn) * 2;
         dst[0] = mean; dst[1] = m2;
-      }
-      if (p.gate_cnt) {
-        // Fused highway gate (GemmNNB::gate_cnt).  Release: every thread's h rows and column partials are visible device-wide
-        // before the counter moves; the workgroup that finds mtiles - 1 earlier arrivals acquires and runs the tile's gate.
-        __threadfence();
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(lds_all);
-        if (tid == 0) {
-          unsigned* cnt = p.gate_cnt + (long)b * (gridDim.x / mtiles) + ntile;
-          const unsigned old = atomicAdd(cnt, 1u);
-          const int last = old == (unsigned)mtiles - 1u;
-          if (last) atomicExch(cnt, 0u);                  // self-resetting: zero again for the next launch (capture-safe, no memset node)
-          *flag = last;
-        }
-        __syncthreads();
-        const int last = *flag;
-        __syncthreads();
-        if (last) {
-          __threadfence();
-          highway_gate_tile<BN>(p, b, ntile, n0, reinterpret_cast<float*>(lds_all));
-        }
       }
     }
     NN_STAMP_AT(3);
@@ -1233,11 +1115,8 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   // the kernels address one batch item's input rows and the weight planes with 32-bit byte offsets (buffer loads)
   SSV_CHECK(((long)g.Kpad * g.sxc + (long)g.Lx * (g.sxn > 0 ? g.sxn : 1)) * 4 < (1L << 31) && (long)g.KT * ((g.M + 15) / 16) * (g.Kpad / 32) * 1024 < (1L << 31),
             SSV_UNSUPPORTED, "gemm_nn_bf3: a batch item's input or the weight planes span 2 GiB or more");
-  SSV_CHECK(!g.f16 || (g.a_inv && g.x_amax && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales");
+  SSV_CHECK(!g.f16 || (g.a_inv && ((g.x_amax && g.x_namax > 0) || (g.epi && g.x_namax == 0))), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales");
   SSV_CHECK(!g.colstats || (g.M % 64 == 0 && g.scn == 1 && !g.epi && !g.perm_h && !g.R), SSV_BAD_SHAPE, "gemm_nn_bf3: column statistics need M %% 64 == 0 and a plain epilogue");
-  SSV_CHECK(!g.gate_cnt || (g.colstats && g.M % 128 == 0 && g.M <= 1024 && g.sxn == 1 && g.sxc == g.N && g.Kc == g.M / 2 && g.gate_g1 && g.gate_b1 && g.gate_g2 && g.gate_b2 && g.gate_y &&
-                            (!g.gate_amax || g.gate_namax >= ssv_cdiv(g.N, 32))),
-            SSV_BAD_SHAPE, "gemm_nn_bf3: the fused highway gate needs column statistics, M = 2 Kc <= 1024 and a dense input");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
 }
 
@@ -1305,21 +1184,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   float as = 1.f, xs = 1.f, us = 1.f;
   auto scales = [&]() {
     if constexpr (F16) {
-#if SSV_F16_ABL & 1
-      as = xs = 1024.f; us = 1.f / (1024.f * 1024.f);
-#elif SSV_F16_ABL & 4
-      float sa, sx, ia, ix;
-      ssv_pow2_scale(a_amax[0], sa, ia);
-      ssv_pow2_scale(x_amax[0], sx, ix);
-      as = ssv_uniform(sa); xs = ssv_uniform(sx);
-      us = ssv_uniform(ia * ix);
-#else
       float sa, sx, ia, ix;
       ssv_pow2_scale(ssv_list_max<4>(a_amax, a_namax, amax_sm), sa, ia);       // long lists (B * tiles entries): shared among the waves
       ssv_pow2_scale(ssv_list_max<4>(x_amax, x_namax, amax_sm + 4), sx, ix);
       as = ssv_uniform(sa); xs = ssv_uniform(sx);
       us = ssv_uniform(ia * ix);
-#endif
     }
   };
   const int mt = bxx % mtiles, ct = bxx / mtiles;
@@ -1430,7 +1299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 
   auto loadA = [&](auto set, int b, int t0) __attribute__((always_inline)) {                               // -> AH / AL[set], raw
     constexpr int SET = decltype(set)::value;
-    const unsigned so = (unsigned)((SSV_ABL & 32) ? z * (int)p.sab : b * (int)p.sab + t0) * 4u;   // uniform; (tuning build: the same chunk again and again)
+    const unsigned so = (unsigned)(b * (int)p.sab + t0) * 4u;   // uniform
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1445,7 +1314,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   };
   auto splitA = [&](auto set) __attribute__((always_inline)) {                                             // AH / AL[set]: raw -> (hi, lo), in place
     constexpr int SET = decltype(set)::value;
-    if (SSV_ABL & 2) return;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1456,7 +1324,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       }
   };
   auto loadX = [&](int b, int t0, int j) __attribute__((always_inline)) {                                  // -> rx (/ mx)
-    const int base = (SSV_ABL & 16) ? z * (int)p.sxb + 64 : b * (int)p.sxb + t0 + shj[j];   // (tuning build: the same tile again and again)
+    const int base = b * (int)p.sxb + t0 + shj[j];
     int dd[NX];
 #pragma unroll
     for (int r = 0; r < NX; ++r) dd[r] = load8c(Xp, base + xrow[r], x_span, rx[r]);
@@ -1478,8 +1346,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       const int f = tid + 256 * r;
       const int kg = f % KG, c = f / KG;
       uint4 h, l;
-      if (SSV_ABL & 4) { h = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[r][0])); l = __builtin_bit_cast(uint4, *reinterpret_cast<const f32x4*>(&rx[r][4])); }
-      else if (!edge) split8p<F16>(rx[r], xs, h, l);
+      if (!edge) split8p<F16>(rx[r], xs, h, l);
       else split_edge(rx[r], mx[r], xs, h, l);
       Xh[kg * NCH + (c ^ kg)] = h; Xl[kg * NCH + (c ^ kg)] = l;          // XOR swizzle, see the slot comment above
     }
@@ -1541,13 +1408,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
         for (int i = 0; i < WM; ++i) {
           const uint4 a_h = AH[CUR::value][i][s2];
           const uint4 a_l = AL[CUR::value][i][s2];
-#if (SSV_ABL & 1)
-          acc[i][j][q][0] += __builtin_bit_cast(float, a_l.x ^ bh.x ^ a_h.y ^ bl.y);
-#else
           acc[i][j][q] = mma16<F16>(a_l, bh, acc[i][j][q]);
           acc[i][j][q] = mma16<F16>(a_h, bl, acc[i][j][q]);
           acc[i][j][q] = mma16<F16>(a_h, bh, acc[i][j][q]);
-#endif
         }
       }
       NT_STAMP(1);
@@ -1598,7 +1461,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
   }
 
-  if ((SSV_ABL & 8) && p.M > 0) return;
   float* __restrict__ Cz = Cp + (long)z * p.scz;
 #pragma unroll
   for (int i = 0; i < WM; ++i)

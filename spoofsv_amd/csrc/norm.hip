@@ -15,6 +15,9 @@
 #include "ssv_common.h"
 
 #define LN_EPS 1e-5f
+// channel steps of loads in flight per thread in the backward kernels (the step being computed included), see ln_gate_bwd_kernel;
+// depths 2, 4, 6, 8 were measured in-step: equal within 1 % -- 4 keeps the hot instantiations at 128 VGPRs (4 waves per SIMD)
+#define LN_PIPE(CPT) ((CPT) < 4 ? (CPT) : 4)
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
@@ -238,6 +241,15 @@ int ssv_launch_ln_gate_fwd_stream(const float* H, const float* X, long x_bs, con
   return ssv_check_launch("ln_gate_fwd_stream");
 }
 
+// Tuning builds only (-DSSV_LN_STAMP): thread 0 of each of the first 4096 workgroups of ln_gate_bwd_kernel records s_memrealtime (100 MHz, one
+// clock for the device) at entry and exit and the shader clock after its load / reduce / store phases; tools/ln_stamps.py reads them.
+#ifdef SSV_LN_STAMP
+__device__ unsigned long long ssv_ln_stamps[4096 * 8];
+extern "C" int ssv_debug_ln_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssv_ln_stamps), sizeof(ssv_ln_stamps)); }
+#define LN_STAMP(k, v) do { const unsigned w_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && w_ < 4096u) ssv_ln_stamps[w_ * 8 + (k)] = (v); } while (0)
+#else
+#define LN_STAMP(k, v) do {} while (0)
+#endif
 // part layout: [block][6][C] = dgamma1, dbeta1, dgamma2, dbeta2, dbiasH1, dbiasH2
 template <int CPT, int G>
 __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
@@ -248,6 +260,8 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
   __shared__ float red[4 * 16 * G];
   __shared__ float amx[G / 4];
   float am = 0.f;
+  LN_STAMP(0, __builtin_amdgcn_s_memrealtime());
+  LN_STAMP(1, __builtin_readcyclecounter());
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4;
   int bx, by;
   xcd_tile(bx, by);
@@ -269,25 +283,39 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
   float xh1[CPT], xh2[CPT], a1[CPT], a2[CPT];
   float* pblk = part + ((long)by * gridDim.x + bx) * 6 * C;
   float sa1 = 0.f, sah1 = 0.f, sa2 = 0.f, sah2 = 0.f;
+  // Load stream, software-pipelined (round 4).  With the loads of channel step i under `if (valid)` hipcc kept each step in a
+  // block of its own: 8 loads, s_waitcnt vmcnt(0), arithmetic, stores, next step -- one exposed memory round trip (~1.1 us under
+  // load) per step, 16 in a row: 33-40 k of a workgroup's ~42 k cycles (tools/ln_stamps.py), and only ~10 KB in flight per CU,
+  // i.e. 2.5-3 TB/s by Little's law whatever the HBM could deliver.  Now the loads are UNCONDITIONAL (channel and column clamped
+  // into the tensor: always legal; the validity mask is applied where the values are used) and steps i+1 .. i+PD-1 are in
+  // flight while step i is computed.  Same arithmetic in the same order: results are bit-identical.
+  constexpr int PD = LN_PIPE(CPT);
+  const unsigned tc = (unsigned)min(t, L - 1);
+  float qdy[PD], qx[PD], qh1[PD], qh2[PD], qg1[PD], qb1[PD], qg2[PD], qb2[PD];
+  auto issue = [&](int i) __attribute__((always_inline)) {
+    const int sl = i % PD, c = min(g + G * i, C - 1);
+    const unsigned o = (unsigned)c * (unsigned)L + tc;
+    qdy[sl] = dYb[o]; qx[sl] = Xb[o]; qh1[sl] = Hb1[o]; qh2[sl] = Hb2[o];
+    qg1[sl] = g1[c]; qb1[sl] = b1[c]; qg2[sl] = g2[c]; qb2[sl] = b2[c];
+  };
+#pragma unroll
+  for (int i = 0; i < PD - 1 && i < CPT; ++i) issue(i);
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + G * i;
+    const int c = g + G * i, sl = i % PD;
     const bool v = tv && c < C;
-    float dn1 = 0.f, dn2 = 0.f, gg1 = 0.f, gg2 = 0.f;
-    xh1[i] = 0.f; xh2[i] = 0.f;
-    if (v) {
-      const float dy = dYb[o0 + i * ostep];
-      const float x = Xb[o0 + i * ostep];
-      gg1 = g1[c]; gg2 = g2[c];
-      xh1[i] = (Hb1[o0 + i * ostep] - mu1) * r1;
-      xh2[i] = (Hb2[o0 + i * ostep] - mu2) * r2;
-      const float n1 = xh1[i] * gg1 + b1[c];
-      const float n2 = xh2[i] * gg2 + b2[c];
-      const float s = sigmoidf_(n1);
-      dn2 = dy * s;
-      dn1 = dy * (n2 - x) * s * (1.f - s);
-      dXb[o0 + i * ostep] = dy * (1.f - s);
-    }
+    if (i + PD - 1 < CPT) issue(i + PD - 1);
+    __builtin_amdgcn_sched_barrier(0);             // the loads above stay above: or the scheduler sinks them back to their use
+    const float dy = v ? qdy[sl] : 0.f, x = qx[sl];
+    const float gg1 = v ? qg1[sl] : 0.f, gg2 = v ? qg2[sl] : 0.f;
+    xh1[i] = v ? (qh1[sl] - mu1) * r1 : 0.f;
+    xh2[i] = v ? (qh2[sl] - mu2) * r2 : 0.f;
+    const float n1 = xh1[i] * gg1 + qb1[sl];
+    const float n2 = xh2[i] * gg2 + qb2[sl];
+    const float s = sigmoidf_(n1);
+    const float dn2 = dy * s;
+    const float dn1 = dy * (n2 - x) * s * (1.f - s);
+    if (v) dXb[o0 + i * ostep] = dy * (1.f - s);
     // per-channel parameter-gradient partials over this block's 16 columns
     const float p0 = col_sum(dn1 * xh1[i]), p1 = col_sum(dn1), p2 = col_sum(dn2 * xh2[i]), p3 = col_sum(dn2);
     if (col == 0 && c < C) { pblk[c] = p0; pblk[C + c] = p1; pblk[2 * C + c] = p2; pblk[3 * C + c] = p3; }
@@ -296,7 +324,12 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
   }
   const float inv = 1.f / (float)C;
   float gs[4] = {sa1, sah1, sa2, sah2};
+#ifdef SSV_LN_STAMP
+  asm volatile("" : "+v"(gs[0]), "+v"(gs[1]), "+v"(gs[2]), "+v"(gs[3]));     // every load of the first phase has landed
+#endif
+  LN_STAMP(2, __builtin_readcyclecounter());
   group_sums<G, 4>(gs, red, col, g);
+  LN_STAMP(3, __builtin_readcyclecounter());
   const float m1 = gs[0] * inv, mh1 = gs[1] * inv, m2 = gs[2] * inv, mh2 = gs[3] * inv;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
@@ -309,6 +342,12 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
     const float q0 = col_sum(d1), q1 = col_sum(d2);
     if (col == 0 && c < C) { pblk[4 * C + c] = q0; pblk[5 * C + c] = q1; }
   }
+  LN_STAMP(4, __builtin_readcyclecounter());
+#ifdef SSV_LN_STAMP
+  __builtin_amdgcn_s_waitcnt(0);                    // (stamp builds: the stores of this wave have been acknowledged)
+  LN_STAMP(5, __builtin_readcyclecounter());
+  LN_STAMP(6, __builtin_amdgcn_s_memrealtime());
+#endif
   if (amax) {                                    // max |dH| of this tile: operand scale of the two conv gradients (split-fp16)
     am = ssv_wg_max<G / 4>(am, amx);
     if (threadIdx.x == 0) {
@@ -399,21 +438,30 @@ __global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
   float xh[CPT], a[CPT];
   float* pblk = part + ((long)by * gridDim.x + bx) * 3 * C;
   float sa = 0.f, sah = 0.f;
+  // software-pipelined unconditional loads, masks applied at use: see ln_gate_bwd_kernel
+  constexpr int PD = LN_PIPE(CPT);
+  const unsigned tc = (unsigned)min(t, L - 1);
+  float qdy[PD], qx[PD], qg[PD], qb[PD];
+  auto issue = [&](int i) __attribute__((always_inline)) {
+    const int sl = i % PD, c = min(g + G * i, C - 1);
+    const unsigned o = (unsigned)c * (unsigned)L + tc;
+    qdy[sl] = dYb[o]; qx[sl] = Xb[o]; qg[sl] = gam[c]; qb[sl] = bet[c];
+  };
+#pragma unroll
+  for (int i = 0; i < PD - 1 && i < CPT; ++i) issue(i);
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = g + G * i;
+    const int c = g + G * i, sl = i % PD;
     const bool v = tv && c < C;
-    float dn = 0.f, gg = 0.f;
-    xh[i] = 0.f;
-    if (v) {
-      const float dy = dYb[o0 + i * ostep];
-      gg = gam[c];
-      xh[i] = (Xb[o0 + i * ostep] - mu) * r;
-      const float n = xh[i] * gg + bet[c];
-      if (act == 1) dn = n > 0.f ? dy : 0.f;
-      else if (act == 2) { const float s = sigmoidf_(n); dn = dy * s * (1.f - s); }
-      else dn = dy;
-    }
+    if (i + PD - 1 < CPT) issue(i + PD - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const float dy = v ? qdy[sl] : 0.f, gg = v ? qg[sl] : 0.f;
+    xh[i] = v ? (qx[sl] - mu) * r : 0.f;
+    const float n = xh[i] * gg + qb[sl];
+    float dn;
+    if (act == 1) dn = n > 0.f ? dy : 0.f;
+    else if (act == 2) { const float s = sigmoidf_(n); dn = dy * s * (1.f - s); }
+    else dn = dy;
     const float p0 = col_sum(dn * xh[i]), p1 = col_sum(dn);
     if (col == 0 && c < C) { pblk[c] = p0; pblk[C + c] = p1; }
     a[i] = dn * gg;

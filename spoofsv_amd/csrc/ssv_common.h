@@ -88,14 +88,6 @@ struct GemmNNB {
   // colstats[((b * (M / 64) + m / 64) * N + n) * 2 + {0, 1}] = mean and sum of squared deviations of C(b, 64-row group, n)
   // over the group's 64 rows, bias included.  Needs M % 64 == 0, unit column stride, no LSTM epilogue.  Null: not wanted.
   float* colstats;
-  // Fused highway gate (highwayConv forward, models/TTSModel.py:78-83; needs colstats): C = h (B, 2C, L) is the conv output.  Every
-  // workgroup releases its rows and column partials, bumps gate_cnt[b * column tiles + column tile]; the LAST arriver of a column
-  // tile (its row tiles are neighbours in the XCD order: one L2) runs both LayerNorms and the gate for that tile -- y = s n2 + (1 - s) x
-  // with x = this GEMM's own input X (unit column stride, sxc = L) -- and resets the counter.  gate_cnt: caller-owned, zero before the
-  // FIRST launch only.  gate_amax: one max |y| per column tile, the rest of the item's gate_namax entries zeroed.  Null: off.
-  unsigned* gate_cnt;
-  const float* gate_g1; const float* gate_b1; const float* gate_g2; const float* gate_b2;
-  float* gate_y; long gate_ybs; float* gate_stats; float* gate_amax; int gate_namax;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
