@@ -48,10 +48,10 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 __device__ __forceinline__ void split2h(float a, float b, float s, unsigned& h, unsigned& l) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // s: the (wave-uniform) scale, in a scalar register -- one constant-bus operand per instruction, no VGPR for it
-  // (Round 4, measured in-step, no kernel moved by more than the run-to-run 1-2 %: (i) scale by v_pk_mul_f32, hi by v_cvt_pk_f16_f32, lo by two
-  //  v_fma_mix -- 2 full-rate + 2 half-rate instructions per pair instead of these 4 half-rate ones (tools/probe/valu_rate.hip: 5 vs 9-11
-  //  cycles), bit-identical; (ii) the slot's validity folded into a per-thread scale, sparing the select per element.  The split is not
-  //  what these kernels wait for.)
+  // (Round 4, measured in-step and on the GE2E embedder, nothing moved by more than the run-to-run 1 %: (i) scale by v_pk_mul_f32, hi by
+  //  v_cvt_pk_f16_f32, lo by two v_fma_mix -- 2 full-rate + 2 half-rate instructions per pair instead of these 4 half-rate ones
+  //  (tools/probe/valu_rate.hip: 5 vs 9-11 cycles), bit-identical; (ii) the slot's validity folded into a per-thread scale, sparing the
+  //  select per element.  The split is not what these kernels wait for; MI355X_MICROARCH.md prices packed f32 VALU beside MFMAs as an anti-lever.)
   asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a), "s"(s));
   asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(b), "s"(s));
   asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "s"(s), "v"(h));
@@ -578,6 +578,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ssv_nn_stamps[127] = __builtin_readcyclecounter();     // the first workgroup's entry, for the ramp
 #endif
   if constexpr (KT == 1) {
+    NN_STAMP_AT(1);
     if (nchunks > 0) {
       loadA(0, 0, 0);
       prefetchX(0);
@@ -588,17 +589,23 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     __syncthreads();
     auto pair = [&](auto steady, int ch) __attribute__((always_inline)) -> bool {
       constexpr bool ST = decltype(steady)::value;
+      NN_STAMP(0);
       tap(0, 0, ch);
+      NN_STAMP(1);
       if (!ST && ch + 1 >= nchunks) return false;
       commitX(ch + 1);
+      NN_STAMP(2);
       if (ST || ch + 2 < nchunks) { prefetchX(ch + 2); loadA(0, 0, ch + 2); }
+      NN_STAMP(3);
       __syncthreads();
+      NN_STAMP(4);
       tap(1, 0, ch + 1);
       if (ST || ch + 2 < nchunks) {
         commitX(ch + 2);
         if (ST || ch + 3 < nchunks) { prefetchX(ch + 3); loadA(1, 0, ch + 3); }
       }
       __syncthreads();
+      NN_STAMP(5);
       return true;
     };
     int ch = 0;
@@ -1136,10 +1143,14 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
 // (8 steps); read back with ssv_debug_nt_stamps().  Results are unaffected.
 #ifdef SSV_NT_STAMP
 __device__ unsigned long long ssv_nt_stamps[64];
+__device__ unsigned long long ssv_nt_wg[4096 * 4];      // per workgroup (first 4096): s_memrealtime at entry / exit, shader clock at entry / exit
+extern "C" int ssv_debug_nt_wg(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssv_nt_wg), sizeof(ssv_nt_wg)); }
+#define NT_WG(k, v) do { const unsigned w_ = blockIdx.z * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && w_ < 4096u) ssv_nt_wg[w_ * 4 + (k)] = (v); } while (0)
 #define NT_STAMP(k) do { if (stamp_on && (unsigned)(stamp_s - 24) < 8u) ssv_nt_stamps[(stamp_s - 24) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 extern "C" int ssv_debug_nt_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssv_nt_stamps), sizeof(ssv_nt_stamps)); }
 #else
 #define NT_STAMP(k) do {} while (0)
+#define NT_WG(k, v) do {} while (0)
 #endif
 #ifndef SSV_NT_FD
 #define SSV_NT_FD 1         // LDS fragment groups read ahead of the MFMAs (see the step loop)
@@ -1159,6 +1170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   __shared__ float amax_sm[8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  NT_WG(0, __builtin_amdgcn_s_memrealtime()); NT_WG(2, __builtin_readcyclecounter());
   const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);   // a slab's tiles share an XCD
   const int bxx = (int)(wg % gridDim.x);
   int z = (int)(wg / gridDim.x);
@@ -1461,6 +1473,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
   }
 
+  NT_WG(3, __builtin_readcyclecounter());            // end of the chunk loop
   float* __restrict__ Cz = Cp + (long)z * p.scz;
 #pragma unroll
   for (int i = 0; i < WM; ++i)
@@ -1476,6 +1489,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
           if (gc < p.Nc) Cz[(long)gm * p.scm + (long)gc * p.scc + (long)j * p.scj] = F16 ? acc[i][j][q][r] * us : acc[i][j][q][r];
         }
     }
+#ifdef SSV_NT_STAMP
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  NT_WG(1, __builtin_amdgcn_s_memrealtime());
 }
 
 // Tile plan for the weight gradient.  The output (M x Nc x KT) is small, so the reduction axis (batch x time) is cut into

@@ -358,6 +358,162 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
   }
 }
 
+// ---- wide-tile backward (round 4) ---------------------------------------------------------------------------------------
+// Same mathematics as ln_gate_bwd_kernel on a tile of 16 * VEC columns x ALL channels with 1024 threads: thread (cq, g) owns VEC
+// consecutive columns (one 4 * VEC-byte access per channel row: 64 * VEC contiguous bytes of a row per 16 lanes instead of 64) of channels
+// g, g + 64, ... (CPT steps).  Why: stamps (tools/ln_stamps.py) showed the 16-column kernel's workgroups spending 85 % of their ~20 us waiting
+// for 16 dependent batches of 4-byte loads; with the loads pipelined (above) the kernel moved by 5 % only -- what remains is the rate the
+// memory system gives 64-byte row pieces.  Here every load of the tile is issued before the first is used (CPT * 4 vector loads in flight per
+// thread, landing IN the arrays that later hold xhat / a), rows are read by raw buffer loads whose range is the batch item (no clamps, no
+// branches: a piece past the item's end reads 0, columns past L are masked at use).
+// Cross-group sums: 64 groups -> LDS [64][4 sums][16 VEC columns], summed in a fixed order by the first 64 * VEC threads.
+// Partial rows / scale-list entries keep the 16-column kernels' numbering: tile bx owns rows VEC * bx .. VEC * bx + VEC - 1 of the item's
+// ceil(L / 16) rows (the first carries the tile's sums, the others are zeroed) and entries likewise.
+template <int CPT, int VEC>
+__global__ __launch_bounds__(1024) void ln_gate_bwd_wide_kernel(
+    const float* __restrict__ dY, long dy_bs, const float* __restrict__ H, const float* __restrict__ X, long x_bs,
+    const float* __restrict__ stats,
+    const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
+    float* __restrict__ dH, float* __restrict__ dXres, long dx_bs, float* __restrict__ part, float* __restrict__ amax, int C, int L) {
+  constexpr int G = 64, TC = 16 * VEC;
+  typedef float vecf __attribute__((ext_vector_type(VEC), aligned(4)));
+  __shared__ float red[G * 4 * TC];                 // [g][sum][column of the tile]
+  __shared__ float tot[4 * TC];
+  __shared__ float amx[16];
+  const int cq = threadIdx.x & 15, g = threadIdx.x >> 4;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int t = bx * TC + VEC * cq, b = by;
+  bool cv[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) cv[j] = t + j < L;
+  const float* __restrict__ Hb1 = H + (long)b * 2 * C * L;
+  float* __restrict__ dHb1 = dH + (long)b * 2 * C * L;
+  float* __restrict__ dHb2 = dHb1 + (long)C * L;
+  float* __restrict__ dXb = dXres + (long)b * dx_bs;
+  // buffer resources over this batch item's rows: a load may run past a row (into the next one: masked) or past the item (reads 0)
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY + (long)b * dy_bs), 0, C * L * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (long)b * x_bs), 0, C * L * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Hb1), 0, 2 * C * L * 4, 0x00020000);
+  auto ldv = [&](__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[VEC]) __attribute__((always_inline)) {
+    if constexpr (VEC == 4) { const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
+    else if constexpr (VEC == 2) { typedef float f2 __attribute__((ext_vector_type(2))); const f2 q = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); v[0] = q[0]; v[1] = q[1]; }
+    else v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+  };
+  // every load of the tile first: they land in the arrays that later hold xhat1, xhat2, a1, a2
+  float xh1[CPT][VEC], xh2[CPT][VEC], a1[CPT][VEC], a2[CPT][VEC];     // raw: h1, h2, dy, x
+  float pg1[CPT], pb1[CPT], pg2[CPT], pb2[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = min(g + G * i, C - 1);
+    const unsigned o = ((unsigned)c * (unsigned)L + (unsigned)t) * 4u;
+    ldv(rh, o, xh1[i]); ldv(rh, o + (unsigned)C * (unsigned)L * 4u, xh2[i]); ldv(rdy, o, a1[i]); ldv(rx, o, a2[i]);
+    pg1[i] = g1[c]; pb1[i] = b1[c]; pg2[i] = g2[c]; pb2[i] = b2[c];
+  }
+  float mu1[VEC], r1[VEC], mu2[VEC], r2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float* sb = stats + (long)b * 4 * L + min(t + j, L - 1);
+    mu1[j] = sb[0]; r1[j] = sb[L]; mu2[j] = sb[2L * L]; r2[j] = sb[3L * L];
+  }
+  const int nrow16 = (L + 15) >> 4;
+  float* pblk = part + ((long)by * nrow16 + (long)VEC * bx) * 6 * C;          // this tile's first partial row (16-column numbering)
+  float sa1[VEC], sah1[VEC], sa2[VEC], sah2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sa1[j] = sah1[j] = sa2[j] = sah2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + G * i;
+    const bool cok = c < C;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, dxr[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const bool v = cok && cv[j];
+      const float dy = v ? a1[i][j] : 0.f, x = a2[i][j];
+      const float gg1 = v ? pg1[i] : 0.f, gg2 = v ? pg2[i] : 0.f;
+      const float h1 = v ? (xh1[i][j] - mu1[j]) * r1[j] : 0.f;
+      const float h2 = v ? (xh2[i][j] - mu2[j]) * r2[j] : 0.f;
+      const float n1 = h1 * gg1 + pb1[i], n2 = h2 * gg2 + pb2[i];
+      const float s = sigmoidf_(n1);
+      const float dn2 = dy * s, dn1 = dy * (n2 - x) * s * (1.f - s);
+      dxr[j] = dy * (1.f - s);
+      q0 += dn1 * h1; q1 += dn1; q2 += dn2 * h2; q3 += dn2;
+      xh1[i][j] = h1; xh2[i][j] = h2; a1[i][j] = dn1 * gg1; a2[i][j] = dn2 * gg2;
+      sa1[j] += a1[i][j]; sah1[j] += a1[i][j] * h1; sa2[j] += a2[i][j]; sah2[j] += a2[i][j] * h2;
+    }
+    if (cok) {
+      float* dst = dXb + (long)c * L + t;
+      if (cv[VEC - 1]) { vecf o; for (int j = 0; j < VEC; ++j) o[j] = dxr[j]; *reinterpret_cast<vecf*>(dst) = o; }
+      else for (int j = 0; j < VEC; ++j) if (cv[j]) dst[j] = dxr[j];
+    }
+    q0 = col_sum(q0); q1 = col_sum(q1); q2 = col_sum(q2); q3 = col_sum(q3);
+    if (cq == 0 && cok) { pblk[c] = q0; pblk[C + c] = q1; pblk[2 * C + c] = q2; pblk[3 * C + c] = q3; }
+  }
+  // cross-group sums
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    red[(g * 4 + 0) * TC + VEC * cq + j] = sa1[j]; red[(g * 4 + 1) * TC + VEC * cq + j] = sah1[j];
+    red[(g * 4 + 2) * TC + VEC * cq + j] = sa2[j]; red[(g * 4 + 3) * TC + VEC * cq + j] = sah2[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 * TC) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < G; ++k) sum += red[k * 4 * TC + threadIdx.x];
+    tot[threadIdx.x] = sum;
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)C;
+  float m1[VEC], mh1[VEC], m2[VEC], mh2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    m1[j] = tot[0 * TC + VEC * cq + j] * inv; mh1[j] = tot[1 * TC + VEC * cq + j] * inv;
+    m2[j] = tot[2 * TC + VEC * cq + j] * inv; mh2[j] = tot[3 * TC + VEC * cq + j] * inv;
+  }
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + G * i;
+    const bool cok = c < C;
+    float d1[VEC], d2[VEC], q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const bool v = cok && cv[j];
+      d1[j] = v ? r1[j] * (a1[i][j] - m1[j] - xh1[i][j] * mh1[j]) : 0.f;
+      d2[j] = v ? r2[j] * (a2[i][j] - m2[j] - xh2[i][j] * mh2[j]) : 0.f;
+      am = fmaxf(am, fmaxf(fabsf(d1[j]), fabsf(d2[j])));
+      q0 += d1[j]; q1 += d2[j];
+    }
+    if (cok) {
+      float* o1 = dHb1 + (long)c * L + t;
+      float* o2 = dHb2 + (long)c * L + t;
+      if (cv[VEC - 1]) {
+        vecf u, w;
+        for (int j = 0; j < VEC; ++j) { u[j] = d1[j]; w[j] = d2[j]; }
+        *reinterpret_cast<vecf*>(o1) = u; *reinterpret_cast<vecf*>(o2) = w;
+      } else for (int j = 0; j < VEC; ++j) if (cv[j]) { o1[j] = d1[j]; o2[j] = d2[j]; }
+    }
+    q0 = col_sum(q0); q1 = col_sum(q1);
+    if (cq == 0 && cok) { pblk[4 * C + c] = q0; pblk[5 * C + c] = q1; }
+  }
+  // the other partial rows of this tile's columns (16-column numbering) carry nothing
+  for (int r = 1; r < VEC; ++r) {
+    if (VEC * bx + r >= nrow16) break;
+    float* z = pblk + (long)r * 6 * C;
+    for (int e = threadIdx.x; e < 6 * C; e += 1024) z[e] = 0.f;
+  }
+  if (amax) {
+    am = ssv_wg_max<16>(am, amx);
+    if (threadIdx.x == 0) {
+      const int na = ssv_amax_rows_(L);
+      float* al = amax + (long)b * na;
+      al[VEC * bx] = am;
+      for (int r = 1; r < VEC; ++r) if (VEC * bx + r < na) al[VEC * bx + r] = 0.f;
+      if (bx == (int)gridDim.x - 1) for (int e = VEC * (int)gridDim.x; e < na; ++e) al[e] = 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int CPT, int G>
 __global__ __launch_bounds__(16 * G) void ln_act_fwd_kernel(
@@ -487,6 +643,122 @@ __global__ __launch_bounds__(16 * G) void ln_act_bwd_kernel(
       const int na = ssv_amax_rows_(L);            // list length: >= the tiles of this kernel; the last tile zeroes the rest
       amax[(long)b * na + bx] = am;
       if (bx == (int)gridDim.x - 1) for (int e = gridDim.x; e < na; ++e) amax[(long)b * na + e] = 0.f;
+    }
+  }
+}
+
+// Wide-tile form of ln_act_bwd_kernel (see ln_gate_bwd_wide_kernel): 16 * VEC columns x all channels, 1024 threads, every load first.
+template <int CPT, int VEC>
+__global__ __launch_bounds__(1024) void ln_act_bwd_wide_kernel(
+    const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs, const float* __restrict__ stats,
+    const float* __restrict__ gam, const float* __restrict__ bet,
+    float* __restrict__ dX, long dx_bs, float* __restrict__ part, float* __restrict__ amax, int C, int L, int act) {
+  constexpr int G = 64, TC = 16 * VEC;
+  typedef float vecf __attribute__((ext_vector_type(VEC), aligned(4)));
+  __shared__ float red[G * 2 * TC];
+  __shared__ float tot[2 * TC];
+  __shared__ float amx[16];
+  const int cq = threadIdx.x & 15, g = threadIdx.x >> 4;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int t = bx * TC + VEC * cq, b = by;
+  bool cv[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) cv[j] = t + j < L;
+  float* __restrict__ dXb = dX + (long)b * dx_bs;
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY + (long)b * dy_bs), 0, C * L * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (long)b * x_bs), 0, C * L * 4, 0x00020000);
+  auto ldv = [&](__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[VEC]) __attribute__((always_inline)) {
+    if constexpr (VEC == 4) { const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
+    else if constexpr (VEC == 2) { typedef float f2 __attribute__((ext_vector_type(2))); const f2 q = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); v[0] = q[0]; v[1] = q[1]; }
+    else v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+  };
+  float xh[CPT][VEC], a[CPT][VEC];                  // raw: x, dy
+  float pg[CPT], pb[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = min(g + G * i, C - 1);
+    const unsigned o = ((unsigned)c * (unsigned)L + (unsigned)t) * 4u;
+    ldv(rx, o, xh[i]); ldv(rdy, o, a[i]);
+    pg[i] = gam[c]; pb[i] = bet[c];
+  }
+  float mu[VEC], r[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { const float* sb = stats + (long)b * 2 * L + min(t + j, L - 1); mu[j] = sb[0]; r[j] = sb[L]; }
+  const int nrow16 = (L + 15) >> 4;
+  float* pblk = part + ((long)by * nrow16 + (long)VEC * bx) * 3 * C;
+  float sa[VEC], sah[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sa[j] = sah[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + G * i;
+    const bool cok = c < C;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const bool v = cok && cv[j];
+      const float dy = v ? a[i][j] : 0.f, gg = v ? pg[i] : 0.f;
+      const float h = v ? (xh[i][j] - mu[j]) * r[j] : 0.f;
+      const float n = h * gg + pb[i];
+      float dn;
+      if (act == 1) dn = n > 0.f ? dy : 0.f;
+      else if (act == 2) { const float s = sigmoidf_(n); dn = dy * s * (1.f - s); }
+      else dn = dy;
+      q0 += dn * h; q1 += dn;
+      xh[i][j] = h; a[i][j] = dn * gg;
+      sa[j] += a[i][j]; sah[j] += a[i][j] * h;
+    }
+    q0 = col_sum(q0); q1 = col_sum(q1);
+    if (cq == 0 && cok) { pblk[c] = q0; pblk[C + c] = q1; }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { red[(g * 2 + 0) * TC + VEC * cq + j] = sa[j]; red[(g * 2 + 1) * TC + VEC * cq + j] = sah[j]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * TC) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < G; ++k) sum += red[k * 2 * TC + threadIdx.x];
+    tot[threadIdx.x] = sum;
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)C;
+  float m[VEC], mh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { m[j] = tot[VEC * cq + j] * inv; mh[j] = tot[TC + VEC * cq + j] * inv; }
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + G * i;
+    const bool cok = c < C;
+    float d[VEC], q0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      d[j] = (cok && cv[j]) ? r[j] * (a[i][j] - m[j] - xh[i][j] * mh[j]) : 0.f;
+      am = fmaxf(am, fabsf(d[j]));
+      q0 += d[j];
+    }
+    if (cok) {
+      float* o = dXb + (long)c * L + t;
+      if (cv[VEC - 1]) { vecf u; for (int j = 0; j < VEC; ++j) u[j] = d[j]; *reinterpret_cast<vecf*>(o) = u; }
+      else for (int j = 0; j < VEC; ++j) if (cv[j]) o[j] = d[j];
+    }
+    q0 = col_sum(q0);
+    if (cq == 0 && cok) pblk[2 * C + c] = q0;
+  }
+  for (int rr = 1; rr < VEC; ++rr) {
+    if (VEC * bx + rr >= nrow16) break;
+    float* z = pblk + (long)rr * 3 * C;
+    for (int e = threadIdx.x; e < 3 * C; e += 1024) z[e] = 0.f;
+  }
+  if (amax) {
+    am = ssv_wg_max<16>(am, amx);
+    if (threadIdx.x == 0) {
+      const int na = ssv_amax_rows_(L);
+      float* al = amax + (long)b * na;
+      al[VEC * bx] = am;
+      for (int rr = 1; rr < VEC; ++rr) if (VEC * bx + rr < na) al[VEC * bx + rr] = 0.f;
+      if (bx == (int)gridDim.x - 1) for (int e = VEC * (int)gridDim.x; e < na; ++e) al[e] = 0.f;
     }
   }
 }
@@ -737,12 +1009,12 @@ int ssv_reduce_partial_rows(const float* part, float* out, int n, int nblk, hipS
 // faster on 32 groups (half the registers per thread: 224 -> ~130 VGPRs in the gate backward, so twice the waves per CU);
 // the 513-channel backward is fastest on 64 groups (113 -> 92 us at L = 1300), its forward on 16.
 // SSV_LN_GROUPS forces G (tuning aid).
-static void ln_log(const char* name, int cpt, int g, dim3 grid, double bytes_per_elem, int B, int C, int L) {
+static void ln_log(const char* name, int cpt, int g, dim3 grid, double bytes_per_elem, int B, int C, int L, int threads = 0) {
   if (!ssv_shape_log_on()) return;
   char nm[96], note[64];
   snprintf(nm, sizeof nm, "%s<%d, %d>", name, cpt, g);
   snprintf(note, sizeof note, "B=%d C=%d L=%d", B, C, L);
-  ssv_shape_log(nm, grid, dim3(16 * g), 0.0, bytes_per_elem * B * C * L, note);
+  ssv_shape_log(nm, grid, dim3(threads ? threads : 16 * g), 0.0, bytes_per_elem * B * C * L, note);
 }
 static int ln_groups(int C, bool bwd) {
   if (const char* e = ssv_tuning(SSV_T_LN_GROUPS)) { const int g = atoi(e); if (g == 16 || g == 32 || g == 64) return g; }
@@ -786,6 +1058,15 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
 #define LN_BYTES 28.0
 #define CALL(N, G) hipLaunchKernelGGL((ln_gate_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L)
   if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
+  // wide tiles (see ln_gate_bwd_wide_kernel), measured in-step against the 16-column kernel (round 4, B = 32): C = 512: L = 186 -21 %, L = 1300
+  // -11.5 %; C = 256: L = 1300 -13.6 %, L = 325 and 650 equal (192 / 352 workgroups of 1024 threads leave CUs idle: the 16-column kernel stays)
+  if (C % 64 == 0 && C >= 128 && (C > 256 ? L >= 64 : L >= 1024) && (long)2 * C * L * 4 < (1L << 31) &&
+      (!amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 16))) {
+#define WIDE(N, V) do { dim3 gw(ssv_cdiv(L, 16 * V), B); ln_log("ln_gate_bwd_wide_kernel", N, V, gw, LN_BYTES, B, C, L, 1024); \
+      hipLaunchKernelGGL((ln_gate_bwd_wide_kernel<N, V>), gw, dim3(1024), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L); } while (0)
+    if (C <= 128) WIDE(2, 4); else if (C <= 256) WIDE(4, 4); else WIDE(8, 2);
+#undef WIDE
+  } else
   LN_DISPATCH(true, C, L, CALL);
 #undef CALL
 #undef LN_NAME
@@ -815,6 +1096,12 @@ int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs
 #define LN_NAME "ln_act_bwd_kernel"
 #define LN_BYTES 12.0
 #define CALL(N, G) hipLaunchKernelGGL((ln_act_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, amax, C, L, act)
+  if (C > 256 && C <= 576 && L >= 64 && (long)C * L * 4 < (1L << 31) && (!amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 16))) {
+#define WIDE(N, V) do { dim3 gw(ssv_cdiv(L, 16 * V), B); ln_log("ln_act_bwd_wide_kernel", N, V, gw, LN_BYTES, B, C, L, 1024); \
+      hipLaunchKernelGGL((ln_act_bwd_wide_kernel<N, V>), gw, dim3(1024), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, amax, C, L, act); } while (0)
+    if (C <= 512) WIDE(8, 4); else WIDE(9, 4);
+#undef WIDE
+  } else
   LN_DISPATCH(true, C, L, CALL);
 #undef CALL
 #undef LN_NAME

@@ -19,6 +19,17 @@ for (C, L, k, d) in ((256, 325, 3, 3), (512, 186, 3, 3), (512, 1300, 3, 1)):
     buf = (ctypes.c_ulonglong * 64)()
     rc = _lib.lib().ssv_debug_nt_stamps(buf)
     print("C%d L%d k%d rc=%d" % (C, L, k, rc))
+    import numpy as np
+    wgb = (ctypes.c_ulonglong * (4096 * 4))()
+    ctypes.CDLL(_lib.LIBPATH).ssv_debug_nt_wg(wgb)
+    a = np.frombuffer(wgb, dtype=np.uint64).reshape(4096, 4).astype(np.int64)
+    a = a[a[:, 1] > 0]
+    t0 = a[:, 0].min()
+    ent, ext = (a[:, 0] - t0) * 0.01, (a[:, 1] - t0) * 0.01
+    loop = a[:, 3] - a[:, 2]
+    q = lambda v: "%.1f / %.1f / %.1f" % tuple(np.percentile(v, [10, 50, 90]))
+    print("  %d workgroups: entry us 10/50/90 %% = %s (last %.1f) | exit us = %s (last %.1f) | residence us = %s | entry -> end of chunk loop, cycles = %s" % (
+        len(a), q(ent), ent.max(), q(ext), ext.max(), q(ext - ent), q(loop)))
     prev_end = None
     for s in range(8):
         t = [buf[s * 8 + i] for i in range(7)]
