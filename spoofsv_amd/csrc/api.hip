@@ -40,8 +40,7 @@ int ssv_precision() {
   }
   return g_precision;
 }
-static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_Z", "SSV_NT_FORCE", "SSV_LSTM_SEQUENTIAL", "SSV_NNB_WIDE", "SSV_NNB_TILE",
-                                                       "SSV_NNB_FORCE", "SSV_NT_PLAN", "SSV_NN_TILE", "SSV_LN_GROUPS", "SSV_LN_NOSTREAM", "SSV_NT_OLDZ"};
+static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_FORCE", "SSV_NNB_FORCE", "SSV_LN_GROUPS"};
 static char g_knob_val[SSV_T_COUNT][512];
 static const char* g_knob[SSV_T_COUNT];
 static int g_knobs_loaded = 0;
@@ -364,9 +363,8 @@ static int nt_slabs(long tiles_all, int njobs, int B, int L, int kt, int M, int 
 }
 static int dw_splits(int B, int M, int Nc, int k, int L = 0) {
   const int tiles = ssv_nt_bf3_tiles(k == 3 ? 3 : 1, M, Nc);
-  int z = ssv_tuning(SSV_T_NT_OLDZ) ? ssv_cdiv(ssv_nt_bf3_target(k == 3 ? 3 : 1, M, Nc), tiles) : nt_slabs(tiles, 1, B, L, k == 3 ? 3 : 1, M, Nc);
-  if (const char* e = ssv_tuning(SSV_T_NT_Z)) { const int v = atoi(e); if (v > 0) z = v; }
-  if (const char* e = ssv_tuning(SSV_T_NT_FORCE)) {      // "M:Nc:k=Z;..." -- one shape's slab count inside a whole step (tools/sweep_step_tiles.py)
+  int z = nt_slabs(tiles, 1, B, L, k == 3 ? 3 : 1, M, Nc);
+  if (const char* e = ssv_tuning(SSV_T_NT_FORCE)) {      // "M:Nc:k=Z;..." -- one shape's slab count inside a whole step (tools/sweep_force.sh)
     char key[48];
     snprintf(key, sizeof key, "%d:%d:%d=", M, Nc, k);
     const char* hit = strstr(e, key);
@@ -436,7 +434,7 @@ extern "C" int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int
   const int kt = k == 3 ? 3 : 1;
   if (njobs < 1) njobs = 1;
   const long tiles = (long)ssv_nt_bf3_tiles(kt, Cout, Cin) * njobs;
-  int z = ssv_tuning(SSV_T_NT_OLDZ) ? ssv_cdiv(ssv_nt_bf3_target(kt, Cout, Cin), tiles) : nt_slabs(tiles, njobs, B, L, kt, Cout, Cin);
+  int z = nt_slabs(tiles, njobs, B, L, kt, Cout, Cin);
   if (z > B) z = B;
   if (z < 1) z = 1;
   return z;
@@ -486,7 +484,7 @@ extern "C" int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* 
 // ---- highwayConv ---------------------------------------------------------------------------------------
 // Column statistics of h come out of the conv kernel's epilogue (64-row groups) when the split-MFMA kernel runs and the two
 // halves are whole groups; the LayerNorm / gate forward is then a streaming kernel without reductions (norm.hip).
-static inline bool hw_colstats(int B, int C, int L) { return use_bf3(B, L, C, 2 * C) && C % 64 == 0 && C <= 512 && !ssv_tuning(SSV_T_LN_NOSTREAM); }
+static inline bool hw_colstats(int B, int C, int L) { return use_bf3(B, L, C, 2 * C) && C % 64 == 0 && C <= 512; }
 static inline size_t hw_colstats_bytes(int B, int C, int L) { return align256((size_t)B * (2 * C / 64) * L * 2 * sizeof(float)); }
 extern "C" size_t ssv_highway_conv1d_fwd_workspace(int B, int C, int L, int k) {
   return ssv_conv1d_fwd_workspace(C, 2 * C, k) + (hw_colstats(B, C, L) ? hw_colstats_bytes(B, C, L) : 0);
@@ -993,7 +991,7 @@ extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const floa
             ssv_lstm_fwd_workspace(Bn, T, F, H, layers));
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
-  if (ssv_precision() >= 1 && lstm_wave_ok(Bn, H) && !ssv_tuning(SSV_T_LSTM_SEQUENTIAL))
+  if (ssv_precision() >= 1 && lstm_wave_ok(Bn, H))
     return lstm_fwd_wave(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, base, st);
   float* xt = (float*)(base + s.xt);
   float* xp = (float*)(base + s.xp);

@@ -323,13 +323,10 @@ int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, 
 // sets, the chunk loop is unrolled by two).  Only the input tile, which all four waves share, is staged in LDS -- this
 // removes 2/3 of the LDS writes and 1/4 of the LDS reads of a version that staged both operands.
 // (third waves per SIMD for the small k = 1 tile: 168 VGPRs in the split-bf16 form, 174 in the split-fp16 one without the bound -- +22 % time)
-#ifndef SSV_NN_FD
-#define SSV_NN_FD 1         // LDS fragment blocks read ahead of the MFMAs (see tap())
-#endif
 // Tuning builds only (-DSSV_NN_STAMP): thread 0 of workgroup (0, 0) records s_memtime at five points of every K chunk; ssv_debug_nn_stamps().
 #ifdef SSV_NN_STAMP
 #ifndef SSV_NN_STAMP_WG
-#define SSV_NN_STAMP_WG 0
+#define SSV_NN_STAMP_WG 0     // (stamp builds) 1: the launch's last workgroup instead of its first
 #endif
 __device__ unsigned long long ssv_nn_stamps[128];
 __device__ unsigned long long ssv_nn_rt[4096];        // s_memrealtime (100 MHz, one clock for the device) at entry / exit of the first 2048 workgroups
@@ -344,23 +341,10 @@ extern "C" int ssv_debug_nn_stamps(unsigned long long* out) { return (int)hipMem
 #define NN_STAMP_AT(slot) do {} while (0)
 #define NN_RT(which) do {} while (0)
 #endif
-#ifndef SSV_NN_XBUF
 #define SSV_NN_XBUF(KT, WM, NT) (!((KT) == 3 && (NT) == 6))   // input rows by buffer loads (ssv_buf) or through pointers: in-step, per tile -- the k = 1
                                                              // tiles are 5-12 % faster with buffer loads, the 96-column k = 3 tiles 4-6 % with pointers, the rest equal
-#endif
-#ifndef SSV_NN_ABUF
-#define SSV_NN_ABUF(KT, WM, NT) 1                             // weight fragments: buffer loads everywhere (equal or 1-3 % faster)
-#endif
-#ifndef SSV_NN_FD_BIG
-#define SSV_NN_FD_BIG 1     // ... of the 128-row k = 3 tiles
-#endif
-#ifndef SSV_NN_STEADY3
-#define SSV_NN_STEADY3 1
-#endif
 // waves per SIMD the register allocation must leave room for
-#ifndef SSV_NNB_WAVES
 #define SSV_NNB_WAVES(KT, WM, NT, EPI) ((KT) == 1 && (WM) == 2 && (NT) == 4 && (EPI) == 0 ? 3 : 2)
-#endif
 template <int KT, int WM, int NT, int EPI, int F16>
 __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int BM = 64 * WM, BN = 16 * NT;
@@ -430,20 +414,11 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(p.Ahi + (long)b * p.sab), rsAl = ssv_buf(p.Alo + (long)b * p.sab);   // (see ssv_buf)
   auto loadA = [&](int set, int j, int ch) {
     const unsigned ub = (unsigned)((j * aplane + (long)ch * 512) * 2);                                  // wave-uniform byte offset
-    if constexpr (SSV_NN_ABUF(KT, WM, NT)) {
+    // (buffer loads everywhere: equal or 1-3 % faster than loads through pointers, measured in-step per tile)
 #pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        Ah_[set][j][i] = ssv_buf_u4(rsAh, arowb[i], ub);
-        Al_[set][j][i] = ssv_buf_u4(rsAl, arowb[i], ub);
-      }
-    } else {
-      const char* __restrict__ hb = reinterpret_cast<const char*>(p.Ahi + (long)b * p.sab) + ub;
-      const char* __restrict__ lb = reinterpret_cast<const char*>(p.Alo + (long)b * p.sab) + ub;
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        Ah_[set][j][i] = *reinterpret_cast<const uint4*>(hb + arowb[i]);
-        Al_[set][j][i] = *reinterpret_cast<const uint4*>(lb + arowb[i]);
-      }
+    for (int i = 0; i < WM; ++i) {
+      Ah_[set][j][i] = ssv_buf_u4(rsAh, arowb[i], ub);
+      Al_[set][j][i] = ssv_buf_u4(rsAl, arowb[i], ub);
     }
   };
   // Input staging, two halves.  prefetchX only ISSUES loads (raw values, addresses clamped into the batch item so every
@@ -538,7 +513,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
 
   // The input fragments of column block t + FD are read from LDS before the MFMAs of block t are issued (2 reads, 3 WM MFMAs per
   // block): hipcc on its own issues a block's reads right in front of its MFMAs and parks the wave for the LDS latency NT times per tap.
-  constexpr int FD = (KT == 3 && WM == 2 && NT >= 6) ? SSV_NN_FD_BIG : (SSV_NN_FD < NT) ? SSV_NN_FD : NT - 1;
+  constexpr int FD = NT > 1 ? 1 : 0;
   auto tap = [&](int set, int j, int ch) {
     const uint4* Xh = lds[ch & 1];
     const uint4* Xl = lds[ch & 1] + X_SLOTS;
@@ -644,8 +619,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     int ch = 0;
     // (the steady form holds more values live: 140 -> 190 VGPRs for the 64 x 112 tile, whose hot launches are 768 workgroups and need
     // three per CU to run in one round -- +20 % on it; the 64 x 96 tile's launches are 512 workgroups and gain 7 % from it)
-    constexpr bool STEADY3 = SSV_NN_STEADY3 != 0;
-    for (; STEADY3 && ch + 2 < nchunks; ++ch) chunk(ST_{}, ch);
+    for (; ch + 2 < nchunks; ++ch) chunk(ST_{}, ch);
     for (; ch < nchunks; ++ch) chunk(TL_{}, ch);
   }
 
@@ -1036,20 +1010,13 @@ static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
 template <int KT>
 static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   {
-    int wm = 0, nt = 0, nwn = 0;
-    const char* e = ssv_tuning(SSV_T_NNB_WIDE);
-    if (e && g.sxn == 1 && g.scn == 1 && !g.colstats && sscanf(e, "%d,%d,%d", &wm, &nt, &nwn) == 3) {
-#define SSV_W(A_, C_, D_) if (wm == A_ && nt == C_ && nwn == D_) return launch_nnbw<KT, A_, C_, D_>(g, st, smin, span)
-      SSV_W(2, 7, 3); SSV_W(1, 7, 3); SSV_W(2, 7, 2); SSV_W(2, 6, 2); SSV_W(1, 6, 2); SSV_W(2, 4, 4); SSV_W(2, 7, 4);
-#undef SSV_W
-    }
-    // measured (tools/sweep_nn_tiles.py): the wide workgroup wins for kernel-size-1 convolutions over long sequences
+    // measured (round-1 tile sweep; in-step re-check: tools/sweep_force.sh): the wide workgroup wins for kernel-size-1 convolutions over long sequences
     // (SSRN's 513-channel layers: 150 -> 205 TFLOP/s); the k=3 layers are as fast or faster on the 4-wave kernel.
     // 128 x 192 tiles (8 waves) are the faster wide shape (513 -> 512 channels: 104 -> 87 us, 256 -> 512: 60 -> 49 us) except
-    // when M leaves a nearly empty last row tile (M = 513), where the 16-wave 128 x 448 tile loses less (tools/sweep_wide.py)
+    // when M leaves a nearly empty last row tile (M = 513), where the 16-wave 128 x 448 tile loses less (round-1 sweep)
     // ... and only when the 128 x 192 tiling still gives every CU a workgroup: a single long utterance (the vocoder's DFT
     // at B = 1: 1026 x 1300 x 1024) is 27-56 wide tiles, a fifth of the chip; the cost model below then picks small tiles.
-    if (KT == 1 && !e && !g.epi && !g.perm_h && !g.colstats && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256 &&
+    if (KT == 1 && !g.epi && !g.perm_h && !g.colstats && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256 &&
         (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 192) * g.B >= 256)
       return (g.M % 128 == 0) ? launch_nnbw<KT, 2, 6, 2>(g, st, smin, span) : launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
   }
@@ -1058,16 +1025,12 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   //  shape inside the step with SSV_NNB_FORCE, tools/sweep_force.sh: every one of ten shapes +0.03..+0.2 ms; instantiations removed)
   int wm = 2, nt = 7;
   bool forced = false;
-  if (const char* e = ssv_tuning(SSV_T_NNB_TILE)) {
-    int a = 0, c = 0;
-    if (sscanf(e, "%d,%d", &a, &c) == 2 && (a == 1 || a == 2)) for (int x : nts) if (x == c) { wm = a; nt = c; forced = true; }
-  }
   // LSTM wavefront with two or more layers in one launch (the steady state of the GE2E embedder: 2 x 3072 x 880 x 1536): the
   // cost model below picks 64 x 112 tiles; measured over the 122 steps of config 5, 128 x 64 tiles are 6 % faster
   // (13.8 -> 13.0 ms; 128 x 96: 13.5, 128 x 112: 14.2, 64 x 96: 14.8) as long as they still give every CU two workgroups.
   if (!forced && g.epi && g.lstm_D > 0 && g.B >= 2 && (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 64) * g.B >= 512) { wm = 2; nt = 4; forced = true; }
   if (!forced) {
-    // tuning aid (tools/sweep_step_tiles.py): SSV_NNB_FORCE="kt:M:N=a,c;kt:M:N=a,c;..." forces the tile of one problem shape
+    // tuning aid (tools/sweep_force.sh): SSV_NNB_FORCE="kt:M:N=a,c;kt:M:N=a,c;..." forces the tile of one problem shape
     // inside a whole training step, where a tile's effect on its neighbours shows (isolated timings miss it)
     if (const char* e = ssv_tuning(SSV_T_NNB_FORCE)) {
       char key[48];
@@ -1152,9 +1115,7 @@ extern "C" int ssv_debug_nt_stamps(unsigned long long* out) { return (int)hipMem
 #define NT_STAMP(k) do {} while (0)
 #define NT_WG(k, v) do {} while (0)
 #endif
-#ifndef SSV_NT_FD
-#define SSV_NT_FD 1         // LDS fragment groups read ahead of the MFMAs (see the step loop)
-#endif
+constexpr int NT_FD = 1;      // LDS fragment groups read ahead of the MFMAs (see the step loop)
 template <int KT, int WM, int NTC, int F16>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
   constexpr int KB = 64, KG = KB / 8, KS = KB / 32;         // time steps per chunk, k-groups, MFMA k-steps
@@ -1249,7 +1210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     const int f = tid + 256 * r;
     xrow[r] = min(c0 + f / KG, p.Nc - 1) * (int)p.sxc + 8 * (f % KG);
   }
-  const bool rows_in_m = m0 + 64 * WM <= p.M, rows_in_c = c0 + NCH <= p.Nc;
+  const bool rows_in_c = c0 + NCH <= p.Nc;
 
   auto load8 = [&](const float* __restrict__ base, int off, float (&v)[8]) {
     // uniform base + zero-extended 32-bit BYTE offset (operands span < 2^30 elements): the saddr form of global_load
@@ -1400,22 +1361,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       // block of one k-step: 2 reads, 3 WM MFMAs).  Left to itself hipcc issues a group's reads right in front of its MFMAs and
       // parks the wave on lgkmcnt for the LDS latency eight times per step -- a third of the wave's cycles by the SQ counters.
       constexpr int G = KS * NTC;
-      uint4 fb[SSV_NT_FD + 1][2];
+      uint4 fb[NT_FD + 1][2];
       auto frag = [&](int g, uint4 (&f)[2]) __attribute__((always_inline)) {
         const int kg = (g / NTC) * 4 + kq;
         const int xs_ = kg * NCH + (((g % NTC) * 16 + nq) ^ kg);
         f[0] = Xh[xs_]; f[1] = Xl[xs_];
       };
 #pragma unroll
-      for (int g = 0; g < SSV_NT_FD; ++g) frag(g, fb[g]);
+      for (int g = 0; g < NT_FD; ++g) frag(g, fb[g]);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        if (g + SSV_NT_FD < G) frag(g + SSV_NT_FD, fb[(g + SSV_NT_FD) % (SSV_NT_FD + 1)]);
+        if (g + NT_FD < G) frag(g + NT_FD, fb[(g + NT_FD) % (NT_FD + 1)]);
         __builtin_amdgcn_sched_barrier(0);                                   // or the scheduler sinks the reads back to their use
         const int s2 = g / NTC, q = g % NTC;
         if (s2 > 0 && q == 0 && ct0[0] + 32 * s2 >= p.La) break;           // ragged last chunk: the k-steps from here on lie past the row end (the input tile is zero there)
-        const uint4 bh = fb[g % (SSV_NT_FD + 1)][0];
-        const uint4 bl = fb[g % (SSV_NT_FD + 1)][1];
+        const uint4 bh = fb[g % (NT_FD + 1)][0];
+        const uint4 bl = fb[g % (NT_FD + 1)][1];
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
           const uint4 a_h = AH[CUR::value][i][s2];
@@ -1497,17 +1458,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 
 // Tile plan for the weight gradient.  The output (M x Nc x KT) is small, so the reduction axis (batch x time) is cut into
 // Z slabs that are summed afterwards; slab traffic (Z x output, written and read back) competes with the operand reads,
-// so smaller tiles with fewer slabs win when the output is small.  SSV_NT_PLAN="wm,ntc" forces a tile (tuning aid).
+// so smaller tiles with fewer slabs win when the output is small.
 void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
-  int a = 0, c = 0;
-  if (const char* e = ssv_tuning(SSV_T_NT_PLAN)) {
-    if (sscanf(e, "%d,%d", &a, &c) == 2 && (a == 1 || a == 2) && (c == 2 || c == 4 || c == 6)) {
-      if (KT == 3 && c == 6) c = 4;
-      *wm = a; *ntc = c;
-      return;
-    }
-  }
-  // measured (tools/sweep_nt.py): k=3 -- the largest tile wins at every hot shape; k=1 carries a third of the MFMAs per
+  // measured (round-1 sweep; in-step re-check with SSV_NT_FORCE, tools/prof_env.sh): k=3 -- the largest tile wins at every hot shape; k=1 carries a third of the MFMAs per
   // staged byte, so only large outputs (513 x 513) keep the 128 x 96 tile, smaller ones take 64 x 64 tiles with fewer slabs
   if (KT == 3) { *wm = 2; *ntc = 4; }
   else if (Nc <= 48) { *wm = 2; *ntc = 2; }
@@ -1521,12 +1474,6 @@ int ssv_nt_bf3_wg_per_cu(int KT, int wm, int ntc) {
   if (KT == 3) return wm == 2 ? 2 : (ntc >= 4 ? 3 : 4);
   if (wm == 2) return ntc >= 6 ? 2 : 3;
   return ntc >= 6 ? 3 : (ntc >= 4 ? 4 : 5);
-}
-// workgroups to aim for when choosing the number of batch slabs
-int ssv_nt_bf3_target(int KT, int M, int Nc) {
-  int wm, ntc;
-  ssv_nt_bf3_tile(KT, M, Nc, &wm, &ntc);
-  return (KT == 1 && wm == 2 && ntc == 6) ? 1024 : 512;
 }
 int ssv_nt_bf3_tiles(int KT, int M, int Nc) {
   int wm, ntc;

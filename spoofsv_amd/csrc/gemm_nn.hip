@@ -190,15 +190,9 @@ static int launch_cfg(const GemmNN& g, hipStream_t st, int smin, int span) {
 
 // Tile choice.  Every workgroup of these grids is resident at once (<= 4 per CU), so the kernel lasts as long
 // as the most loaded CU: ceil(tiles / 256) workgroups, each costing about its MFMA count plus a per-chunk
-// staging/barrier overhead that grows with the tile perimeter.  SSV_NN_TILE="WM,NT" overrides (tuning knob).
+// staging/barrier overhead that grows with the tile perimeter.
 static void pick_tile(const GemmNN& g, int* wm_out, int* nt_out) {
   static const int nts[] = {8, 7, 6, 4, 2};
-  if (const char* e = ssv_tuning(SSV_T_NN_TILE)) {
-    int wm = 0, nt = 0;
-    if (sscanf(e, "%d,%d", &wm, &nt) == 2 && (wm == 1 || wm == 2)) {
-      for (int c : nts) if (c == nt) { *wm_out = wm; *nt_out = nt; return; }
-    }
-  }
   double best = 1e30;
   for (int wm = 1; wm <= 2; ++wm)
     for (int nt : nts) {

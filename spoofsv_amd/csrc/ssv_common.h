@@ -108,12 +108,11 @@ int ssv_launch_absmax(const float* x, long x_bs, int B, long n, float* out, int 
 int ssv_nt_bf3_tiles(int KT, int M, int Nc);
 void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc);
 int ssv_nt_bf3_wg_per_cu(int KT, int wm, int ntc);        // co-resident workgroups per CU of that instantiation (its register count)
-int ssv_nt_bf3_target(int KT, int M, int Nc);  // workgroups to aim for when choosing the slab count   // output tiles of the weight-gradient kernel for this problem
 int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA, 2 = split-fp16 MFMA with power-of-two operand scales (default)
-// Tuning knobs from the environment (SSV_NT_Z, SSV_NNB_TILE, ...): read ONCE at first use -- a launch must not cost
-// half a dozen getenv() scans of the environment block -- and again only when a tuning script calls ssv_reload_tuning().
-enum { SSV_T_NT_Z, SSV_T_NT_FORCE, SSV_T_LSTM_SEQUENTIAL, SSV_T_NNB_WIDE, SSV_T_NNB_TILE, SSV_T_NNB_FORCE, SSV_T_NT_PLAN, SSV_T_NN_TILE,
-       SSV_T_LN_GROUPS, SSV_T_LN_NOSTREAM, SSV_T_NT_OLDZ, SSV_T_COUNT };
+// The three tuning knobs that remain (per-shape overrides for in-step sweeps: SSV_NNB_FORCE="kt:M:N=wm,nt;...", SSV_NT_FORCE="M:Nc:k=Z;...",
+// SSV_LN_GROUPS for tools/bench_ln.py): read from the environment ONCE at first use -- a launch must not cost getenv() scans -- and
+// again only when a tuning script calls ssv_reload_tuning() (exported, not part of include/ssv_hip.h).
+enum { SSV_T_NT_FORCE, SSV_T_NNB_FORCE, SSV_T_LN_GROUPS, SSV_T_COUNT };
 const char* ssv_tuning(int knob);          // value of the knob or nullptr
 int ssv_pack_job_blocks(const ssv_pack_job& j);           // workgroups one job of ssv_conv_pack_multi takes
 int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, float* amax_ws, hipStream_t st);   // amax_ws != null: split-fp16 planes

@@ -1,19 +1,30 @@
 #!/usr/bin/env python3
-"""Copy the summaries tools/profile_round3.sh left under gpurun_out/r3/profiles/ (and the full bench line gpurun_out/r3/bench_full.json) into
-profiles/, keeping the hand-written headers of the tracked files and refreshing the figures they quote."""
-import json, re, shutil
-ms = json.loads(open('gpurun_out/r3/profiles/trace.json').read().strip().splitlines()[-1])['ms_per_step']
-d = json.loads(open('gpurun_out/r3/bench_full.json').read().strip().splitlines()[-1])
-hdr = open('profiles/round3_bench_kernel_stats_f16x2.txt').read().split('  time%   calls')[0]
-hdr = re.sub(r'\(\d+\.\d ms per step here, \d+\.\d\n# un-profiled', '(%.1f ms per step here, %.1f\n# un-profiled' % (ms, d['ms_per_step']), hdr)
-open('profiles/round3_bench_kernel_stats_f16x2.txt', 'w').write(hdr + open('gpurun_out/r3/profiles/bench_f16x2.txt').read())
-adv_h = open('profiles/round3_adversarial_kernel_stats.txt').read().split('  time%   calls')[0]
-open('profiles/round3_adversarial_kernel_stats.txt', 'w').write(adv_h + open('gpurun_out/r3/profiles/adversarial.txt').read())
-shutil.copy('gpurun_out/r3/profiles/shapes.tsv', 'profiles/round3_shapes.tsv')
+"""Copy the summaries tools/profile_round4.sh left under gpurun_out/r4/profiles/ (and the full bench line gpurun_out/r4/bench_full.json) into
+profiles/ with a header that says what was run, and refresh profiles/traffic.json (the PMC record bench.py's roofline.traffic reads)."""
+import json, os, shutil
+R = 'gpurun_out/r4/profiles'
+ms = json.loads(open(R + '/trace.json').read().strip().splitlines()[-1])['ms_per_step']
+d = json.loads(open('gpurun_out/r4/bench_full.json').read().strip().splitlines()[-1])
+hdr = ("# Round 4 (final), MI355X (gfx950), split-fp16 arithmetic (the default): `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ge2e --no-adversarial\n"
+       "# --no-fp32 --no-roofline` under rocprofv3 (tools/profile_round4.sh): (1) --kernel-trace --stats, with the library's shape log (SSV_SHAPE_LOG) giving\n"
+       "# the algorithmic FLOP / bytes of every launch shape -> \"achieved\" and \"frac\" of the roof per (kernel, grid); (2) --pmc FETCH_SIZE and (3) --pmc WRITE_SIZE\n"
+       "# in separate passes; (4) one SQ pass with the MFMA-busy column.  Profiled runs hold a lower clock than un-profiled ones (%.1f ms per step here, %.1f\n"
+       "# un-profiled on the same box, profiles/round4_bench_line.json): compare rows of this file with each other, not with bench.py's wall clock.\n"
+       "# Summary by tools/summarize_prof.py.\n" % (ms, d['ms_per_step']))
+open('profiles/round4_bench_kernel_stats.txt', 'w').write(hdr + open(R + '/bench_f16x2.txt').read())
+adv_h = ("# Round 4 (final), MI355X: the WGAN-GP cycle of train_ssrn --adversarial (1 G + 5 D iterations, B = 32, hipGraph replay), split-fp16 arithmetic:\n"
+         "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_adversarial.py   (the last line gives the device-busy share of the replayed part)\n")
+open('profiles/round4_adversarial_kernel_stats.txt', 'w').write(adv_h + open(R + '/adversarial.txt').read())
+shutil.copy(R + '/shapes.tsv', 'profiles/round4_shapes.tsv')
 t = json.load(open('profiles/traffic.json'))
-t['f16x2'] = json.load(open('gpurun_out/r3/profiles/traffic_f16x2.json'))
+t['f16x2'] = json.load(open(R + '/traffic_f16x2.json'))
 json.dump(t, open('profiles/traffic.json', 'w'), indent=1)
-open('profiles/round3_bench_line.json', 'w').write(json.dumps(d) + "\n")
+# the raw per-launch counter rows the traffic figure was averaged from (so that roofline.traffic can be recomputed from a committed file)
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    src = R + '/headline_%s.csv' % c
+    if os.path.exists(src):
+        shutil.copy(src, 'profiles/round4_headline_%s.csv' % c)
+open('profiles/round4_bench_line.json', 'w').write(json.dumps(d) + "\n")
 c = d['config']
 print("profiled %.2f ms; line %.3f ms = %.0f; roofline %.3f (%.2f us, traffic %s); bf16x3 %.2f; fp32 %.1f; adv %.2f / %.2f = %.0f; ge2e %.2f ms %.0f utt/s frac %.3f; cpu %.0f x%.0f" % (
     ms, d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['us_per_launch'], d['roofline']['traffic'], c['fast_bf16x3_ms_per_step'], c['fp32_exact_ms_per_step'],

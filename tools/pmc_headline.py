@@ -30,7 +30,7 @@ def entry(fetch_dir, write_dir, profile):
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "--json":
-    print(json.dumps(entry(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "profiles/round3_bench_kernel_stats_f16x2.txt"), indent=1))
+    print(json.dumps(entry(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "profiles/round4_bench_kernel_stats.txt"), indent=1))
     sys.exit(0)
 
 import torch

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-3 profiles of the benchmark (GPU box): kernel trace with per-kernel roofline columns, the PMC passes the guide prescribes
+# Round-4 profiles of the benchmark (GPU box): kernel trace with per-kernel roofline columns, the PMC passes the guide prescribes
 # (FETCH_SIZE and WRITE_SIZE in separate passes; SQ counters in a third), and the adversarial cycle's kernel trace.
-# Output: gpurun_out/r3/profiles/*.txt -- copy what is to be judged into profiles/.
+# Output: gpurun_out/r4/profiles/*.txt -- copy what is to be judged into profiles/.
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3/profiles
+O=$R/gpurun_out/r4/profiles
 mkdir -p $O
 B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ge2e --no-adversarial --no-fp32 --no-roofline"
 run() { tag=$1; shift; rm -rf /tmp/p_$tag; (cd /tmp && timeout -k 10 400 rocprofv3 "$@" --output-format csv -d /tmp/p_$tag -- $B > $O/$tag.json 2> $O/$tag.err) || echo "$tag: rc=$?"; }
@@ -24,4 +24,6 @@ head -30 $O/bench_f16x2.txt
 # the headline kernel alone, for roofline.traffic
 for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/p_h$c; (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p_h$c -- python3 $R/tools/pmc_headline.py > /dev/null 2> $O/headline_$c.err) || echo "headline $c rc=$?"; done
 python3 $R/tools/pmc_headline.py --json /tmp/p_hFETCH_SIZE /tmp/p_hWRITE_SIZE > $O/traffic_f16x2.json 2>> $O/summarize.err
+# the headline kernel's counter rows themselves (one line per launch), so the figure can be recomputed from a committed file
+for c in FETCH_SIZE WRITE_SIZE; do f=$(ls /tmp/p_h$c/*/*counter_collection.csv /tmp/p_h$c/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && (head -1 "$f"; grep "gemm_nn_bf3_kernel<3, 1, 7" "$f") > $O/headline_$c.csv; done
 cat $O/traffic_f16x2.json
