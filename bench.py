@@ -549,19 +549,22 @@ def launch_ranks(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, SSV_BENCH_CHILD="1")
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
     live = list(procs)
-    while live and rc == 0:
-        time.sleep(0.2)
-        for p in list(live):
-            c = p.poll()
-            if c is not None:
-                live.remove(p)
-                if c != 0:
-                    rc = c if c > 0 else 1
+    try:
+        while live and rc == 0:
+            time.sleep(0.2)
+            for p in list(live):
+                c = p.poll()
+                if c is not None:
+                    live.remove(p)
+                    if c != 0:
+                        rc = c if c > 0 else 1
+    except KeyboardInterrupt:           # the launcher is being stopped: take the ranks (exactly these PIDs) down with it
+        rc = 130
     for p in live:                      # a rank failed: the others would wait in a collective for ever
         p.terminate()
     for p in live:

@@ -109,3 +109,64 @@ def test_split_fp16_one_element_2_to_20_above_the_rest_meets_the_documented_boun
     # items 1..3 have scales of their own (per batch item): same accuracy as without the outlier
     for b in range(1, B):
         assert _rl2(y16[b], yd[b]) <= 1.5 * _rl2(y32[b], yd[b]) + 1e-9, b
+
+
+def _gate_ref(h, x, g1, b1, g2, b2):
+    """models/TTSModel.py:79-83 on (B, C, L) tensors in float64."""
+    C = x.shape[1]
+    ln = lambda t, g, b: F.layer_norm(t.permute(0, 2, 1), (C,), g, b, 1e-5).permute(0, 2, 1)
+    s = torch.sigmoid(ln(h[:, :C], g1, b1))
+    return s * ln(h[:, C:], g2, b2) + (1 - s) * x
+
+
+@pytest.mark.parametrize("B,C,L", [(3, 320, 77), (2, 512, 70), (2, 192, 1030), (1, 384, 64), (2, 256, 1089), (2, 448, 33)])
+def test_highway_gate_backward_wide_tile_kernels_at_ragged_shapes(B, C, L):
+    """The LayerNorm / gate backward on its wide-tile kernels (round 4: 1024 threads, 32- or 64-column tiles; chosen for C > 256 or
+    L >= 1024) at shapes that are multiples of nothing: ragged last column tile, last channel step partly empty, and one shape below
+    the rule (16-column kernel) for comparison -- every gradient against float64 autograd of the reference's expression."""
+    from spoofsv_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    h = torch.randn(B, 2 * C, L, generator=gen)
+    x = torch.randn(B, C, L, generator=gen)
+    ps = [torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3, torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3]
+    gy = torch.randn(B, C, L, generator=gen)
+    ref_in = [t.double().requires_grad_(True) for t in (h, x, *ps)]
+    _gate_ref(*ref_in).backward(gy.double())
+    dev_in = [t.to(DEV).requires_grad_(True) for t in (h, x, *ps)]
+    y = ops.highway_gate_dd(*dev_in)
+    y.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    for name, a, b in zip(("h", "x", "g1", "b1", "g2", "b2"), dev_in, ref_in):
+        e = _rl2(a.grad, b.grad)
+        assert e < 3e-6, (name, (B, C, L), e)
+
+
+@pytest.mark.parametrize("B,C,L,act", [(2, 513, 129, 1), (2, 576, 65, 2), (3, 320, 1030, 0), (2, 272, 40, 1)])
+def test_channel_layernorm_act_backward_wide_tile_kernels_at_ragged_shapes(B, C, L, act):
+    """Same for LayerNorm + activation after a 1x1 convolution (models/TTSModel.py:128-131, :353-361): the conv + LN + act operator's
+    backward runs ln_act_bwd (wide tiles for 256 < C <= 576) -- input, weight, bias and LayerNorm parameter gradients vs float64."""
+    from spoofsv_amd import ops
+    gen = torch.Generator().manual_seed(6)
+    Cin = 48
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(C, Cin, 1, generator=gen) * 0.2
+    bias = torch.randn(C, generator=gen) * 0.1
+    gam, bet = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3
+    gy = torch.randn(B, C, L, generator=gen)
+
+    def ref(x, w, bias, gam, bet):
+        n = F.layer_norm(F.conv1d(x, w, bias).permute(0, 2, 1), (C,), gam, bet, 1e-5).permute(0, 2, 1)
+        return torch.relu(n) if act == 1 else torch.sigmoid(n) if act == 2 else n
+    ref_in = [t.double().requires_grad_(True) for t in (x, w, bias, gam, bet)]
+    ref(*ref_in).backward(gy.double())
+    import spoofsv_amd
+    prev = spoofsv_amd.set_precision("fp32")           # exact products: what is tested here is the LayerNorm backward
+    try:
+        dev_in = [t.to(DEV).requires_grad_(True) for t in (x, w, bias, gam, bet)]
+        ops.pointwise_conv_ln_act(*dev_in, None, act).backward(gy.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        spoofsv_amd.set_precision(prev)
+    for name, a, b in zip(("x", "w", "bias", "gamma", "beta"), dev_in, ref_in):
+        e = _rl2(a.grad, b.grad)
+        assert e < 5e-6, (name, (B, C, L, act), e)
