@@ -102,7 +102,8 @@ int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const 
                            void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L);
 /* dx: gradient w.r.t. the pre-LN input; pgrads (3,C) = dgamma, dbeta, sum_{b,t} dx (bias gradient of
- * the producing conv). */
+ * the producing conv).   pgrads may be NULL: the parameter gradients are not wanted
+ * (the partial rows stay unsummed in ws) -- the gradient penalty's input-gradient pass, train/adversarial_wasserstein_gp.py:303-304. */
 int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* stats,
                            const float* gamma, const float* beta, float* dx, long dx_bs, float* pgrads,
                            int B, int C, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
@@ -174,7 +175,7 @@ int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_b
 
 /* Building block of the above: only the gate + two LayerNorm backward.  dh (B,2C,L) dense = dL/dh (the conv output
  * gradient), dxres = dy*(1-gate) (the residual-path part of dL/dx), pgrads (6,C) as above.  A caller can then run
- * ssv_conv1d_bwd_data(dh, ..., dx_add = dxres) and ssv_conv1d_bwd_weight(dh, x, ...) on two different streams. */
+ * ssv_conv1d_bwd_data(dh, ..., dx_add = dxres) and ssv_conv1d_bwd_weight(dh, x, ...) on two different streams.  pgrads may be NULL (as in ssv_channel_ln_act_bwd). */
 size_t ssv_highway_gate_bwd_workspace(int B, int C, int L);
 int ssv_highway_gate_bwd(const float* dy, long dy_bs, const float* x, long x_bs,
                          const float* g1, const float* b1, const float* g2, const float* b2,

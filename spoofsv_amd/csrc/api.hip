@@ -476,7 +476,7 @@ extern "C" size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L) {
 }
 extern "C" int ssv_channel_ln_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* stats, const float* gamma, const float* beta,
                                       float* dx, long dx_bs, float* pgrads, int B, int C, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
-  SSV_CHECK(dy && x && stats && gamma && beta && dx && pgrads && B > 0 && C > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "channel_ln_act_bwd: bad argument");
+  SSV_CHECK(dy && x && stats && gamma && beta && dx && B > 0 && C > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "channel_ln_act_bwd: bad argument");   // pgrads may be NULL
   SSV_CHECK(ws && ws_bytes >= ssv_channel_ln_act_bwd_workspace(B, C, L), SSV_BAD_SHAPE, "channel_ln_act_bwd: workspace too small");
   return ssv_launch_ln_act_bwd(dy, dy_bs, x, x_bs, stats, gamma, beta, dx, dx_bs, (float*)ws, pgrads, B, C, L, act, (hipStream_t)stream);
 }
@@ -577,7 +577,7 @@ extern "C" size_t ssv_highway_gate_bwd_workspace(int B, int C, int L) {
 extern "C" int ssv_highway_gate_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* g1, const float* b1,
                                     const float* g2, const float* b2, const float* h, const float* stats, float* dh, float* dxres,
                                     long dx_bs, float* pgrads, int B, int C, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
-  SSV_CHECK(dy && x && g1 && b1 && g2 && b2 && h && stats && dh && dxres && pgrads && B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_gate_bwd: bad argument");
+  SSV_CHECK(dy && x && g1 && b1 && g2 && b2 && h && stats && dh && dxres && B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_gate_bwd: bad argument");   // pgrads may be NULL
   SSV_CHECK(ws && ws_bytes >= ssv_highway_gate_bwd_workspace(B, C, L), SSV_BAD_SHAPE, "highway_gate_bwd: workspace too small");
   return ssv_launch_ln_gate_bwd(dy, dy_bs, h, x, x_bs, stats, g1, b1, g2, b2, dh, dxres, dx_bs, (float*)ws, pgrads, B, C, L, (hipStream_t)stream);
 }

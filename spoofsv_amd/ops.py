@@ -8,6 +8,7 @@ Layout convention: activations are (B, C, T) float32 with contiguous rows (strid
 stride(1) == T); the batch stride is free, so channel slices of a wider tensor are passed without
 copies.  Each Function cites the reference code its forward replaces.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -438,6 +439,24 @@ def _dd_amax(t):
     return amax_of(t) if (t is not None and _f16() and _bf3_shape(t)) else None
 
 
+_INPUT_ONLY = False
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    """Within the block the backward of the critic's twice-differentiable operators produces the INPUT gradient only.  The gradient
+    penalty's first pass, ``torch.autograd.grad(outputs=D(x_mid), inputs=x_mid, create_graph=True)``
+    (train/adversarial_wasserstein_gp.py:303-304), asks for nothing else -- but a Python Function cannot see which of its gradients the
+    engine will use (``ctx.needs_input_grad`` is fixed at forward time), so without this every convolution also ran its weight-gradient
+    GEMM, slab reduction and bias row sums, and every LayerNorm / gate its parameter-gradient reductions, for results nobody reads."""
+    global _INPUT_ONLY
+    prev, _INPUT_ONLY = _INPUT_ONLY, True
+    try:
+        yield
+    finally:
+        _INPUT_ONLY = prev
+
+
 class ConvFwdDD(torch.autograd.Function):
     """y = conv1d(x, w) + bias, kernel 1 or 3, "same" or causal zero padding (the bias is added by the kernel's epilogue)."""
 
@@ -460,6 +479,8 @@ class ConvFwdDD(torch.autograd.Function):
         k, dilation, causal, has_bias = ctx.cfg
         dya = _dd_amax(dy)
         dx = ConvBwdDataDD.apply(dy, w, x.shape[1], k, dilation, causal, dya) if ctx.needs_input_grad[0] else None
+        if _INPUT_ONLY:                       # (input_grads_only: the gradient penalty's first pass)
+            return dx, None, None, None, None, None, None
         dw = ConvBwdWeightDD.apply(dy, x, k, dilation, causal, dya, ctx.x_amax) if ctx.needs_input_grad[1] else None
         db = BiasGradFn.apply(dy) if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None, None, None
@@ -709,13 +730,15 @@ class ChannelLnBwdDD(torch.autograd.Function):
         gy, gybs = _act3(gy, "grad")
         B, C, L = x.shape
         dx = torch.empty((B, C, L), dtype=_F32, device=x.device)
-        pg = torch.empty((3, C), dtype=_F32, device=x.device)
+        pg = None if _INPUT_ONLY else torch.empty((3, C), dtype=_F32, device=x.device)      # (None: the partial rows are not summed)
         nb = _lib.query("ssv_channel_ln_act_bwd_workspace", B, C, L)
         ws = _ws(nb, x.device)
         _lib.call("ssv_channel_ln_act_bwd", _p(gy), gybs, _p(x), xbs, _p(stats), _p(gamma), _p(beta), _p(dx), C * L, _p(pg),
                   B, C, L, 0, _p(ws), nb, _stream())
         ctx.save_for_backward(gy, x, gamma, stats)
         ctx.set_materialize_grads(False)
+        if pg is None:
+            return dx, None, None
         return dx, pg[0], pg[1]
 
     @staticmethod
@@ -768,13 +791,15 @@ class HighwayGateBwdDD(torch.autograd.Function):
         B, C, L = x.shape
         dh = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
         dx = torch.empty((B, C, L), dtype=_F32, device=x.device)
-        pg = torch.empty((6, C), dtype=_F32, device=x.device)
+        pg = None if _INPUT_ONLY else torch.empty((6, C), dtype=_F32, device=x.device)
         nb = _lib.query("ssv_highway_gate_bwd_workspace", B, C, L)
         ws = _ws(nb, x.device)
         _lib.call("ssv_highway_gate_bwd", _p(gy), gybs, _p(x), xbs, _p(g1), _p(b1), _p(g2), _p(b2), _p(h), _p(stats), _p(dh), _p(dx),
                   C * L, _p(pg), B, C, L, _p(ws), nb, _stream())
         ctx.save_for_backward(gy, h, x, g1, b1, g2, b2, stats)
         ctx.set_materialize_grads(False)
+        if pg is None:
+            return dh, dx, None, None, None, None
         return dh, dx, pg[0], pg[1], pg[2], pg[3]
 
     @staticmethod

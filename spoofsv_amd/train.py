@@ -774,7 +774,10 @@ class AdversarialGraphStep:
         else:
             segs = backward_segments(self.cuts, [seed(top + la if la is not None else top)], None, self.ddp_syn, self.defer)
         self._segs = segs
-        segs[0]()
+        # the first segment holds the critic: a generator iteration needs its INPUT gradient only (the critic's own parameter gradients
+        # would be discarded: the reference zeroes them before the next critic iteration, train/adversarial_wasserstein_gp.py:264-265)
+        with ops.input_grads_only():
+            segs[0]()
         total = base_g + weight * g[3]
         self.g_out = (g[0], g[1], g[2], g[3], total)
         self._g_terms = None
@@ -795,7 +798,8 @@ class AdversarialGraphStep:
         scale = self.ddp_disc.grad_scale if self.ddp_disc is not None else 1.0
         mid = (self.coeff * gt + (1 - self.coeff) * pred).requires_grad_(True)
         out = self.disc(mid)
-        grads = torch.autograd.grad(outputs=out, inputs=mid, grad_outputs=torch.ones_like(out), retain_graph=True, create_graph=True)[0]
+        with ops.input_grads_only():        # only d out / d mid is asked for: no weight / bias / LayerNorm parameter gradients in this pass
+            grads = torch.autograd.grad(outputs=out, inputs=mid, grad_outputs=torch.ones_like(out), retain_graph=True, create_graph=True)[0]
         loss_gp = ops.grad_penalty(grads, self.lam)          # mean(lam * (||grad||_2 - 1)^2), :305-308
         loss_gp.backward(torch.full_like(loss_gp, scale))
         # disc(pred) and disc(gt) as ONE critic call on the concatenated batch: the critic has no cross-sample operation

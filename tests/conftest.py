@@ -20,3 +20,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _arithmetic_mode_does_not_leak(request):
+    """A GPU test that switches the library's arithmetic mode (ssv_set_precision) must not change it for the tests that run after it in
+    the same process: whatever the test did, the mode it found is put back."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    from spoofsv_amd import _lib
+    before = _lib.precision()
+    yield
+    if _lib.precision() != before:
+        _lib.lib().ssv_set_precision(before)

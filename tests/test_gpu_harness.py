@@ -450,9 +450,9 @@ def test_ge2e_harness_trains_checkpoints_and_verifies(tmp_path):
     """GE2E/train_speech_embedder.py end to end on synthetic preprocessed TI-SV data: train (HIP forward + backward),
     checkpoint, then the mixture / no-spoof verification tests and the spoof-rate pass over the saved matrices."""
     import numpy as np
-    import spoofsv_amd
     from spoofsv_amd import ge2e_harness as GH
-    spoofsv_amd.set_precision("bf16x3")
+    # (runs in the default arithmetic; an earlier version switched the process to split-bf16 here and never switched back, so every test
+    # that ran after it in the same process -- e.g. the single-process arm of the data-parallel comparisons -- ran in another mode)
     rng = np.random.RandomState(3)
     for split, nspk in (("train", 8), ("test", 4)):
         d = tmp_path / split

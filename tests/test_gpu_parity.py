@@ -391,12 +391,20 @@ def test_ge2e_loss_backward_golden_and_full_size_vs_oracle():
     assert abs(float(L2.b.grad) - float(bo.grad)) < 1e-3 * (1 + abs(float(bo.grad)))
 
 
-def test_ge2e_training_iteration_golden():
+def _ge2e_train_mode(precision):
+    """The GE2E training kernels (LSTM forward keeping every frame, backpropagation through time) exist in the split modes; the exact-fp32
+    parametrisation of this module runs them in split-bf16, the other two in their own arithmetic (split-fp16: forward products fp32-grade)."""
+    import spoofsv_amd
+    if precision == "fp32":
+        spoofsv_amd.set_precision("bf16x3")          # (the autouse fixture restores the mode after the test)
+
+
+def test_ge2e_training_iteration_golden(precision):
     """G10: one iteration of GE2E/train_speech_embedder.py:70-86 -- HIP forward + backward, then torch's own clip_grad_norm_
     and SGD as the reference uses them -- against the loss, gradients and updated parameters of the reference's modules."""
     import spoofsv_amd
     from spoofsv_amd.ge2e import GE2ELoss, SpeechEmbedder
-    spoofsv_amd.set_precision("bf16x3")                        # the training kernels exist in the split-bf16 mode only
+    _ge2e_train_mode(precision)
     g = load("ge2e_train.npz")
     N, M, T, H, P = [int(v) for v in g["dims"]]
     m = SpeechEmbedder(nmels=40, hidden=H, num_layer=3, proj=P)
@@ -420,12 +428,12 @@ def test_ge2e_training_iteration_golden():
         assert rel_err(v, t(g["p1/" + k])) < 1e-4, (k, rel_err(v, t(g["p1/" + k])))
 
 
-def test_ge2e_backward_midsize_vs_oracle():
+def test_ge2e_backward_midsize_vs_oracle(precision):
     """LSTM backpropagation through time at a ragged mid size (37 utterances, 21 frames, hidden 96) against autograd over
     the CPU oracle, with a random upstream gradient on the embeddings."""
     import spoofsv_amd
     from spoofsv_amd.ge2e import SpeechEmbedder
-    spoofsv_amd.set_precision("bf16x3")
+    _ge2e_train_mode(precision)
     torch.manual_seed(4)
     m = SpeechEmbedder(nmels=40, hidden=96, num_layer=3, proj=64)
     with torch.no_grad():
@@ -503,11 +511,11 @@ def test_conv1d_dd_second_order_vs_torch(k, d):
 
 
 @pytest.mark.parametrize("layers,T", [(1, 5), (2, 1), (3, 2)])
-def test_ge2e_backward_edge_shapes_vs_oracle(layers, T):
+def test_ge2e_backward_edge_shapes_vs_oracle(layers, T, precision):
     """Backpropagation through time at the edges of the wavefront: a single layer, a single frame, fewer frames than layers."""
     import spoofsv_amd
     from spoofsv_amd.ge2e import SpeechEmbedder
-    spoofsv_amd.set_precision("bf16x3")
+    _ge2e_train_mode(precision)
     torch.manual_seed(10 * layers + T)
     m = SpeechEmbedder(nmels=40, hidden=32, num_layer=layers, proj=16)
     with torch.no_grad():
