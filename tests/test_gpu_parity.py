@@ -621,6 +621,9 @@ def _oracle_pass(rec, dt, force=None):
 # L2 -- no "plus the float32 oracle's own error" term any more, and the fp32-grade modes (exact fp32, split-fp16) share one bar.
 _GRAD_ALLOWANCE = {"fp32": 2e-5, "f16x2": 2e-5, "bf16x3": 5e-4}
 _KINK_NOISE = {"fp32": 1e-5, "f16x2": 1e-5, "bf16x3": 1e-3}
+# max |entry error| / rms of its tensor, over every entry of every parameter gradient (measured at full size, B = 8: exact fp32 1.1e-5 / 4.1e-5,
+# split-fp16 2.1e-5 / 3.4e-5, split-bf16 9.3e-4): one bar for the two fp32-grade modes
+_ENTRY_ALLOWANCE = {"fp32": 2e-4, "f16x2": 2e-4, "bf16x3": 5e-3}
 
 
 @pytest.mark.parametrize("kind", ["text2mel", "ssrn"])
@@ -685,6 +688,16 @@ def _check_grads_on_hip_sides(o, m, sides, precision, what):
     print("%s %s: %d kink sides (ReLU / L1) differ from float64 (all at noise level); worst gradient rel L2 %.2e on the HIP path's sides, "
           "%.2e against the un-forced float64 oracle" % (what, precision, flips, worst, worst_free))
     assert not bad, (worst, flips, bad)
+    # element-wise, EVERY parameter tensor: the largest absolute error of any entry against the tensor's own rms (an entry-by-entry
+    # criterion without a relative floor: a wrong small entry cannot hide behind large ones as in a norm, nor behind a floor)
+    worst_abs, worst_abs_k = 0.0, None
+    for k, p in m.named_parameters():
+        e = exact[k].double()
+        a = float((p.grad.detach().cpu().double() - e).abs().max() / (e.pow(2).mean().sqrt() + 1e-30))
+        if a > worst_abs:
+            worst_abs, worst_abs_k = a, k
+    print("%s %s: largest entry error / tensor rms over all parameters: %.2e (%s)" % (what, precision, worst_abs, worst_abs_k))
+    assert worst_abs < _ENTRY_ALLOWANCE[precision], (worst_abs_k, worst_abs)
     big = sorted(((p.numel(), k) for k, p in m.named_parameters()), reverse=True)[:6]
     for _, k in big:        # element-wise: every entry within 5 % (split-bf16: 20 %) of itself, or of 5 % of the tensor's RMS for entries near zero
         w = worst_elementwise(dict(m.named_parameters())[k].grad, exact[k], floor=5e-2)
