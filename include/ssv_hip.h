@@ -100,6 +100,15 @@ size_t ssv_channel_ln_act_fwd_workspace(int B, int C, int L);
 int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* gamma, const float* beta,
                            float* y, long y_bs, float* y_amax, float* stats, int B, int C, int L, int act,
                            void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* The whole forward of such a link: y = act(LN(conv1x1(x) + bias [+ s])) -- models/TTSModel.py:128-131, :173-180 (s = fc(spk), (B,Cout)),
+ * :218-231, :343-361.  pre (B,Cout,L) dense = the LayerNorm's input and stats (B,2,L) (may be NULL) are kept for
+ * ssv_pointwise_conv_ln_act_bwd.  One launch where the library has the fused kernel for the shape (a workgroup owns all output rows of
+ * its column tile), otherwise the product followed by the LayerNorm kernel; x_amax / w_packed / y_amax as in ssv_conv1d_fwd /
+ * ssv_channel_ln_act_fwd. */
+size_t ssv_pointwise_conv_ln_act_fwd_workspace(int Cin, int Cout);
+int ssv_pointwise_conv_ln_act_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
+                                  const float* s, const float* gamma, const float* beta, float* pre, float* stats, float* y, long y_bs, float* y_amax,
+                                  int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L);
 /* dx: gradient w.r.t. the pre-LN input; pgrads (3,C) = dgamma, dbeta, sum_{b,t} dx (bias gradient of
  * the producing conv).   pgrads may be NULL: the parameter gradients are not wanted

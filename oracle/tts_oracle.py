@@ -28,7 +28,9 @@ class kink_sides:
 
     ``with kink_sides() as r:`` records, per F.relu / abs-mean call in call order, ``r.taps[i] = (x > 0, rms of x, x)``.
     ``with kink_sides(force=masks):`` replaces the i-th ReLU by ``x * masks[i]`` and the L1 loss's ``|d|`` by ``d * (2 masks[i] -
-    1)``, i.e. evaluates the function (and, through autograd, its gradient) with every element held on the GIVEN side.  The
+    1)`` (a boolean mask: d > 0) or by ``d * masks[i]`` (a floating-point mask: the SIGN of d in {-1, 0, +1} -- an entry that is exactly
+    zero in the evaluation being matched has gradient 0 there, as torch.abs gives it), i.e. evaluates the function (and, through
+    autograd, its gradient) with every element held on the GIVEN side.  The
     gradient of a network with ReLUs and an L1 loss is discontinuous where such an argument crosses zero, so two correct
     evaluations whose forward values differ by rounding noise can disagree by a whole gradient term there; forcing the sides
     makes their gradients comparable (tests/test_gpu_parity.py::test_bench_workload_full_size_training_step_vs_oracle)."""
@@ -64,7 +66,8 @@ def _abs_mean(d):
     if r is None:
         return torch.mean(torch.abs(d))
     if r.force is not None:
-        return torch.mean(d * (2 * r.force.pop(0).to(d.dtype) - 1))
+        m = r.force.pop(0)
+        return torch.mean(d * (m.to(d.dtype) if m.is_floating_point() else 2 * m.to(d.dtype) - 1))
     dd = d.detach()
     r.taps.append((dd > 0, float(dd.pow(2).mean().sqrt()), dd))
     return torch.mean(torch.abs(d))

@@ -213,10 +213,13 @@ static GemmNNB nnb_zero() {
 // split-fp16: `a_inv` = where the resident planes keep 2^-ea (packed only); xa_given / xa_n = the caller's scale list of x or
 // null; the tail of ws (conv_aux_bytes: after `ws_main` bytes) holds the pack kernel's aux floats and the fallback list.
 static inline size_t conv_aux_bytes() { return SSV_F16_AUX_BYTES + AMAX_FB_BYTES; }
+// (pw != null: the 1x1 product finishes LayerNorm + activation in its own launch, gemm_pwln_kernel; y is then `pre`)
+struct PwLnArgs { const float* gamma; const float* beta; float* y; long ybs; float* stats; float* y_amax; int namax; int act; };
+int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta, float* y, long ybs, float* stats, float* y_amax, int namax, int act, hipStream_t st);
 static int conv_nn(const float* x, long x_bs, const float* w, const void* packed, long w_sm, long w_sk, const float* bias, const float* bias_b,
                    const float* r, long r_bs, float* y, long y_bs, int B, int K, int M, int L, int k, const int* shift,
                    bool bf3, void* ws, hipStream_t st, const float* a_inv = nullptr, const float* xa_given = nullptr, int xa_n = 0, size_t ws_main = 0,
-                   float* colstats = nullptr) {
+                   float* colstats = nullptr, const PwLnArgs* pw = nullptr) {
   if (bf3) {
     const int Kpad = pad32(K);
     const unsigned short* hi = (const unsigned short*)(packed ? packed : ws);
@@ -241,6 +244,7 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
     g.R = r; g.srb = r_bs; g.srm = L;
     g.M = M; g.N = L; g.Kc = K; g.KT = k; g.B = B;
     for (int j = 0; j < 3; ++j) g.shift[j] = shift[j];
+    if (pw) return ssv_launch_gemm_pwln(g, pw->gamma, pw->beta, pw->y, pw->ybs, pw->stats, pw->y_amax, pw->namax, pw->act, st);
     return ssv_launch_gemm_nn_bf3(g, st);
   }
   GemmNN g = nn_zero();
@@ -470,6 +474,30 @@ extern "C" int ssv_channel_ln_act_fwd(const float* x, long x_bs, const float* ga
   SSV_CHECK(B <= 65535, SSV_UNSUPPORTED, "channel_ln_act_fwd: batch %d exceeds grid.y", B);
   (void)ws; (void)ws_bytes;
   return ssv_launch_ln_act_fwd(x, x_bs, gamma, beta, y, y_bs, stats, B, C, L, act, (hipStream_t)stream, y_amax);
+}
+// ---- 1x1 conv + LayerNorm (+ activation), forward ---------------------------------------------------------------------------
+// y = act(LN(conv1x1(x) + bias [+ s])) with pre = the LayerNorm's input and stats (B,2,L) = mean / rstd per column kept for the backward.
+// One launch (gemm_pwln_kernel: a workgroup owns all output rows of its column tile and finishes the LayerNorm from its accumulators)
+// where that form is the faster one in-step, else the product followed by the LayerNorm kernel -- same results up to summation order.
+// (round 4, in-step and same box, fused against product + LayerNorm kernel: 513 x 1300 139.8 against 111.7 + 43.6 us; M = 256 / N = 325 29.1 against 19.5 + 12.5;
+//  M = 512 / N = 186 33.9 against 29.1 + ~13; M = 512 / N = 1300 90.9 against 70.2 + 24: the fused form everywhere the split-MFMA kernels run)
+static bool pwln_fused(int B, int Cin, int Cout, int L) { return use_bf3(B, L, Cin, Cout) && Cout <= 640 && B <= 65535; }
+extern "C" size_t ssv_pointwise_conv_ln_act_fwd_workspace(int Cin, int Cout) { return ssv_conv1d_fwd_workspace(Cin, Cout, 1); }
+extern "C" int ssv_pointwise_conv_ln_act_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
+                                             const float* s, const float* gamma, const float* beta, float* pre, float* stats, float* y, long y_bs, float* y_amax,
+                                             int B, int Cin, int Cout, int L, int act, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  SSV_CHECK(x && w && gamma && beta && pre && y && B > 0 && Cin > 0 && Cout > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "pointwise_conv_ln_act_fwd: bad argument");
+  SSV_CHECK(x_bs >= (long)Cin * L && y_bs >= (long)Cout * L, SSV_BAD_SHAPE, "pointwise_conv_ln_act_fwd: batch stride smaller than C*L");
+  if (pwln_fused(B, Cin, Cout, L) && y_bs == (long)Cout * L && (!y_amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 64))) {
+    SSV_CHECK((w_packed && !(use_f16() && !x_amax)) || (ws && ws_bytes >= ssv_pointwise_conv_ln_act_fwd_workspace(Cin, Cout)), SSV_BAD_SHAPE,
+              "pointwise_conv_ln_act_fwd: workspace too small");
+    int shift[3] = {0, 0, 0};
+    PwLnArgs pw = {gamma, beta, y, y_bs, stats, y_amax, ssv_amax_rows_(L), act};
+    return conv_nn(x, x_bs, w, w_packed, (long)Cin, 1, bias, s, nullptr, 0, pre, (long)Cout * L, B, Cin, Cout, L, 1, shift, true, ws, (hipStream_t)stream,
+                   packed_inv(w_packed, Cout, Cin, 1, 0), x_amax, x_namax, 2 * split_bytes(Cout, Cin, 1), nullptr, &pw);
+  }
+  SSV_TRY(ssv_conv1d_fwd(x, x_bs, x_amax, x_namax, w, w_packed, bias, s, pre, (long)Cout * L, nullptr, B, Cin, Cout, L, 1, 1, 0, ws, ws_bytes, stream));
+  return ssv_channel_ln_act_fwd(pre, (long)Cout * L, gamma, beta, y, y_bs, y_amax, stats, B, Cout, L, act, nullptr, 0, stream);
 }
 extern "C" size_t ssv_channel_ln_act_bwd_workspace(int B, int C, int L) {
   return align256((size_t)ssv_ln_gate_bwd_nblk(B, L) * 3 * C * sizeof(float));

@@ -1517,3 +1517,263 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
 #undef SSV_NT
   return ssv_fail(SSV_UNSUPPORTED, "gemm_nt_bf3: no tile %d,%d for kernel size %d", wm, ntc, g.KT);
 }
+
+// ---- 1x1 conv + LayerNorm over channels (+ activation) in ONE launch (round 4) ------------------------------------------------
+// y = act(LN(W x + bias [+ s]))  -- models/TTSModel.py:128-131, :173-180, :218-231, :343-361.  Until round 4 every such link was two
+// launches (the k = 1 GEMM, then the LayerNorm kernel re-reading its output).  A 1x1 convolution and a channel LayerNorm are both
+// per-column operations, so a workgroup that owns ALL output rows of a column tile can finish the LayerNorm from its accumulators:
+// no cross-workgroup step, no second pass over `pre`.  8 waves split the M axis (wave w: row blocks w * WMB .. w * WMB + WMB - 1, so
+// BM = 128 * WMB >= M), every wave all 16 * NT columns; weight fragments go L2 -> registers (private rows per wave, two sets), the
+// input tile is staged in LDS once per 32-channel chunk (two images, one barrier per chunk) exactly as in gemm_nn_bf3_kernel.  The
+// price is the weight stream: every workgroup reads all of W (the row-tiled kernels re-read X instead).
+// Epilogue: pre = acc * us + bias (+ s[b]) is stored; column sums of a lane's rows -> the 4 row-quads of the wave (cross-row shuffles)
+// -> the 8 waves (LDS), mean, then the same for the squared deviations (a true two-pass variance, as ln_act_fwd_kernel); y = act(n).
+struct PwLn {
+  GemmNNB g;                      // A planes, X, C = pre (B, M, N), bias, bias_b, f16 scales
+  const float* gamma; const float* beta;
+  float* y; long ybs; float* stats; float* y_amax; int namax; int act;
+};
+template <int WMB, int NT, int F16>
+__global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
+  const GemmNNB& p = q.g;
+  constexpr int BN = 16 * NT;
+  constexpr int X_SLOTS = 4 * BN;                      // 16-byte slots of one 32-channel chunk: [k-group][column]
+  static_assert(X_SLOTS <= 512, "one slot per thread");
+  constexpr int IMG = 2 * X_SLOTS;
+  __shared__ uint4 lds[2][IMG];
+  __shared__ float red[8][BN];
+  __shared__ float colv[2][BN];
+  __shared__ float amx[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int ntile = (int)(wg % gridDim.x), b = (int)(wg / gridDim.x);
+  const int n0 = ntile * BN;
+  const int kq = lane >> 4, nq = lane & 15;
+  const int nchunks = p.Kpad / 32;
+  const float* __restrict__ Xb = p.X + (long)b * p.sxb;
+
+  f32x4 acc[WMB][NT];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // weight fragments: two register sets (chunk c + 1 loaded while chunk c multiplies) while they fit; from 4 row blocks per wave on, one set,
+  // re-loaded right after the chunk's MFMAs have been issued (accumulators + two sets would not fit the 256 registers of an 8-wave workgroup)
+  constexpr int NSET = WMB >= 4 ? 1 : 2;
+  uint4 Ah_[NSET][WMB], Al_[NSET][WMB];
+  float rx[8];
+
+  const int MB = (p.M + 15) >> 4;
+  unsigned arowb[WMB];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) arowb[i] = (unsigned)(((long)min(wave * WMB + i, MB - 1) * nchunks * 512 + lane * 8) * 2);
+  const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(p.Ahi), rsAl = ssv_buf(p.Alo), rsX = ssv_buf(Xb);
+  auto loadA = [&](int set, int ch) {
+    const unsigned ub = (unsigned)ch * 1024u;
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) { Ah_[set][i] = ssv_buf_u4(rsAh, arowb[i], ub); Al_[set][i] = ssv_buf_u4(rsAl, arowb[i], ub); }
+  };
+  const int Lrow = (int)p.sxc;
+  const int skg = tid / BN, scol = tid % BN;             // this thread's staging slot (k-group, column) when tid < X_SLOTS
+  const bool stager = tid < X_SLOTS;
+  const bool cvs = stager && n0 + scol < p.Lx;
+  const unsigned voffb = (unsigned)((stager ? 8 * skg : 0) * Lrow + min(n0 + scol, p.Lx - 1)) * 4u;
+  const bool ragged = (p.Kc & 31) != 0;
+  float xs = 1.f, xinv = 1.f, ainv = 1.f;
+  if constexpr (F16) ainv = *p.a_inv;
+  auto prefetchX = [&](int ch) {
+    if (!ragged || ch + 1 < nchunks) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rx[i] = ssv_buf_f32(rsX, voffb, (unsigned)((ch * 32 + i) * Lrow) * 4u);
+    } else {
+      const unsigned colo = voffb - (unsigned)(8 * (stager ? skg : 0) * Lrow) * 4u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rx[i] = ssv_buf_f32(rsX, (unsigned)min(ch * 32 + 8 * skg + i, p.Kc - 1) * (unsigned)Lrow * 4u + colo, 0u);
+    }
+  };
+  auto commitX = [&](int ch) {
+    if (!stager) return;
+    const bool last_ragged = ragged && ch + 1 == nchunks;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (cvs && (!last_ragged || ch * 32 + 8 * skg + i < p.Kc)) ? rx[i] : 0.f;
+    uint4 h, l;
+    split8s<F16>(v, xs, h, l);
+    lds[ch & 1][tid] = h; lds[ch & 1][X_SLOTS + tid] = l;
+  };
+  auto tap = [&](int set, int ch) {
+    const uint4* Xh = lds[ch & 1];
+    const uint4* Xl = lds[ch & 1] + X_SLOTS;
+    uint4 fb[2][2];
+    auto frag = [&](int t, uint4 (&f)[2]) __attribute__((always_inline)) { const int s_ = kq * BN + t * 16 + nq; f[0] = Xh[s_]; f[1] = Xl[s_]; };
+    frag(0, fb[0]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t + 1 < NT) frag(t + 1, fb[(t + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const uint4 bh = fb[t & 1][0], bl = fb[t & 1][1];
+#pragma unroll
+      for (int i = 0; i < WMB; ++i) {
+        acc[i][t] = mma16<F16>(Al_[set][i], bh, acc[i][t]);
+        acc[i][t] = mma16<F16>(Ah_[set][i], bl, acc[i][t]);
+        acc[i][t] = mma16<F16>(Ah_[set][i], bh, acc[i][t]);
+      }
+    }
+  };
+  loadA(0, 0);
+  prefetchX(0);
+  if constexpr (F16) {
+    float sc, inv;
+    ssv_pow2_scale(ssv_wave_list_max(p.x_amax + (long)b * p.x_amax_bs, p.x_namax), sc, inv);
+    xs = ssv_uniform(sc); xinv = ssv_uniform(inv);
+  }
+  commitX(0);
+  if (nchunks > 1) prefetchX(1);
+  if constexpr (NSET == 2) {
+    if (nchunks > 1) loadA(1, 1);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ch += 2) {
+      tap(0, ch);
+      if (ch + 1 >= nchunks) break;
+      commitX(ch + 1);
+      if (ch + 2 < nchunks) { prefetchX(ch + 2); loadA(0, ch + 2); }
+      __syncthreads();
+      tap(NSET - 1, ch + 1);
+      if (ch + 2 < nchunks) {
+        commitX(ch + 2);
+        if (ch + 3 < nchunks) { prefetchX(ch + 3); loadA(NSET - 1, ch + 3); }
+      }
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      tap(0, ch);
+      __builtin_amdgcn_sched_barrier(0);            // the re-load stays behind this chunk's MFMAs
+      if (ch + 1 < nchunks) {
+        loadA(0, ch + 1);
+        commitX(ch + 1);
+        if (ch + 2 < nchunks) prefetchX(ch + 2);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: pre, LayerNorm over the M rows of every column, activation
+  const float us = F16 ? ssv_uniform(xinv * ainv) : 1.f;
+  float* __restrict__ Cb = p.C + (long)b * p.scb;
+  float* __restrict__ Yb = q.y + (long)b * q.ybs;
+  float csum[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) csum[t] = 0.f;
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gm = (wave * WMB + i) * 16 + kq * 4 + r;
+      const bool rv = gm < p.M;
+      const int gmc = min(gm, p.M - 1);
+      float add = 0.f;
+      if (p.bias) add += p.bias[gmc];
+      if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gmc];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float v = rv ? (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add : 0.f;
+        acc[i][t][r] = v;
+        csum[t] += v;
+        const int gn = n0 + t * 16 + nq;
+        if (rv && gn < p.N) Cb[(long)gm * p.scm + gn] = v;
+      }
+    }
+  auto col_reduce = [&](float (&v)[NT], int slot) __attribute__((always_inline)) {       // sum over all rows of the tile; result in colv[slot][column]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { v[t] += __shfl_xor(v[t], 16); v[t] += __shfl_xor(v[t], 32); }
+    if (kq == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) red[wave][t * 16 + nq] = v[t];
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s_ += red[w][tid];
+      colv[slot][tid] = s_;
+    }
+    __syncthreads();
+  };
+  col_reduce(csum, 0);
+  const float invM = 1.f / (float)p.M;
+  float mean[NT], qs[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { mean[t] = colv[0][t * 16 + nq] * invM; qs[t] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool rv = (wave * WMB + i) * 16 + kq * 4 + r < p.M;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { const float d = rv ? acc[i][t][r] - mean[t] : 0.f; qs[t] += d * d; }
+    }
+  col_reduce(qs, 1);
+  float rstd[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) rstd[t] = rsqrtf(colv[1][t * 16 + nq] * invM + 1e-5f);
+  if (q.stats && wave == 0 && kq == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int gn = n0 + t * 16 + nq;
+      if (gn < p.N) { q.stats[(long)b * 2 * p.N + gn] = mean[t]; q.stats[(long)b * 2 * p.N + p.N + gn] = rstd[t]; }
+    }
+  }
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gm = (wave * WMB + i) * 16 + kq * 4 + r;
+      if (gm >= p.M) continue;
+      const float ga = q.gamma[gm], be = q.beta[gm];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int gn = n0 + t * 16 + nq;
+        float n = (acc[i][t][r] - mean[t]) * rstd[t] * ga + be;
+        if (q.act == 1) n = fmaxf(n, 0.f);
+        else if (q.act == 2) n = 1.f / (1.f + __expf(-n));
+        if (gn < p.N) { Yb[(long)gm * p.N + gn] = n; am = fmaxf(am, fabsf(n)); }
+      }
+    }
+  if (q.y_amax) {                         // one entry per column tile, the rest of the item's list zeroed by the last tile
+    am = ssv_wg_max<8>(am, amx);
+    if (tid == 0) {
+      float* al = q.y_amax + (long)b * q.namax;
+      al[ntile] = am;
+      if (ntile == (int)gridDim.x - 1) for (int e = gridDim.x; e < q.namax; ++e) al[e] = 0.f;
+    }
+  }
+}
+// WMB row blocks per wave (BM = 128 * WMB >= M), NT column blocks.  Returns SSV_UNSUPPORTED when no instantiation fits.
+int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta, float* y, long ybs, float* stats, float* y_amax, int namax, int act,
+                         hipStream_t st) {
+  SSV_CHECK(g.KT == 1 && g.sxn == 1 && g.scn == 1 && !g.epi && !g.perm_h && !g.R && !g.colstats && g.Kpad % 32 == 0, SSV_UNSUPPORTED, "gemm_pwln: plain 1x1 products only");
+  SSV_CHECK(g.M <= 640 && g.B <= 65535, SSV_UNSUPPORTED, "gemm_pwln: %d output channels (max 640)", g.M);
+  SSV_CHECK(!g.f16 || (g.a_inv && g.x_amax && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_pwln: split-fp16 needs operand scales");
+  PwLn q;
+  q.g = g; q.gamma = gamma; q.beta = beta; q.y = y; q.ybs = ybs; q.stats = stats; q.y_amax = y_amax; q.namax = namax; q.act = act;
+  const int wmb = ssv_cdiv(ssv_cdiv(g.M, 16), 8);
+  const int nt = 4;
+  const dim3 grid(ssv_cdiv(g.N, 16 * nt), g.B);
+  SSV_CHECK(!y_amax || namax >= (int)grid.x, SSV_BAD_SHAPE, "gemm_pwln: scale list shorter than the column tiles");
+  if (ssv_shape_log_on()) {
+    char nm[96], note[96];
+    snprintf(nm, sizeof nm, "gemm_pwln_kernel<%d, %d, %d>", wmb, nt, g.f16);
+    snprintf(note, sizeof note, "B=%d M=%d N=%d K=%d k=1 +LN", g.B, g.M, g.N, g.Kc);
+    ssv_shape_log(nm, grid, dim3(512), 2.0 * g.B * g.M * g.N * g.Kc, 4.0 * ((double)g.B * g.Kc * g.N + 2.0 * g.B * g.M * g.N + (double)g.M * g.Kc), note);
+  }
+#define SSV_PW(W_) if (wmb == W_) { \
+    if (g.f16) hipLaunchKernelGGL((gemm_pwln_kernel<W_, 4, 1>), grid, dim3(512), 0, st, q); \
+    else hipLaunchKernelGGL((gemm_pwln_kernel<W_, 4, 0>), grid, dim3(512), 0, st, q); \
+    return ssv_check_launch("gemm_pwln"); }
+  SSV_PW(1) SSV_PW(2) SSV_PW(3) SSV_PW(4) SSV_PW(5)
+#undef SSV_PW
+  return ssv_fail(SSV_UNSUPPORTED, "gemm_pwln: no instantiation for %d rows", g.M);
+}

@@ -343,11 +343,10 @@ class PointwiseConvLnActFn(torch.autograd.Function):
         pre = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
         y = torch.empty((B, Cout, L), dtype=_F32, device=x.device)
         stats = torch.empty((B, 2, L), dtype=_F32, device=x.device) if train else None
-        _conv_fwd(x, xbs, w, bias, sb, pre, Cout * L, 1, 1, 0, x_amax)
-        nbl = _lib.query("ssv_channel_ln_act_fwd_workspace", B, Cout, L)
-        wsl = _ws(nbl, x.device)
-        _lib.call("ssv_channel_ln_act_fwd", _p(pre), Cout * L, _p(gamma), _p(beta), _p(y), Cout * L, _p(y_amax), _p(stats),
-                  B, Cout, L, act, _p(wsl), nbl, _stream())
+        nb = _lib.query("ssv_pointwise_conv_ln_act_fwd_workspace", Cin, Cout)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_pointwise_conv_ln_act_fwd", _p(x), xbs, *_an(x_amax), _p(w), resident.lookup(w), _p(bias), _p(sb), _p(gamma), _p(beta),
+                  _p(pre), _p(stats), _p(y), Cout * L, _p(y_amax), B, Cin, Cout, L, act, _p(ws), nb, _stream())
         if train:
             ctx.save_for_backward(x, w, gamma, beta, pre, stats)
             ctx.x_amax = x_amax
