@@ -801,13 +801,22 @@ class AdversarialGraphStep:
         with ops.input_grads_only():        # only d out / d mid is asked for: no weight / bias / LayerNorm parameter gradients in this pass
             grads = torch.autograd.grad(outputs=out, inputs=mid, grad_outputs=torch.ones_like(out), retain_graph=True, create_graph=True)[0]
         loss_gp = ops.grad_penalty(grads, self.lam)          # mean(lam * (||grad||_2 - 1)^2), :305-308
-        loss_gp.backward(torch.full_like(loss_gp, scale))
         # disc(pred) and disc(gt) as ONE critic call on the concatenated batch: the critic has no cross-sample operation
         # (LayerNorm is per column, dropout per element), so mean(disc(pred) - disc(gt)) is unchanged and the iteration runs
         # a third fewer (small, launch-bound) critic kernels
         both = self.disc(torch.cat((pred, gt), dim=0))
         loss_d = torch.mean(both[:B] - both[B:])
-        loss_d.backward(torch.full_like(loss_d, scale))
+        # The reference calls loss_gp.backward() and loss_D.backward() (:309, :315): the second call ADDS into every critic parameter's .grad,
+        # one small element-wise launch per parameter and iteration (~30: most of the at::native launches of the captured cycle).  Same sums,
+        # two launches: both gradient lists from torch.autograd.grad, added by one multi-tensor torch._foreach_add_.
+        params = [p for p in self.disc.parameters() if p.requires_grad]
+        g_gp = torch.autograd.grad(loss_gp, params, grad_outputs=torch.full_like(loss_gp, scale), allow_unused=True)
+        g_d = torch.autograd.grad(loss_d, params, grad_outputs=torch.full_like(loss_d, scale), allow_unused=True)
+        pairs = [(a, b) for a, b in zip(g_gp, g_d) if a is not None and b is not None]
+        if pairs:
+            torch._foreach_add_([a for a, _ in pairs], [b for _, b in pairs])
+        for p, a, b in zip(params, g_gp, g_d):
+            p.grad = a if a is not None else b
         self.d_out = (loss_d.detach(), loss_gp.detach())
 
     def _d_pack(self):
