@@ -215,7 +215,6 @@ static GemmNNB nnb_zero() {
 static inline size_t conv_aux_bytes() { return SSV_F16_AUX_BYTES + AMAX_FB_BYTES; }
 // (pw != null: the 1x1 product finishes LayerNorm + activation in its own launch, gemm_pwln_kernel; y is then `pre`)
 struct PwLnArgs { const float* gamma; const float* beta; float* y; long ybs; float* stats; float* y_amax; int namax; int act; };
-int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta, float* y, long ybs, float* stats, float* y_amax, int namax, int act, hipStream_t st);
 static int conv_nn(const float* x, long x_bs, const float* w, const void* packed, long w_sm, long w_sk, const float* bias, const float* bias_b,
                    const float* r, long r_bs, float* y, long y_bs, int B, int K, int M, int L, int k, const int* shift,
                    bool bf3, void* ws, hipStream_t st, const float* a_inv = nullptr, const float* xa_given = nullptr, int xa_n = 0, size_t ws_main = 0,

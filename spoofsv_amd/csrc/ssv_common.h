@@ -90,6 +90,10 @@ struct GemmNNB {
   float* colstats;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
+// 1x1 product (g: KT = 1, unit strides, no residual / LSTM epilogue, M <= 640) that finishes LayerNorm over its M rows and the activation in
+// the same launch: g.C receives the LayerNorm's input `pre`; y (B, M, N) dense, stats (B, 2, N) or null, y_amax: namax entries per item or null
+int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta, float* y, long ybs, float* stats, float* y_amax, int namax, int act,
+                         hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
 bool ssv_nt_bf3_fits(const GemmNT& g);          // operands addressable with the kernel's 32-bit element offsets
 // nch_total / ch_off: this source fills K chunks [ch_off, ch_off + Kpad/32) of planes that have nch_total chunks per row block
