@@ -318,6 +318,7 @@ def kernel_roofline(dev):
         table = (L_.WgradJob * njobs)()
         sh = (ctypes.c_int * 3)()
         L_.call("ssv_conv_shifts", k, 1, 1, sh)
+        max_shift = max(abs(v) for v in sh)
         for t, x_, dy_, dw_, xa_, dya_ in zip(table, xs, dys, dws, xa, dya):
             t.dy, t.x, t.dw, t.part, t.pgrads = dy_.data_ptr(), x_.data_ptr(), dw_.data_ptr(), None, None
             t.shift[0], t.shift[1], t.shift[2] = sh[0], sh[1], sh[2]
@@ -326,7 +327,7 @@ def kernel_roofline(dev):
         tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
         nb = L_.query("ssv_conv1d_bwd_weight_multi_workspace", njobs, B, C, 2 * C, L, k)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        run = lambda: L_.call("ssv_conv1d_bwd_weight_multi", P(tdev), njobs, 2 * C * L, C * L, B, C, 2 * C, L, k, 0, 0, P(ws), nb, st)
+        run = lambda: L_.call("ssv_conv1d_bwd_weight_multi", P(tdev), njobs, 2 * C * L, C * L, B, C, 2 * C, L, k, max_shift, 0, 0, P(ws), nb, st)
         run(); run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 2 (1 + split-fp16 operand scales) */
+int ssv_version(void);            /* ABI version, currently 3 (2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
 /* Arithmetic of the conv GEMMs (the reference computes in fp32: requirements.txt:5, nn.Conv1d at models/TTSModel.py:59):
@@ -138,6 +138,8 @@ int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const float* x, l
  * only the slab boundaries (hence the fp32 summation order over the batch) differ from the one-layer entry.
  * jobs_dev: device array of njobs jobs.  Per job: dy (B,Cout,L) = dH, x (B,Cin,L), dw (Cout,Cin,k) out, part (nblk, n2) partial
  * rows or NULL, pgrads (n2) out or NULL, shift[j] = (j - j0) * dilation as ssv_conv_shifts returns them.
+ * max_shift: the caller's bound on |shift[j]| over all jobs (the table lives on the device; the entry plans its kernel from the
+ * bound), or -1 for "unknown" (the general kernel).  A job whose shifts exceed a stated bound gets NaN gradients, not wrong ones.
  * Split-bf16 mode only, B*L >= 256 (ssv_conv1d_bwd_weight_multi_ok). */
 typedef struct {
   const float* dy; const float* x; float* dw; const float* part; float* pgrads;
@@ -149,7 +151,7 @@ int ssv_conv_shifts(int k, int dilation, int causal, int* shift3);
 int ssv_conv1d_bwd_weight_multi_ok(int B, int Cin, int Cout, int L, int k);
 int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int Cout, int L, int k);   /* the Z the entry will use */
 size_t ssv_conv1d_bwd_weight_multi_workspace(int njobs, int B, int Cin, int Cout, int L, int k);
-int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int njobs, long dy_bs, long x_bs, int B, int Cin, int Cout, int L, int k,
+int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int njobs, long dy_bs, long x_bs, int B, int Cin, int Cout, int L, int k, int max_shift,
                                 int n2, int nblk, void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* highwayConv backward without the weight gradient: dx, plus dh (B,2C,L) dense and part (ssv_ln_partial_rows(B,L), 6C) for the job. */
 int ssv_ln_partial_rows(int B, int L);

@@ -92,7 +92,7 @@ extern "C" int ssv_set_precision(int mode) {
   return prev;
 }
 extern "C" int ssv_get_precision(void) { return ssv_precision(); }
-extern "C" int ssv_version(void) { return 2; }
+extern "C" int ssv_version(void) { return 3; }
 extern "C" const char* ssv_arch(void) { return "gfx950"; }
 extern "C" const char* ssv_last_error(void) { return g_err; }
 
@@ -150,7 +150,7 @@ static GemmNT nt_zero() {
   g.C = nullptr; g.scz = g.scm = 0; g.scc = 1; g.scj = 0;
   g.M = g.Nc = 0; g.KT = 1; g.B = 1; g.Z = 1; g.bstep = 1;
   g.shift[0] = g.shift[1] = g.shift[2] = 0;
-  g.jobs = nullptr; g.njobs = 0;
+  g.jobs = nullptr; g.njobs = 0; g.max_shift = -1;
   g.f16 = 0; g.a_amax = g.x_amax = nullptr; g.a_namax = g.x_namax = 0;
   return g;
 }
@@ -445,7 +445,7 @@ extern "C" int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int
 extern "C" size_t ssv_conv1d_bwd_weight_multi_workspace(int njobs, int B, int Cin, int Cout, int L, int k) {
   return align256((size_t)njobs * ssv_conv1d_bwd_weight_multi_splits(njobs, B, Cin, Cout, L, k) * Cout * Cin * k * sizeof(float));
 }
-extern "C" int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int njobs, long dy_bs, long x_bs, int B, int Cin, int Cout, int L, int k,
+extern "C" int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int njobs, long dy_bs, long x_bs, int B, int Cin, int Cout, int L, int k, int max_shift,
                                            int n2, int nblk, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(jobs_dev && njobs > 0 && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "conv1d_bwd_weight_multi: bad argument");
   SSV_CHECK(ssv_conv1d_bwd_weight_multi_ok(B, Cin, Cout, L, k), SSV_UNSUPPORTED, "conv1d_bwd_weight_multi: shape or arithmetic mode not supported");
@@ -459,7 +459,7 @@ extern "C" int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int nj
   g.X = nullptr; g.sxb = x_bs; g.sxc = L; g.Lx = L;
   g.C = (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = 1; g.scj = Cin;                 // slabs [job][z][m][j][c]
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
-  g.jobs = jobs_dev; g.njobs = njobs;
+  g.jobs = jobs_dev; g.njobs = njobs; g.max_shift = max_shift;
   g.f16 = use_f16() ? 1 : 0;                     // the jobs carry their operands' scale lists (the caller saw to that)
   SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
   return ssv_launch_reduce_pair_multi(jobs_dev, njobs, (const float*)ws, Cout, Cin, k, Z, n2, nblk, st);

@@ -46,6 +46,7 @@ struct GemmNT {
   // several problems of one shape in one launch (split-bf16 kernel only): grid.z = njobs * Z, entry z belongs to job z / Z and
   // takes A = jobs[job].dy, X = jobs[job].x, the job's shifts, and slab (z % Z) of the job's slab region C + job * Z * scz
   const ssv_wgrad_job* jobs; int njobs;
+  int max_shift;           // with a job table: the caller's bound on |shift| over all jobs (picks the k = 3 ring kernel when <= 64); < 0 = unknown
   // split-fp16 arithmetic (split-bf16 kernel only): both operands are scaled while they are split, by the power of two that
   // the maximum over ALL entries of their partial-maxima lists gives (the reduction runs over the batch, so one scale per
   // tensor); with a job table the lists are the job's (dy_amax / x_amax, n_amax entries each side as stored in the job).

@@ -214,7 +214,8 @@ class DeferredWgrad:
                 slot[2].record()
             nb = _lib.query("ssv_conv1d_bwd_weight_multi_workspace", n, B, Cin, Cout, L, k)
             ws = _ws(nb, dev)
-            _lib.call("ssv_conv1d_bwd_weight_multi", _p(slot[1]), n, dy_bs, x_bs, B, Cin, Cout, L, k, n2, nblk, _p(ws), nb, _stream())
+            max_shift = max(abs(v) for job in jobs for v in job[6])
+            _lib.call("ssv_conv1d_bwd_weight_multi", _p(slot[1]), n, dy_bs, x_bs, B, Cin, Cout, L, k, max_shift, n2, nblk, _p(ws), nb, _stream())
         self.jobs = {}
         self.pending.clear()
 

@@ -170,3 +170,93 @@ def test_channel_layernorm_act_backward_wide_tile_kernels_at_ragged_shapes(B, C,
     for name, a, b in zip(("x", "w", "bias", "gamma", "beta"), dev_in, ref_in):
         e = _rl2(a.grad, b.grad)
         assert e < 5e-6, (name, (B, C, L, act), e)
+
+
+RING_SHAPES = [
+    # B, Cin, Cout, L, d, causal   (k = 3 everywhere: the weight gradient's ring kernel, gemm_nt3r_kernel)
+    (2, 256, 512, 325, 1, False), (2, 256, 512, 325, 27, True), (3, 64, 128, 186, 3, False), (3, 64, 128, 186, 27, False),
+    (1, 64, 128, 128, 9, True), (1, 64, 128, 64, 1, False), (5, 64, 128, 65, 3, True), (2, 64, 128, 63, 27, True),
+    (2, 80, 100, 70, 9, False), (4, 24, 40, 33, 1, True), (2, 200, 130, 129, 3, False), (7, 72, 200, 191, 27, False),
+    (2, 64, 64, 1300, 1, False), (32, 64, 128, 8, 1, False), (3, 64, 128, 193, 27, True), (2, 64, 128, 100, 13, False),
+]
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x2", 2e-6), ("bf16x3", 2e-5)])
+def test_weight_gradient_ring_kernel_ragged_shapes_dilations_and_item_boundaries(prec, tol):
+    """The k = 3 weight gradient stages its input once per 64-step chunk into a ring of time-major LDS rows and reads every tap's operand by
+    transposed reads at shifted rows (round 4).  What can go wrong there is all about edges: rows before an item's first and past its last
+    time step (zeros of the convolution's padding), the virtual time line running from one batch item into the next, ring wrap-around
+    (the mirror rows), row lengths that are multiples of nothing, channel and row tiles partly empty, the longest shifts the entry takes
+    (54: dilation 27, causal) -- each against float64 autograd of nn.Conv1d's expression (models/TTSModel.py:59-61, :78)."""
+    gen = torch.Generator().manual_seed(21)
+    for (B, Cin, Cout, L, d, causal) in RING_SHAPES:
+        x = torch.randn(B, Cin, L, generator=gen)
+        w = torch.randn(Cout, Cin, 3, generator=gen) * 0.05
+        dy = torch.randn(B, Cout, L, generator=gen)
+        _, _, wref = _reference(x, w, dy, 3, d, causal)
+        _, _, wg = _hip(x, w, dy, 3, d, causal, prec)
+        assert bool(torch.isfinite(wg).all()), (B, Cin, Cout, L, d, causal)
+        # per tap: a wrong edge shows in one tap only and would hide in the norm over all three
+        for j in range(3):
+            e = _rl2(wg[:, :, j], wref[:, :, j])
+            print("%-6s B%d Cin%d Cout%d L%d d%d %s tap %d: %.2e" % (prec, B, Cin, Cout, L, d, "causal" if causal else "same", j, e))
+            assert e <= tol, ((B, Cin, Cout, L, d, causal), j, e)
+        worst = float((wg.double().cpu() - wref).abs().max() / wref.abs().max())
+        assert worst <= 20 * tol, ((B, Cin, Cout, L, d, causal), worst)
+
+
+def _multi_wgrad(xs, dys, specs, k, max_shift, prec):
+    """ssv_conv1d_bwd_weight_multi on equal-shaped jobs with their own (dilation, causal); returns the dw tensors."""
+    import ctypes
+    import spoofsv_amd
+    from spoofsv_amd import ops, _lib
+    prev = spoofsv_amd.set_precision(prec)
+    try:
+        B, Cin, L = xs[0].shape
+        Cout = dys[0].shape[1]
+        xg, dyg = [t.to(DEV) for t in xs], [t.to(DEV) for t in dys]
+        dws = [torch.full((Cout, Cin, k), 7.0, device=DEV) for _ in xs]
+        xa, dya = [ops.amax_of(t) for t in xg], [ops.amax_of(t) for t in dyg]
+        table = (_lib.WgradJob * len(xs))()
+        for t, x_, dy_, dw_, xa_, dya_, (d, causal) in zip(table, xg, dyg, dws, xa, dya, specs):
+            sh = (ctypes.c_int * 3)()
+            _lib.call("ssv_conv_shifts", k, d, int(causal), sh)
+            t.dy, t.x, t.dw, t.part, t.pgrads = dy_.data_ptr(), x_.data_ptr(), dw_.data_ptr(), None, None
+            t.shift[0], t.shift[1], t.shift[2] = sh[0], sh[1], sh[2]
+            t.dy_amax, t.x_amax, t.dy_namax, t.x_namax = dya_.data_ptr(), xa_.data_ptr(), dya_.numel(), xa_.numel()
+        tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(DEV)
+        nb = _lib.query("ssv_conv1d_bwd_weight_multi_workspace", len(xs), B, Cin, Cout, L, k)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.call("ssv_conv1d_bwd_weight_multi", P(tdev), len(xs), Cout * L, Cin * L, B, Cin, Cout, L, k, max_shift, 0, 0, P(ws), nb,
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return dws
+    finally:
+        spoofsv_amd.set_precision(prev)
+
+
+def test_batched_weight_gradient_with_mixed_dilations_and_the_shift_bound():
+    """ssv_conv1d_bwd_weight_multi: jobs of one shape but different dilations in ONE launch (what the training step does with its
+    highway stacks: dilations 1, 3, 9, 27 share a launch).  The job table lives on the device, so the caller states a bound on the
+    shifts: with the true bound the ring kernel runs, with -1 the general kernel -- both within the split-fp16 bar of float64 -- and a
+    bound that a job exceeds must poison THAT job's gradient (NaN), not return a wrong one."""
+    gen = torch.Generator().manual_seed(31)
+    B, Cin, Cout, L, k = 6, 128, 256, 200, 3
+    specs = [(1, False), (27, True), (9, False), (3, True), (27, False)]
+    xs = [torch.randn(B, Cin, L, generator=gen) for _ in specs]
+    dys = [torch.randn(B, Cout, L, generator=gen) for _ in specs]
+    ws = [torch.zeros(Cout, Cin, k) for _ in specs]
+    refs = [_reference(x, w, dy, k, d, causal)[2] for x, w, dy, (d, causal) in zip(xs, ws, dys, specs)]
+    for max_shift in (54, 64, -1):
+        got = _multi_wgrad(xs, dys, specs, k, max_shift, "f16x2")
+        for (d, causal), g, r in zip(specs, got, refs):
+            e = _rl2(g, r)
+            print("max_shift %3d  d%-2d %-6s: %.2e" % (max_shift, d, "causal" if causal else "same", e))
+            assert e <= 2e-6, (max_shift, d, causal, e)
+    got = _multi_wgrad(xs, dys, specs, k, 27, "f16x2")           # the causal dilation-27 job shifts by 54
+    for (d, causal), g, r in zip(specs, got, refs):
+        if d == 27 and causal:
+            assert bool(torch.isnan(g).all()), "a job beyond the stated shift bound must come back as NaN"
+        else:
+            assert _rl2(g, r) <= 2e-6, (d, causal)

@@ -78,7 +78,7 @@ def by_shape(path, shapes, top=40):
             flops, nbytes, note = hit
             if flops > 0:
                 t = flops / (avg * 1e-6) / 1e12
-                roof = PEAK_SPLIT_TFLOPS if ("bf3" in k[0] or "pwln" in k[0]) else PEAK_F32_TFLOPS
+                roof = PEAK_SPLIT_TFLOPS if ("bf3" in k[0] or "pwln" in k[0] or "nt3r" in k[0]) else PEAK_F32_TFLOPS
                 ach, frac = "%.0f TF/s" % t, "%.3f" % (t / roof)
             elif nbytes > 0:
                 t = nbytes / (avg * 1e-6) / 1e12
