@@ -344,11 +344,17 @@ extern "C" int ssv_debug_nn_stamps(unsigned long long* out) { return (int)hipMem
 #define SSV_NN_XBUF(KT, WM, NT) (!((KT) == 3 && (NT) == 6))   // input rows by buffer loads (ssv_buf) or through pointers: in-step, per tile -- the k = 1
                                                              // tiles are 5-12 % faster with buffer loads, the 96-column k = 3 tiles 4-6 % with pointers, the rest equal
 // waves per SIMD the register allocation must leave room for
+#ifndef SSV_NN_HALO_SMALL
+#define SSV_NN_HALO_SMALL 16  // k = 3 layers whose taps span at most this many columns run the narrow-halo instantiation (tuning builds: -1 = never)
+#endif
 #define SSV_NNB_WAVES(KT, WM, NT, EPI) ((KT) == 1 && (WM) == 2 && (NT) == 4 && (EPI) == 0 ? 3 : 2)
-template <int KT, int WM, int NT, int EPI, int F16>
+// HW: the halo (columns beyond the tile that the taps reach) the instantiation stages for -- 54 (dilation 27, any form) or 16: most layers of the
+// models have dilation 1 or 3, and with the 54-column halo a third of the loads, splits and LDS stores of their chunks went into columns no tap reads
+// (112 + 54 -> 176 staged columns = 3 slots per thread; 112 + 16 -> 128 = 2).
+template <int KT, int WM, int NT, int EPI, int F16, int HW = 54>
 __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int BM = 64 * WM, BN = 16 * NT;
-  constexpr int HALO = (KT == 1) ? 0 : 54;
+  constexpr int HALO = (KT == 1) ? 0 : HW;
   constexpr int WX = ((BN + HALO + 15) / 16) * 16;         // staged columns, plane = WX*16 B = multiple of 256 B
   constexpr int X_SLOTS = 4 * WX;
   constexpr int NX = (X_SLOTS + 255) / 256;
@@ -997,10 +1003,17 @@ static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   }
   if (ssv_shape_log_on()) {
     char nm[96], note[96];
-    snprintf(nm, sizeof nm, "gemm_nn_bf3_kernel<%d, %d, %d, 0, %d>", KT, WM, NT, g.f16);
+    snprintf(nm, sizeof nm, "gemm_nn_bf3_kernel<%d, %d, %d, 0, %d, %d>", KT, WM, NT, g.f16, (KT == 3 && span <= SSV_NN_HALO_SMALL) ? SSV_NN_HALO_SMALL : 54);
     snprintf(note, sizeof note, "B=%d M=%d N=%d K=%d k=%d%s", g.B, g.M, g.N, g.Kc, KT, g.colstats ? " +colstats" : "");
     ssv_shape_log(nm, dim3(mtiles * ntiles, g.B), dim3(256), 2.0 * g.B * g.M * g.N * g.Kc * KT,
                   4.0 * ((double)g.B * g.Kc * g.N + (double)g.B * g.M * g.N * (g.R ? 2 : 1) + (double)g.M * g.Kc * KT), note);
+  }
+  if constexpr (KT == 3) {
+    if (span <= SSV_NN_HALO_SMALL) {
+      if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0, 1, SSV_NN_HALO_SMALL>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+      else hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0, 0, SSV_NN_HALO_SMALL>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+      return ssv_check_launch("gemm_nn_bf3");
+    }
   }
   if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0, 1>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
   else hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 0, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
