@@ -287,7 +287,7 @@ def kernel_roofline(dev):
         return e0.elapsed_time(e1) / reps
 
     def time_conv_dw(B, C, L, k, nset):
-        """ms per call of the weight gradient of the same conv (gemm_nt_bf3_kernel + its slab reduction), cold operands."""
+        """ms per call of the weight gradient of the same conv (gemm_nt3r_kernel + its slab reduction), cold operands."""
         xs = [torch.randn(B, C, L, device=dev) for _ in range(nset)]
         dys = [torch.randn(B, 2 * C, L, device=dev) for _ in range(nset)]
         xa, dya = amax(xs), amax(dys)
@@ -347,15 +347,15 @@ def kernel_roofline(dev):
     # both split modes execute 3 sixteen-bit MFMAs (bf16 or fp16: same dense peak) per algorithmic fp32 product: the roof for
     # ALGORITHMIC flops is peak/3
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-    name = {2: "gemm_nn_bf3_kernel<3,1,7,0,1> (split-fp16 MFMA: fp16 hi+lo of power-of-two scaled operands, 3 fp16 MFMAs per fp32 product)",
-            1: "gemm_nn_bf3_kernel<3,1,7,0,0> (split-bf16 MFMA, 3 bf16 MFMAs per fp32 product)", 0: "gemm_nn_kernel<KT=3> (fp32 MFMA)"}[mode]
+    name = {2: "gemm_nn_bf3_kernel<3,1,7,0,1,16> (split-fp16 MFMA: fp16 hi+lo of power-of-two scaled operands, 3 fp16 MFMAs per fp32 product)",
+            1: "gemm_nn_bf3_kernel<3,1,7,0,0,16> (split-bf16 MFMA, 3 bf16 MFMAs per fp32 product)", 0: "gemm_nn_kernel<KT=3> (fp32 MFMA)"}[mode]
     tmpl = "1" if mode == 2 else "0"
     # the same measurement for the step's most expensive single launch (SSRN highwayConv C=512, L=1300: 130.9 GFLOP)
     # and for the weight gradient of the headline shape (kernel + slab reduction), so the line shows the range, not one point
     others = []
-    for label, fn, (b_, c_, l_) in (("Conv1d fwd C=512->1024 L=1300 (gemm_nn_bf3_kernel<3,2,7,0,%s>)" % tmpl, time_conv_fwd, (32, 512, 1300)),
-                                     ("Conv1d weight gradient C=256->512 L=325 (gemm_nt_bf3_kernel<3,2,4,%s> + reduce_slabs_perm)" % tmpl, time_conv_dw, (32, 256, 325)),
-                                     ("Conv1d weight gradient C=512->1024 L=1300 (gemm_nt_bf3_kernel<3,2,4,%s> + reduce_slabs_perm)" % tmpl, time_conv_dw, (32, 512, 1300))):
+    for label, fn, (b_, c_, l_) in (("Conv1d fwd C=512->1024 L=1300 (gemm_nn_bf3_kernel<3,2,7,0,%s,16>)" % tmpl, time_conv_fwd, (32, 512, 1300)),
+                                     ("Conv1d weight gradient C=256->512 L=325 (gemm_nt3r_kernel<2,%s> + reduce_slabs_perm)" % tmpl, time_conv_dw, (32, 256, 325)),
+                                     ("Conv1d weight gradient C=512->1024 L=1300 (gemm_nt3r_kernel<2,%s> + reduce_slabs_perm)" % tmpl, time_conv_dw, (32, 512, 1300))):
         m_ = fn(b_, c_, l_, k, 4 if l_ > 1000 else 20)
         f_ = 2.0 * b_ * l_ * (2 * c_) * c_ * k
         a_ = f_ / (m_ * 1e-3) / 1e12
@@ -363,7 +363,7 @@ def kernel_roofline(dev):
     if split:
         m_ = time_conv_dw_multi(32, 256, 325, 3, 16)
         a_ = flops / (m_ * 1e-3) / 1e12
-        others.append({"kernel": "Conv1d weight gradient C=256->512 L=325, 16 layers in one launch (gemm_nt_bf3_kernel<3,2,4> with a job table, "
+        others.append({"kernel": "Conv1d weight gradient C=256->512 L=325, 16 layers in one launch (gemm_nt3r_kernel<2> with a job table, "
                                  "2 slabs per layer, + reduce_pair_multi): per layer", "us_per_launch": round(m_ * 1e3, 2), "achieved": round(a_, 2),
                        "frac": round(a_ / peak, 4)})
     lib_ref = None
