@@ -260,3 +260,29 @@ def test_batched_weight_gradient_with_mixed_dilations_and_the_shift_bound():
             assert bool(torch.isnan(g).all()), "a job beyond the stated shift bound must come back as NaN"
         else:
             assert _rl2(g, r) <= 2e-6, (d, causal)
+
+
+@pytest.mark.parametrize("d,causal", [(7, False), (8, False), (8, True), (9, False), (9, True), (1, True)])
+def test_conv_forward_and_data_gradient_on_both_sides_of_the_narrow_halo_rule(d, causal):
+    """The k = 3 forward / data-gradient kernels come in two instantiations: a 16-column halo for layers whose taps span at most 16
+    columns, 54 otherwise (csrc/gemm_bf3.hip, SSV_NN_HALO_SMALL).  Dilations 7 and 8 are the last ones on the narrow side (span 14 / 16),
+    9 the first on the wide side: forward, data gradient and weight gradient against float64 at a row length that is a multiple of
+    nothing, so that the last column tile is partly empty and its halo runs off the row (nn.Conv1d with the reference's padding,
+    models/TTSModel.py:59-61)."""
+    gen = torch.Generator().manual_seed(41)
+    B, Cin, Cout, L, k = 3, 128, 256, 333, 3
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(Cout, Cin, k, generator=gen) * 0.05
+    dy = torch.randn(B, Cout, L, generator=gen)
+    ref = _reference(x, w, dy, k, d, causal)
+    for prec, tol in (("f16x2", 2e-6), ("bf16x3", 3e-5)):
+        got = _hip(x, w, dy, k, d, causal, prec)
+        for name, a, b in zip(("fwd", "dgrad", "wgrad"), got, ref):
+            e = _rl2(a, b)
+            print("%-6s d%d %-6s %-5s %.2e" % (prec, d, "causal" if causal else "same", name, e))
+            assert e <= tol, (prec, d, causal, name, e)
+            # the columns next to the row's ends are where a wrong halo shows: compare them on their own
+            if name != "wgrad":
+                edge = torch.cat((a[..., : 2 * d + 2].double().cpu() - b[..., : 2 * d + 2], a[..., -(2 * d + 2):].double().cpu() - b[..., -(2 * d + 2):]), -1)
+                scale = b.abs().max()
+                assert float(edge.abs().max() / scale) <= 40 * tol, (prec, d, causal, name)
