@@ -17,6 +17,29 @@ def call(name, *a):
     return orig_call(name, *a)
 _lib.call = call
 ops._lib.call = call
+# who PRODUCED the tensor whose list is missing: every autograd Function of ops tags what its forward / backward returns
+import inspect
+def _tagging(cls, which):
+    fn = getattr(cls, which)
+    def wrapped(*a, **k):
+        out = fn(*a, **k)
+        for t in (out if isinstance(out, tuple) else (out,)):
+            if isinstance(t, torch.Tensor):
+                try: t._ssv_src = "%s.%s" % (cls.__name__, which)
+                except Exception: pass
+        return out
+    setattr(cls, which, staticmethod(wrapped))
+for _, cls in inspect.getmembers(ops, inspect.isclass):
+    if issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function:
+        _tagging(cls, "forward"); _tagging(cls, "backward")
+orig_amax = ops.amax_of
+def amax_of(x):
+    h = getattr(x, "_ssv_amax", None)
+    if not (h is not None and h[1] == x._version and h[0].shape[0] == x.shape[0]):
+        srcs[(PHASE, getattr(x, "_ssv_src", "torch / unknown") + " " + str(tuple(x.shape[1:])))] += 1
+    return orig_amax(x)
+srcs = collections.Counter()
+ops.amax_of = amax_of
 dev = "cuda:0"
 for kind in ("text2mel", "ssrn"):
     torch.manual_seed(0)
@@ -40,3 +63,6 @@ for ph in sorted(set(k[0] for k in sites)):
     print("== %s: %d ssv_absmax launches" % (ph, tot))
     for (p, key), v in sorted(sites.items(), key=lambda kv: -kv[1]):
         if p == ph: print("   %3d  %s" % (v, key))
+print("\nproducers of the tensors that had no list (phase, producer, shape per item):")
+for (ph, key), v in sorted(srcs.items(), key=lambda kv: (kv[0][0], -kv[1])):
+    if "warm" not in ph: print("   %-12s %3d  %s" % (ph, v, key))
