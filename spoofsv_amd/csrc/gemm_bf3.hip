@@ -1489,12 +1489,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 //     item's last chunk; what such a zero multiplies is input data of the tensor itself, i.e. finite).  No per-tap edge cases;
 //   * rows 256 .. 287 mirror rows 0 .. 31 (written with block 4i's first rows), so a k-step (32 rows) that starts in the last rows of
 //     the ring runs on linearly: every read address is lane constant + a per-(chunk, tap, k-step) SCALAR.
+// The dH side: a lane's fragment of a 32-step k-step is two 16-byte tuples, steps 4 kq .. 4 kq + 3 and 16 + 4 kq .. 19 + 4 kq (so that one load
+// instruction touches 64 CONTIGUOUS bytes of each of its 16 rows, not four 16-byte pieces spread over 128: -1.3 % in-step), split in place pair by
+// pair: dword q of the fragment = steps (4 kq + q, 16 + 4 kq + q).  Any order is right as long as the input side uses it: read 0 of a
+// fragment names rows (0, 16, 1, 17) + 4 kq of the k-step, read 1 rows (2, 18, 3, 19) + 4 kq.
 // Bank conflicts (cdna_hip_programming.md section 2: 64 dword banks per 32-lane half for the transposed read): a half reads 8 row
-// pieces of 32 bytes -- rows u + {0,1,4,5,8,9,12,13} (+2 for the second read) of one 16-channel block.  With 128-byte rows these would
-// share two 32-byte bank groups; the 32-byte piece `cb` of row r is therefore stored at piece cb ^ ((r >> 2) & 3): the 8 pieces of a
-// half land on 8 distinct bank groups for every u (no linear row stride does that for this row set, tools/tr_layout_search.py).
-// The order of a window's 8 time steps inside a fragment is the dH side's (dword q = steps q, q + 4; see split8p): read 0 names rows
-// (0, 4, 1, 5), read 1 rows (2, 6, 3, 7).
+// pieces of 32 bytes -- rows u + {0,1,4,5,16,17,20,21} (+2 for the second read) of one 16-channel block.  With 128-byte rows these would
+// share two 32-byte bank groups; the 32-byte piece `cb` of row r is therefore stored at piece cb ^ (bit 2 of r | bit 4 of r << 1): the 8 pieces
+// of a half land on 8 distinct bank groups for every u (checked exhaustively; no linear row stride does that for the rows a split-in-place
+// fragment names, tools/tr_layout_search.py).
 typedef short ssv_s4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) ssv_s4 ssv_lds_s4;
 typedef unsigned ssv_u2 __attribute__((ext_vector_type(2)));
@@ -1574,7 +1577,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt3r_kernel(const GemmNT p, const
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xp), 0,
       (int)(((long)(p.B - 1) * p.sxb + (long)(p.Nc - 1) * p.sxc + p.Lx) * 4), 0x00020000);
   // (rows / channels past a ragged tile's end are not clamped: they read other rows of the tensor or zeros, and feed accumulators nobody stores)
-  const unsigned arow = (unsigned)(((m0 + wave * WM * 16 + nq) * (int)p.sam + 8 * kq) * 4);
+  const unsigned arow = (unsigned)(((m0 + wave * WM * 16 + nq) * (int)p.sam + 4 * kq) * 4);
   const unsigned a16 = 16u * (unsigned)p.sam * 4u;            // one 16-row block further (scalar)
   // staging: wave w owns the 16-channel piece w of every row; lane = cq + 4 tq: channels 16 w + 4 cq .. + 3, rows 4 tq .. 4 tq + 3 of the block
   const int cq = lane >> 4, tq = lane & 15;               // 4 consecutive lanes = 64 contiguous bytes of one channel row
@@ -1582,18 +1585,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt3r_kernel(const GemmNT p, const
   const unsigned x1 = (unsigned)p.sxc * 4u;                   // one channel further (scalar)
   const bool rows_in_c = c0 + NCH <= p.Nc;
   const unsigned ringb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
-  const unsigned waddr = ringb + (unsigned)(4 * tq) * ROWB + (unsigned)((wave ^ (tq & 3)) << 5) + (unsigned)cq * 8u;
+  const unsigned waddr = ringb + (unsigned)(4 * tq) * ROWB + (unsigned)((wave ^ ((tq & 1) | (((tq >> 2) & 1) << 1))) << 5) + (unsigned)cq * 8u;
   // fragment reads: lane (kq, 4 q + pp) of read r names row 8 kq + rsel[r][q]; the piece swizzle of that row depends on the tap's shift
   const int q4 = (lane >> 2) & 3, pp = lane & 3;
   int lrow[2];
-  lrow[0] = 8 * kq + (q4 >> 1) + 4 * (q4 & 1);               // q = 0..3 -> rows 0, 4, 1, 5
+  lrow[0] = 4 * kq + (q4 >> 1) + 16 * (q4 & 1);              // q = 0..3 -> rows 0, 16, 1, 17 of the k-step (+ 4 kq)
   lrow[1] = lrow[0] + 2;
   unsigned lbase[2], key5[KT][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     lbase[r] = ringb + (unsigned)lrow[r] * ROWB + (unsigned)pp * 8u;
 #pragma unroll
-    for (int j = 0; j < KT; ++j) key5[j][r] = (unsigned)(((shj[j] + lrow[r]) >> 2) & 3) << 5;
+    for (int j = 0; j < KT; ++j) { const int rr = shj[j] + lrow[r]; key5[j][r] = (unsigned)(((rr >> 2) & 1) | (((rr >> 4) & 1) << 1)) << 5; }
   }
 
   const int nb = (p.B - z + p.bstep - 1) / p.bstep;
@@ -1615,7 +1618,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt3r_kernel(const GemmNT p, const
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) {
         AH[SET][i][s2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(arow + (so + i * a16)) + s2 * 128, 0, 0));
-        AL[SET][i][s2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(arow + (so + i * a16)) + s2 * 128 + 16, 0, 0));
+        AL[SET][i][s2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(arow + (so + i * a16)) + s2 * 128 + 64, 0, 0));
       }
   };
   // one of the chunk's 4 WM dH loads / 4 input loads: the chunk loop issues them one at a time between its MFMA groups
@@ -1623,7 +1626,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt3r_kernel(const GemmNT p, const
     constexpr int SET = decltype(set)::value;
     const unsigned so = ((unsigned)b * (unsigned)p.sab + (unsigned)t0) * 4u;
     const int i = idx / (2 * KS), s2 = (idx / 2) % KS, hf = idx % 2;
-    const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(arow + (so + i * a16)) + s2 * 128 + 16 * hf, 0, 0));
+    const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(arow + (so + i * a16)) + s2 * 128 + 64 * hf, 0, 0));
     if (hf) AL[SET][i][s2] = v; else AH[SET][i][s2] = v;
   };
   auto loadX1 = [&](int b, int t0, int ci) __attribute__((always_inline)) {
@@ -1642,9 +1645,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt3r_kernel(const GemmNT p, const
         v[0] = __builtin_bit_cast(float, t0_.x); v[1] = __builtin_bit_cast(float, t0_.y); v[2] = __builtin_bit_cast(float, t0_.z); v[3] = __builtin_bit_cast(float, t0_.w);
         v[4] = __builtin_bit_cast(float, t1_.x); v[5] = __builtin_bit_cast(float, t1_.y); v[6] = __builtin_bit_cast(float, t1_.z); v[7] = __builtin_bit_cast(float, t1_.w);
         if (ragged) {
-          const int nv = p.La - (t0 + 32 * s2 + 8 * kq);
+          const int nv = p.La - (t0 + 32 * s2 + 4 * kq);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = e < nv ? v[e] : 0.f;
+          for (int e = 0; e < 8; ++e) v[e] = (e >= 4 ? e + 12 : e) < nv ? v[e] : 0.f;      // (the second tuple holds steps 16 .. 19 of the lane's window)
         }
         split8p<F16>(v, as, AH[SET][i][s2], AL[SET][i][s2]);
       }
