@@ -566,7 +566,13 @@ def launch_ranks(n):
                         rc = c if c > 0 else 1
     except KeyboardInterrupt:           # the launcher is being stopped: take the ranks (exactly these PIDs) down with it
         rc = 130
-    for p in live:                      # a rank failed: the others would wait in a collective for ever
+    # a rank failed: the others would wait in a collective for ever.  They get a few seconds to report an error of their own
+    # (the usual case: every rank stops at the same check), then exactly these PIDs are ended.
+    grace = time.time() + 10.0
+    while live and rc != 130 and time.time() < grace:
+        time.sleep(0.2)
+        live = [p for p in live if p.poll() is None]
+    for p in live:
         p.terminate()
     for p in live:
         try:

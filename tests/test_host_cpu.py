@@ -608,11 +608,12 @@ def test_bench_refuses_a_world_size_that_is_not_the_gpus_asked_for():
 
 def test_bench_gpus_n_without_a_launcher_starts_n_ranks_and_propagates_their_failure():
     """`python bench.py --gpus 2` with no WORLD_SIZE becomes two ranks (children of a parent that never touches the GPU).  On this
-    GPU-less host every rank stops at its own "needs a ROCm GPU" check: two such messages, one per rank, and the parent's exit
+    GPU-less host every rank stops at its own "needs a ROCm GPU" check: one such message per rank that reached it, and the parent's exit
     code is non-zero with nothing on stdout."""
     r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
     if torch.cuda.is_available():
         import pytest
         pytest.skip("GPU present: the launched ranks would run the benchmark (covered by tests/test_gpu_ddp.py)")
     assert r.returncode != 0 and r.stdout.strip() == ""
-    assert r.stderr.count("needs a ROCm GPU") == 2, r.stderr
+    # one message per rank that got as far as the check before the launcher ended it (the launcher waits 10 s for the others)
+    assert 1 <= r.stderr.count("needs a ROCm GPU") <= 2, r.stderr
