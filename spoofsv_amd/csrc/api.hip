@@ -246,6 +246,8 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
     if (pw) return ssv_launch_gemm_pwln(g, pw->gamma, pw->beta, pw->y, pw->ybs, pw->stats, pw->y_amax, pw->namax, pw->act, st);
     return ssv_launch_gemm_nn_bf3(g, st);
   }
+  if (L == 1 && k == 1 && w_sk == 1 && w_sm == K && !r)          // nn.Linear on a (B, K) matrix (the speaker-code layers): see linear_len1_fwd_kernel
+    return ssv_launch_linear_len1_fwd(x, x_bs, w, bias, bias_b, M, y, y_bs, B, K, M, st);
   GemmNN g = nn_zero();
   for (int j = 0; j < 3; ++j) g.shift[j] = shift[j];
   const float* a = w;
@@ -415,6 +417,10 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
       g.f16 = 1; g.a_amax = la.p; g.a_namax = la.n * B; g.x_amax = lx.p; g.x_namax = lx.n * B;
     }
     SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
+  } else if (L == 1 && k == 1) {                       // see linear_len1_wgrad_kernel; writes dw itself, whatever Z says
+    SSV_TRY(ssv_launch_linear_len1_wgrad(dy, dy_bs, x, x_bs, dw, B, Cin, Cout, st));
+    if (part) SSV_TRY(ssv_reduce_partial_rows(part, pgrads, n2, nblk, st));
+    return 0;
   } else SSV_TRY(ssv_launch_gemm_nt(g, st));
   if (part) {
     if (Z > 1 && nblk <= 768) return ssv_launch_reduce_pair((const float*)ws, dw, Cout, Cin, k, Z, part, pgrads, n2, nblk, st);

@@ -176,6 +176,63 @@ int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hip
   return ssv_check_launch("pack_wt");
 }
 
+// ---- 1x1 convolution over a length-1 sequence (= nn.Linear on a (B, K) matrix: the speaker-code layers audioEncoder.fc1 / fc2,
+// models/TTSModel.py:148-151, 159-160).  The tiled GEMM kernels spend a serial chain of per-item round trips on these 3 MFLOP
+// (forward 21 us, weight gradient 44 us per launch in-step); plain fp32 dot products from LDS take a few microseconds.
+//   y(b, m) = sum_c w(m, c) x(b, c) + bias(m) + bias_b(b, m):  a workgroup owns 8 rows m and up to 32 items b, K in chunks of 64.
+__global__ __launch_bounds__(256) void linear_len1_fwd_kernel(const float* __restrict__ x, long x_bs, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ bias_b, long sbb, float* __restrict__ y, long y_bs, int B, int K, int M) {
+  __shared__ float ws[8][65], xs[32][65];
+  const int tid = threadIdx.x, bl = tid & 31, mi = tid >> 5;
+  const int m0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 8 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      ws[r][c] = (m0 + r < M && k0 + c < K) ? w[(long)(m0 + r) * K + k0 + c] : 0.f;
+    }
+    for (int e = tid; e < 32 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      xs[r][c] = (b0 + r < B && k0 + c < K) ? x[(long)(b0 + r) * x_bs + k0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int c = 0; c < 64; ++c) acc = __builtin_fmaf(ws[mi][c], xs[bl][c], acc);
+  }
+  const int m = m0 + mi, b = b0 + bl;
+  if (m < M && b < B) {
+    if (bias) acc += bias[m];
+    if (bias_b) acc += bias_b[(long)b * sbb + m];
+    y[(long)b * y_bs + m] = acc;
+  }
+}
+int ssv_launch_linear_len1_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b, long sbb, float* y, long y_bs,
+                               int B, int K, int M, hipStream_t st) {
+  hipLaunchKernelGGL(linear_len1_fwd_kernel, dim3(ssv_cdiv(M, 8), ssv_cdiv(B, 32)), dim3(256), 0, st, x, x_bs, w, bias, bias_b, sbb, y, y_bs, B, K, M);
+  return ssv_check_launch("linear_len1_fwd");
+}
+//   dw(m, c) = sum_b dy(b, m) x(b, c): a thread per entry, c fastest (x coalesced, dy one address per 64 lanes or two).
+__global__ __launch_bounds__(256) void linear_len1_wgrad_kernel(const float* __restrict__ dy, long dy_bs, const float* __restrict__ x, long x_bs,
+                                                                float* __restrict__ dw, int B, int K, int M) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * K) return;
+  const int m = (int)(i / K), c = (int)(i % K);
+  float acc = 0.f;
+  int b = 0;
+  for (; b + 3 < B; b += 4) {
+    const float d0 = dy[(long)b * dy_bs + m], d1 = dy[(long)(b + 1) * dy_bs + m], d2 = dy[(long)(b + 2) * dy_bs + m], d3 = dy[(long)(b + 3) * dy_bs + m];
+    const float x0 = x[(long)b * x_bs + c], x1 = x[(long)(b + 1) * x_bs + c], x2 = x[(long)(b + 2) * x_bs + c], x3 = x[(long)(b + 3) * x_bs + c];
+    acc = __builtin_fmaf(d0, x0, acc); acc = __builtin_fmaf(d1, x1, acc); acc = __builtin_fmaf(d2, x2, acc); acc = __builtin_fmaf(d3, x3, acc);
+  }
+  for (; b < B; ++b) acc = __builtin_fmaf(dy[(long)b * dy_bs + m], x[(long)b * x_bs + c], acc);
+  dw[i] = acc;
+}
+int ssv_launch_linear_len1_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, int B, int K, int M, hipStream_t st) {
+  hipLaunchKernelGGL(linear_len1_wgrad_kernel, dim3(ssv_cdiv((long)M * K, 256)), dim3(256), 0, st, dy, dy_bs, x, x_bs, dw, B, K, M);
+  return ssv_check_launch("linear_len1_wgrad");
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = v;

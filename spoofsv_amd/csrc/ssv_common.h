@@ -130,6 +130,9 @@ int ssv_launch_reduce_pair(const float* slabs, float* out, int M, int Nc, int KT
 int ssv_launch_reduce_pair_multi(const ssv_wgrad_job* jobs, int njobs, const float* slabs, int M, int Nc, int KT, int Z, int n2, int nblk, hipStream_t st);
 int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hipStream_t st);
 int ssv_launch_fill(float* p, float v, long n, hipStream_t st);
+int ssv_launch_linear_len1_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b, long sbb, float* y, long y_bs,
+                               int B, int K, int M, hipStream_t st);
+int ssv_launch_linear_len1_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, int B, int K, int M, hipStream_t st);
 
 static inline int ssv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // Profiling aid (env SSV_SHAPE_LOG=<file>): every distinct (kernel, grid) a launcher issues is appended once as

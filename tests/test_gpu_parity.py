@@ -487,6 +487,25 @@ def test_deconv_k2s2_forward_backward_vs_float64_and_both_weight_gradient_routes
     assert torch.isnan(outs[1][1]).all()                      # dw = NULL: nothing written
 
 
+@pytest.mark.parametrize("B,K,M", [(32, 200, 256), (5, 70, 13), (40, 64, 8), (1, 3, 1), (33, 129, 257)])
+def test_linear_on_a_length_one_sequence_vs_float64(B, K, M):
+    """The speaker-code layers (`audioEncoder.fc1 / fc2`, models/TTSModel.py:148-151 and :159-160: nn.Linear on the (B, D) speaker code)
+    run as a 1x1 convolution over a length-1 sequence; below 256 (item, step) pairs that takes the two plain-fp32 kernels of
+    csrc/misc.hip (`linear_len1_*`).  Forward, weight, bias and input gradient against float64 at ragged shapes (K and M not
+    multiples of the 64 / 8 the kernels tile by, more than one block of 32 items)."""
+    from spoofsv_amd import ops
+    torch.manual_seed(B + K + M)
+    x0, w0, b0, dy0 = torch.randn(B, K, 1), torch.randn(M, K, 1) * 0.2, torch.randn(M) * 0.1, torch.randn(B, M, 1)
+    xr, wr, br = [v.double().requires_grad_(True) for v in (x0, w0, b0)]
+    yr = torch.nn.functional.conv1d(xr, wr, br)
+    yr.backward(dy0.double())
+    xg, wg, bg = [v.clone().to(DEV).requires_grad_(True) for v in (x0, w0, b0)]
+    yg = ops.conv1d(xg, wg, bg)
+    yg.backward(dy0.to(DEV))
+    for a, r, n in ((yg.detach(), yr.detach(), "y"), (xg.grad, xr.grad, "dx"), (wg.grad, wr.grad, "dw"), (bg.grad, br.grad, "db")):
+        assert rel_l2(a.cpu().double(), r) < 2e-6, (n, rel_l2(a.cpu().double(), r))
+
+
 @pytest.mark.parametrize("k,d", [(1, 1), (3, 1), (3, 3)])
 def test_conv1d_dd_second_order_vs_torch(k, d):
     """ops.conv1d_dd (forward / data-gradient / weight-gradient Functions that differentiate into each other) against
