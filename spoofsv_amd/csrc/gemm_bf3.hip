@@ -1902,6 +1902,16 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
 // price is the weight stream: every workgroup reads all of W (the row-tiled kernels re-read X instead).
 // Epilogue: pre = acc * us + bias (+ s[b]) is stored; column sums of a lane's rows -> the 4 row-quads of the wave (cross-row shuffles)
 // -> the 8 waves (LDS), mean, then the same for the squared deviations (a true two-pass variance, as ln_act_fwd_kernel); y = act(n).
+// Tuning builds only (-DSSV_PW_STAMP): thread 0 of every workgroup (the first 1024) records s_memrealtime at entry and exit and the shader
+// clock at six points (entry | first chunk staged | chunk loop done | pre stored + column sums | variance | y stored); ssv_debug_pw_stamps().
+#ifdef SSV_PW_STAMP
+__device__ unsigned long long ssv_pw_stamps[1024 * 8];
+extern "C" int ssv_debug_pw_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssv_pw_stamps), sizeof(ssv_pw_stamps)); }
+#define PW_STAMP(k) do { const unsigned w_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && w_ < 1024u) \
+    ssv_pw_stamps[w_ * 8 + (k)] = ((k) >= 6) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); } while (0)
+#else
+#define PW_STAMP(k) do {} while (0)
+#endif
 struct PwLn {
   GemmNNB g;                      // A planes, X, C = pre (B, M, N), bias, bias_b, f16 scales
   const float* gamma; const float* beta;
@@ -1925,6 +1935,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   const int kq = lane >> 4, nq = lane & 15;
   const int nchunks = p.Kpad / 32;
   const float* __restrict__ Xb = p.X + (long)b * p.sxb;
+  PW_STAMP(6); PW_STAMP(0);
 
   f32x4 acc[WMB][NT];
 #pragma unroll
@@ -2006,6 +2017,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   if constexpr (NSET == 2) {
     if (nchunks > 1) loadA(1, 1);
     __syncthreads();
+    PW_STAMP(1);
     for (int ch = 0; ch < nchunks; ch += 2) {
       tap(0, ch);
       if (ch + 1 >= nchunks) break;
@@ -2021,6 +2033,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
     }
   } else {
     __syncthreads();
+    PW_STAMP(1);
     for (int ch = 0; ch < nchunks; ++ch) {
       tap(0, ch);
       __builtin_amdgcn_sched_barrier(0);            // the re-load stays behind this chunk's MFMAs
@@ -2034,6 +2047,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   }
 
   // ---- epilogue: pre, LayerNorm over the M rows of every column, activation
+  PW_STAMP(2);
   const float us = F16 ? ssv_uniform(xinv * ainv) : 1.f;
   float* __restrict__ Cb = p.C + (long)b * p.scb;
   float* __restrict__ Yb = q.y + (long)b * q.ybs;
@@ -2076,6 +2090,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
     __syncthreads();
   };
   col_reduce(csum, 0);
+  PW_STAMP(3);
   const float invM = 1.f / (float)p.M;
   float mean[NT], qs[NT];
 #pragma unroll
@@ -2089,6 +2104,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
       for (int t = 0; t < NT; ++t) { const float d = rv ? acc[i][t][r] - mean[t] : 0.f; qs[t] += d * d; }
     }
   col_reduce(qs, 1);
+  PW_STAMP(4);
   float rstd[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) rstd[t] = rsqrtf(colv[1][t * 16 + nq] * invM + 1e-5f);
@@ -2116,6 +2132,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
         if (gn < p.N) { Yb[(long)gm * p.N + gn] = n; am = fmaxf(am, fabsf(n)); }
       }
     }
+  PW_STAMP(5); PW_STAMP(7);
   if (q.y_amax) {                         // one entry per column tile, the rest of the item's list zeroed by the last tile
     am = ssv_wg_max<8>(am, amx);
     if (tid == 0) {
