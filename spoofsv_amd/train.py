@@ -624,6 +624,8 @@ class TrainStep:
 
     def prepare(self):
         self.stepper.prepare()
+        if self.defer is not None:
+            self.defer.finish_uploads()
         return self
 
     def __call__(self, *batch):
@@ -737,6 +739,8 @@ class AdversarialGraphStep:
             self.g_stepper.warmup = self.d_stepper.warmup = 0
             self.g_stepper.prepare()
             self.d_stepper.prepare()
+            if self.defer is not None:
+                self.defer.finish_uploads()
 
     def _forward(self):
         if self.kind == "text2mel":
