@@ -7,9 +7,14 @@
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ s, float* __restrict__ out, long n, int Z, long stride) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float acc = 0.f;
-  for (int z = 0; z < Z; ++z) acc += s[(long)z * stride + i];
-  out[i] = acc;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};                         // four slabs in flight
+  int z = 0;
+  for (; z + 3 < Z; z += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] += s[(long)(z + u) * stride + i];
+  }
+  for (; z < Z; ++z) a[0] += s[(long)z * stride + i];
+  out[i] = (a[0] + a[1]) + (a[2] + a[3]);
 }
 int ssv_launch_reduce_slabs(const float* slabs, float* out, long n, int Z, long stride, hipStream_t st) {
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, st, slabs, out, n, Z, stride);
@@ -27,11 +32,16 @@ __device__ __forceinline__ void reduce_perm_block(const float* __restrict__ s, f
   const long q = (long)block * 256 + threadIdx.x;
   if (KT == 1) {
     if (q >= P) return;
-    float a0 = 0.f, a1 = 0.f;
+    float a[8];                                               // eight slabs in flight (two before: Z / 2 memory round trips in a row, Z = 16 .. 32 for the k = 1 layers)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
     int z = 0;
-    for (; z + 1 < Z; z += 2) { a0 += s[(long)z * n + q]; a1 += s[(long)(z + 1) * n + q]; }
-    if (z < Z) a0 += s[(long)z * n + q];
-    out[q] = a0 + a1;
+    for (; z + 7 < Z; z += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += s[(long)(z + u) * n + q];
+    }
+    for (; z < Z; ++z) a[0] += s[(long)z * n + q];
+    out[q] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     return;
   }
   if (q < P) {

@@ -939,29 +939,41 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd2_kernel(
 }
 
 // Sum the per-workgroup partial rows part[blk][n] in two levels, in a fixed order (bitwise reproducible).
+#ifndef SSV_RED_ROWS
+#define SSV_RED_ROWS 32
+#endif
 // Level 1: workgroup (x, y) folds rows y, y+RED_ROWS, ... into row y IN PLACE (every element of row y is read
 // and written by the same thread, so no other workgroup touches it).  Level 2: out[i] = sum of rows 0..RED_ROWS-1.
-#define RED_ROWS 64
+#define RED_ROWS SSV_RED_ROWS
+// (eight rows in flight per thread and trip at both levels: with two / four these launches were chains of 5 + 16 memory round trips --
+//  11 + 6.4 us per use, eleven uses per training step)
 __global__ __launch_bounds__(256) void reduce_partials_l1_kernel(float* __restrict__ part, int n, int nblk) {
   const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (i >= n || y >= nblk) return;
-  float s0 = 0.f, s1 = 0.f;
+  float s[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s[q] = 0.f;
   int k = y;
-  for (; k + RED_ROWS < nblk; k += 2 * RED_ROWS) { s0 += part[(long)k * n + i]; s1 += part[(long)(k + RED_ROWS) * n + i]; }
-  if (k < nblk) s0 += part[(long)k * n + i];
-  part[(long)y * n + i] = s0 + s1;
+  for (; k + 7 * RED_ROWS < nblk; k += 8 * RED_ROWS) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] += part[(long)(k + q * RED_ROWS) * n + i];
+  }
+  for (; k < nblk; k += RED_ROWS) s[0] += part[(long)k * n + i];
+  part[(long)y * n + i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 __global__ __launch_bounds__(256) void reduce_partials_l2_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int rows) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s[q] = 0.f;
   int k = 0;
-  for (; k + 3 < rows; k += 4) {
-    s0 += part[(long)k * n + i]; s1 += part[(long)(k + 1) * n + i];
-    s2 += part[(long)(k + 2) * n + i]; s3 += part[(long)(k + 3) * n + i];
+  for (; k + 7 < rows; k += 8) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] += part[(long)(k + q) * n + i];
   }
-  for (; k < rows; ++k) s0 += part[(long)k * n + i];
-  out[i] = (s0 + s1) + (s2 + s3);
+  for (; k < rows; ++k) s[0] += part[(long)k * n + i];
+  out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 // One launch for moderate block counts: a workgroup owns 32 outputs; its 8 row groups each fold rows rg, rg+8, ... and
 // the eight sums are combined through LDS in a fixed order.

@@ -1130,5 +1130,16 @@ def spec_losses(y, gt):
     return out[0], out[1]
 
 
+def spec_losses_vec(y, gt):
+    """(l1, binary divergence) as ONE 2-vector: a training step seeds its backward with a constant gradient vector for it instead of
+    summing two selected scalars (each select's backward is a zeros + a scatter + an add of two 2-vectors: tiny launches in a row between
+    the end of the forward and the start of the backward)."""
+    return SpecLossFn.apply(y, gt)
+
+
+def guided_att_loss_vec(a, gaw):
+    return GuidedAttLossFn.apply(a, gaw)
+
+
 def guided_att_loss(a, gaw):
     return GuidedAttLossFn.apply(a, gaw)[0]

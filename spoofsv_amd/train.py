@@ -568,6 +568,7 @@ class TrainStep:
         self.static = [b.clone() for b in batch] if (graph and batch is not None) else None
         self.batch = self.static if self.static is not None else batch
         self.out = self.att = None
+        self._seeds = {}              # (entries, value, device) -> constant gradient vector that seeds the backward
         self.loss_log = None          # a list: receives the loss terms of every EAGERLY executed iteration (warm-up; not replays)
         seg = ddp is not None and ddp.arena is not None
         if graph and ddp is not None and not seg:
@@ -596,24 +597,36 @@ class TrainStep:
         if self.defer is not None:
             self.defer.begin_step()
         scale = self.ddp.grad_scale if (self.ddp is not None and self.ddp.arena is not None) else 1.0
-        seed = lambda t: (t, torch.full_like(t, scale))
+        # The loss terms stay the vectors the loss kernels wrote -- (l1, bd) and (att) -- and the backward is seeded with CONSTANT gradient
+        # vectors for them (made once, outside any capture): summing selected scalars put ~7 launches of a few microseconds each
+        # (select backward: zeros + scatter, adds, the seed's fill) in a row between the forward's last kernel and the backward's first.
+        def seed(v):
+            key = (v.numel(), float(scale), v.device)
+            g = self._seeds.get(key)
+            if g is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("TrainStep: run one eager iteration before capturing (the backward's seed vectors are made then)")
+                g = self._seeds[key] = torch.full((v.numel(),), float(scale), dtype=v.dtype, device=v.device)
+            return (v, g)
         if self.kind == "text2mel":
             mel, text, spk = self.batch
             with _cuts_installed(self.model, self.cuts):
                 pred, att = self.model(shift_right(mel), text, spk)
-            l1, bd, la = text2mel_losses(pred, att, mel, self.gaw)
-            self.out, self.att = (l1.detach(), bd.detach(), la.detach()), att.detach()
+            lv, av = ops.spec_losses_vec(pred, mel), ops.guided_att_loss_vec(att, self.gaw)
+            lvd, avd = lv.detach(), av.detach()
+            self.out, self.att = (lvd[0], lvd[1], avd[0]), att.detach()
             if "dec_in" in self.cuts.rec:
-                segs = backward_segments(self.cuts, [seed(l1 + bd)], {"dec_in": [seed(la)]}, self.ddp, self.defer)
+                segs = backward_segments(self.cuts, [seed(lv)], {"dec_in": [seed(av)]}, self.ddp, self.defer)
             else:
-                segs = backward_segments(self.cuts, [seed(l1 + bd + la)], None, self.ddp, self.defer)
+                segs = backward_segments(self.cuts, [seed(lv), seed(av)], None, self.ddp, self.defer)
         else:
             mel, lin = self.batch
             with _cuts_installed(self.model, self.cuts):
                 pred = self.model(mel)
-            l1, bd = ops.spec_losses(pred, lin)
-            self.out = (l1.detach(), bd.detach())
-            segs = backward_segments(self.cuts, [seed(l1 + bd)], None, self.ddp, self.defer)
+            lv = ops.spec_losses_vec(pred, lin)
+            lvd = lv.detach()
+            self.out = (lvd[0], lvd[1])
+            segs = backward_segments(self.cuts, [seed(lv)], None, self.ddp, self.defer)
         self._segs = segs
         if self.loss_log is not None and not torch.cuda.is_current_stream_capturing():
             self.loss_log.append(torch.stack([o.reshape(()) for o in self.out]).clone())
