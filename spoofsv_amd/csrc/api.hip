@@ -158,7 +158,13 @@ static GemmNT nt_zero() {
 // ---- Conv1d ----------------------------------------------------------------------------------------
 static inline int pad32(int n) { return (n + 31) & ~31; }
 static inline size_t split_bytes(int rows, int K, int k) { return align256((size_t)k * ((rows + 15) / 16 * 16) * pad32(K) * sizeof(unsigned short)); }
-static inline bool use_bf3(int B, int L, int Cin, int Cout) { return ssv_precision() >= 1 && (long)B * L >= 128 && Cin >= 8 && Cout >= 16; }
+// Channel counts below 32 (the tail of the WGAN-GP critics: 64 -> 16 -> 8 -> 1 channels, models/discriminator.py:31-38) take the exact-fp32
+// kernels in all three products of a convolution: such a launch is 5 us either way, and the split-MFMA path would need a scale list per
+// operand -- one ssv_absmax launch each for tensors whose producers (pooling, dropout, second-order LayerNorm) emit none (ops._tiny_conv).
+#define SSV_MIN_SPLIT_CHANNELS 32
+static inline bool use_bf3(int B, int L, int Cin, int Cout) {
+  return ssv_precision() >= 1 && (long)B * L >= 128 && Cin >= SSV_MIN_SPLIT_CHANNELS && Cout >= SSV_MIN_SPLIT_CHANNELS;
+}
 static inline bool use_f16() { return ssv_precision() == 2; }
 
 // ---- split-fp16 operand scales (ssv_common.h, "split-fp16") ------------------------------------------------------------
@@ -408,7 +414,7 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
   if (Z == 1) { g.C = dw; g.scz = n; g.scm = (long)Cin * k; g.scc = k; g.scj = 1; }
   else { g.C = (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = 1; g.scj = Cin; }     // slabs [z][m][j][c]
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
-  if (ssv_precision() >= 1 && (long)B * L >= 256 && ssv_nt_bf3_fits(g)) {
+  if (ssv_precision() >= 1 && (long)B * L >= 256 && Cin >= SSV_MIN_SPLIT_CHANNELS && Cout >= SSV_MIN_SPLIT_CHANNELS && ssv_nt_bf3_fits(g)) {
     if (use_f16()) {
       float* fb = (float*)((char*)ws + bwd_weight_main(B, Cin, Cout, L, k));
       AmaxList la, lx;
@@ -433,7 +439,7 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
 // ---- several equal-shaped weight gradients in one launch (see include/ssv_hip.h) ------------------------------------------
 extern "C" int ssv_conv_shifts(int k, int dilation, int causal, int* shift3) { return conv_shifts(k, dilation, causal, shift3); }
 extern "C" int ssv_conv1d_bwd_weight_multi_ok(int B, int Cin, int Cout, int L, int k) {
-  if (ssv_precision() < 1 || (k != 1 && k != 3) || (long)B * L < 256 || L < 8) return 0;
+  if (ssv_precision() < 1 || (k != 1 && k != 3) || (long)B * L < 256 || L < 8 || Cin < SSV_MIN_SPLIT_CHANNELS || Cout < SSV_MIN_SPLIT_CHANNELS) return 0;
   GemmNT g = nt_zero();
   g.sab = (long)Cout * L; g.sam = L; g.La = L; g.sxb = (long)Cin * L; g.sxc = L; g.Lx = L;
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = 1; g.bstep = 1;

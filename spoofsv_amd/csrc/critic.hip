@@ -58,13 +58,20 @@ extern "C" int ssv_act_dropout_fwd(const float* x, float* y, float* d, long n, f
   return 0;
 }
 // y = x * d (the backward of the op above, and the backward of that)
+// (four elements per thread as one 16-byte access when the three pointers allow it: 32 launches per pair of critic iterations, most of
+//  them over 10 M elements, ran one 4-byte element per thread)
 __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ x, const float* __restrict__ d, float* __restrict__ y, long n) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) y[i] = x[i] * d[i];
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n && ((((size_t)x) | ((size_t)d) | ((size_t)y)) & 15) == 0) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i), b = *reinterpret_cast<const f32x4*>(d + i);
+    *reinterpret_cast<f32x4*>(y + i) = a * b;
+  } else {
+    for (long e = i; e < n && e < i + 4; ++e) y[e] = x[e] * d[e];
+  }
 }
 extern "C" int ssv_mul(const float* x, const float* d, float* y, long n, ssv_stream_t stream) {
   SSV_CHECK(x && d && y && n > 0, SSV_BAD_SHAPE, "mul: bad argument");
-  hipLaunchKernelGGL(mul_kernel, dim3(ssv_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, d, y, n);
+  hipLaunchKernelGGL(mul_kernel, dim3(ssv_cdiv(ssv_cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, x, d, y, n);
   return ssv_check_launch("mul");
 }
 

@@ -449,8 +449,16 @@ class Conv1dFn(torch.autograd.Function):
 # Split-fp16 operand scales (``*_amax``: the tensor's scale list or None): every tensor that enters these Functions as a GEMM
 # operand has its list computed ONCE (``_dd_amax``: the producer's tag or one ssv_absmax launch) and handed to every product that
 # reads it -- x serves the forward and the weight gradient, dy both gradients -- instead of one fallback launch per product.
-def _dd_amax(t):
-    return amax_of(t) if (t is not None and _f16() and _bf3_shape(t)) else None
+def _tiny_conv(cin, cout):
+    """Mirrors SSV_MIN_SPLIT_CHANNELS of csrc/api.hip: a convolution with fewer than 32 input or output channels runs all three of its
+    products on the exact-fp32 kernels, which read no scale lists."""
+    return min(int(cin), int(cout)) < 32
+
+
+def _dd_amax(t, cin=None, cout=None):
+    if t is None or not (_f16() and _bf3_shape(t)) or (cin is not None and _tiny_conv(cin, cout)):
+        return None
+    return amax_of(t)
 
 
 _INPUT_ONLY = False
@@ -491,7 +499,7 @@ class ConvFwdDD(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         k, dilation, causal, has_bias = ctx.cfg
-        dya = _dd_amax(dy)
+        dya = _dd_amax(dy, x.shape[1], w.shape[0])
         dx = ConvBwdDataDD.apply(dy, w, x.shape[1], k, dilation, causal, dya) if ctx.needs_input_grad[0] else None
         if _INPUT_ONLY:                       # (input_grads_only: the gradient penalty's first pass)
             return dx, None, None, None, None, None, None
@@ -535,7 +543,7 @@ class ConvBwdDataDD(torch.autograd.Function):
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
         k, dilation, causal = ctx.cfg
-        xa = _dd_amax(ddx)
+        xa = _dd_amax(ddx, w.shape[1], w.shape[0])
         g_dy = ConvFwdDD.apply(ddx, w, None, k, dilation, causal, xa) if ctx.needs_input_grad[0] else None
         g_w = ConvBwdWeightDD.apply(dy, ddx, k, dilation, causal, ctx.dy_amax, xa) if ctx.needs_input_grad[1] else None
         return g_dy, g_w, None, None, None, None, None
@@ -565,7 +573,7 @@ class ConvBwdWeightDD(torch.autograd.Function):
 
 def conv1d_dd(x, w, bias=None, k=1, dilation=1, causal=False):
     """Conv1d (kernel 1 or 3) differentiable to any order on the HIP kernels; the bias is added in the kernel's epilogue."""
-    return ConvFwdDD.apply(x, w, bias, k, dilation, bool(causal), _dd_amax(x))
+    return ConvFwdDD.apply(x, w, bias, k, dilation, bool(causal), _dd_amax(x, w.shape[1], w.shape[0]))
 
 
 # ------------------------------------------------------------------------------------------- critics: dropout / leaky-ReLU / pooling / penalty
