@@ -189,37 +189,34 @@ int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hip
 // ---- 1x1 convolution over a length-1 sequence (= nn.Linear on a (B, K) matrix: the speaker-code layers audioEncoder.fc1 / fc2,
 // models/TTSModel.py:148-151, 159-160).  The tiled GEMM kernels spend a serial chain of per-item round trips on these 3 MFLOP
 // (forward 21 us, weight gradient 44 us per launch in-step); plain fp32 dot products from LDS take a few microseconds.
-//   y(b, m) = sum_c w(m, c) x(b, c) + bias(m) + bias_b(b, m):  a workgroup owns 8 rows m and up to 32 items b, K in chunks of 64.
+//   y(b, m) = sum_c w(m, c) x(b, c) + bias(m) + bias_b(b, m):  a thread per output, m fastest (x is one address per item, w a row per lane
+//   read 16 bytes at a time and served by the cache: 205 KB in all), four independent partial sums.
+//   (First form: 8 x 32 outputs per workgroup with w and x staged in LDS in chunks of 64 -- 32 workgroups, four load / barrier round trips
+//   each: 23.7 us per launch in-step against 21 us for the tiled GEMM it replaced.)
 __global__ __launch_bounds__(256) void linear_len1_fwd_kernel(const float* __restrict__ x, long x_bs, const float* __restrict__ w, const float* __restrict__ bias,
                                                               const float* __restrict__ bias_b, long sbb, float* __restrict__ y, long y_bs, int B, int K, int M) {
-  __shared__ float ws[8][65], xs[32][65];
-  const int tid = threadIdx.x, bl = tid & 31, mi = tid >> 5;
-  const int m0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
-  float acc = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 64) {
-    __syncthreads();
-    for (int e = tid; e < 8 * 64; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      ws[r][c] = (m0 + r < M && k0 + c < K) ? w[(long)(m0 + r) * K + k0 + c] : 0.f;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)B * M) return;
+  const int m = (int)(t % M), b = (int)(t / M);
+  const float* __restrict__ wr = w + (long)m * K;
+  const float* __restrict__ xr = x + (long)b * x_bs;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int k = 0;
+  if ((K & 3) == 0 && (((size_t)w | (size_t)x) & 15) == 0 && (x_bs & 3) == 0) {
+    for (; k + 3 < K; k += 4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k), xv = *reinterpret_cast<const f32x4*>(xr + k);
+      a0 = __builtin_fmaf(wv[0], xv[0], a0); a1 = __builtin_fmaf(wv[1], xv[1], a1); a2 = __builtin_fmaf(wv[2], xv[2], a2); a3 = __builtin_fmaf(wv[3], xv[3], a3);
     }
-    for (int e = tid; e < 32 * 64; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      xs[r][c] = (b0 + r < B && k0 + c < K) ? x[(long)(b0 + r) * x_bs + k0 + c] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 16
-    for (int c = 0; c < 64; ++c) acc = __builtin_fmaf(ws[mi][c], xs[bl][c], acc);
   }
-  const int m = m0 + mi, b = b0 + bl;
-  if (m < M && b < B) {
-    if (bias) acc += bias[m];
-    if (bias_b) acc += bias_b[(long)b * sbb + m];
-    y[(long)b * y_bs + m] = acc;
-  }
+  for (; k < K; ++k) a0 = __builtin_fmaf(wr[k], xr[k], a0);
+  float acc = (a0 + a1) + (a2 + a3);
+  if (bias) acc += bias[m];
+  if (bias_b) acc += bias_b[(long)b * sbb + m];
+  y[(long)b * y_bs + m] = acc;
 }
 int ssv_launch_linear_len1_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b, long sbb, float* y, long y_bs,
                                int B, int K, int M, hipStream_t st) {
-  hipLaunchKernelGGL(linear_len1_fwd_kernel, dim3(ssv_cdiv(M, 8), ssv_cdiv(B, 32)), dim3(256), 0, st, x, x_bs, w, bias, bias_b, sbb, y, y_bs, B, K, M);
+  hipLaunchKernelGGL(linear_len1_fwd_kernel, dim3(ssv_cdiv((long)B * M, 256)), dim3(256), 0, st, x, x_bs, w, bias, bias_b, sbb, y, y_bs, B, K, M);
   return ssv_check_launch("linear_len1_fwd");
 }
 //   dw(m, c) = sum_b dy(b, m) x(b, c): a thread per entry, c fastest (x coalesced, dy one address per 64 lanes or two).
