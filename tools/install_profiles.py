@@ -8,8 +8,8 @@ d = json.loads(open('gpurun_out/r4/bench_full.json').read().strip().splitlines()
 hdr = ("# Round 4 (final), MI355X (gfx950), split-fp16 arithmetic (the default): `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ge2e --no-adversarial\n"
        "# --no-fp32 --no-roofline` under rocprofv3 (tools/profile_round4.sh): (1) --kernel-trace --stats, with the library's shape log (SSV_SHAPE_LOG) giving\n"
        "# the algorithmic FLOP / bytes of every launch shape -> \"achieved\" and \"frac\" of the roof per (kernel, grid); (2) --pmc FETCH_SIZE and (3) --pmc WRITE_SIZE\n"
-       "# in separate passes; (4) one SQ pass with the MFMA-busy column.  Profiled runs hold a lower clock than un-profiled ones (%.1f ms per step here, %.1f\n"
-       "# un-profiled on the same box, profiles/round4_bench_line.json): compare rows of this file with each other, not with bench.py's wall clock.\n"
+       "# in separate passes; (4) one SQ pass with the MFMA-busy column.  Profiled runs hold a lower clock than un-profiled ones, and boxes differ by +-4 %% (%.1f ms per step here; the\n"
+       "# un-profiled line profiles/round4_bench_line.json, %.1f ms, was taken in a later call, possibly on another box): compare rows of this file with each other, not with bench.py's wall clock.\n"
        "# Summary by tools/summarize_prof.py.\n" % (ms, d['ms_per_step']))
 open('profiles/round4_bench_kernel_stats.txt', 'w').write(hdr + open(R + '/bench_f16x2.txt').read())
 adv_h = ("# Round 4 (final), MI355X: the WGAN-GP cycle of train_ssrn --adversarial (1 G + 5 D iterations, B = 32, hipGraph replay), split-fp16 arithmetic:\n"
