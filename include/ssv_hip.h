@@ -153,8 +153,13 @@ int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int Cout, int 
 size_t ssv_conv1d_bwd_weight_multi_workspace(int njobs, int B, int Cin, int Cout, int L, int k);
 int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int njobs, long dy_bs, long x_bs, int B, int Cin, int Cout, int L, int k, int max_shift,
                                 int n2, int nblk, void* ws, size_t ws_bytes, ssv_stream_t stream);
-/* highwayConv backward without the weight gradient: dx, plus dh (B,2C,L) dense and part (ssv_ln_partial_rows(B,L), 6C) for the job. */
+/* highwayConv backward without the weight gradient: dx, plus dh (B,2C,L) dense and the partial rows `part` for the job.
+ * `part` has room for ssv_ln_partial_rows(B, L) rows (of 6C floats; 3 Cout for the pointwise entry); the launch WRITES the first
+ * ssv_ln_bwd_partial_rows(gate, B, C, L, with_amax) of them -- one per column tile of the kernel it picks for the shape (gate = 1: highway
+ * gate over C channels, 0: LayerNorm + activation over C = Cout channels; with_amax = whether the call passes a scale-list output) -- and
+ * that count is the `nblk` of the job (the rest of the buffer is not read). */
 int ssv_ln_partial_rows(int B, int L);
+int ssv_ln_bwd_partial_rows(int gate, int B, int C, int L, int with_amax);
 size_t ssv_highway_conv1d_bwd_data_workspace(int B, int C, int L, int k);
 int ssv_highway_conv1d_bwd_data(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
                                 const float* g1, const float* b1, const float* g2, const float* b2, const float* h, const float* stats,

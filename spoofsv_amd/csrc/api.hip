@@ -101,6 +101,8 @@ extern "C" const char* ssv_last_error(void) { return g_err; }
 int ssv_launch_ln_gate_fwd(const float*, long, const float*, long, const float*, const float*, const float*, const float*, float*, long, float*, int, int, int, hipStream_t, float* = nullptr);
 int ssv_launch_ln_gate_bwd(const float*, long, const float*, const float*, long, const float*, const float*, const float*, const float*, const float*, float*, float*, long, float*, float*, int, int, int, hipStream_t, float* = nullptr);
 int ssv_ln_gate_bwd_nblk(int B, int L);
+int ssv_ln_gate_bwd_rows(int B, int C, int L, bool has_amax);      // partial rows the backward launch of this shape writes (norm.hip)
+int ssv_ln_act_bwd_rows(int B, int C, int L, bool has_amax);
 int ssv_launch_ln_gate_fwd_stream(const float* H, const float* X, long x_bs, const float* colstats, const float* g1, const float* b1, const float* g2, const float* b2,
                                   float* Y, long y_bs, float* stats, float* amax, int B, int C, int L, hipStream_t st);
 int ssv_launch_ln_bwd2(const float*, long, const float*, long, const float*, long, const float*, const float*, float*, long, float*, long, float*, float*, int, int, int, hipStream_t);
@@ -580,7 +582,7 @@ extern "C" int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const 
   if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, da, dn, w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, base + s.wt, s.slabs - s.wt, stream));
   if (ds) SSV_TRY(ssv_rowsum(dpre, pbs, ds, B, Cout, L, stream));               // gradient of the broadcast (B, Cout, 1) term
   return conv1d_bwd_weight_impl(dpre, pbs, x, x_bs, dw, B, Cin, Cout, L, 1, 1, 0, base + s.slabs, s.total - s.slabs, stream,
-                                (const float*)(base + s.part), pgrads, 3 * Cout, ssv_ln_gate_bwd_nblk(B, L), da, dn, x_amax, x_namax);
+                                (const float*)(base + s.part), pgrads, 3 * Cout, ssv_ln_act_bwd_rows(B, Cout, L, da != nullptr), da, dn, x_amax, x_namax);
 }
 
 // ---- second order (gradient penalty through the critics) and the gate forward alone ------------------------------------
@@ -652,10 +654,13 @@ extern "C" int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* 
   // dx += conv^T(dH)
   SSV_TRY(ssv_conv1d_bwd_data(dH, (long)2 * C * L, da, dn, w, w_packed, dx, dx, dx_bs, B, C, 2 * C, L, k, dilation, causal, base + s.wt, s.slabs - s.wt, stream));
   return conv1d_bwd_weight_impl(dH, (long)2 * C * L, x, x_bs, dw, B, C, 2 * C, L, k, dilation, causal, base + s.slabs, s.total - s.slabs, stream,
-                                (const float*)(base + s.part), pgrads, 6 * C, ssv_ln_gate_bwd_nblk(B, L), da, dn, x_amax, x_namax);
+                                (const float*)(base + s.part), pgrads, 6 * C, ssv_ln_gate_bwd_rows(B, C, L, da != nullptr), da, dn, x_amax, x_namax);
 }
 
 extern "C" int ssv_ln_partial_rows(int B, int L) { return ssv_ln_gate_bwd_nblk(B, L); }
+extern "C" int ssv_ln_bwd_partial_rows(int gate, int B, int C, int L, int with_amax) {
+  return gate ? ssv_ln_gate_bwd_rows(B, C, L, with_amax != 0) : ssv_ln_act_bwd_rows(B, C, L, with_amax != 0);
+}
 extern "C" size_t ssv_highway_conv1d_bwd_data_workspace(int B, int C, int L, int k) { (void)B; (void)L; return ssv_conv1d_bwd_data_workspace(C, 2 * C, k); }
 extern "C" int ssv_highway_conv1d_bwd_data(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, const void* w_packed,
                                            const float* g1, const float* b1, const float* g2, const float* b2, const float* h, const float* stats,

@@ -367,8 +367,10 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_kernel(
 // thread, landing IN the arrays that later hold xhat / a), rows are read by raw buffer loads whose range is the batch item (no clamps, no
 // branches: a piece past the item's end reads 0, columns past L are masked at use).
 // Cross-group sums: 64 groups -> LDS [64][4 sums][16 VEC columns], summed in a fixed order by the first 64 * VEC threads.
-// Partial rows / scale-list entries keep the 16-column kernels' numbering: tile bx owns rows VEC * bx .. VEC * bx + VEC - 1 of the item's
-// ceil(L / 16) rows (the first carries the tile's sums, the others are zeroed) and entries likewise.
+// Partial rows are COMPACT: one row per tile, gridDim.x rows per item (ssv_ln_gate_bwd_rows / ssv_ln_act_bwd_rows tell the callers how many
+// rows a launch writes; until the round-4 second session a tile also zeroed VEC - 1 rows of the 16-column numbering, which every reduction
+// then read: 2,624 rows for 672 at L = 1300).  Scale-list entries keep the 16-column numbering: tile bx owns entries VEC * bx .. VEC * bx +
+// VEC - 1 of the item's list (the first carries the tile's maximum, the others are zeroed).
 template <int CPT, int VEC>
 __global__ __launch_bounds__(1024) void ln_gate_bwd_wide_kernel(
     const float* __restrict__ dY, long dy_bs, const float* __restrict__ H, const float* __restrict__ X, long x_bs,
@@ -416,8 +418,7 @@ __global__ __launch_bounds__(1024) void ln_gate_bwd_wide_kernel(
     const float* sb = stats + (long)b * 4 * L + min(t + j, L - 1);
     mu1[j] = sb[0]; r1[j] = sb[L]; mu2[j] = sb[2L * L]; r2[j] = sb[3L * L];
   }
-  const int nrow16 = (L + 15) >> 4;
-  float* pblk = part + ((long)by * nrow16 + (long)VEC * bx) * 6 * C;          // this tile's first partial row (16-column numbering)
+  float* pblk = part + ((long)by * gridDim.x + bx) * 6 * C;                    // this tile's partial row: one per tile, compact (ssv_ln_gate_bwd_rows)
   float sa1[VEC], sah1[VEC], sa2[VEC], sah2[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) sa1[j] = sah1[j] = sa2[j] = sah2[j] = 0.f;
@@ -495,12 +496,6 @@ __global__ __launch_bounds__(1024) void ln_gate_bwd_wide_kernel(
     }
     q0 = col_sum(q0); q1 = col_sum(q1);
     if (cq == 0 && cok) { pblk[4 * C + c] = q0; pblk[5 * C + c] = q1; }
-  }
-  // the other partial rows of this tile's columns (16-column numbering) carry nothing
-  for (int r = 1; r < VEC; ++r) {
-    if (VEC * bx + r >= nrow16) break;
-    float* z = pblk + (long)r * 6 * C;
-    for (int e = threadIdx.x; e < 6 * C; e += 1024) z[e] = 0.f;
   }
   if (amax) {
     am = ssv_wg_max<16>(am, amx);
@@ -685,8 +680,7 @@ __global__ __launch_bounds__(1024) void ln_act_bwd_wide_kernel(
   float mu[VEC], r[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { const float* sb = stats + (long)b * 2 * L + min(t + j, L - 1); mu[j] = sb[0]; r[j] = sb[L]; }
-  const int nrow16 = (L + 15) >> 4;
-  float* pblk = part + ((long)by * nrow16 + (long)VEC * bx) * 3 * C;
+  float* pblk = part + ((long)by * gridDim.x + bx) * 3 * C;                    // one partial row per tile, compact (ssv_ln_act_bwd_rows)
   float sa[VEC], sah[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) sa[j] = sah[j] = 0.f;
@@ -745,11 +739,6 @@ __global__ __launch_bounds__(1024) void ln_act_bwd_wide_kernel(
     }
     q0 = col_sum(q0);
     if (cq == 0 && cok) pblk[2 * C + c] = q0;
-  }
-  for (int rr = 1; rr < VEC; ++rr) {
-    if (VEC * bx + rr >= nrow16) break;
-    float* z = pblk + (long)rr * 3 * C;
-    for (int e = threadIdx.x; e < 3 * C; e += 1024) z[e] = 0.f;
   }
   if (amax) {
     am = ssv_wg_max<16>(am, amx);
@@ -1060,7 +1049,23 @@ int ssv_launch_ln_gate_fwd(const float* H, long h_bs, const float* X, long x_bs,
   return ssv_check_launch("ln_gate_fwd");
 }
 
-int ssv_ln_gate_bwd_nblk(int B, int L) { return B * ssv_cdiv(L, 16); }
+int ssv_ln_gate_bwd_nblk(int B, int L) { return B * ssv_cdiv(L, 16); }      // upper bound of the partial rows a backward launch writes (buffer sizes)
+// Columns per tile / 16 of the backward launch for this shape (1: the 16-column kernels; 2 or 4: the wide-tile kernels), and the partial rows it
+// writes -- one per tile, compact.  The ONE place the choice is made: the launchers and every caller that sums the rows ask here.
+// wide tiles (see ln_gate_bwd_wide_kernel), measured in-step against the 16-column kernel (round 4, B = 32): C = 512: L = 186 -21 %, L = 1300
+// -11.5 %; C = 256: L = 1300 -13.6 %, L = 325 and 650 equal (192 / 352 workgroups of 1024 threads leave CUs idle: the 16-column kernel stays)
+int ssv_ln_gate_bwd_vec(int C, int L, bool has_amax) {
+  if (C <= 512 && C % 64 == 0 && C >= 128 && (C > 256 ? L >= 64 : L >= 1024) && (long)2 * C * L * 4 < (1L << 31) &&
+      (!has_amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 16)))
+    return C <= 256 ? 4 : 2;
+  return 1;
+}
+int ssv_ln_act_bwd_vec(int C, int L, bool has_amax) {
+  if (C > 256 && C <= 576 && L >= 64 && (long)C * L * 4 < (1L << 31) && (!has_amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 16))) return 4;
+  return 1;
+}
+int ssv_ln_gate_bwd_rows(int B, int C, int L, bool has_amax) { return B * ssv_cdiv(L, 16 * ssv_ln_gate_bwd_vec(C, L, has_amax)); }
+int ssv_ln_act_bwd_rows(int B, int C, int L, bool has_amax) { return B * ssv_cdiv(L, 16 * ssv_ln_act_bwd_vec(C, L, has_amax)); }
 
 int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const float* X, long x_bs, const float* stats,
                            const float* g1, const float* b1, const float* g2, const float* b2, float* dH, float* dXres,
@@ -1070,10 +1075,8 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
 #define LN_BYTES 28.0
 #define CALL(N, G) hipLaunchKernelGGL((ln_gate_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L)
   if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
-  // wide tiles (see ln_gate_bwd_wide_kernel), measured in-step against the 16-column kernel (round 4, B = 32): C = 512: L = 186 -21 %, L = 1300
-  // -11.5 %; C = 256: L = 1300 -13.6 %, L = 325 and 650 equal (192 / 352 workgroups of 1024 threads leave CUs idle: the 16-column kernel stays)
-  if (C % 64 == 0 && C >= 128 && (C > 256 ? L >= 64 : L >= 1024) && (long)2 * C * L * 4 < (1L << 31) &&
-      (!amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 16))) {
+  const int vec = ssv_ln_gate_bwd_vec(C, L, amax != nullptr);
+  if (vec > 1) {
 #define WIDE(N, V) do { dim3 gw(ssv_cdiv(L, 16 * V), B); ln_log("ln_gate_bwd_wide_kernel", N, V, gw, LN_BYTES, B, C, L, 1024); \
       hipLaunchKernelGGL((ln_gate_bwd_wide_kernel<N, V>), gw, dim3(1024), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L); } while (0)
     if (C <= 128) WIDE(2, 4); else if (C <= 256) WIDE(4, 4); else WIDE(8, 2);
@@ -1085,7 +1088,7 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
 #undef LN_BYTES
   SSV_TRY(ssv_check_launch("ln_gate_bwd"));
   if (!pgrads) return 0;        // the caller sums the partial rows itself (fused with the weight-gradient slab sum)
-  return reduce_partials(part, pgrads, 6 * C, (int)(grid.x * grid.y), st);
+  return reduce_partials(part, pgrads, 6 * C, B * ssv_cdiv(L, 16 * vec), st);
 }
 
 int ssv_launch_ln_act_fwd(const float* X, long x_bs, const float* gam, const float* bet, float* Y, long y_bs, float* stats,
@@ -1108,7 +1111,8 @@ int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs
 #define LN_NAME "ln_act_bwd_kernel"
 #define LN_BYTES 12.0
 #define CALL(N, G) hipLaunchKernelGGL((ln_act_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, amax, C, L, act)
-  if (C > 256 && C <= 576 && L >= 64 && (long)C * L * 4 < (1L << 31) && (!amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 16))) {
+  const int vec = ssv_ln_act_bwd_vec(C, L, amax != nullptr);
+  if (vec > 1) {
 #define WIDE(N, V) do { dim3 gw(ssv_cdiv(L, 16 * V), B); ln_log("ln_act_bwd_wide_kernel", N, V, gw, LN_BYTES, B, C, L, 1024); \
       hipLaunchKernelGGL((ln_act_bwd_wide_kernel<N, V>), gw, dim3(1024), 0, st, dY, dy_bs, X, x_bs, stats, gam, bet, dX, dx_bs, part, amax, C, L, act); } while (0)
     if (C <= 512) WIDE(8, 4); else WIDE(9, 4);
@@ -1120,7 +1124,7 @@ int ssv_launch_ln_act_bwd(const float* dY, long dy_bs, const float* X, long x_bs
 #undef LN_BYTES
   SSV_TRY(ssv_check_launch("ln_act_bwd"));
   if (!pgrads) return 0;        // the caller sums the partial rows itself (fused with the weight-gradient slab sum)
-  return reduce_partials(part, pgrads, 3 * C, (int)(grid.x * grid.y), st);
+  return reduce_partials(part, pgrads, 3 * C, B * ssv_cdiv(L, 16 * vec), st);
 }
 
 // ---- second-order launchers (critics: at most 256 channels, 16 groups) ------------------------------------------------

@@ -283,11 +283,12 @@ class HighwayConvFn(torch.autograd.Function):
             f16 = _f16()
             dh_amax = _amax_out(B, L, x.device) if f16 else None
             x_amax = (ctx.x_amax if ctx.x_amax is not None else amax_of(x)) if f16 else None
+            rows = _lib.query("ssv_ln_bwd_partial_rows", 1, B, C, L, int(f16))          # the rows the gate backward writes (one per tile of its kernel)
             nb = _lib.query("ssv_highway_conv1d_bwd_data_workspace", B, C, L, k)
             ws = _ws(nb, x.device)
             _lib.call("ssv_highway_conv1d_bwd_data", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
                       _p(h), _p(stats), _p(dx), C * L, _p(dh), _p(dh_amax), _p(part), B, C, L, k, dilation, causal, _p(ws), nb, _stream())
-            _DEFER.add(dh, 2 * C * L, x, xbs, dw, part, pg, k, dilation, causal, 6 * C, nblk, dh_amax, x_amax)
+            _DEFER.add(dh, 2 * C * L, x, xbs, dw, part, pg, k, dilation, causal, 6 * C, rows, dh_amax, x_amax)
             return (dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3]) + (None,) * 5
         nb = _lib.query("ssv_highway_conv1d_bwd_workspace", B, C, L, k)
         ws = _ws(nb, x.device)
@@ -389,11 +390,12 @@ class PointwiseConvLnActFn(torch.autograd.Function):
             f16 = _f16()
             dpre_amax = _amax_out(B, L, x.device) if f16 else None
             x_amax = (ctx.x_amax if ctx.x_amax is not None else amax_of(x)) if f16 else None
+            rows = _lib.query("ssv_ln_bwd_partial_rows", 0, B, Cout, L, int(f16))
             nb = _lib.query("ssv_pointwise_conv_ln_act_bwd_data_workspace", B, Cin, Cout, L)
             ws = _ws(nb, x.device)
             _lib.call("ssv_pointwise_conv_ln_act_bwd_data", _p(dy), dybs, _p(w), resident.lookup(w), _p(gamma), _p(beta), _p(pre), _p(stats),
                       _p(dx), Cin * L, _p(ds), _p(dpre), _p(dpre_amax), _p(part), B, Cin, Cout, L, ctx.act, _p(ws), nb, _stream())
-            _DEFER.add(dpre, Cout * L, x, xbs, dw, part, pg, 1, 1, 0, 3 * Cout, nblk, dpre_amax, x_amax)
+            _DEFER.add(dpre, Cout * L, x, xbs, dw, part, pg, 1, 1, 0, 3 * Cout, rows, dpre_amax, x_amax)
             return dx, dw, pg[2], pg[0], pg[1], ds, None, None, None
         nb = _lib.query("ssv_pointwise_conv_ln_act_bwd_workspace", B, Cin, Cout, L)
         ws = _ws(nb, x.device)
