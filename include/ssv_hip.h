@@ -29,7 +29,8 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 3 (2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd) */
+int ssv_version(void);            /* ABI version, currently 4 (2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
+                                    4 = compact partial rows: the nblk of a weight-gradient job is ssv_ln_bwd_partial_rows(...), not ssv_ln_partial_rows(B, L)) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
 /* Arithmetic of the conv GEMMs (the reference computes in fp32: requirements.txt:5, nn.Conv1d at models/TTSModel.py:59):

@@ -92,7 +92,7 @@ extern "C" int ssv_set_precision(int mode) {
   return prev;
 }
 extern "C" int ssv_get_precision(void) { return ssv_precision(); }
-extern "C" int ssv_version(void) { return 3; }
+extern "C" int ssv_version(void) { return 4; }
 extern "C" const char* ssv_arch(void) { return "gfx950"; }
 extern "C" const char* ssv_last_error(void) { return g_err; }
 
