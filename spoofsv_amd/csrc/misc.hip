@@ -91,6 +91,21 @@ int ssv_launch_reduce_slabs_perm(const float* slabs, float* out, int M, int Nc, 
   return ssv_check_launch("reduce_slabs_perm");
 }
 
+// Rows rg, rg + 8, rg + 16, ... of column i of the partial-row matrix part[nblk][n2], sixteen loads in flight per trip (four before: up to
+// 768 rows are 24 memory round trips in a row per thread at 8 row groups -- the row half was what these launches waited for), fixed order.
+template <typename P>
+__device__ __forceinline__ float ssv_fold_rows(P part, int n2, int nblk, int i, int rg) {
+  float a[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) a[u] = 0.f;
+  int k = rg;
+  for (; k + 120 < nblk; k += 128) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] += part[(long)(k + 8 * u) * n2 + i];
+  }
+  for (; k < nblk; k += 8) a[0] += part[(long)k * n2 + i];
+  return (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
+}
 // Both parameter-gradient reductions of one highwayConv backward in ONE launch: workgroups [0, nA) sum the weight-gradient
 // slabs (exactly reduce_slabs_perm_kernel), workgroups [nA, nA + nB) sum the LayerNorm / bias partial rows (exactly
 // reduce_partials_1_kernel: a workgroup owns 32 outputs, 8 row groups, fixed order).  Same arithmetic per element as the two
@@ -105,16 +120,7 @@ __global__ __launch_bounds__(256) void reduce_pair_kernel(const float* __restric
   }
   const int li = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int i = ((int)blockIdx.x - nA) * 32 + li;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < n2) {
-    int k = rg;
-    for (; k + 24 < nblk; k += 32) {
-      s0 += part[(long)k * n2 + i]; s1 += part[(long)(k + 8) * n2 + i];
-      s2 += part[(long)(k + 16) * n2 + i]; s3 += part[(long)(k + 24) * n2 + i];
-    }
-    for (; k < nblk; k += 8) s0 += part[(long)k * n2 + i];
-  }
-  red[rg][li] = (s0 + s1) + (s2 + s3);
+  red[rg][li] = i < n2 ? ssv_fold_rows(part, n2, nblk, i, rg) : 0.f;
   __syncthreads();
   if (rg == 0 && i < n2) {
     float t = 0.f;
@@ -145,16 +151,7 @@ __global__ __launch_bounds__(256) void reduce_pair_multi_kernel(const ssv_wgrad_
   const __attribute__((address_space(1))) float* __restrict__ part = (const __attribute__((address_space(1))) float*)jb.part;   // (table pointer: see ssv_global)
   const int li = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int i = ((int)blockIdx.x - nA) * 32 + li;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < n2) {
-    int k = rg;
-    for (; k + 24 < nblk; k += 32) {
-      s0 += part[(long)k * n2 + i]; s1 += part[(long)(k + 8) * n2 + i];
-      s2 += part[(long)(k + 16) * n2 + i]; s3 += part[(long)(k + 24) * n2 + i];
-    }
-    for (; k < nblk; k += 8) s0 += part[(long)k * n2 + i];
-  }
-  red[rg][li] = (s0 + s1) + (s2 + s3);
+  red[rg][li] = i < n2 ? ssv_fold_rows(part, n2, nblk, i, rg) : 0.f;
   __syncthreads();
   if (rg == 0 && i < n2) {
     float t = 0.f;

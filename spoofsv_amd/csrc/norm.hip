@@ -970,16 +970,18 @@ __global__ __launch_bounds__(256) void reduce_partials_1_kernel(const float* __r
   __shared__ float red[8][32];
   const int li = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + li;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float a[16];                                        // sixteen rows in flight per trip (see ssv_fold_rows in misc.hip: the same fold)
+#pragma unroll
+  for (int u = 0; u < 16; ++u) a[u] = 0.f;
   if (i < n) {
     int k = rg;
-    for (; k + 24 < nblk; k += 32) {
-      s0 += part[(long)k * n + i]; s1 += part[(long)(k + 8) * n + i];
-      s2 += part[(long)(k + 16) * n + i]; s3 += part[(long)(k + 24) * n + i];
+    for (; k + 120 < nblk; k += 128) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] += part[(long)(k + 8 * u) * n + i];
     }
-    for (; k < nblk; k += 8) s0 += part[(long)k * n + i];
+    for (; k < nblk; k += 8) a[0] += part[(long)k * n + i];
   }
-  red[rg][li] = (s0 + s1) + (s2 + s3);
+  red[rg][li] = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
   __syncthreads();
   if (rg == 0 && i < n) {
     float t = 0.f;
