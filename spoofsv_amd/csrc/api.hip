@@ -213,6 +213,7 @@ static GemmNNB nnb_zero() {
   g.gates_out = nullptr;
   g.f16 = 0; g.a_inv = nullptr; g.x_amax = nullptr; g.x_namax = 0; g.x_amax_bs = 0;
   g.colstats = nullptr;
+  g.xrow_w = nullptr; g.xrow_sk = 0;
   return g;
 }
 
@@ -252,6 +253,7 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
     g.M = M; g.N = L; g.Kc = K; g.KT = k; g.B = B;
     for (int j = 0; j < 3; ++j) g.shift[j] = shift[j];
     if (pw) return ssv_launch_gemm_pwln(g, pw->gamma, pw->beta, pw->y, pw->ybs, pw->stats, pw->y_amax, pw->namax, pw->act, st);
+    if (k == 1 && M > 128 && M % 128 == 1) { g.xrow_w = w + (long)(M - 1) * w_sm; g.xrow_sk = w_sk; }     // (GemmNNB::xrow_w; the launcher decides)
     return ssv_launch_gemm_nn_bf3(g, st);
   }
   if (L == 1 && k == 1 && w_sk == 1 && w_sm == K && !r)          // nn.Linear on a (B, K) matrix (the speaker-code layers): see linear_len1_fwd_kernel

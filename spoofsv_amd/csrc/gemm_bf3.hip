@@ -806,7 +806,10 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
 // "issue raw loads, mask at commit" staging and hoisted addressing as above.
 // (two 8-wave workgroups per CU = 4 waves per SIMD need <= 128 VGPRs: the split-bf16 form of the 128 x 192 tile has 122, the split-fp16 one 134
 // without the bound -- +42 % time; the second __launch_bounds__ argument is waves per SIMD in HIP)
-template <int KT, int WM, int NT, int NWN, int F16>
+#ifndef SSV_NNBW_XROW
+#define SSV_NNBW_XROW 1      // (tuning builds: 0 = M = 128 j + 1 on the 16-wave kernel with a fifth row tile, as before)
+#endif
+template <int KT, int WM, int NT, int NWN, int F16, int XR = 0>
 __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm_nn_bf3w_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int T = 256 * NWN;
   constexpr int BM = 64 * WM, BN = 16 * NT * NWN;
@@ -819,6 +822,12 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
   uint4* Al = lds + A_SLOTS;
   uint4* Xh = lds + 2 * A_SLOTS;
   uint4* Xl = Xh + X_SLOTS;
+  // XR: the launch covers rows 0 .. M - 2 with its tiles (p.M is the FULL row count); row M - 1 is added by the workgroups of row tile 0 as fp32
+  // dot products of its weights (xw, staged once) with the raw input values every staging thread holds before it splits them
+  constexpr int XW_MAX = XR ? 1056 : 1;
+  __shared__ float xw[XW_MAX];
+  __shared__ float xsum[XR ? 4 * WX : 1];
+  static_assert(!XR || (KT == 1 && X_SLOTS <= 2 * T), "extra row: k = 1, at most two slots per thread");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
@@ -830,6 +839,14 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
   const int W = BN + span;
   const int nchunks = p.Kpad / 32;
   const int kq = lane >> 4, nq = lane & 15;
+  const int Mt = XR ? p.M - 1 : p.M;                      // rows the tiles cover
+  const bool xr_on = XR && mt == 0;
+  float xacc[NX];
+#pragma unroll
+  for (int r = 0; r < NX; ++r) xacc[r] = 0.f;
+  if constexpr (XR) {
+    if (xr_on) for (int k = tid; k < nchunks * 32; k += T) xw[k] = k < p.Kc ? p.xrow_w[(long)k * p.xrow_sk] : 0.f;    // (visible after the loop's first barrier)
+  }
 
   f32x4 acc[WM][NT];
 #pragma unroll
@@ -914,6 +931,13 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] = (((cvmask >> r) & 1) && ch * 32 + 8 * kg + i < p.Kc) ? rx[r][i] : 0.f;
         }
+        if constexpr (XR) {
+          if (xr_on) {
+            const float* wq = xw + ch * 32 + 8 * (e / WX);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xacc[r] = __builtin_fmaf(wq[i], v[i], xacc[r]);
+          }
+        }
         uint4 h, l;
         split8s<F16>(v, xs, h, l);
         Xh[e] = h; Xl[e] = l;
@@ -969,7 +993,7 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gm = m0 + wm * WM * 16 + i * 16 + kq * 4 + r;
-      if (gm >= p.M) continue;
+      if (gm >= Mt) continue;
       float add = 0.f;
       if (p.bias) add += p.bias[gm];
       if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gm];
@@ -982,8 +1006,39 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
         Cb[(long)gm * p.scm + gn] = v;
       }
     }
+  if constexpr (XR) {
+    if (xr_on) {                                            // (workgroup-uniform) row M - 1: the four k-groups' partial sums of a column, then bias and residual
+#pragma unroll
+      for (int r = 0; r < NX; ++r) { const int e = tid + T * r; if (e < X_SLOTS) xsum[e] = xacc[r]; }
+      __syncthreads();
+      for (int c = tid; c < WX; c += T) {
+        const int gn = n0 + c, gm = p.M - 1;
+        if (c < BN && gn < p.N) {
+          float v = (xsum[c] + xsum[WX + c]) + (xsum[2 * WX + c] + xsum[3 * WX + c]);
+          if (p.bias) v += p.bias[gm];
+          if (p.bias_b) v += p.bias_b[(long)b * p.sbb + gm];
+          if (Rb) v += Rb[(long)gm * p.srm + gn];
+          Cb[(long)gm * p.scm + gn] = v;
+        }
+      }
+    }
+  }
 }
 
+// rows 0 .. M - 2 in tiles, row M - 1 beside the staging (GemmNNB::xrow_w)
+static int launch_nnbw_xrow(const GemmNNB& g, hipStream_t st, int smin, int span) {
+  const int mtiles = ssv_cdiv(g.M - 1, 128), ntiles = ssv_cdiv(g.N, 192);
+  if (ssv_shape_log_on()) {
+    char nm[96], note[96];
+    snprintf(nm, sizeof nm, "gemm_nn_bf3w_kernel<1, 2, 6, 2, %d, 1>", g.f16);
+    snprintf(note, sizeof note, "B=%d M=%d N=%d K=%d k=1 (last row beside the tiles)", g.B, g.M, g.N, g.Kc);
+    ssv_shape_log(nm, dim3(mtiles * ntiles, g.B), dim3(512), 2.0 * g.B * g.M * g.N * g.Kc,
+                  4.0 * ((double)g.B * g.Kc * g.N + (double)g.B * g.M * g.N + (double)g.M * g.Kc), note);
+  }
+  if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3w_kernel<1, 2, 6, 2, 1, 1>), dim3(mtiles * ntiles, g.B), dim3(512), 0, st, g, mtiles, smin, span);
+  else hipLaunchKernelGGL((gemm_nn_bf3w_kernel<1, 2, 6, 2, 0, 1>), dim3(mtiles * ntiles, g.B), dim3(512), 0, st, g, mtiles, smin, span);
+  return ssv_check_launch("gemm_nn_bf3w (extra row)");
+}
 template <int KT, int WM, int NT, int NWN>
 static int launch_nnbw(const GemmNNB& g, hipStream_t st, int smin, int span) {
   const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT * NWN);
@@ -1039,7 +1094,11 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
     // at B = 1: 1026 x 1300 x 1024) is 27-56 wide tiles, a fifth of the chip; the cost model below then picks small tiles.
     if (KT == 1 && !g.epi && !g.perm_h && !g.colstats && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256 &&
         (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 192) * g.B >= 256)
+    {
+      // M = 128 j + 1 (SSRN's 513 channels): the last row beside the tiles of the 128 x 192 kernel (120.6 -> see DESIGN 4.6) instead of a fifth row tile
+      if (SSV_NNBW_XROW && g.xrow_w && g.M % 128 == 1 && g.Kpad <= 1056 && g.scn == 1 && g.sxn == 1) return launch_nnbw_xrow(g, st, smin, span);
       return (g.M % 128 == 0) ? launch_nnbw<KT, 2, 6, 2>(g, st, smin, span) : launch_nnbw<KT, 2, 7, 4>(g, st, smin, span);
+    }
   }
   static const int nts[] = {7, 6, 4, 2};
   // (round 3: 64 x 176 and 64 x 192 tiles -- 22 % less L2 -> CU operand traffic per launch at C = 256, L = 325 -- were forced per

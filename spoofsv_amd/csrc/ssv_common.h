@@ -89,6 +89,11 @@ struct GemmNNB {
   // colstats[((b * (M / 64) + m / 64) * N + n) * 2 + {0, 1}] = mean and sum of squared deviations of C(b, 64-row group, n)
   // over the group's 64 rows, bias included.  Needs M % 64 == 0, unit column stride, no LSTM epilogue.  Null: not wanted.
   float* colstats;
+  // One output row beyond the last full 128-row tile, kept out of the MFMA tiles (gemm_nn_bf3w_kernel<.., XR = 1>, k = 1): M = 128 j + 1 output
+  // rows -- the 513-channel layers of SSRN -- cost a whole extra row tile of MFMAs for ONE row otherwise.  xrow_w[k * xrow_sk], k < Kc, is that
+  // row of the fp32 weight; the kernel launches over M - 1 rows and the workgroups of row tile 0 add the row as plain fp32 dot products
+  // from the values they stage anyway.  Null: not used.
+  const float* xrow_w; long xrow_sk;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 // 1x1 product (g: KT = 1, unit strides, no residual / LSTM epilogue, M <= 640) that finishes LayerNorm over its M rows and the activation in
