@@ -252,8 +252,8 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
     g.R = r; g.srb = r_bs; g.srm = L;
     g.M = M; g.N = L; g.Kc = K; g.KT = k; g.B = B;
     for (int j = 0; j < 3; ++j) g.shift[j] = shift[j];
+    if (k == 1 && M > 128 && M % 128 == 1) { g.xrow_w = w + (long)(M - 1) * w_sm; g.xrow_sk = w_sk; }     // (GemmNNB::xrow_w; the launchers decide)
     if (pw) return ssv_launch_gemm_pwln(g, pw->gamma, pw->beta, pw->y, pw->ybs, pw->stats, pw->y_amax, pw->namax, pw->act, st);
-    if (k == 1 && M > 128 && M % 128 == 1) { g.xrow_w = w + (long)(M - 1) * w_sm; g.xrow_sk = w_sk; }     // (GemmNNB::xrow_w; the launcher decides)
     return ssv_launch_gemm_nn_bf3(g, st);
   }
   if (L == 1 && k == 1 && w_sk == 1 && w_sm == K && !r)          // nn.Linear on a (B, K) matrix (the speaker-code layers): see linear_len1_fwd_kernel

@@ -1971,12 +1971,15 @@ extern "C" int ssv_debug_pw_stamps(unsigned long long* out) { return (int)hipMem
 #else
 #define PW_STAMP(k) do {} while (0)
 #endif
+#ifndef SSV_PWLN_XROW
+#define SSV_PWLN_XROW 1      // (tuning builds: 0 = M = 513 on five row blocks per wave, as before)
+#endif
 struct PwLn {
   GemmNNB g;                      // A planes, X, C = pre (B, M, N), bias, bias_b, f16 scales
   const float* gamma; const float* beta;
   float* y; long ybs; float* stats; float* y_amax; int namax; int act;
 };
-template <int WMB, int NT, int F16>
+template <int WMB, int NT, int F16, int XR = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   const GemmNNB& p = q.g;
   constexpr int BN = 16 * NT;
@@ -1987,6 +1990,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   __shared__ float red[8][BN];
   __shared__ float colv[2][BN];
   __shared__ float amx[8];
+  // XR: row M - 1 (M = 128 j + 1: the 513-channel layers) is kept out of the MFMA row blocks -- a fifth row block per wave for ONE row otherwise
+  // -- and comes from fp32 dot products of its weights (xw, staged once) with the raw values the staging threads hold before they split them
+  __shared__ float xw[XR ? 1056 : 1];
+  __shared__ float xsum[XR ? 4 * BN : 1];
+  __shared__ float xrow[XR ? 2 * BN : 1];                // the row's pre-activation per column, then its normalised value
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int ntile = (int)(wg % gridDim.x), b = (int)(wg / gridDim.x);
@@ -2007,10 +2015,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   uint4 Ah_[NSET][WMB], Al_[NSET][WMB];
   float rx[8];
 
+  const int Mt = XR ? p.M - 1 : p.M;                     // rows in the MFMA row blocks
   const int MB = (p.M + 15) >> 4;
   unsigned arowb[WMB];
 #pragma unroll
   for (int i = 0; i < WMB; ++i) arowb[i] = (unsigned)(((long)min(wave * WMB + i, MB - 1) * nchunks * 512 + lane * 8) * 2);
+  float xacc = 0.f;
+  if constexpr (XR) {
+    for (int k = tid; k < nchunks * 32; k += 512) xw[k] = k < p.Kc ? p.xrow_w[(long)k * p.xrow_sk] : 0.f;      // (visible after the first barrier)
+  }
   const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(p.Ahi), rsAl = ssv_buf(p.Alo), rsX = ssv_buf(Xb);
   auto loadA = [&](int set, int ch) {
     const unsigned ub = (unsigned)ch * 1024u;
@@ -2041,6 +2054,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (cvs && (!last_ragged || ch * 32 + 8 * skg + i < p.Kc)) ? rx[i] : 0.f;
+    if constexpr (XR) {
+      const float* wq = xw + ch * 32 + 8 * skg;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xacc = __builtin_fmaf(wq[i], v[i], xacc);
+    }
     uint4 h, l;
     split8s<F16>(v, xs, h, l);
     lds[ch & 1][tid] = h; lds[ch & 1][X_SLOTS + tid] = l;
@@ -2071,6 +2089,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
     ssv_pow2_scale(ssv_wave_list_max(p.x_amax + (long)b * p.x_amax_bs, p.x_namax), sc, inv);
     xs = ssv_uniform(sc); xinv = ssv_uniform(inv);
   }
+  if constexpr (XR) __syncthreads();                     // xw is staged
   commitX(0);
   if (nchunks > 1) prefetchX(1);
   if constexpr (NSET == 2) {
@@ -2118,8 +2137,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gm = (wave * WMB + i) * 16 + kq * 4 + r;
-      const bool rv = gm < p.M;
-      const int gmc = min(gm, p.M - 1);
+      const bool rv = gm < Mt;
+      const int gmc = min(gm, Mt - 1);
       float add = 0.f;
       if (p.bias) add += p.bias[gmc];
       if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gmc];
@@ -2132,6 +2151,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
         if (rv && gn < p.N) Cb[(long)gm * p.scm + gn] = v;
       }
     }
+  const float invM = 1.f / (float)p.M;
+  if constexpr (XR) {                                     // row M - 1: the four k-groups' partial sums of a column, bias; stored, and kept for the LayerNorm
+    if (stager) xsum[tid] = xacc;                         // (slot tid = skg * BN + scol)
+    __syncthreads();
+    if (tid < BN) {
+      const int gm = p.M - 1, gn = n0 + tid;
+      float v = (xsum[tid] + xsum[BN + tid]) + (xsum[2 * BN + tid] + xsum[3 * BN + tid]);
+      if (p.bias) v += p.bias[gm];
+      if (p.bias_b) v += p.bias_b[(long)b * p.sbb + gm];
+      if (gn >= p.N) v = 0.f;
+      else Cb[(long)gm * p.scm + gn] = v;
+      xrow[tid] = v;
+    }
+  }
+  // xtra: what thread tid < BN adds to its column's sum (the extra row's term); the reduction's own barrier orders xrow before its use
   auto col_reduce = [&](float (&v)[NT], int slot) __attribute__((always_inline)) {       // sum over all rows of the tile; result in colv[slot][column]
 #pragma unroll
     for (int t = 0; t < NT; ++t) { v[t] += __shfl_xor(v[t], 16); v[t] += __shfl_xor(v[t], 32); }
@@ -2144,13 +2178,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
       float s_ = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) s_ += red[w][tid];
+      if constexpr (XR) {
+        if (slot == 0) s_ += xrow[tid];
+        else { const float d = n0 + tid < p.N ? xrow[tid] - colv[0][tid] * invM : 0.f; s_ += d * d; }
+      }
       colv[slot][tid] = s_;
     }
     __syncthreads();
   };
   col_reduce(csum, 0);
   PW_STAMP(3);
-  const float invM = 1.f / (float)p.M;
   float mean[NT], qs[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { mean[t] = colv[0][t * 16 + nq] * invM; qs[t] = 0.f; }
@@ -2158,7 +2195,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   for (int i = 0; i < WMB; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool rv = (wave * WMB + i) * 16 + kq * 4 + r < p.M;
+      const bool rv = (wave * WMB + i) * 16 + kq * 4 + r < Mt;
 #pragma unroll
       for (int t = 0; t < NT; ++t) { const float d = rv ? acc[i][t][r] - mean[t] : 0.f; qs[t] += d * d; }
     }
@@ -2180,7 +2217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gm = (wave * WMB + i) * 16 + kq * 4 + r;
-      if (gm >= p.M) continue;
+      if (gm >= Mt) continue;
       const float ga = q.gamma[gm], be = q.beta[gm];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -2191,6 +2228,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
         if (gn < p.N) { Yb[(long)gm * p.N + gn] = n; am = fmaxf(am, fabsf(n)); }
       }
     }
+  if constexpr (XR) {
+    if (tid < BN && n0 + tid < p.N) {                      // row M - 1 of y (colv is final: behind the second reduction's barrier)
+      const int gm = p.M - 1;
+      float n = (xrow[tid] - colv[0][tid] * invM) * rsqrtf(colv[1][tid] * invM + 1e-5f) * q.gamma[gm] + q.beta[gm];
+      if (q.act == 1) n = fmaxf(n, 0.f);
+      else if (q.act == 2) n = 1.f / (1.f + __expf(-n));
+      Yb[(long)gm * p.N + n0 + tid] = n;
+      am = fmaxf(am, fabsf(n));
+    }
+  }
   PW_STAMP(5); PW_STAMP(7);
   if (q.y_amax) {                         // one entry per column tile, the rest of the item's list zeroed by the last tile
     am = ssv_wg_max<8>(am, amx);
@@ -2209,13 +2256,15 @@ int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta
   SSV_CHECK(!g.f16 || (g.a_inv && g.x_amax && g.x_namax > 0), SSV_BAD_SHAPE, "gemm_pwln: split-fp16 needs operand scales");
   PwLn q;
   q.g = g; q.gamma = gamma; q.beta = beta; q.y = y; q.ybs = ybs; q.stats = stats; q.y_amax = y_amax; q.namax = namax; q.act = act;
-  const int wmb = ssv_cdiv(ssv_cdiv(g.M, 16), 8);
+  // M = 513: four row blocks per wave for rows 0 .. 511 and the last row beside the staging (XR) instead of five row blocks
+  const bool xr = SSV_PWLN_XROW && g.xrow_w && g.M == 513 && g.Kpad <= 1056;
+  const int wmb = xr ? 4 : ssv_cdiv(ssv_cdiv(g.M, 16), 8);
   const int nt = 4;
   const dim3 grid(ssv_cdiv(g.N, 16 * nt), g.B);
   SSV_CHECK(!y_amax || namax >= (int)grid.x, SSV_BAD_SHAPE, "gemm_pwln: scale list shorter than the column tiles");
   if (ssv_shape_log_on()) {
     char nm[96], note[96];
-    snprintf(nm, sizeof nm, "gemm_pwln_kernel<%d, %d, %d>", wmb, nt, g.f16);
+    snprintf(nm, sizeof nm, xr ? "gemm_pwln_kernel<%d, %d, %d, 1>" : "gemm_pwln_kernel<%d, %d, %d>", wmb, nt, g.f16);
     snprintf(note, sizeof note, "B=%d M=%d N=%d K=%d k=1 +LN", g.B, g.M, g.N, g.Kc);
     ssv_shape_log(nm, grid, dim3(512), 2.0 * g.B * g.M * g.N * g.Kc, 4.0 * ((double)g.B * g.Kc * g.N + 2.0 * g.B * g.M * g.N + (double)g.M * g.Kc), note);
   }
@@ -2223,6 +2272,11 @@ int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta
     if (g.f16) hipLaunchKernelGGL((gemm_pwln_kernel<W_, 4, 1>), grid, dim3(512), 0, st, q); \
     else hipLaunchKernelGGL((gemm_pwln_kernel<W_, 4, 0>), grid, dim3(512), 0, st, q); \
     return ssv_check_launch("gemm_pwln"); }
+  if (xr) {
+    if (g.f16) hipLaunchKernelGGL((gemm_pwln_kernel<4, 4, 1, 1>), grid, dim3(512), 0, st, q);
+    else hipLaunchKernelGGL((gemm_pwln_kernel<4, 4, 0, 1>), grid, dim3(512), 0, st, q);
+    return ssv_check_launch("gemm_pwln (extra row)");
+  }
   SSV_PW(1) SSV_PW(2) SSV_PW(3) SSV_PW(4) SSV_PW(5)
 #undef SSV_PW
   return ssv_fail(SSV_UNSUPPORTED, "gemm_pwln: no instantiation for %d rows", g.M);
