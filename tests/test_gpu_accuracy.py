@@ -286,3 +286,27 @@ def test_conv_forward_and_data_gradient_on_both_sides_of_the_narrow_halo_rule(d,
                 edge = torch.cat((a[..., : 2 * d + 2].double().cpu() - b[..., : 2 * d + 2], a[..., -(2 * d + 2):].double().cpu() - b[..., -(2 * d + 2):]), -1)
                 scale = b.abs().max()
                 assert float(edge.abs().max() / scale) <= 40 * tol, (prec, d, causal, name)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,L", [(3, 520, 513, 333), (2, 513, 513, 1300), (5, 1030, 257, 70), (2, 512, 513, 64), (3, 2100, 129, 200)])
+def test_one_by_one_convolutions_with_128_j_plus_1_output_rows(B, Cin, Cout, L):
+    """128 j + 1 output channels (SSRN's 513 frequency bins, models/TTSModel.py:353-361): the wide k = 1 forward / data-gradient kernel keeps
+    the LAST row out of its MFMA tiles and adds it as fp32 dot products beside the staging (csrc/gemm_bf3.hip: gemm_nn_bf3w_kernel<.., XR = 1>;
+    GemmNNB::xrow_w; long sequences only -- the other shapes run the row-tiled kernels with a nearly empty last row tile).  Forward, data
+    gradient (whose output rows are the INPUT channels: 513 -> the extra row there too) and weight gradient against float64, at ragged
+    lengths and channel counts, and the last row on its own (where a wrong row would hide in an L2 norm over 513 rows)."""
+    gen = torch.Generator().manual_seed(B * 1000 + Cin + Cout + L)
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(Cout, Cin, 1, generator=gen) * 0.05
+    dy = torch.randn(B, Cout, L, generator=gen)
+    ref = _reference(x, w, dy, 1, 1, False)
+    for prec, tol in (("f16x2", 2e-6), ("bf16x3", 3e-5)):
+        got = _hip(x, w, dy, 1, 1, False, prec)
+        for name, a, b in zip(("fwd", "dgrad", "wgrad"), got, ref):
+            e = _rl2(a, b)
+            print("%-6s %4d -> %4d L %4d %-5s %.2e" % (prec, Cin, Cout, L, name, e))
+            assert e <= tol, (prec, name, e)
+        # the last output row of the forward and of the weight gradient, and the last input channel's row of the data gradient
+        for name, a, b in (("fwd row", got[0][:, -1], ref[0][:, -1]), ("wgrad row", got[2][-1], ref[2][-1]), ("dgrad row", got[1][:, -1], ref[1][:, -1])):
+            e = _rl2(a, b)
+            assert e <= 2 * tol, (prec, name, e)
