@@ -3,6 +3,8 @@ kernels on the same operands: the claim "fp32-grade" is held here, per GEMM, on 
 unit scale, rows spread over 2^12, an overall scale of 1e-7, outliers -- and on the documented worst case, one element 2^20
 above everything else in its batch item.  The reference computes these products in fp32 (nn.Conv1d, models/TTSModel.py:59,78;
 autograd's data and weight gradients behind train/ordinary.py:237)."""
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -310,3 +312,55 @@ def test_one_by_one_convolutions_with_128_j_plus_1_output_rows(B, Cin, Cout, L):
         for name, a, b in (("fwd row", got[0][:, -1], ref[0][:, -1]), ("wgrad row", got[2][-1], ref[2][-1]), ("dgrad row", got[1][:, -1], ref[1][:, -1])):
             e = _rl2(a, b)
             assert e <= 2 * tol, (prec, name, e)
+
+
+@pytest.mark.parametrize("gate,B,C,L", [(0, 2, 513, 129), (0, 3, 320, 1030), (0, 2, 256, 100), (1, 2, 512, 70), (1, 2, 256, 1089), (1, 3, 192, 77)])
+def test_layernorm_backward_sums_only_the_partial_rows_it_wrote(gate, B, C, L):
+    """The backward kernels leave one partial row of parameter-gradient sums per column tile in the caller's workspace -- compact, one
+    per tile of whichever kernel the shape picks (ABI version 4: ssv_ln_bwd_partial_rows) -- and a reduction sums them.  The workspace is
+    handed over FULL OF NaN: a reduction that read a row nobody wrote (the 16-column numbering of the wide kernels' rows, as before
+    version 4) would return NaN parameter gradients.  Through the C ABI, wide-tile and 16-column shapes, against float64."""
+    from spoofsv_amd import _lib
+    gen = torch.Generator().manual_seed(17 + C + L)
+    q = _lib.query
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gy = torch.randn(B, C, L, generator=gen)
+    x = torch.randn(B, C, L, generator=gen)
+    if gate:
+        h = torch.randn(B, 2 * C, L, generator=gen)
+        ps = [torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3, torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3]
+        ref_in = [t.double().requires_grad_(True) for t in (h, x, *ps)]
+        _gate_ref(*ref_in).backward(gy.double())
+        hd, xd, gyd = h.to(DEV), x.to(DEV), gy.to(DEV)
+        psd = [p.to(DEV) for p in ps]
+        y, stats = torch.empty(B, C, L, device=DEV), torch.empty(B, 4, L, device=DEV)
+        _lib.call("ssv_highway_gate_fwd", P(hd), P(xd), C * L, *[P(p) for p in psd], P(stats), P(y), C * L, None, B, C, L, st)
+        nb = q("ssv_highway_gate_bwd_workspace", B, C, L)
+        ws = torch.full((nb // 4 + 64,), float("nan"), device=DEV)
+        dh, dx, pg = torch.empty(B, 2 * C, L, device=DEV), torch.empty(B, C, L, device=DEV), torch.empty(6, C, device=DEV)
+        _lib.call("ssv_highway_gate_bwd", P(gyd), C * L, P(xd), C * L, *[P(p) for p in psd], P(hd), P(stats), P(dh), P(dx), C * L, P(pg), B, C, L, P(ws), nb, st)
+        torch.cuda.synchronize()
+        got = {"g1": pg[0], "b1": pg[1], "g2": pg[2], "b2": pg[3]}
+        want = dict(zip(("g1", "b1", "g2", "b2"), (t.grad for t in ref_in[2:])))
+    else:
+        gam, bet = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3
+        ref_in = [t.double().requires_grad_(True) for t in (x, gam, bet)]
+        F.layer_norm(ref_in[0].permute(0, 2, 1), (C,), ref_in[1], ref_in[2], 1e-5).permute(0, 2, 1).backward(gy.double())
+        xd, gyd, gd, bd = x.to(DEV), gy.to(DEV), gam.to(DEV), bet.to(DEV)
+        y, stats = torch.empty(B, C, L, device=DEV), torch.empty(B, 2, L, device=DEV)
+        nbf = q("ssv_channel_ln_act_fwd_workspace", B, C, L)
+        wsf = torch.empty(max(nbf, 256), dtype=torch.uint8, device=DEV)
+        _lib.call("ssv_channel_ln_act_fwd", P(xd), C * L, P(gd), P(bd), P(y), C * L, None, P(stats), B, C, L, 0, P(wsf), nbf, st)
+        nb = q("ssv_channel_ln_act_bwd_workspace", B, C, L)
+        ws = torch.full((nb // 4 + 64,), float("nan"), device=DEV)
+        dx, pg = torch.empty(B, C, L, device=DEV), torch.empty(3, C, device=DEV)
+        _lib.call("ssv_channel_ln_act_bwd", P(gyd), C * L, P(xd), C * L, P(stats), P(gd), P(bd), P(dx), C * L, P(pg), B, C, L, 0, P(ws), nb, st)
+        torch.cuda.synchronize()
+        got = {"gamma": pg[0], "beta": pg[1]}
+        want = {"gamma": ref_in[1].grad, "beta": ref_in[2].grad}
+    rows = _lib.lib().ssv_ln_bwd_partial_rows(gate, B, C, L, 0)
+    assert 0 < rows <= _lib.lib().ssv_ln_partial_rows(B, L)
+    for name in got:
+        assert bool(torch.isfinite(got[name]).all()), (name, "a row nobody wrote was summed", rows)
+        assert _rl2(got[name], want[name]) < 3e-6, (name, _rl2(got[name], want[name]))
