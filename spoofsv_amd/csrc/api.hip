@@ -376,8 +376,18 @@ static int nt_slabs(long tiles_all, int njobs, int B, int L, int kt, int M, int 
   }
   return best;
 }
+// range slabs of the extra-row kernel (ssv_nt_bf3_xrow): as many slabs as fill the co-resident slots once -- every workgroup then reduces over
+// the same number of 64-step chunks, not over a whole number of batch items
+static int xrow_slabs(long tiles_all, int B, int L) {
+  const long chunks = (long)B * ssv_cdiv(L > 0 ? L : 325, 64);
+  long z = 512 / (tiles_all > 0 ? tiles_all : 1);
+  if (z > chunks) z = chunks;
+  if (z > 64) z = 64;
+  return (int)(z < 1 ? 1 : z);
+}
 static int dw_splits(int B, int M, int Nc, int k, int L = 0) {
   const int tiles = ssv_nt_bf3_tiles(k == 3 ? 3 : 1, M, Nc);
+  if (k != 3 && ssv_nt_bf3_xrow(1, M, Nc)) return xrow_slabs(tiles, B, L);
   int z = nt_slabs(tiles, 1, B, L, k == 3 ? 3 : 1, M, Nc);
   if (const char* e = ssv_tuning(SSV_T_NT_FORCE)) {      // "M:Nc:k=Z;..." -- one shape's slab count inside a whole step (tools/sweep_force.sh)
     char key[48];
@@ -419,6 +429,7 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
   else { g.C = (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = 1; g.scj = Cin; }     // slabs [z][m][j][c]
   g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
   if (ssv_precision() >= 1 && (long)B * L >= 256 && Cin >= SSV_MIN_SPLIT_CHANNELS && Cout >= SSV_MIN_SPLIT_CHANNELS && ssv_nt_bf3_fits(g)) {
+    if (k != 3 && ssv_nt_bf3_xrow(1, Cout, Cin)) g.bstep = 0;            // range slabs (dw_splits chose Z for them)
     if (use_f16()) {
       float* fb = (float*)((char*)ws + bwd_weight_main(B, Cin, Cout, L, k));
       AmaxList la, lx;
@@ -453,6 +464,7 @@ extern "C" int ssv_conv1d_bwd_weight_multi_splits(int njobs, int B, int Cin, int
   const int kt = k == 3 ? 3 : 1;
   if (njobs < 1) njobs = 1;
   const long tiles = (long)ssv_nt_bf3_tiles(kt, Cout, Cin) * njobs;
+  if (kt == 1 && ssv_nt_bf3_xrow(1, Cout, Cin)) return xrow_slabs(tiles, B, L);
   int z = nt_slabs(tiles, njobs, B, L, kt, Cout, Cin);
   if (z > B) z = B;
   if (z < 1) z = 1;
@@ -474,7 +486,7 @@ extern "C" int ssv_conv1d_bwd_weight_multi(const ssv_wgrad_job* jobs_dev, int nj
   g.A = nullptr; g.sab = dy_bs; g.sam = L; g.La = L;
   g.X = nullptr; g.sxb = x_bs; g.sxc = L; g.Lx = L;
   g.C = (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = 1; g.scj = Cin;                 // slabs [job][z][m][j][c]
-  g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
+  g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = (k != 3 && ssv_nt_bf3_xrow(1, Cout, Cin)) ? 0 : Z;      // (0: range slabs)
   g.jobs = jobs_dev; g.njobs = njobs; g.max_shift = max_shift;
   g.f16 = use_f16() ? 1 : 0;                     // the jobs carry their operands' scale lists (the caller saw to that)
   SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));

@@ -1199,7 +1199,15 @@ constexpr int NT_FD = 1;      // LDS fragment groups read ahead of the MFMAs (se
 #ifndef SSV_NT_RING
 #define SSV_NT_RING 1         // 0 (tuning builds): the k = 3 weight gradient on gemm_nt_bf3_kernel, as before round 4's ring kernel
 #endif
-template <int KT, int WM, int NTC, int F16>
+// XR (k = 1): M = 128 j + 1 rows (the 513-channel layers): the tiles cover rows 0 .. M - 2 and row M - 1 of the product is added by the workgroups of
+// row tile 0 as fp32 dot products of dH(M - 1, t) with the raw input values every staging thread holds before it splits them -- a fifth row tile
+// of MFMAs for ONE row otherwise (30 tiles of 128 x 96 for 24).  It pays only together with RANGE slabs (p.bstep == 0: slab z reduces over the
+// z-th of Z equal ranges of the launch's B x tchunks chunks, not over whole batch items): with whole items 24 x 16 workgroups do the same two
+// items each as 30 x 16 did, and the launch lasts as long as its slowest workgroup.
+#ifndef SSV_NT_XROW
+#define SSV_NT_XROW 1        // (tuning builds: 0 = a row tile of its own for the last row and whole-item slabs, as before)
+#endif
+template <int KT, int WM, int NTC, int F16, int XR = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
   constexpr int KB = 64, KG = KB / 8, KS = KB / 32;         // time steps per chunk, k-groups, MFMA k-steps
   constexpr int NCH = 16 * NTC;
@@ -1262,6 +1270,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 
   float rx[NX][8];                     // raw loads in flight: the tile of step s + 2
   int mx[NX];                          // edge windows only: validity bits (low 8) | offset clamp distance << 8
+  static_assert(!XR || (KT == 1 && (256 % KG) == 0), "extra row: k = 1; a thread's slots share their k-group");
+  const bool xr_on = XR && mt == 0;
+  float xacc[XR ? NX : 1];
+  uint4 xra[XR ? 2 : 1];               // dH(M - 1, t0 + 8 kg .. + 7) of the tile in flight (raw; what lies past the row meets masked input)
+#pragma unroll
+  for (int r = 0; r < (XR ? NX : 1); ++r) xacc[r] = 0.f;
   // dH fragments: two sets of (hi, lo) register tuples; set n & 1 is chunk n's.  The next chunk's windows are LOADED into the other
   // set (a window's two 16-byte loads = its two tuples) and split there in place, dword by dword (split8p's order of the time steps):
   // no staging registers.  (The split of the next set woven behind the MFMAs of a chunk's last tap -- one half-rate split instruction
@@ -1288,6 +1302,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   int arow[WM], xrow[NX];
 #pragma unroll
   for (int i = 0; i < WM; ++i) arow[i] = (min(m0 + wave * WM * 16 + i * 16 + nq, p.M - 1) * (int)p.sam + 8 * kq) * 4;     // BYTE offset of the buffer loads
+  const int xra_off = ((p.M - 1) * (int)p.sam + 8 * (tid % KG)) * 4;
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
     const int f = tid + 256 * r;
@@ -1318,8 +1333,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     const int m = row_ok ? (int)((0xFFu << sl) & (0xFFu >> sh) & 0xFFu) : 0;
     return m | (d << 8);
   };
-  auto split_edge = [&](const float (&raw)[8], int meta, float sc, uint4& h, uint4& l) {
-    float v[8];
+  auto edge_vals = [&](const float (&raw)[8], int meta, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = raw[i];
     const int d = meta >> 8;
@@ -1335,17 +1349,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = ((meta >> i) & 1) ? v[i] : 0.f;
+  };
+  auto split_edge = [&](const float (&raw)[8], int meta, float sc, uint4& h, uint4& l) {
+    float v[8];
+    edge_vals(raw, meta, v);
     split8p<F16>(v, sc, h, l);
   };
 
   // chunk cursors (wave-uniform): batch item and first time step of chunks n .. n+3
-  const int nb = (p.B - z + p.bstep - 1) / p.bstep;
-  const int total = nb * tchunks;                                           // chunks this workgroup reduces over
-  int cb[4], ct0[4];
-  cb[0] = z; ct0[0] = 0;
+  // whole-item slabs (bstep > 0): slab z reduces over items z, z + bstep, ...;  range slabs (bstep == 0): over the z-th of Z equal ranges of the
+  // item-major sequence of all B x tchunks chunks (a finer cut: the work per workgroup need not be a whole number of items)
+  const int bstep = p.bstep > 0 ? p.bstep : 1;
+  int total, cb[4], ct0[4];
+  if (p.bstep > 0) {
+    total = ((p.B - z + p.bstep - 1) / p.bstep) * tchunks;                  // chunks this workgroup reduces over
+    cb[0] = z; ct0[0] = 0;
+  } else {
+    const int all = p.B * tchunks, per = (all + p.Z - 1) / p.Z, start = z * per;
+    total = max(min(per, all - start), 0);
+    cb[0] = start / tchunks; ct0[0] = (start % tchunks) * KB;
+  }
   auto next_chunk = [&](int b, int t0, int& nb_, int& nt0) __attribute__((always_inline)) {
     nt0 = t0 + KB; nb_ = b;
-    if (nt0 >= tchunks * KB) { nt0 = 0; nb_ = b + p.bstep; }
+    if (nt0 >= tchunks * KB) { nt0 = 0; nb_ = b + bstep; }
   };
 #pragma unroll
   for (int k = 1; k < 4; ++k) next_chunk(cb[k - 1], ct0[k - 1], cb[k], ct0[k]);
@@ -1384,6 +1410,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     int dd[NX];
 #pragma unroll
     for (int r = 0; r < NX; ++r) dd[r] = load8c(Xp, base + xrow[r], x_span, rx[r]);
+    if constexpr (XR) {                // every workgroup issues them (a branch around loads costs hipcc's waitcnt bookkeeping more than two L2 hits)
+      const unsigned so = (unsigned)(b * (int)p.sab + t0) * 4u;
+      xra[0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, xra_off, (int)so, 0));
+      xra[1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, xra_off + 16, (int)so, 0));
+    }
     if (x_edge(t0, j)) {
 #pragma unroll
       for (int r = 0; r < NX; ++r) {
@@ -1405,6 +1436,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       if (!edge) split8p<F16>(rx[r], xs, h, l);
       else split_edge(rx[r], mx[r], xs, h, l);
       Xh[kg * NCH + (c ^ kg)] = h; Xl[kg * NCH + (c ^ kg)] = l;          // XOR swizzle, see the slot comment above
+      if constexpr (XR) {
+        if (xr_on) {                   // row M - 1 of the product: dH(M - 1, t) x(c, t) over this slot's 8 time steps
+          float av[8], xv[8];
+          raw8(xra[0], xra[1], av);
+          if (!edge) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[i] = rx[r][i];
+          } else edge_vals(rx[r], mx[r], xv);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xacc[r] = __builtin_fmaf(av[i], xv[i], xacc[r]);
+        }
+      }
     }
   };
   using P0 = std::integral_constant<int, 0>;
@@ -1524,7 +1567,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gm = m0 + wave * WM * 16 + i * 16 + kq * 4 + r;
-      if (gm >= p.M) continue;
+      if (gm >= (XR ? p.M - 1 : p.M)) continue;
 #pragma unroll
       for (int j = 0; j < KT; ++j)
 #pragma unroll
@@ -1533,6 +1576,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
           if (gc < p.Nc) Cz[(long)gm * p.scm + (long)gc * p.scc + (long)j * p.scj] = F16 ? acc[i][j][q][r] * us : acc[i][j][q][r];
         }
     }
+  if constexpr (XR) {
+    if (xr_on) {                       // row M - 1: a channel's 8 k-groups are 8 neighbouring lanes (slot f = tid + 256 r: kg = f % 8, channel = f / 8)
+#pragma unroll
+      for (int r = 0; r < NX; ++r) {
+        float v = xacc[r];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        const int f = tid + 256 * r, gc = c0 + f / KG;
+        if ((f % KG) == 0 && gc < p.Nc) Cz[(long)(p.M - 1) * p.scm + (long)gc * p.scc] = v;
+      }
+    }
+  }
 #ifdef SSV_NT_STAMP
   __builtin_amdgcn_s_waitcnt(0);
 #endif
@@ -1895,7 +1949,13 @@ int ssv_nt_bf3_wg_per_cu(int KT, int wm, int ntc) {
 int ssv_nt_bf3_tiles(int KT, int M, int Nc) {
   int wm, ntc;
   ssv_nt_bf3_tile(KT, M, Nc, &wm, &ntc);
-  return ssv_cdiv(M, 64 * wm) * ssv_cdiv(Nc, 16 * ntc);
+  return ssv_cdiv(ssv_nt_bf3_xrow(KT, M, Nc) ? M - 1 : M, 64 * wm) * ssv_cdiv(Nc, 16 * ntc);
+}
+// the k = 1 weight gradient of 128 j + 1 output rows on the 128 x 96 tile: last row beside the staging, range slabs (gemm_nt_bf3_kernel<.., XR = 1>)
+bool ssv_nt_bf3_xrow(int KT, int M, int Nc) {
+  int wm, ntc;
+  ssv_nt_bf3_tile(KT, M, Nc, &wm, &ntc);
+  return SSV_NT_XROW && KT == 1 && wm == 2 && ntc == 6 && M > 128 && M % 128 == 1;
 }
 
 // the kernel addresses both operands with 32-bit element offsets
@@ -1905,14 +1965,16 @@ bool ssv_nt_bf3_fits(const GemmNT& g) {
          (long)g.B * g.sab < lim && (long)g.B * g.sxb < lim && g.La >= 8 && g.Lx >= 8;
 }
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
-  SSV_CHECK(g.M > 0 && g.Nc > 0 && g.La > 0 && g.B > 0 && g.Z > 0 && g.bstep > 0, SSV_BAD_SHAPE, "gemm_nt_bf3: empty problem");
+  SSV_CHECK(g.M > 0 && g.Nc > 0 && g.La > 0 && g.B > 0 && g.Z > 0 && g.bstep >= 0, SSV_BAD_SHAPE, "gemm_nt_bf3: empty problem");      // (bstep == 0: range slabs)
   SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nt_bf3: kernel_size %d", g.KT);
   SSV_CHECK(g.sat == 1 && g.sxn == 1, SSV_UNSUPPORTED, "gemm_nt_bf3: rows must be contiguous in time");
   SSV_CHECK(g.Z <= 65535, SSV_UNSUPPORTED, "gemm_nt_bf3: Z=%d exceeds grid.z", g.Z);
   SSV_CHECK(ssv_nt_bf3_fits(g), SSV_UNSUPPORTED, "gemm_nt_bf3: an operand spans 2^30 elements or more");
   int wm, ntc;
   ssv_nt_bf3_tile(g.KT, g.M, g.Nc, &wm, &ntc);
-  const int mtiles = ssv_cdiv(g.M, 64 * wm);
+  const bool xr = ssv_nt_bf3_xrow(g.KT, g.M, g.Nc);       // (then the caller chose range slabs: bstep == 0)
+  SSV_CHECK(g.bstep > 0 || xr, SSV_UNSUPPORTED, "gemm_nt_bf3: range slabs are built for the extra-row kernel only");
+  const int mtiles = ssv_cdiv(xr ? g.M - 1 : g.M, 64 * wm);
   const int nz = g.jobs ? g.njobs * g.Z : g.Z;
   SSV_CHECK(nz <= 65535, SSV_UNSUPPORTED, "gemm_nt_bf3: %d slabs exceed grid.z", nz);
   const dim3 grid(mtiles * ssv_cdiv(g.Nc, 16 * ntc), 1, nz);
@@ -1930,7 +1992,7 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
     char nm[96], note[96];
     const int nj = g.jobs ? g.njobs : 1;
     if (ring_ms >= 0) snprintf(nm, sizeof nm, "gemm_nt3r_kernel<%d, %d>", wm, g.f16);
-    else snprintf(nm, sizeof nm, "gemm_nt_bf3_kernel<%d, %d, %d, %d>", g.KT, wm, ntc, g.f16);
+    else snprintf(nm, sizeof nm, xr ? "gemm_nt_bf3_kernel<%d, %d, %d, %d, 1>" : "gemm_nt_bf3_kernel<%d, %d, %d, %d>", g.KT, wm, ntc, g.f16);
     snprintf(note, sizeof note, "jobs=%d B=%d M=%d Nc=%d L=%d k=%d Z=%d", nj, g.B, g.M, g.Nc, g.La, g.KT, g.Z);
     ssv_shape_log(nm, grid, dim3(256), 2.0 * nj * g.B * g.M * g.Nc * g.La * g.KT,
                   4.0 * nj * ((double)g.B * g.M * g.La + (double)g.B * g.Nc * g.Lx + (double)g.Z * g.M * g.Nc * g.KT), note);
@@ -1940,6 +2002,11 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
     if (g.f16) hipLaunchKernelGGL((gemm_nt3r_kernel<2, 1>), grid, dim3(256), 0, st, g, mtiles, tchunks, ring_ms);
     else hipLaunchKernelGGL((gemm_nt3r_kernel<2, 0>), grid, dim3(256), 0, st, g, mtiles, tchunks, ring_ms);
     return ssv_check_launch("gemm_nt3r");
+  }
+  if (xr) {
+    if (g.f16) hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 6, 1, 1>), grid, dim3(256), 0, st, g, mtiles);
+    else hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 6, 0, 1>), grid, dim3(256), 0, st, g, mtiles);
+    return ssv_check_launch("gemm_nt_bf3 (extra row)");
   }
 #define SSV_NT(K_, A_, C_) if (g.KT == K_ && wm == A_ && ntc == C_) { \
     if (g.f16) hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_, 1>), grid, dim3(256), 0, st, g, mtiles); \

@@ -41,7 +41,7 @@ struct GemmNT {
   const float* A; long sab, sam, sat; int La;
   const float* X; long sxb, sxc, sxn; int Lx;
   float* C; long scz, scm, scc, scj;
-  int M, Nc, KT, B, Z, bstep;
+  int M, Nc, KT, B, Z, bstep;   // bstep > 0: slab z reduces over batch items z, z + bstep, ...; bstep == 0 (gemm_nt_bf3's extra-row kernel): over the z-th of Z equal chunk ranges
   int shift[3];
   // several problems of one shape in one launch (split-bf16 kernel only): grid.z = njobs * Z, entry z belongs to job z / Z and
   // takes A = jobs[job].dy, X = jobs[job].x, the job's shifts, and slab (z % Z) of the job's slab region C + job * Z * scz
@@ -101,6 +101,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta, float* y, long ybs, float* stats, float* y_amax, int namax, int act,
                          hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
+bool ssv_nt_bf3_xrow(int KT, int M, int Nc);    // this shape runs the extra-row kernel: its callers cut RANGE slabs (GemmNT::bstep = 0)
 bool ssv_nt_bf3_fits(const GemmNT& g);          // operands addressable with the kernel's 32-bit element offsets
 // nch_total / ch_off: this source fills K chunks [ch_off, ch_off + Kpad/32) of planes that have nch_total chunks per row block
 // (two matrices side by side along K, e.g. [W_ih | W_hh]); 0, 0 = the plane holds this source only.

@@ -292,11 +292,12 @@ def test_conv_forward_and_data_gradient_on_both_sides_of_the_narrow_halo_rule(d,
 
 @pytest.mark.parametrize("B,Cin,Cout,L", [(3, 520, 513, 333), (2, 513, 513, 1300), (5, 1030, 257, 70), (2, 512, 513, 64), (3, 2100, 129, 200)])
 def test_one_by_one_convolutions_with_128_j_plus_1_output_rows(B, Cin, Cout, L):
-    """128 j + 1 output channels (SSRN's 513 frequency bins, models/TTSModel.py:353-361): the wide k = 1 forward / data-gradient kernel keeps
-    the LAST row out of its MFMA tiles and adds it as fp32 dot products beside the staging (csrc/gemm_bf3.hip: gemm_nn_bf3w_kernel<.., XR = 1>;
-    GemmNNB::xrow_w; long sequences only -- the other shapes run the row-tiled kernels with a nearly empty last row tile).  Forward, data
-    gradient (whose output rows are the INPUT channels: 513 -> the extra row there too) and weight gradient against float64, at ragged
-    lengths and channel counts, and the last row on its own (where a wrong row would hide in an L2 norm over 513 rows)."""
+    """128 j + 1 output channels (SSRN's 513 frequency bins, models/TTSModel.py:353-361): the wide k = 1 forward / data-gradient kernel and
+    the k = 1 weight-gradient kernel keep the LAST row out of their MFMA tiles and add it as fp32 dot products beside the staging
+    (csrc/gemm_bf3.hip: gemm_nn_bf3w_kernel<.., XR = 1> for long sequences, gemm_nt_bf3_kernel<.., XR = 1> with RANGE slabs -- a workgroup's
+    chunk range starts and ends inside batch items).  Forward, data gradient (whose output rows are the INPUT channels: 513 -> the extra
+    row there too) and weight gradient against float64, at ragged lengths and channel counts (more slabs than chunks at L = 64, item
+    boundaries inside every range), and the last row on its own (where a wrong row would hide in an L2 norm over 513 rows)."""
     gen = torch.Generator().manual_seed(B * 1000 + Cin + Cout + L)
     x = torch.randn(B, Cin, L, generator=gen)
     w = torch.randn(Cout, Cin, 1, generator=gen) * 0.05
