@@ -82,6 +82,10 @@ def lib():
     # loaded first serves both -- and a process where the system runtime came first and torch initialised the device second
     # fails its first kernel launch with "no ROCm-capable device".  Load torch's first, always.
     import torch  # noqa: F401
+    e = os.environ.get("SSV_PRECISION")
+    if e and e not in ("fp32", "0", "bf16x3", "1", "f16x2", "2"):
+        # the library aborts on an unknown value (a typo must not run a job in another arithmetic than the one asked for)
+        raise RuntimeError("SSV_PRECISION=%r is not one of fp32|0, bf16x3|1, f16x2|2" % e)
     L = ctypes.CDLL(LIBPATH)
     _protos = parse_header()
     missing = [n for n in _protos if not hasattr(L, n)]

@@ -33,9 +33,10 @@ int ssv_precision() {
     else if (!strcmp(e, "fp32") || !strcmp(e, "0")) g_precision = 0;
     else if (!strcmp(e, "bf16x3") || !strcmp(e, "1")) g_precision = 1;
     else {
-      // a typo must not silently select another arithmetic than the one asked for
-      fprintf(stderr, "libssv_hip: SSV_PRECISION=%s is not one of fp32|0, bf16x3|1, f16x2|2: using the default f16x2\n", e);
-      g_precision = 2;
+      // a typo must not silently select another arithmetic than the one asked for: no arithmetic at all.  (The Python loader
+      // checks the variable before the first call and raises there; a C host gets this message and an abort.)
+      fprintf(stderr, "libssv_hip: SSV_PRECISION=%s is not one of fp32|0, bf16x3|1, f16x2|2\n", e);
+      abort();
     }
   }
   return g_precision;
@@ -362,7 +363,6 @@ static int nt_slabs(long tiles_all, int njobs, int B, int L, int kt, int M, int 
   ssv_nt_bf3_tile(kt, M, Nc, &wm, &ntc);
   const int per_cu = ssv_nt_bf3_wg_per_cu(kt, wm, ntc);
   const long slots = 256L * per_cu;
-  if (L <= 0) L = 325;
   // per workgroup and batch item: 2 x (64 wm) x (16 ntc) x kt x L flop at ~0.55 TFLOP/s per resident workgroup (2 per CU; scaled
   // when more fit); per slab and job: the output written and read back at ~4 TB/s
   const double t_item = 2.0 * 64 * wm * 16 * ntc * kt * L / (0.55e12 * 2.0 / per_cu);
@@ -379,22 +379,42 @@ static int nt_slabs(long tiles_all, int njobs, int B, int L, int kt, int M, int 
 // range slabs of the extra-row kernel (ssv_nt_bf3_xrow): as many slabs as fill the co-resident slots once -- every workgroup then reduces over
 // the same number of 64-step chunks, not over a whole number of batch items
 static int xrow_slabs(long tiles_all, int B, int L) {
-  const long chunks = (long)B * ssv_cdiv(L > 0 ? L : 325, 64);
+  const long chunks = (long)B * ssv_cdiv(L, 64);
   long z = 512 / (tiles_all > 0 ? tiles_all : 1);
   if (z > chunks) z = chunks;
   if (z > 64) z = 64;
   return (int)(z < 1 ? 1 : z);
 }
-static int dw_splits(int B, int M, int Nc, int k, int L = 0) {
-  const int tiles = ssv_nt_bf3_tiles(k == 3 ? 3 : 1, M, Nc);
-  if (k != 3 && ssv_nt_bf3_xrow(1, M, Nc)) return xrow_slabs(tiles, B, L);
-  int z = nt_slabs(tiles, 1, B, L, k == 3 ? 3 : 1, M, Nc);
+// the predicate of the split-MFMA weight-gradient launch (conv1d_bwd_weight_impl), for dense operands: what the workspace queries can know
+static bool nt_bf3_runs(int B, int M, int Nc, int L) {
+  if (ssv_precision() < 1 || (long)B * L < 256 || Nc < SSV_MIN_SPLIT_CHANNELS || M < SSV_MIN_SPLIT_CHANNELS) return false;
+  GemmNT g = nt_zero();
+  g.sab = (long)M * L; g.sam = L; g.La = L; g.sxb = (long)Nc * L; g.sxc = L; g.Lx = L;
+  g.M = M; g.Nc = Nc; g.KT = 1; g.B = B; g.Z = 1; g.bstep = 1;
+  return ssv_nt_bf3_fits(g);
+}
+static int nt_force(int z, int M, int Nc, int k) {
   if (const char* e = ssv_tuning(SSV_T_NT_FORCE)) {      // "M:Nc:k=Z;..." -- one shape's slab count inside a whole step (tools/sweep_force.sh)
     char key[48];
     snprintf(key, sizeof key, "%d:%d:%d=", M, Nc, k);
     const char* hit = strstr(e, key);
     if (hit && (hit == e || hit[-1] == ';')) { const int v = atoi(hit + strlen(key)); if (v > 0) z = v; }
   }
+  return z;
+}
+// L: the reduction length per batch item.  Required: a caller whose workspace query has no length (the transposed conv) passes
+// SSV_NOMINAL_L so that query and launch agree by construction.
+#define SSV_NOMINAL_L 325
+static int dw_splits(int B, int M, int Nc, int k, int L) {
+  const int tiles = ssv_nt_bf3_tiles(k == 3 ? 3 : 1, M, Nc);
+  // range slabs only when the extra-row kernel will really run (same predicate as the launch): the fp32 fallback cuts whole-item slabs, Z <= B
+  if (k != 3 && ssv_nt_bf3_xrow(1, M, Nc) && nt_bf3_runs(B, M, Nc, L)) {
+    int z = nt_force(xrow_slabs(tiles, B, L), M, Nc, k);
+    const long chunks = (long)B * ssv_cdiv(L, 64);
+    if (z > chunks) z = (int)chunks;
+    return z < 1 ? 1 : z;
+  }
+  int z = nt_force(nt_slabs(tiles, 1, B, L, k == 3 ? 3 : 1, M, Nc), M, Nc, k);
   if (z > B) z = B;
   if (z < 1) z = 1;
   return z;
@@ -421,15 +441,18 @@ static int conv1d_bwd_weight_impl(const float* dy, long dy_bs, const float* x, l
   hipStream_t st = (hipStream_t)stream;
   GemmNT g = nt_zero();
   SSV_TRY(conv_shifts(k, dilation, causal, g.shift));
-  const int Z = dw_splits(B, Cout, Cin, k, L);
+  int Z = dw_splits(B, Cout, Cin, k, L);
   const long n = (long)Cout * Cin * k;
   g.A = dy; g.sab = dy_bs; g.sam = L; g.La = L;
   g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
+  g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B;
+  const bool bf3 = ssv_precision() >= 1 && (long)B * L >= 256 && Cin >= SSV_MIN_SPLIT_CHANNELS && Cout >= SSV_MIN_SPLIT_CHANNELS && ssv_nt_bf3_fits(g);
+  if (!bf3 && Z > B) Z = B;        // (range-slab count chosen for dense operands, strided ones do not fit the split kernel: whole-item slabs, no empty ones)
   if (Z == 1) { g.C = dw; g.scz = n; g.scm = (long)Cin * k; g.scc = k; g.scj = 1; }
   else { g.C = (float*)ws; g.scz = n; g.scm = (long)Cin * k; g.scc = 1; g.scj = Cin; }     // slabs [z][m][j][c]
-  g.M = Cout; g.Nc = Cin; g.KT = k; g.B = B; g.Z = Z; g.bstep = Z;
-  if (ssv_precision() >= 1 && (long)B * L >= 256 && Cin >= SSV_MIN_SPLIT_CHANNELS && Cout >= SSV_MIN_SPLIT_CHANNELS && ssv_nt_bf3_fits(g)) {
-    if (k != 3 && ssv_nt_bf3_xrow(1, Cout, Cin)) g.bstep = 0;            // range slabs (dw_splits chose Z for them)
+  g.Z = Z; g.bstep = Z;
+  if (bf3) {
+    if (k != 3 && ssv_nt_bf3_xrow(1, Cout, Cin)) g.bstep = 0;            // range slabs (dw_splits chose Z for them; any Z <= chunks is valid)
     if (use_f16()) {
       float* fb = (float*)((char*)ws + bwd_weight_main(B, Cin, Cout, L, k));
       AmaxList la, lx;
@@ -831,7 +854,7 @@ extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* x_a
   }
   return 0;
 }
-static int deconv_splits(int B, int Cin, int Cout) { return dw_splits(B, Cin, Cout, 1); }
+static int deconv_splits(int B, int Cin, int Cout) { return dw_splits(B, Cin, Cout, 1, SSV_NOMINAL_L); }     // (ssv_deconv1d_k2s2_bwd_workspace has no length)
 extern "C" size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout) {
   return align256((size_t)deconv_splits(B, Cin, Cout) * Cin * Cout * 2 * sizeof(float)) + align256((size_t)B * Cout * sizeof(float)) +
          deconv_pack_bytes(Cin, Cout) + conv_aux_bytes();
@@ -1181,8 +1204,8 @@ extern "C" int ssv_lstm_train_fwd(const float* x, const float* const* w_ih, cons
 }
 
 struct LstmBwdWs { size_t dgates, dxc, dx0, dcarry, dhtop, rs, wt0, wtc, wtc_stride, slabs, total; };
-static size_t lstm_dw_slab_bytes(int T, int H, int Fin) {
-  return align256((size_t)dw_splits(T, 4 * H, Fin, 1) * 4 * H * Fin * sizeof(float));
+static size_t lstm_dw_slab_bytes(int Bn, int T, int H, int Fin) {
+  return align256((size_t)dw_splits(T, 4 * H, Fin, 1, Bn) * 4 * H * Fin * sizeof(float));        // "batch" = frames, reduction length = utterances
 }
 static LstmBwdWs lstm_bwd_ws(int Bn, int T, int F, int H, int layers) {
   LstmBwdWs s;
@@ -1196,14 +1219,15 @@ static LstmBwdWs lstm_bwd_ws(int Bn, int T, int F, int H, int layers) {
   s.wtc = s.wt0 + 2 * split_bytes(H, 4 * H, 1);                    // W_hh[0]^T
   s.wtc_stride = 2 * split_bytes(2 * H, 4 * H, 1);                 // [W_ih | W_hh]^T of a layer >= 1
   s.slabs = s.wtc + (size_t)(layers > 1 ? layers - 1 : 0) * s.wtc_stride;
-  s.total = s.slabs + zmax(lstm_dw_slab_bytes(T, H, H), lstm_dw_slab_bytes(T, H, F));
+  // every (items, M, Nc) lstm_weight_grad is called with: W_ih over T frames (Fin = F or H), W_hh over T - 1
+  s.total = s.slabs + zmax(zmax(lstm_dw_slab_bytes(Bn, T, H, H), lstm_dw_slab_bytes(Bn, T > 1 ? T - 1 : 1, H, H)), lstm_dw_slab_bytes(Bn, T, H, F));
   return s;
 }
 extern "C" size_t ssv_lstm_bwd_workspace(int Bn, int T, int F, int H, int layers) { return lstm_bwd_ws(Bn, T, F, H, layers).total; }
 // dW (M x Nc) = sum over `items` frames of A_item (M x Bn) X_item^T (Nc x Bn): the conv weight-gradient kernel with time = batch
 static int lstm_weight_grad(const float* A, long sab, const float* X, long sxb, float* dw, int M, int Nc, int Bn, int items, void* slabs, hipStream_t st) {
   GemmNT g = nt_zero();
-  const int Z = dw_splits(items, M, Nc, 1);
+  const int Z = dw_splits(items, M, Nc, 1, Bn);
   const long n = (long)M * Nc;
   g.A = A; g.sab = sab; g.sam = Bn; g.La = Bn;
   g.X = X; g.sxb = sxb; g.sxc = Bn; g.Lx = Bn;

@@ -94,6 +94,11 @@ def grad_block(params, rows, cols, device):
     return v if v is not None else torch.empty((rows, cols), dtype=torch.float32, device=device)
 
 
+def _remove_hooks(hooks):
+    while hooks:
+        hooks.pop().remove()
+
+
 class GradArena:
     def __init__(self, plan, device=None, align=4):
         self.names, self.ranges, self.slots = [], [], {}
@@ -121,17 +126,29 @@ class GradArena:
         dev = device if device is not None else self.params[0].device
         self.flat = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
         ref = weakref.ref(self)
+
+        def unclaim(o):
+            # autograd rejects any hook result that is not None, also once the arena is gone: always return None
+            def hook(_p):
+                a = ref()
+                if a is not None:
+                    a.claimed.discard(o)
+                return None
+            return hook
+
         for p in self.params:
             o, n = self.slots[id(p)]
             _SLOTS[p.data_ptr()] = (ref, o, n, weakref.ref(p))
             if p.requires_grad:
                 # AccumulateGrad has run for p (all of its users in this backward have delivered): its slot may be handed out again
-                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, o=o, r=ref: r() is not None and r().claimed.discard(o)))
+                self._hooks.append(p.register_post_accumulate_grad_hook(unclaim(o)))
+        # an arena that is dropped without release() must not leave its hooks on the parameters (they would pile up with
+        # every new arena over the same model): the finalizer owns the handle list, not the arena
+        self._finalizer = weakref.finalize(self, _remove_hooks, self._hooks)
 
     def release(self):
-        for h in self._hooks:
-            h.remove()
-        self._hooks = []
+        """Detach the arena from its parameters: hooks removed, slots forgotten.  Idempotent."""
+        _remove_hooks(self._hooks)
         for p in self.params:
             e = _SLOTS.get(p.data_ptr())
             if e is not None and e[0]() is self:

@@ -492,7 +492,7 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
                 loss_disc = torch.mean(-disc_syn)
                 # adaptive weight of the critic term (:290): plain Python floats, as the reference's .item() calls
                 loss = base + (float(base) / abs(float(loss_disc))) * loss_disc
-                with ops.input_grads_only():      # the critic's own parameter gradients of a G iteration are zeroed unread (:264-265)
+                with ops.input_grads_only(disc):      # the critic's own parameter gradients of a G iteration are zeroed unread (:264-265)
                     loss.backward()
                 opt_syn.step()
                 logs["loss_train_log_syn"].append(float(loss))
@@ -502,7 +502,7 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
                 coeff = torch.rand(B).view(B, 1, 1).expand(B, C, T).to(dev)          # CPU RNG, as :300
                 mid = (coeff * gt.detach() + (1 - coeff) * pred.detach()).requires_grad_(True)
                 out_mid = disc(mid)
-                with ops.input_grads_only():      # this pass asks for d out / d mid only (ops.input_grads_only)
+                with ops.input_grads_only(disc):      # this pass asks for d out / d mid only (ops.input_grads_only)
                     grads = torch.autograd.grad(outputs=out_mid, inputs=mid, grad_outputs=torch.ones_like(out_mid),
                                                 retain_graph=True, create_graph=True)[0]
                 loss_gp = torch.mean(cfg["LAMBDA"] * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)

@@ -131,6 +131,7 @@ class DeferredWgrad:
         self.cursor = 0
         self.pending = set()           # addresses of the parameters whose gradient is queued and not yet flushed
         self._side = None              # stream for the table uploads of a capture (see flush)
+        self._frozen = []              # device tables of CAPTURED launches: written once, never reused (replays read them for ever)
 
     def __enter__(self):
         global _DEFER
@@ -192,8 +193,10 @@ class DeferredWgrad:
         slot = self.slots[self.cursor]
         if slot[0].numel() < nbytes or slot[1].device != dev:
             raise RuntimeError("DeferredWgrad: the sequence of weight-gradient launches changed between iterations")
-        if slot[2] is not None and not capturing:
-            slot[2].synchronize()          # the previous iteration's copy out of this pinned table has executed
+        if slot[2] is not None:
+            # the previous copy out of this pinned table has executed (eager iteration: on the launch stream; capture: on the side
+            # stream, which runs outside the capture -- waiting for it here is a host wait, legal while capturing)
+            slot[2].synchronize()
         self.cursor += 1
         return slot
 
@@ -218,18 +221,26 @@ class DeferredWgrad:
                 # The table of a captured launch is CONSTANT (the addresses of the capture's own tensors): it is uploaded once, now,
                 # on a stream outside the capture, instead of by a copy node that every replay would run in front of the launch
                 # (11 such nodes of ~4 us per training step).  ``finish_uploads`` (after the capture) waits for it.
+                # It goes into a device table of its OWN (allocated here, from the capture's pool, and kept for the life of this
+                # object): an eager iteration through the same DeferredWgrad after the capture -- a logged or debug step -- rewinds
+                # the cursor and rewrites the slots' tables, and the replays must keep reading the captured addresses.
+                dtable = torch.empty(len(raw), dtype=torch.uint8, device=dev)
+                self._frozen.append(dtable)
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=dev)
                 with torch.cuda.stream(self._side):
-                    slot[1].copy_(slot[0], non_blocking=True)
+                    dtable.copy_(slot[0][:len(raw)], non_blocking=True)
+                    slot[2] = torch.cuda.Event()          # the pinned table may be refilled once this copy has executed
+                    slot[2].record()
             else:
-                slot[1].copy_(slot[0], non_blocking=True)
+                dtable = slot[1]
+                dtable.copy_(slot[0], non_blocking=True)
                 slot[2] = torch.cuda.Event()
                 slot[2].record()
             nb = _lib.query("ssv_conv1d_bwd_weight_multi_workspace", n, B, Cin, Cout, L, k)
             ws = _ws(nb, dev)
             max_shift = max(abs(v) for job in jobs for v in job[6])
-            _lib.call("ssv_conv1d_bwd_weight_multi", _p(slot[1]), n, dy_bs, x_bs, B, Cin, Cout, L, k, max_shift, n2, nblk, _p(ws), nb, _stream())
+            _lib.call("ssv_conv1d_bwd_weight_multi", _p(dtable), n, dy_bs, x_bs, B, Cin, Cout, L, k, max_shift, n2, nblk, _p(ws), nb, _stream())
         self.jobs = {}
         self.pending.clear()
 
@@ -463,18 +474,29 @@ def _dd_amax(t, cin=None, cout=None):
     return amax_of(t)
 
 
-_INPUT_ONLY = False
+_INPUT_ONLY = None        # None, or the set of parameter addresses whose gradients the current backward does not want
+
+
+def _skip_param_grads(*params):
+    """True when every given parameter belongs to the module ``input_grads_only`` was entered for."""
+    if _INPUT_ONLY is None:
+        return False
+    return all(p is not None and p.data_ptr() in _INPUT_ONLY for p in params)
 
 
 @contextlib.contextmanager
-def input_grads_only():
-    """Within the block the backward of the critic's twice-differentiable operators produces the INPUT gradient only.  The gradient
-    penalty's first pass, ``torch.autograd.grad(outputs=D(x_mid), inputs=x_mid, create_graph=True)``
-    (train/adversarial_wasserstein_gp.py:303-304), asks for nothing else -- but a Python Function cannot see which of its gradients the
-    engine will use (``ctx.needs_input_grad`` is fixed at forward time), so without this every convolution also ran its weight-gradient
-    GEMM, slab reduction and bias row sums, and every LayerNorm / gate its parameter-gradient reductions, for results nobody reads."""
+def input_grads_only(module):
+    """Within the block the backward of the twice-differentiable operators produces the INPUT gradient only -- for the operators whose
+    parameters belong to ``module`` (the critic).  The gradient penalty's first pass, ``torch.autograd.grad(outputs=D(x_mid),
+    inputs=x_mid, create_graph=True)`` (train/adversarial_wasserstein_gp.py:303-304), asks for nothing else -- but a Python Function
+    cannot see which of its gradients the engine will use (``ctx.needs_input_grad`` is fixed at forward time), so without this every
+    convolution also ran its weight-gradient GEMM, slab reduction and bias row sums, and every LayerNorm / gate its
+    parameter-gradient reductions, for results nobody reads.  The generator's backward runs inside the same block on generator
+    iterations (the critic is the head of its tape): an operator over any OTHER parameter -- a generator layer that adopts ``conv1d_dd``
+    / ``channel_ln_dd`` one day -- keeps all of its gradients."""
     global _INPUT_ONLY
-    prev, _INPUT_ONLY = _INPUT_ONLY, True
+    prev = _INPUT_ONLY
+    _INPUT_ONLY = frozenset(p.data_ptr() for p in module.parameters())
     try:
         yield
     finally:
@@ -503,7 +525,7 @@ class ConvFwdDD(torch.autograd.Function):
         k, dilation, causal, has_bias = ctx.cfg
         dya = _dd_amax(dy, x.shape[1], w.shape[0])
         dx = ConvBwdDataDD.apply(dy, w, x.shape[1], k, dilation, causal, dya) if ctx.needs_input_grad[0] else None
-        if _INPUT_ONLY:                       # (input_grads_only: the gradient penalty's first pass)
+        if _skip_param_grads(w):              # (input_grads_only: the gradient penalty's first pass, the critic under a generator iteration)
             return dx, None, None, None, None, None, None
         dw = ConvBwdWeightDD.apply(dy, x, k, dilation, causal, dya, ctx.x_amax) if ctx.needs_input_grad[1] else None
         db = BiasGradFn.apply(dy) if (has_bias and ctx.needs_input_grad[2]) else None
@@ -754,7 +776,7 @@ class ChannelLnBwdDD(torch.autograd.Function):
         gy, gybs = _act3(gy, "grad")
         B, C, L = x.shape
         dx = torch.empty((B, C, L), dtype=_F32, device=x.device)
-        pg = None if _INPUT_ONLY else torch.empty((3, C), dtype=_F32, device=x.device)      # (None: the partial rows are not summed)
+        pg = None if _skip_param_grads(gamma, beta) else torch.empty((3, C), dtype=_F32, device=x.device)      # (None: the partial rows are not summed)
         nb = _lib.query("ssv_channel_ln_act_bwd_workspace", B, C, L)
         ws = _ws(nb, x.device)
         _lib.call("ssv_channel_ln_act_bwd", _p(gy), gybs, _p(x), xbs, _p(stats), _p(gamma), _p(beta), _p(dx), C * L, _p(pg),
@@ -815,7 +837,7 @@ class HighwayGateBwdDD(torch.autograd.Function):
         B, C, L = x.shape
         dh = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
         dx = torch.empty((B, C, L), dtype=_F32, device=x.device)
-        pg = None if _INPUT_ONLY else torch.empty((6, C), dtype=_F32, device=x.device)
+        pg = None if _skip_param_grads(g1, b1, g2, b2) else torch.empty((6, C), dtype=_F32, device=x.device)
         nb = _lib.query("ssv_highway_gate_bwd_workspace", B, C, L)
         ws = _ws(nb, x.device)
         _lib.call("ssv_highway_gate_bwd", _p(gy), gybs, _p(x), xbs, _p(g1), _p(b1), _p(g2), _p(b2), _p(h), _p(stats), _p(dh), _p(dx),

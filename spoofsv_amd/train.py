@@ -264,6 +264,20 @@ class DataParallelRanks:
         else:
             self.params = [p for p in params if p.requires_grad]
 
+    def close(self):
+        """Teardown: outstanding collectives awaited, the gradient arena detached from the parameters (hooks and slots), so the
+        same model can be wrapped again or trained without the wrapper.  Also runs when the wrapper is garbage-collected."""
+        self.finish()
+        if self.arena is not None:
+            self.arena.release()
+
+    def __del__(self):
+        try:
+            if self.arena is not None:
+                self.arena.release()
+        except Exception:
+            pass
+
     @property
     def n_buckets(self):
         return len(self.arena.ranges) if self.arena is not None else 1
@@ -793,7 +807,7 @@ class AdversarialGraphStep:
         self._segs = segs
         # the first segment holds the critic: a generator iteration needs its INPUT gradient only (the critic's own parameter gradients
         # would be discarded: the reference zeroes them before the next critic iteration, train/adversarial_wasserstein_gp.py:264-265)
-        with ops.input_grads_only():
+        with ops.input_grads_only(self.disc):
             segs[0]()
         total = base_g + weight * g[3]
         self.g_out = (g[0], g[1], g[2], g[3], total)
@@ -815,7 +829,7 @@ class AdversarialGraphStep:
         scale = self.ddp_disc.grad_scale if self.ddp_disc is not None else 1.0
         mid = (self.coeff * gt + (1 - self.coeff) * pred).requires_grad_(True)
         out = self.disc(mid)
-        with ops.input_grads_only():        # only d out / d mid is asked for: no weight / bias / LayerNorm parameter gradients in this pass
+        with ops.input_grads_only(self.disc):        # only d out / d mid is asked for: no weight / bias / LayerNorm parameter gradients in this pass
             grads = torch.autograd.grad(outputs=out, inputs=mid, grad_outputs=torch.ones_like(out), retain_graph=True, create_graph=True)[0]
         loss_gp = ops.grad_penalty(grads, self.lam)          # mean(lam * (||grad||_2 - 1)^2), :305-308
         # disc(pred) and disc(gt) as ONE critic call on the concatenated batch: the critic has no cross-sample operation

@@ -410,6 +410,35 @@ def test_grad_arena_parameter_used_twice_in_one_backward_is_summed_not_overwritt
     ar.release()
 
 
+def test_grad_arena_dropped_without_release_leaves_no_hooks_and_a_later_backward_runs():
+    """An arena that is garbage-collected (a DataParallelRanks dropped between two train() calls on the same model) must not leave
+    post-accumulate hooks behind: a hook that returned anything but None made the next backward raise 'hook returned bool', and
+    stale hooks piled up with every new arena over the same parameters."""
+    import gc
+    from spoofsv_amd import gradarena
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(6))
+    x1 = torch.randn(6)
+    for _ in range(3):
+        ar = gradarena.GradArena([("only", [[w]])])
+        w.grad = None
+        _TwiceFn.apply(x1, w).sum().backward()
+        assert w.grad.data_ptr() == ar.slot(w).data_ptr()
+        del ar
+        gc.collect()
+        assert len(w._post_accumulate_grad_hooks or {}) == 0
+        assert gradarena.view(w) is None                  # the slot of a dead arena is stale
+        w.grad = None
+        _TwiceFn.apply(x1, w).sum().backward()            # used to raise TypeError: expected Variable, but hook returned 'bool'
+        assert torch.allclose(w.grad, x1)
+    # the hook itself returns None whether or not the arena is alive
+    ar = gradarena.GradArena([("only", [[w]])])
+    hook = list(w._post_accumulate_grad_hooks.values())[0]
+    assert hook(w) is None
+    ar.release(); ar.release()                            # idempotent
+    assert len(w._post_accumulate_grad_hooks or {}) == 0
+
+
 def _segmented_iteration(net, x, y, ddp):
     """forward with cuts, backward segment by segment, each bucket's all-reduce started right after its segment."""
     from spoofsv_amd import train
