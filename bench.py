@@ -46,6 +46,11 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true", help="skip the isolated-kernel roofline measurements (profiling runs)")
     ap.add_argument("--ge2e", action="store_true", help="measure BASELINE config 5 (GE2E speaker embedder) instead and print its JSON line")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--check-replicas", action="store_true",
+                    help="N > 1: after the timed steps (and the adversarial cycles) all-gather a checksum of every model's parameters and fail unless all ranks hold the same replica")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rehearse ONLY the launch plumbing of --gpus N, without touching a GPU: N ranks, gloo rendezvous on 127.0.0.1, local-rank folding, "
+                         "one all-gather, ONE JSON line from rank 0, non-zero exit if any rank dies (runs on a GPU-less host)")
     ap.add_argument("--precision", choices=["f16x2", "bf16x3", "fp32"], default="f16x2",
                     help="conv GEMM arithmetic: split-fp16 MFMA with power-of-two operand scales (default, ~2^-22 per product = fp32-grade), "
                          "split-bf16 MFMA (~2^-16, narrower than the reference: opt-in) or exact fp32 MFMA")
@@ -98,7 +103,7 @@ class Trainer:
         return [[float(v) for v in t.cpu()] for t in self.stepper.loss_log[:2]]
 
 
-def adversarial_cycle_ms(kind, batch, dev, world=1, cycles=3):
+def adversarial_cycle_ms(kind, batch, dev, world=1, cycles=3, check_replicas=False):
     """One full WGAN-GP cycle of the reference (1 generator + RATIO=5 critic iterations,
     train/adversarial_wasserstein_gp.py:261-322): generator on the HIP path, critic on the twice-differentiable HIP conv / LayerNorm / gate ops
     with gradient penalty, both iterations replayed from captured hipGraphs (train.AdversarialGraphStep); with N > 1 data
@@ -149,7 +154,26 @@ def adversarial_cycle_ms(kind, batch, dev, world=1, cycles=3):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
+    if check_replicas:
+        ok, rows = replica_checksums(list(model.parameters()) + list(disc.parameters()), dev, world)
+        if not ok:
+            raise SystemExit("bench: %s generator / critic replicas differ across ranks after the adversarial cycles: %r" % (kind, rows))
     return dt / (6 * cycles) * 1e3
+
+
+def replica_checksums(params, dev, world):
+    """(equal, [per-rank checksum pairs]): every rank's (sum, sum of |.|) over all parameters in float64, all-gathered.  Data-parallel
+    replicas apply the SAME averaged gradient to the SAME weights, so the checksums must be equal BITWISE on every rank -- a rank that
+    missed a bucket's all-reduce, or replayed a graph over stale gradients, shows here."""
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1).double() for p in params])
+        mine = torch.stack([flat.sum(), flat.abs().sum()])
+    if world == 1:
+        return True, [mine.tolist()]
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    rows = [g.tolist() for g in got]
+    return all(r == rows[0] for r in rows), rows
 
 
 ADV_MASK_SEED = 99
@@ -582,6 +606,53 @@ def launch_ranks(n):
     return rc
 
 
+class _stdout_on_stderr:
+    """The contract is ONE JSON line on stdout; librccl prints a version banner there when its communicator comes up and gloo a
+    "connected to N peer ranks" line: while a process group is being created, file descriptor 1 points at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def launch_check(args):
+    """`--launch-check`: everything `--gpus N` does BEFORE the first GPU call, and the exit path after the last one, with gloo and no
+    device: rank / world from the environment, local-rank folding onto the visible devices (here: onto one), rendezvous on
+    127.0.0.1, one all-gather (each rank's (rank, pid)), rank 0's ONE JSON line, barrier, teardown.  SSV_LAUNCH_CHECK_DIE=<rank>
+    makes that rank exit 3 after the rendezvous (the parent must then end the others and return non-zero)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    ndev = max(torch.cuda.device_count(), 1)           # (counting devices does not initialise HIP)
+    folded = local % ndev
+    with _stdout_on_stderr():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    if os.environ.get("SSV_LAUNCH_CHECK_DIE") == str(rank):
+        sys.exit(3)
+    mine = torch.tensor([rank, os.getpid(), folded], dtype=torch.int64)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    dist.barrier()
+    if rank == 0:
+        ranks = sorted(int(g[0]) for g in got)
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": ranks, "distinct_pids": len({int(g[1]) for g in got}),
+                          "devices_visible": ndev, "local_ranks_folded_onto": sorted({int(g[2]) for g in got}), "dist_backend": "gloo"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.ge2e:
@@ -593,6 +664,8 @@ def main():
         raise SystemExit("bench: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
+    if args.launch_check:
+        return launch_check(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -614,22 +687,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("SSV_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
-        # librccl prints a version banner on STDOUT when its communicator comes up; the contract is ONE JSON line there, so the
-        # file descriptor points at stderr until the communicator exists (created eagerly: device_id + a first collective)
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        # (the communicator is created eagerly -- device_id + a first collective -- while stdout points at stderr)
+        with _stdout_on_stderr():
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             else:
                 dist.init_process_group(backend, rank=rank, world_size=world)
             dist.all_reduce(torch.zeros(1, device=dev))
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
     if world > 1 and dist.get_world_size() != args.gpus:
         raise SystemExit("bench: process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
     from spoofsv_amd import _lib
@@ -675,6 +740,13 @@ def main():
     split = {"text2mel": timed([t2m], args.steps, 0), "ssrn": timed([ssr], args.steps, 0)}      # per model, not part of `value`
     frames_per_step = args.batch * T_MEL * world
     loss_t2m, loss_ssrn = t2m.loss, ssr.loss
+    replicas_equal = None
+    if args.check_replicas:
+        for tr in (t2m, ssr):
+            ok, rows = replica_checksums(list(tr.model.parameters()), dev, world)
+            if not ok:
+                raise SystemExit("bench: %s replicas differ across ranks after %d steps: %r" % (tr.kind, args.steps + args.warmup, rows))
+        replicas_equal = True
     first = {"text2mel": t2m.first_losses(), "ssrn": ssr.first_losses()}      # iterations 0 and 1, for the oracle check below
     if not (loss_t2m == loss_t2m and loss_ssrn == loss_ssrn):
         raise SystemExit("non-finite loss in the benchmark step")
@@ -699,12 +771,14 @@ def main():
                       "ssrn_fps": round(frames_per_step / split["ssrn"], 1),
                       "final_loss_text2mel": round(loss_t2m, 5), "final_loss_ssrn": round(loss_ssrn, 5)}}
     cfg = res["config"]          # scalars only: the driver's parser keeps flat keys
+    if replicas_equal is not None:
+        cfg["replica_checksums_equal"] = True       # (a difference is a non-zero exit, never a false on the line); adversarial models are checked below
     del t2m, ssr
     torch.cuda.empty_cache()
     if not args.no_adversarial:
         # BASELINE config 3 (--adversarial; config 4 when N > 1): reported beside the headline, never inside `value`
-        a1 = adversarial_cycle_ms("text2mel", args.batch, dev, world)
-        a2 = adversarial_cycle_ms("ssrn", args.batch, dev, world)
+        a1 = adversarial_cycle_ms("text2mel", args.batch, dev, world, check_replicas=args.check_replicas)
+        a2 = adversarial_cycle_ms("ssrn", args.batch, dev, world, check_replicas=args.check_replicas)
         cfg.update({"adversarial_text2mel_ms": round(a1, 3), "adversarial_ssrn_ms": round(a2, 3),
                     "adversarial_text2mel_fps": round(frames_per_step / a1 * 1e3, 1), "adversarial_ssrn_fps": round(frames_per_step / a2 * 1e3, 1),
                     "adversarial_combined_fps": round(frames_per_step / (a1 + a2) * 1e3, 1),

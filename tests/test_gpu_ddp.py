@@ -465,3 +465,63 @@ def test_bench_gpus_2_starts_two_ranks_by_itself_and_reports_them():
     if torch.cuda.device_count() < 2:
         r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode != 0 and "one GPU per rank" in r.stderr and r.stdout.strip() == ""
+
+
+_REHEARSAL_RANKS = 4      # + this pytest process = 5 processes on the card; the GPU boxes allow 6 at once ("process guard"), so 8 is not possible here
+
+
+def _rehearsal_args(n):
+    return ["--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "4", "--check-replicas",
+            "--no-cpu-baseline", "--no-ge2e", "--no-fp32", "--no-roofline"]
+
+
+def _check_rehearsal_line(r, n):
+    import json
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == n and cfg["global_batch"] == 4 * n and cfg["parallelism"] == "dp%d" % n and rec["dist_backend"] == "gloo"
+    assert cfg["replica_checksums_equal"] is True                       # Text2Mel + SSRN after the steps; the adversarial models exit non-zero if not
+    assert cfg["adversarial_text2mel_ms"] > 0 and cfg["adversarial_ssrn_ms"] > 0
+    return rec
+
+
+def test_bench_many_rank_rehearsal_on_one_gpu_with_the_adversarial_cycle_and_replica_checksums():
+    """Config 4's whole launch structure with more than two processes: `python bench.py --gpus 4` starts four ranks that share the one
+    GPU over gloo -- four captures in thread_local mode side by side, four process-group inits, `local % ndev`, a free port -- runs the
+    segmented data-parallel step of Text2Mel and SSRN AND the WGAN-GP cycle (global adaptive weight, bucketed generator all-reduce,
+    packed critic all-reduce), then all-gathers a checksum of every model's parameters: all replicas bitwise equal, one JSON line,
+    n_gpus = 4.  (Eight ranks cannot share a card here: the boxes stop a job with more than six GPU processes; the eight-process launch
+    itself is rehearsed without a device by tests/test_host_cpu.py.)  train/adversarial_wasserstein_gp.py:183-196."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    n = _REHEARSAL_RANKS
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + _rehearsal_args(n), env=dict(env, SSV_DIST_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=1200)
+    rec = _check_rehearsal_line(r, n)
+    assert abs(rec["value"] - n * 4 * 325 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
+
+
+def test_bench_many_rank_rehearsal_under_the_torchrun_launcher():
+    """The same through the driver's launcher form: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N (the launcher never touches the GPU; the ranks read RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* from its environment)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    n = _REHEARSAL_RANKS
+    port = 29700 + os.getpid() % 200
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py")] + _rehearsal_args(n) + ["--no-adversarial"],
+                       env=dict(env, SSV_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["config"]["replica_checksums_equal"] is True

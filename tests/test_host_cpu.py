@@ -646,3 +646,47 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks_and_propagates_their_fai
     assert r.returncode != 0 and r.stdout.strip() == ""
     # one message per rank that got as far as the check before the launcher ended it (the launcher waits 10 s for the others)
     assert 1 <= r.stderr.count("needs a ROCm GPU") <= 2, r.stderr
+
+
+def test_bench_gpus_8_launch_plumbing_with_eight_processes_no_gpu():
+    """BASELINE config 4 is eight ranks; nothing on this host can run eight GPU processes, but everything `bench.py --gpus 8` does
+    around the GPU work can: eight children of a parent that touches no device, a free rendezvous port on 127.0.0.1, a gloo
+    group of eight, local ranks folded onto the visible devices, one all-gather, ONE JSON line from rank 0, clean teardown
+    (`--launch-check`).  The first real 8-GPU run is then not the first 8-process run of this launcher
+    (train/adversarial_wasserstein_gp.py:183-196 turns multi-GPU on with one flag inside one process)."""
+    import json
+    r = _run_bench(["--gpus", "8", "--launch-check"], {}, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["launch_check"] is True and rec["n_gpus"] == 8 and rec["ranks"] == list(range(8)) and rec["distinct_pids"] == 8
+    assert rec["local_ranks_folded_onto"] == list(range(min(8, rec["devices_visible"])))
+
+
+def test_bench_gpus_8_one_rank_dying_ends_the_other_seven_and_fails():
+    """A rank that exits after the rendezvous (here: rank 5, exit code 3) leaves seven ranks waiting in a collective for ever; the
+    launcher must end exactly those and return non-zero with nothing on stdout -- and within its grace period, not at a timeout."""
+    import time
+    t0 = time.time()
+    r = _run_bench(["--gpus", "8", "--launch-check"], {"SSV_LAUNCH_CHECK_DIE": "5"}, timeout=300)
+    assert r.returncode == 3 and r.stdout.strip() == "", (r.returncode, r.stdout)
+    assert time.time() - t0 < 120
+
+
+def test_bench_launch_check_under_the_torchrun_launcher():
+    """The driver's form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N`; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher's environment."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--launch-check"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0])["ranks"] == list(range(8))
