@@ -13,8 +13,10 @@ HBM before the timed region.  Weak scaling: the per-GPU batch is fixed, gradient
 flat RCCL all-reduce per step.
 
 Rank 0 prints ONE JSON line with the driver's contract plus:
-  roofline      the dominant kernel (dilated Conv1d implicit GEMM, fp32 MFMA) timed with HIP events here
-  cpu_baseline  the CPU oracle (same stock-op sequence the reference runs) on a bounded sample
+  roofline            the dominant kernel (dilated Conv1d implicit GEMM, split-fp16 MFMA) timed with HIP events here
+  cpu_baseline        the CPU oracle (same stock-op sequence the reference runs) on a bounded sample
+  stock_gpu_baseline  the same op sequence on torch's stock GPU kernels (MIOpen / rocBLAS), fp32, eager: the path the reference
+                      itself would take on this GPU (SURVEY.md "facts"); config.eager_ms_per_step = the HIP path without hipGraphs
 """
 import argparse
 import json
@@ -43,6 +45,7 @@ def parse():
     ap.add_argument("--no-adversarial", action="store_true", help="skip the extra WGAN-GP cycle timing")
     ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 timing of the same step")
     ap.add_argument("--no-ge2e", action="store_true", help="skip the GE2E (config 5) figures on the line")
+    ap.add_argument("--no-stock", action="store_true", help="skip the stock-op (MIOpen / rocBLAS) arm on the same GPU and the eager timing of the HIP path")
     ap.add_argument("--no-roofline", action="store_true", help="skip the isolated-kernel roofline measurements (profiling runs)")
     ap.add_argument("--ge2e", action="store_true", help="measure BASELINE config 5 (GE2E speaker embedder) instead and print its JSON line")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
@@ -497,6 +500,62 @@ def cpu_baseline():
     return out
 
 
+def stock_gpu_baseline(dev, batch):
+    """The yardstick SURVEY.md names ("the stock path the new build must beat"): the reference itself on a ROCm box runs every op through
+    torch's stock kernels (MIOpen / rocBLAS / ATen).  Here: the oracle's op sequence (oracle/tts_oracle.py -- nn.functional conv1d,
+    layer_norm, softmax ..., autograd, torch.optim.Adam) with tensors on the GPU, fp32, eager, 1 warm-up + 4 timed training iterations
+    of each model at the workload's batch.  Baseline leg only: nothing of this runs in the timed region of `value`."""
+    from oracle import tts_oracle as TO
+    from spoofsv_amd import train
+    from spoofsv_amd.tts import SSRN, melSyn
+    prev = (torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32, torch.backends.cudnn.benchmark)
+    torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
+    # torch's default is MIOpen's immediate mode (no solver search), which is what a user of the reference gets; SSV_STOCK_BENCHMARK=1
+    # lets MIOpen search (minutes of warm-up) -- DESIGN.md records both
+    torch.backends.cudnn.benchmark = os.environ.get("SSV_STOCK_BENCHMARK") == "1"
+    ms, losses = {}, {}
+    try:
+        for kind in ("text2mel", "ssrn"):
+            torch.manual_seed(1234)
+            if kind == "text2mel":
+                m = melSyn(34, True, 200, 128, 80, 256)
+                mel, text, spk = train.synthetic_text2mel_batch(batch, N_TEXT, T_MEL, seed=0, device=dev)
+                gaw = train.guided_attention_mat(186, 325, device=dev)
+            else:
+                m = SSRN(80, 513, 256)
+                mel, lin = train.synthetic_ssrn_batch(batch, T_MEL, seed=0, device=dev)
+            m.apply(train.init_weights)
+            sd = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in m.state_dict().items()}
+            opt = torch.optim.Adam(list(sd.values()), 2e-4, (0.5, 0.9), 1e-6)
+
+            def one():
+                opt.zero_grad(set_to_none=True)
+                if kind == "text2mel":
+                    Y, A = TO.melsyn_train(train.shift_right(mel), text, spk, sd)
+                    ls = TO.text2mel_losses(Y, A, mel, gaw)
+                else:
+                    ls = TO.ssrn_losses(TO.ssrn(mel, sd), lin)
+                sum(ls).backward()
+                opt.step()
+                return ls
+            ls = one()
+            losses[kind] = [float(v.detach()) for v in ls]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                one()
+            torch.cuda.synchronize()
+            ms[kind] = (time.perf_counter() - t0) / 4 * 1e3
+            del sd, opt, m
+            torch.cuda.empty_cache()
+    finally:
+        torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32, torch.backends.cudnn.benchmark = prev
+    return {"value": round(batch * T_MEL / ((ms["text2mel"] + ms["ssrn"]) * 1e-3), 1), "unit": "mel-frames/s",
+            "text2mel_ms": round(ms["text2mel"], 3), "ssrn_ms": round(ms["ssrn"], 3),
+            "note": "torch stock ops (MIOpen / rocBLAS / ATen) on the same GPU, fp32, eager, autograd + torch.optim.Adam, 1 warm-up + 4 timed iterations per model, B=%d, cudnn.benchmark=%s" % (batch, torch.backends.cudnn.benchmark),
+            "first_losses": losses}
+
+
 def ge2e_config5():
     """BASELINE config 5 (`python bench.py --ge2e`): GE2E d-vector extraction, 88 speakers x 10 utterances x 120 frames x 40 mels --
     LSTM forward + projection + GE2E loss on one MI355X in utterances/s, one full training iteration, and the CPU oracle on
@@ -802,6 +861,23 @@ def main():
             del f1, f2
             torch.cuda.empty_cache()
         spoofsv_amd.set_precision(args.precision)
+    if world == 1 and not args.no_stock:
+        # the same HIP step launched EAGERLY (what a ragged real-data run gets: harness.ordinary_train captures only fixed shapes) ...
+        if use_graph:
+            e1, e2 = Trainer("text2mel", args.batch, dev, rank, world, False), Trainer("ssrn", args.batch, dev, rank, world, False)
+            e1.prepare(); e2.prepare()
+            ep = timed([e1, e2], 10, 2)
+            cfg.update({"eager_ms_per_step": round(ep * 1e3, 3), "eager_value": round(frames_per_step / ep, 1)})
+            del e1, e2
+            torch.cuda.empty_cache()
+        # ... and the stock-op path on the same GPU
+        sg = stock_gpu_baseline(dev, args.batch)
+        stock_first = sg.pop("first_losses")
+        res["stock_gpu_baseline"] = sg
+        cfg["speedup_vs_stock_gpu"] = round(res["value"] / sg["value"], 2)
+        for kind in ("text2mel", "ssrn"):       # same seeds, same batch: the stock arm's first losses are the HIP path's (iteration 0)
+            e = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(first[kind][0], stock_first[kind]))
+            cfg["loss_rel_err_vs_stock_gpu_%s_iter0" % kind] = float("%.3g" % e)
     if rank == 0:
         if not args.no_roofline:
             res["roofline"] = kernel_roofline(dev)

@@ -123,8 +123,9 @@ def text_embedding(textid, sd, prefix, vocab_len):
     """textEmbedding.forward, TTSModel.py:25-35: one-hot scatter then Linear, (B,E,N)."""
     ids = textid.long()
     dt = sd[prefix + ".W.weight"].dtype                    # float32 as in the reference; float64 when the tests want an exact arm
-    one_hot = torch.zeros(ids.shape[0], vocab_len, ids.shape[2], dtype=dt).scatter_(
-        1, ids, torch.ones(ids.shape, dtype=dt))
+    # (on the ids' device, as the reference's `.to(device)`: bench.py's stock-op arm runs this same op sequence on the GPU)
+    one_hot = torch.zeros(ids.shape[0], vocab_len, ids.shape[2], dtype=dt, device=ids.device).scatter_(
+        1, ids, torch.ones(ids.shape, dtype=dt, device=ids.device))
     out = F.linear(one_hot.permute(0, 2, 1), sd[prefix + ".W.weight"], sd[prefix + ".W.bias"])
     return out.permute(0, 2, 1)
 
