@@ -512,7 +512,7 @@ def stock_gpu_baseline(dev, batch):
     torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
     # torch's default is MIOpen's immediate mode (no solver search), which is what a user of the reference gets; SSV_STOCK_BENCHMARK=1
     # lets MIOpen search (minutes of warm-up) -- DESIGN.md records both
-    torch.backends.cudnn.benchmark = os.environ.get("SSV_STOCK_BENCHMARK") == "1"
+    searched = torch.backends.cudnn.benchmark = os.environ.get("SSV_STOCK_BENCHMARK") == "1"
     ms, losses = {}, {}
     try:
         for kind in ("text2mel", "ssrn"):
@@ -552,7 +552,7 @@ def stock_gpu_baseline(dev, batch):
         torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32, torch.backends.cudnn.benchmark = prev
     return {"value": round(batch * T_MEL / ((ms["text2mel"] + ms["ssrn"]) * 1e-3), 1), "unit": "mel-frames/s",
             "text2mel_ms": round(ms["text2mel"], 3), "ssrn_ms": round(ms["ssrn"], 3),
-            "note": "torch stock ops (MIOpen / rocBLAS / ATen) on the same GPU, fp32, eager, autograd + torch.optim.Adam, 1 warm-up + 4 timed iterations per model, B=%d, cudnn.benchmark=%s" % (batch, torch.backends.cudnn.benchmark),
+            "note": "torch stock ops (MIOpen / rocBLAS / ATen) on the same GPU, fp32, eager, autograd + torch.optim.Adam, 1 warm-up + 4 timed iterations per model, B=%d, cudnn.benchmark=%s" % (batch, searched),
             "first_losses": losses}
 
 

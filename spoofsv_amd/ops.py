@@ -127,11 +127,11 @@ class DeferredWgrad:
 
     def __init__(self):
         self.jobs = {}
-        self.slots = []                # [pinned uint8 table, device table, event after the last eager copy]
+        self.slots = []                # [pinned uint8 table, device table (eager launches), event after the last copy out of the pinned table,
+                                       #  a capture's upload pending, device table of the CAPTURED launch (written once), that table in use]
         self.cursor = 0
         self.pending = set()           # addresses of the parameters whose gradient is queued and not yet flushed
         self._side = None              # stream for the table uploads of a capture (see flush)
-        self._frozen = []              # device tables of CAPTURED launches: written once, never reused (replays read them for ever)
 
     def __enter__(self):
         global _DEFER
@@ -150,6 +150,8 @@ class DeferredWgrad:
         """Wait for the table uploads a capture started on the side stream (call after the capture, before the first replay)."""
         if self._side is not None:
             self._side.synchronize()
+        for slot in self.slots:
+            slot[3] = False
 
     @staticmethod
     def accepts(B, Cin, Cout, L, k, nblk, params=()):
@@ -189,14 +191,20 @@ class DeferredWgrad:
                 raise RuntimeError("DeferredWgrad: run one eager iteration before capturing (job tables are pinned buffers, "
                                    "which cannot be allocated during a hipGraph capture)")
             cap = max(4096, nbytes)
-            self.slots.append([torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=dev), None])
+            self.slots.append([torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=dev), None, False,
+                               torch.empty(cap, dtype=torch.uint8, device=dev), False])
         slot = self.slots[self.cursor]
         if slot[0].numel() < nbytes or slot[1].device != dev:
             raise RuntimeError("DeferredWgrad: the sequence of weight-gradient launches changed between iterations")
-        if slot[2] is not None:
-            # the previous copy out of this pinned table has executed (eager iteration: on the launch stream; capture: on the side
-            # stream, which runs outside the capture -- waiting for it here is a host wait, legal while capturing)
-            slot[2].synchronize()
+        if capturing:
+            # (HIP refuses an event synchronize from a capturing thread: "operation not permitted on an event last recorded in a
+            # capturing stream", also for events of other streams.)  The pinned table is free unless an EARLIER capture's upload from
+            # it is still in flight on the side stream: captures must be separated by finish_uploads().
+            if slot[3]:
+                raise RuntimeError("DeferredWgrad: call finish_uploads() after a capture before capturing again")
+            slot[3] = True
+        elif slot[2] is not None:
+            slot[2].synchronize()          # the previous copy out of this pinned table has executed (launch stream, or a capture's side stream)
         self.cursor += 1
         return slot
 
@@ -221,15 +229,20 @@ class DeferredWgrad:
                 # The table of a captured launch is CONSTANT (the addresses of the capture's own tensors): it is uploaded once, now,
                 # on a stream outside the capture, instead of by a copy node that every replay would run in front of the launch
                 # (11 such nodes of ~4 us per training step).  ``finish_uploads`` (after the capture) waits for it.
-                # It goes into a device table of its OWN (allocated here, from the capture's pool, and kept for the life of this
-                # object): an eager iteration through the same DeferredWgrad after the capture -- a logged or debug step -- rewinds
-                # the cursor and rewrites the slots' tables, and the replays must keep reading the captured addresses.
-                dtable = torch.empty(len(raw), dtype=torch.uint8, device=dev)
-                self._frozen.append(dtable)
+                # It goes into the slot's SECOND device table, which eager iterations never write: an eager iteration through the same
+                # DeferredWgrad after the capture -- a logged or debug step -- rewinds the cursor and rewrites the slots' first tables,
+                # and the replays must keep reading the captured addresses.  (Allocated by the eager warm-up, outside any capture: a
+                # block from the capture's own pool may be the recycled memory of an earlier activation OF THE SAME CAPTURE, whose
+                # producer would overwrite the table at every replay -- the upload below is not part of the captured order.)
+                if slot[5]:
+                    raise RuntimeError("DeferredWgrad: this instance already serves a captured step (its frozen job tables are in use); "
+                                       "build a new step object for another capture")
+                slot[5] = True
+                dtable = slot[4]
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=dev)
                 with torch.cuda.stream(self._side):
-                    dtable.copy_(slot[0][:len(raw)], non_blocking=True)
+                    dtable.copy_(slot[0], non_blocking=True)
                     slot[2] = torch.cuda.Event()          # the pinned table may be refilled once this copy has executed
                     slot[2].record()
             else:

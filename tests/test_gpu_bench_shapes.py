@@ -43,7 +43,7 @@ LAYERS = [
 # Relative L2 against float64 per product (tests/test_gpu_accuracy.py holds split-fp16 to <= 2e-6 and 1.5x the exact kernels at B = 4;
 # at B = 32 the weight gradient sums 32 x L terms, so its fp32 accumulation level is what is allowed here) and the largest entry
 # error against the tensor's rms.
-TOL = {"fwd": (2e-6, 2e-5), "dgrad": (2e-6, 2e-5), "wgrad": (4e-6, 4e-5)}
+TOL = {"fwd": (1e-6, 1.5e-5), "dgrad": (1.5e-6, 2e-5), "wgrad": (2e-6, 1.5e-5)}      # measured on MI355X (profiles/round5_b32_shapes.txt): <= 3.6e-7/5.4e-6, 6.2e-7/8.5e-6, 8.7e-7/5.6e-6
 
 
 def _P(t):

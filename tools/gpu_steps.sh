@@ -13,6 +13,7 @@ for spec in "$@"; do
   rc=$?
   echo "== $name rc=$rc $(( $(date +%s) - t0 ))s" | tee -a "$out/steps.log"
   tail -n 4 "$out/$name.log"
+  if grep -q "Memory access fault" "$out/$name.log"; then echo "== $name: GPU memory access fault: stopping" | tee -a "$out/steps.log"; exit 1; fi
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "== $name was killed at its limit: stopping" | tee -a "$out/steps.log"; exit 1; fi
 done
 exit 0
