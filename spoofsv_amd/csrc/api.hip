@@ -41,7 +41,7 @@ int ssv_precision() {
   }
   return g_precision;
 }
-static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_FORCE", "SSV_NNB_FORCE", "SSV_LN_GROUPS"};
+static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_FORCE", "SSV_NNB_FORCE", "SSV_LN_GROUPS", "SSV_LN_PERSIST"};
 static char g_knob_val[SSV_T_COUNT][512];
 static const char* g_knob[SSV_T_COUNT];
 static int g_knobs_loaded = 0;

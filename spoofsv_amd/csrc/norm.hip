@@ -509,6 +509,7 @@ __global__ __launch_bounds__(1024) void ln_gate_bwd_wide_kernel(
   }
 }
 
+
 // ------------------------------------------------------------------------------------------------
 template <int CPT, int G>
 __global__ __launch_bounds__(16 * G) void ln_act_fwd_kernel(
@@ -1066,7 +1067,25 @@ int ssv_ln_act_bwd_vec(int C, int L, bool has_amax) {
   if (C > 256 && C <= 576 && L >= 64 && (long)C * L * 4 < (1L << 31) && (!has_amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 16))) return 4;
   return 1;
 }
-int ssv_ln_gate_bwd_rows(int B, int C, int L, bool has_amax) { return B * ssv_cdiv(L, 16 * ssv_ln_gate_bwd_vec(C, L, has_amax)); }
+// Workgroups per batch item of the PERSISTENT gate backward (ln_gate_bwd_pers_kernel), or 0 when the shape runs the tile kernels: 256 or 512
+// channels (8 channel steps per thread on 32 / 64 groups), B * wpi workgroups = the CUs (SSV_LN_PERSIST=<slots> overrides,
+// 0 switches the kernel off), every workgroup at least one 16-column sub-tile, one scale-list entry per workgroup.
+int ssv_launch_ln_gate_bwd_pers(const float* dY, long dy_bs, const float* H, const float* X, long x_bs, const float* stats, const float* g1, const float* b1,
+                                const float* g2, const float* b2, float* dH, float* dXres, long dx_bs, float* part, float* amax, int B, int C, int L, int wpi,
+                                hipStream_t st);       // norm_pers.hip
+int ssv_ln_gate_bwd_wpi(int B, int C, int L, bool has_amax) {
+  int slots = 256;
+  if (const char* e = ssv_tuning(SSV_T_LN_PERSIST)) slots = atoi(e);
+  if (slots <= 0 || C != 256 || (long)2 * C * L >= (1L << 31) || B > slots) return 0;
+  int wpi = slots / B;
+  if (wpi > ssv_cdiv(L, 16)) wpi = ssv_cdiv(L, 16);
+  if (has_amax && wpi > ssv_amax_rows_(L)) wpi = ssv_amax_rows_(L);
+  return wpi < 1 ? 0 : wpi;
+}
+int ssv_ln_gate_bwd_rows(int B, int C, int L, bool has_amax) {
+  if (const int wpi = ssv_ln_gate_bwd_wpi(B, C, L, has_amax)) return B * wpi;
+  return B * ssv_cdiv(L, 16 * ssv_ln_gate_bwd_vec(C, L, has_amax));
+}
 int ssv_ln_act_bwd_rows(int B, int C, int L, bool has_amax) { return B * ssv_cdiv(L, 16 * ssv_ln_act_bwd_vec(C, L, has_amax)); }
 
 int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const float* X, long x_bs, const float* stats,
@@ -1078,7 +1097,12 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
 #define CALL(N, G) hipLaunchKernelGGL((ln_gate_bwd_kernel<N, G>), grid, dim3(16 * G), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L)
   if (C > 512) return ssv_fail(SSV_UNSUPPORTED, "highway gate over %d channels not supported (max 512)", C);
   const int vec = ssv_ln_gate_bwd_vec(C, L, amax != nullptr);
-  if (vec > 1) {
+  const int wpi = ssv_ln_gate_bwd_wpi(B, C, L, amax != nullptr);
+  if (wpi > 0) {
+    dim3 gp(B * wpi);
+    ln_log("ln_gate_bwd_pers_kernel", C / 32, 32, gp, LN_BYTES, B, C, L);
+    SSV_TRY(ssv_launch_ln_gate_bwd_pers(dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, B, C, L, wpi, st));
+  } else if (vec > 1) {
 #define WIDE(N, V) do { dim3 gw(ssv_cdiv(L, 16 * V), B); ln_log("ln_gate_bwd_wide_kernel", N, V, gw, LN_BYTES, B, C, L, 1024); \
       hipLaunchKernelGGL((ln_gate_bwd_wide_kernel<N, V>), gw, dim3(1024), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L); } while (0)
     if (C <= 128) WIDE(2, 4); else if (C <= 256) WIDE(4, 4); else WIDE(8, 2);
@@ -1090,7 +1114,7 @@ int ssv_launch_ln_gate_bwd(const float* dY, long dy_bs, const float* H, const fl
 #undef LN_BYTES
   SSV_TRY(ssv_check_launch("ln_gate_bwd"));
   if (!pgrads) return 0;        // the caller sums the partial rows itself (fused with the weight-gradient slab sum)
-  return reduce_partials(part, pgrads, 6 * C, B * ssv_cdiv(L, 16 * vec), st);
+  return reduce_partials(part, pgrads, 6 * C, ssv_ln_gate_bwd_rows(B, C, L, amax != nullptr), st);
 }
 
 int ssv_launch_ln_act_fwd(const float* X, long x_bs, const float* gam, const float* bet, float* Y, long y_bs, float* stats,

@@ -123,7 +123,7 @@ int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA, 2 = split
 // The three tuning knobs that remain (per-shape overrides for in-step sweeps: SSV_NNB_FORCE="kt:M:N=wm,nt;...", SSV_NT_FORCE="M:Nc:k=Z;...",
 // SSV_LN_GROUPS for tools/bench_ln.py): read from the environment ONCE at first use -- a launch must not cost getenv() scans -- and
 // again only when a tuning script calls ssv_reload_tuning() (exported, not part of include/ssv_hip.h).
-enum { SSV_T_NT_FORCE, SSV_T_NNB_FORCE, SSV_T_LN_GROUPS, SSV_T_COUNT };
+enum { SSV_T_NT_FORCE, SSV_T_NNB_FORCE, SSV_T_LN_GROUPS, SSV_T_LN_PERSIST, SSV_T_COUNT };
 const char* ssv_tuning(int knob);          // value of the knob or nullptr
 int ssv_pack_job_blocks(const ssv_pack_job& j);           // workgroups one job of ssv_conv_pack_multi takes
 int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, float* amax_ws, hipStream_t st);   // amax_ws != null: split-fp16 planes

@@ -121,11 +121,15 @@ def _gate_ref(h, x, g1, b1, g2, b2):
     return s * ln(h[:, C:], g2, b2) + (1 - s) * x
 
 
-@pytest.mark.parametrize("B,C,L", [(3, 320, 77), (2, 512, 70), (2, 192, 1030), (1, 384, 64), (2, 256, 1089), (2, 448, 33)])
+@pytest.mark.parametrize("B,C,L", [(3, 320, 77), (2, 512, 70), (2, 192, 1030), (1, 384, 64), (2, 256, 1089), (2, 448, 33),
+                                   (32, 256, 325), (32, 256, 1300), (40, 256, 100), (3, 256, 650), (64, 256, 40), (256, 256, 19), (300, 256, 17)])
 def test_highway_gate_backward_wide_tile_kernels_at_ragged_shapes(B, C, L):
     """The LayerNorm / gate backward on its wide-tile kernels (round 4: 1024 threads, 32- or 64-column tiles; chosen for C > 256 or
     L >= 1024) at shapes that are multiples of nothing: ragged last column tile, last channel step partly empty, and one shape below
-    the rule (16-column kernel) for comparison -- every gradient against float64 autograd of the reference's expression."""
+    the rule (16-column kernel) for comparison -- every gradient against float64 autograd of the reference's expression.
+    C = 256 (round 5) runs the PERSISTENT kernel: one workgroup per CU owns a column range of one item and walks it in double-buffered
+    16-column sub-tiles -- the timed step's own launches (32 x 325: 40 / 41 columns = 3 sub-tiles per workgroup; 32 x 1300: 11), ranges
+    shorter than a sub-tile, fewer ranges than CUs, one workgroup per item, and more items than CUs (back on the tile kernel)."""
     from spoofsv_amd import ops
     gen = torch.Generator().manual_seed(5)
     h = torch.randn(B, 2 * C, L, generator=gen)
