@@ -6,7 +6,8 @@
 #include "ssv_common.h"
 
 #define LN_EPS 1e-5f
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (two div_scale, rcp, four fma, div_fmas, div_fixup: ten instructions per element)
+__device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 __device__ __forceinline__ float col_sum(float v) { return ssv_row16_sum(v); }
 
 // ---- persistent backward (round 5) ----------------------------------------------------------------------------------------
@@ -16,8 +17,8 @@ __device__ __forceinline__ float col_sum(float v) { return ssv_row16_sum(v); }
 // batch item -- L / wpi of them, `wpi` workgroups per item chosen so that B * wpi workgroups are one per CU: equal
 // bytes per CU, no second round -- and walks it in 16-column sub-tiles with TWO register sets: the loads of sub-tile k + 1 (and its
 // column statistics) are issued before sub-tile k's first pass, so its sums, its second pass and its stores run under them.  Same
-// arithmetic per element and per column as ln_gate_bwd_kernel (dH, dXres bit-identical); the per-channel parameter-gradient partials
-// of ALL sub-tiles of a workgroup are accumulated in registers (lane `col` of a row keeps the six sums of channel step i == col) and
+// arithmetic per element and per column as ln_gate_bwd_kernel up to the sigmoid's reciprocal; the per-channel parameter-gradient partials
+// of ALL sub-tiles of a workgroup are accumulated per thread and
 // written as ONE partial row per workgroup: B * wpi rows (256) instead of one per tile (672 at L = 325), and one scale-list entry.
 // Sum N per-thread values over the G channel groups of the thread's column, G = 4 * NW: the four groups of a wave first (two lane
 // exchanges per value), then the NW waves through LDS (`red`: [NW][N][16]) in a fixed order.
@@ -53,8 +54,13 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_pers_kernel(
   const int col = threadIdx.x & 15, g = threadIdx.x >> 4, wave = threadIdx.x >> 6;
   const unsigned wg = ssv_xcd_order(blockIdx.x, gridDim.x);
   const int b = (int)(wg / (unsigned)wpi), j = (int)(wg % (unsigned)wpi);
-  const int s0 = (int)((long)j * L / wpi), s1 = (int)((long)(j + 1) * L / wpi);
-  const int ntile = (s1 - s0 + 15) >> 4;
+  // sub-tile k of workgroup j is tile k * wpi + j of the item: at any time the wpi workgroups of an item (neighbours in launch order: one XCD)
+  // work on ADJACENT 16-column tiles, so the two halves of every 128-byte line are asked for at the same time through the same L2.  (With
+  // a contiguous column range per workgroup the other half of each line came due a sub-tile later, ~12 us, by when the L2 had dropped it:
+  // 2.1 TB/s at every length against 2.7-3.5 of the tile kernels.)
+  const int tiles_item = (L + 15) >> 4;
+  const int ntile = (tiles_item - j + wpi - 1) / wpi;
+  const int s1 = L;
   // every stream through a buffer resource: uniform base + ONE per-thread byte offset per sub-tile + a scalar row offset per channel step
   // (with plain pointers hipcc kept a 64-bit VGPR pointer per stream and step: 256 VGPRs + 238 AGPRs for a 16-step form of this kernel)
   const __amdgpu_buffer_rsrc_t rdy = ssv_buf(dY + (long)b * dy_bs), rx = ssv_buf(X + (long)b * x_bs);
@@ -73,7 +79,13 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_pers_kernel(
   }
   float raw[2][CPT][4];                 // per set: dy, x, h1, h2 -> (first pass, in place) a1, a2, xhat1, xhat2
   float cst[2][4];                      // mu1, r1, mu2, r2 of the thread's column
-  float pacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // per-channel parameter-gradient partials: summed over the workgroup's columns PER THREAD (its own column of every sub-tile) and reduced over
+  // the 16 column lanes ONCE at the end -- a reduction per channel step (six butterflies of four DPP stages) was a third of the kernel's VALU work
+  float pacc[6][CPT];
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) pacc[q][i] = 0.f;
   float am = 0.f;
   const unsigned rstep4 = (unsigned)G * (unsigned)L * 4u;
   auto st32 = [](float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) __attribute__((always_inline)) {
@@ -81,7 +93,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_pers_kernel(
   };
   auto issue = [&](auto bufc, int k) __attribute__((always_inline)) {
     constexpr int bf = decltype(bufc)::value;
-    const int t = min(s0 + 16 * k + col, s1 - 1);            // clamped into the range: always legal, masked at use
+    const int t = min(16 * (k * wpi + j) + col, s1 - 1);    // clamped into the item: always legal, masked at use
     const unsigned vo = ((unsigned)g * (unsigned)L + (unsigned)t) * 4u;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_pers_kernel(
   };
   auto process = [&](auto bufc, int k) __attribute__((always_inline)) {
     constexpr int bf = decltype(bufc)::value;
-    const int t = s0 + 16 * k + col;
+    const int t = 16 * (k * wpi + j) + col;
     const bool tv = t < s1;
     const unsigned vo = ((unsigned)g * (unsigned)L + (unsigned)min(t, s1 - 1)) * 4u;
     const float mu1 = cst[bf][0], r1 = cst[bf][1], mu2 = cst[bf][2], r2 = cst[bf][3];
@@ -113,8 +125,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_pers_kernel(
       const float dn2 = dy * s;
       const float dn1 = dy * (n2 - x) * s * (1.f - s);
       if (tv) st32(dy * (1.f - s), wdx, vo, (unsigned)i * rstep4);
-      const float p0 = col_sum(dn1 * xh1), p1 = col_sum(dn1), p2 = col_sum(dn2 * xh2), p3 = col_sum(dn2);
-      if (col == i) { pacc[0] += p0; pacc[1] += p1; pacc[2] += p2; pacc[3] += p3; }
+      pacc[0][i] += dn1 * xh1; pacc[1][i] += dn1; pacc[2][i] += dn2 * xh2; pacc[3][i] += dn2;
       const float a1 = dn1 * gg1, a2 = dn2 * gg2;
       raw[bf][i][0] = a1; raw[bf][i][1] = a2; raw[bf][i][2] = xh1; raw[bf][i][3] = xh2;
       gs[0] += a1; gs[1] += a1 * xh1; gs[2] += a2; gs[3] += a2 * xh2;
@@ -128,8 +139,7 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_pers_kernel(
       const float d2 = tv ? r2 * (raw[bf][i][1] - m2 - raw[bf][i][3] * mh2) : 0.f;
       if (tv) { st32(d1, wh1, vo, (unsigned)i * rstep4); st32(d2, wh2, vo, (unsigned)i * rstep4); }
       am = fmaxf(am, fmaxf(fabsf(d1), fabsf(d2)));
-      const float q0 = col_sum(d1), q1 = col_sum(d2);
-      if (col == i) { pacc[4] += q0; pacc[5] += q1; }
+      pacc[4][i] += d1; pacc[5][i] += d2;
     }
   };
   // The sub-tile whose loads are issued is always one ahead of the one being processed.  The last sub-tiles are peeled: a path that issues
@@ -154,12 +164,16 @@ __global__ __launch_bounds__(16 * G) void ln_gate_bwd_pers_kernel(
   } else {
     process(B0, k);
   }
-  // this workgroup's partial row: lane `col` of channel group g holds the six sums of channel g + G * col
-  if (col < CPT) {
-    const int c = g + G * col;
+  // this workgroup's partial row
+  {
     float* pblk = part + (long)wg * 6 * C;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) pblk[q * C + c] = pacc[q];
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const float t = col_sum(pacc[q][i]);
+        if (col == 0) pblk[q * C + g + G * i] = t;
+      }
   }
   if (amax) {                                    // max |dH| over the workgroup's range: entry j of the item's list, the last workgroup zeroes the rest
     am = ssv_wg_max<NW>(am, amx);
@@ -176,6 +190,6 @@ int ssv_launch_ln_gate_bwd_pers(const float* dY, long dy_bs, const float* H, con
                                 const float* g2, const float* b2, float* dH, float* dXres, long dx_bs, float* part, float* amax, int B, int C, int L, int wpi,
                                 hipStream_t st) {
   if (C != 256 || wpi < 1 || wpi > ssv_cdiv(L, 16)) return ssv_fail(SSV_UNSUPPORTED, "persistent gate backward: C = %d, %d workgroups per item", C, wpi);
-  hipLaunchKernelGGL((ln_gate_bwd_pers_kernel<8, 32, 0>), dim3(B * wpi), dim3(512), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L, wpi);
+  hipLaunchKernelGGL((ln_gate_bwd_pers_kernel<8, 32, 1>), dim3(B * wpi), dim3(512), 0, st, dY, dy_bs, H, X, x_bs, stats, g1, b1, g2, b2, dH, dXres, dx_bs, part, amax, C, L, wpi);
   return ssv_check_launch("ln_gate_bwd_pers");
 }
