@@ -19,7 +19,17 @@
 // depths 2, 4, 6, 8 were measured in-step: equal within 1 % -- 4 keeps the hot instantiations at 128 VGPRs (4 waves per SIMD)
 #define LN_PIPE(CPT) ((CPT) < 4 ? (CPT) : 4)
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+#ifndef SSV_SIGMOID_DIV
+#define SSV_SIGMOID_DIV 0      // (tuning builds: 1 = the IEEE division sequence of rounds 1-4)
+#endif
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (two div_scale, rcp, four fma, div_fmas, div_fixup: ten instructions per element)
+__device__ __forceinline__ float sigmoidf_(float v) {
+#if SSV_SIGMOID_DIV
+  return 1.f / (1.f + __expf(-v));
+#else
+  return __builtin_amdgcn_rcpf(1.f + __expf(-v));
+#endif
+}
 
 // Sum `v` over the G channel groups of this thread's column. `red` is a [G][16] LDS array.
 template <int G>

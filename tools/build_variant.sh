@@ -5,8 +5,9 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../spoofsv_amd/csrc"
 mkdir -p build/ab/$name
-for f in api gemm_nn gemm_nt gemm_bf3 norm attn misc lstm vocoder synth critic; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c $f.hip -o build/ab/$name/$f.o &
+for f in api gemm_nn gemm_nt gemm_bf3 norm norm_pers attn misc lstm vocoder synth critic; do
+  extra=""; [ $f = norm_pers ] && extra="-fno-slp-vectorize"
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $extra "$@" -c $f.hip -o build/ab/$name/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 build/ab/$name/*.o -o build/ab/libssv_hip_$name.so
