@@ -606,7 +606,8 @@ static int hw_fused_tiles(int B, int C, int L, int k, int* bn) {
 extern "C" size_t ssv_highway_conv1d_fused_sync_bytes(int B, int C, int L, int k) {
   int bn = 0;
   const int tiles = hw_fused_tiles(B, C, L, k, &bn);
-  return tiles > 0 ? 256 + (size_t)B * tiles * (2 * bn * 2) * 8 : 0;
+  // 16 control words + an arrival counter per column tile (rounded to 256 bytes), then two tagged words per row tile, half and column
+  return tiles > 0 ? (size_t)(16 + B * ssv_cdiv(L, bn) + 63) / 64 * 256 + (size_t)B * tiles * (2 * bn * 2) * 8 : 0;
 }
 extern "C" int ssv_highway_conv1d_fused_amax_rows(int B, int C, int L, int k) { return hw_fused_tiles(B, C, L, k, nullptr); }
 extern "C" int ssv_highway_conv1d_fwd_fused(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,

@@ -700,10 +700,11 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
     float* stage = reinterpret_cast<float*>(lds_all);             // [NBLK * 16][LDW]: rows 0 .. RH - 1 = H1, RH .. 2 RH - 1 = H2
     float* cst = stage + NBLK * 16 * LDW;                         // [NBLK][BN][2]: (mean, M2) of a block's 16 rows
     float* fin = cst + NBLK * BN * 2;                             // [2][BN][2]: (mean, rstd) of a column, per half
-    float* amxs = fin + 4 * BN;
+    float* amxs = fin + 4 * BN;                                   // [0..3] wave maxima, [4] the poll's verdict
     const int Cc = p.M >> 1, ntiles = (int)gridDim.x / mtiles;
     unsigned* hdr = p.hw_sync;
-    unsigned long long* words = reinterpret_cast<unsigned long long*>(hdr + 64) + ((size_t)((size_t)b * ntiles + ntile) * mtiles) * (2 * BN * 2);
+    const size_t hdr_u32 = (size_t)(16 + gridDim.y * ntiles + 63) / 64 * 64;       // control words + one arrival counter per column tile, 256-byte multiple
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(hdr + hdr_u32) + ((size_t)((size_t)b * ntiles + ntile) * mtiles) * (2 * BN * 2);
     const unsigned epoch = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tag = epoch + 1u;
     __syncthreads();                                              // every wave is done reading the last chunk's image
 #pragma unroll
@@ -732,7 +733,16 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
           cst[(blk * BN + c) * 2] = mean; cst[(blk * BN + c) * 2 + 1] = m2;
         }
       }
-      if (p.C) {                                                  // h, row-contiguous (training: the backward reads it)
+    }
+    // h, row-contiguous (training: the backward reads it).  Issued AFTER the exchange: the polls of the exchange would otherwise queue behind
+    // these stores in each wave's memory pipeline
+    auto store_h = [&]() __attribute__((always_inline)) {
+      if (!p.C) return;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int blk = wave * WM + i;
+        const int rbase = ((wave >> 1) * (p.M >> 5) + mt * (2 * WM) + (wave & 1) * WM + i) * 16;
+        const float* st_ = stage + blk * 16 * LDW;
 #pragma unroll
         for (int it = 0; it < NT; ++it) {
           const int e = lane + 64 * it;
@@ -749,38 +759,58 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
           }
         }
       }
-    }
+    };
     __syncthreads();
-    // this row tile's (mean, M2) per half and column -> published; the other row tiles' -> merged (Chan, equal counts) in tile order
+    // this row tile's (mean, M2) per half and column -> published; then ONE thread counts it in and waits for the column tile's other row tiles
+    // (a poll per thread and word -- 3,584 agent-scope loads per workgroup and round -- starved the very stores it was waiting for: 97 us a launch)
+    float mean_own = 0.f, m2_own = 0.f;
+    const int xhalf = tid / BN, xcol = tid % BN;
+    unsigned* arrive = hdr + 16 + ((size_t)b * ntiles + ntile);          // per column tile; grows by mtiles per launch, never reset
     if (tid < 2 * BN) {
-      const int half = tid / BN, col = tid % BN;
       float mu[2 * WM], mean = 0.f, m2 = 0.f;
 #pragma unroll
-      for (int q = 0; q < 2 * WM; ++q) { const int blk = half * 2 * WM + q; mu[q] = cst[(blk * BN + col) * 2]; mean += mu[q]; m2 += cst[(blk * BN + col) * 2 + 1]; }
+      for (int q = 0; q < 2 * WM; ++q) { const int blk = xhalf * 2 * WM + q; mu[q] = cst[(blk * BN + xcol) * 2]; mean += mu[q]; m2 += cst[(blk * BN + xcol) * 2 + 1]; }
       mean *= 1.f / (float)(2 * WM);
 #pragma unroll
       for (int q = 0; q < 2 * WM; ++q) { const float d = mu[q] - mean; m2 += 16.f * d * d; }
-      unsigned long long* mine = words + ((size_t)mt * 2 + half) * (BN * 2) + col * 2;
+      unsigned long long* mine = words + ((size_t)mt * 2 + xhalf) * (BN * 2) + xcol * 2;
       __hip_atomic_store(mine, ((unsigned long long)tag << 32) | __float_as_uint(mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(mine + 1, ((unsigned long long)tag << 32) | __float_as_uint(m2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mean_own = mean; m2_own = m2;
+    }
+    __builtin_amdgcn_s_waitcnt(0);                                // this wave's words have been written (acknowledged) ...
+    __syncthreads();                                              // ... and so have the other waves'
+    store_h();                                                    // (h drains while the row tiles wait for each other)
+    bool bad = false;
+    if (tid == 0) {
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)mtiles * tag;
+      for (int tries = 0;; ++tries) {                             // bounded: peers that never run are a NaN in y and a flag, not a hung GPU
+        const unsigned c = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(c - target) >= 0) break;
+        if (tries > (1 << 16)) { bad = true; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      amxs[4] = bad ? 1.f : 0.f;
+    }
+    __syncthreads();
+    bad = amxs[4] != 0.f;
+    if (tid < 2 * BN) {
+      const int half = xhalf, col = xcol;
       float pm[8], pq[8];                                         // (at most 8 row tiles: the launcher checks; static indices: registers)
-      bool bad = false;
+      unsigned long long w0[8], w1[8];
 #pragma unroll
       for (int pp = 0; pp < 8; ++pp) {
-        pm[pp] = 0.f; pq[pp] = 0.f;
-        if (pp >= mtiles) continue;
-        if (pp == mt) { pm[pp] = mean; pq[pp] = m2; continue; }
-        const unsigned long long* theirs = words + ((size_t)pp * 2 + half) * (BN * 2) + col * 2;
-        unsigned long long w0, w1;
-        int tries = 0;
-        for (;;) {                                                // bounded: a peer that never runs is a NaN in y and a flag, not a hung GPU
-          w0 = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          w1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) break;
-          if (++tries > (1 << 15)) { bad = true; break; }
-          __builtin_amdgcn_s_sleep(2);
-        }
-        pm[pp] = __uint_as_float((unsigned)w0); pq[pp] = __uint_as_float((unsigned)w1);
+        const unsigned long long* theirs = words + ((size_t)min(pp, mtiles - 1) * 2 + half) * (BN * 2) + col * 2;
+        w0[pp] = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w1[pp] = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int pp = 0; pp < 8; ++pp) {
+        if (pp < mtiles && pp != mt) bad = bad || (unsigned)(w0[pp] >> 32) != tag || (unsigned)(w1[pp] >> 32) != tag;
+        pm[pp] = pp < mtiles ? __uint_as_float((unsigned)w0[pp]) : 0.f;
+        pq[pp] = pp < mtiles ? __uint_as_float((unsigned)w1[pp]) : 0.f;
+        if (pp == mt) { pm[pp] = mean_own; pq[pp] = m2_own; }
       }
       float gmean = 0.f, gm2 = 0.f;
 #pragma unroll

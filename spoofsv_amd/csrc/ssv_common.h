@@ -101,7 +101,8 @@ struct GemmNNB {
   // (bounded polls; see tools/probe/xchg_probe.hip for what that costs), merges them in a fixed order, normalises and gates its own rows from
   // the tile parked in LDS.  X is the gate's residual input as well.  C (may be null: inference) receives h in the natural row order.
   // hw_sync: caller-owned, zeroed ONCE, then only touched by these launches: [0] epoch, [1] finished workgroups, [2] error (a poll limit was
-  // hit: y is NaN), [64 ..] the words.  A launch tags its words epoch + 1; its last workgroup to finish advances the epoch.
+  // hit: y is NaN), [16 ..] one arrival counter per column tile, then (256-byte aligned) the words.  A launch tags its words epoch + 1; its last
+  // workgroup to finish advances the epoch.
   const float* hw_g1; const float* hw_b1; const float* hw_g2; const float* hw_b2;
   float* hw_y; long hw_ybs; float* hw_stats; float* hw_yamax; int hw_namax;
   unsigned* hw_sync;
