@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 5 (5 = ssv_highway_conv1d_fwd_fused; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
+int ssv_version(void);            /* ABI version, currently 4 (2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
                                     4 = compact partial rows: the nblk of a weight-gradient job is ssv_ln_bwd_partial_rows(...), not ssv_ln_partial_rows(B, L)) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -182,21 +182,6 @@ int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_amax, int x
                            float* h, float* stats, float* y, long y_bs, float* y_amax,
                            int B, int C, int L, int k, int dilation, int causal,
                            void* ws, size_t ws_bytes, ssv_stream_t stream);   /* y_amax: as in ssv_channel_ln_act_fwd */
-/* The same in ONE launch (ABI 5; split-MFMA modes, C % 64 == 0, C <= 512, k = 1 or 3): the conv kernel's row tiles hold matching rows
- * of both halves, exchange the LayerNorm partial sums of their columns through `sync` (tagged words, agent-scope accesses, bounded polls) and
- * finish normalisation and gate from their own accumulators -- no second pass over h, no second launch.
- *   sync: ssv_highway_conv1d_fused_sync_bytes(B, C, L, k) bytes (0 = not a fused shape: use ssv_highway_conv1d_fwd), owned by the caller,
- *         ZEROED ONCE when allocated and from then on passed to every call of THIS layer and shape and touched by nothing else (calls that
- *         share a sync area must be ordered on one stream; different layers running on different streams have areas of their own).
- *         ((unsigned*)sync)[2] != 0 afterwards: a workgroup gave up waiting for its peers (they were not running): y holds NaN.
- *   h / stats: both NULL (inference) or both given (training).   y_amax: y_namax >= ssv_highway_conv1d_fused_amax_rows(...) entries per item. */
-size_t ssv_highway_conv1d_fused_sync_bytes(int B, int C, int L, int k);
-int ssv_highway_conv1d_fused_amax_rows(int B, int C, int L, int k);
-int ssv_highway_conv1d_fwd_fused(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
-                                 const float* g1, const float* b1, const float* g2, const float* b2,
-                                 float* h, float* stats, float* y, long y_bs, float* y_amax, int y_namax, void* sync, size_t sync_bytes,
-                                 int B, int C, int L, int k, int dilation, int causal,
-                                 void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_highway_conv1d_bwd_workspace(int B, int C, int L, int k);
 /* Outputs: dx (B,C,L), dw (2C,C,k), pgrads (6,C) = dgamma1, dbeta1, dgamma2, dbeta2, dbias[:C], dbias[C:]. */
 int ssv_highway_conv1d_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed,

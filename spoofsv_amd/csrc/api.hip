@@ -93,7 +93,7 @@ extern "C" int ssv_set_precision(int mode) {
   return prev;
 }
 extern "C" int ssv_get_precision(void) { return ssv_precision(); }
-extern "C" int ssv_version(void) { return 5; }
+extern "C" int ssv_version(void) { return 4; }
 extern "C" const char* ssv_arch(void) { return "gfx950"; }
 extern "C" const char* ssv_last_error(void) { return g_err; }
 
@@ -215,7 +215,6 @@ static GemmNNB nnb_zero() {
   g.f16 = 0; g.a_inv = nullptr; g.x_amax = nullptr; g.x_namax = 0; g.x_amax_bs = 0;
   g.colstats = nullptr;
   g.xrow_w = nullptr; g.xrow_sk = 0;
-  g.hw_g1 = g.hw_b1 = g.hw_g2 = g.hw_b2 = nullptr; g.hw_y = nullptr; g.hw_ybs = 0; g.hw_stats = nullptr; g.hw_yamax = nullptr; g.hw_namax = 0; g.hw_sync = nullptr;
   return g;
 }
 
@@ -226,12 +225,10 @@ static GemmNNB nnb_zero() {
 static inline size_t conv_aux_bytes() { return SSV_F16_AUX_BYTES + AMAX_FB_BYTES; }
 // (pw != null: the 1x1 product finishes LayerNorm + activation in its own launch, gemm_pwln_kernel; y is then `pre`)
 struct PwLnArgs { const float* gamma; const float* beta; float* y; long ybs; float* stats; float* y_amax; int namax; int act; };
-// (hw != null: the highway conv finishes both LayerNorms and the gate in its own launch, GemmNNB::hw_*; y of conv_nn is then `h`, may be null)
-struct HwArgs { const float* g1; const float* b1; const float* g2; const float* b2; float* y; long ybs; float* stats; float* y_amax; int namax; unsigned* sync; };
 static int conv_nn(const float* x, long x_bs, const float* w, const void* packed, long w_sm, long w_sk, const float* bias, const float* bias_b,
                    const float* r, long r_bs, float* y, long y_bs, int B, int K, int M, int L, int k, const int* shift,
                    bool bf3, void* ws, hipStream_t st, const float* a_inv = nullptr, const float* xa_given = nullptr, int xa_n = 0, size_t ws_main = 0,
-                   float* colstats = nullptr, const PwLnArgs* pw = nullptr, const HwArgs* hw = nullptr) {
+                   float* colstats = nullptr, const PwLnArgs* pw = nullptr) {
   if (bf3) {
     const int Kpad = pad32(K);
     const unsigned short* hi = (const unsigned short*)(packed ? packed : ws);
@@ -258,10 +255,6 @@ static int conv_nn(const float* x, long x_bs, const float* w, const void* packed
     for (int j = 0; j < 3; ++j) g.shift[j] = shift[j];
     if (k == 1 && M > 128 && M % 128 == 1) { g.xrow_w = w + (long)(M - 1) * w_sm; g.xrow_sk = w_sk; }     // (GemmNNB::xrow_w; the launchers decide)
     if (pw) return ssv_launch_gemm_pwln(g, pw->gamma, pw->beta, pw->y, pw->ybs, pw->stats, pw->y_amax, pw->namax, pw->act, st);
-    if (hw) {
-      g.epi = 2; g.hw_g1 = hw->g1; g.hw_b1 = hw->b1; g.hw_g2 = hw->g2; g.hw_b2 = hw->b2; g.hw_y = hw->y; g.hw_ybs = hw->ybs; g.hw_stats = hw->stats;
-      g.hw_yamax = hw->y_amax; g.hw_namax = hw->namax; g.hw_sync = hw->sync;
-    }
     return ssv_launch_gemm_nn_bf3(g, st);
   }
   if (L == 1 && k == 1 && w_sk == 1 && w_sm == K && !r)          // nn.Linear on a (B, K) matrix (the speaker-code layers): see linear_len1_fwd_kernel
@@ -592,42 +585,6 @@ extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_
   }
   SSV_TRY(ssv_conv1d_fwd(x, x_bs, x_amax, x_namax, w, w_packed, bias, nullptr, h, (long)2 * C * L, nullptr, B, C, 2 * C, L, k, dilation, causal, ws, ws_bytes, stream));
   return ssv_launch_ln_gate_fwd(h, (long)2 * C * L, x, x_bs, g1, b1, g2, b2, y, y_bs, stats, B, C, L, (hipStream_t)stream, y_amax);
-}
-
-// The whole highwayConv forward in ONE launch (round 5): the conv kernel's row tiles exchange their LayerNorm partial sums and finish
-// normalisation and gate themselves (GemmNNB::hw_*, gemm_nn_bf3_kernel<.., EPI = 2>).  `sync`: see include/ssv_hip.h.
-static int hw_fused_tiles(int B, int C, int L, int k, int* bn) {
-  if (!hw_colstats(B, C, L) || (k != 1 && k != 3) || (long)B * L < 256) return 0;
-  int wm = 0, nt = 0;
-  const int tiles = ssv_nnb_hw_tiles(B, 2 * C, L, C, k, &wm, &nt);
-  if (bn) *bn = 16 * nt;
-  return tiles;
-}
-extern "C" size_t ssv_highway_conv1d_fused_sync_bytes(int B, int C, int L, int k) {
-  int bn = 0;
-  const int tiles = hw_fused_tiles(B, C, L, k, &bn);
-  // 16 control words + an arrival counter per column tile (rounded to 256 bytes), then two tagged words per row tile, half and column
-  return tiles > 0 ? (size_t)(16 + B * ssv_cdiv(L, bn) + 63) / 64 * 256 + (size_t)B * tiles * (2 * bn * 2) * 8 : 0;
-}
-extern "C" int ssv_highway_conv1d_fused_amax_rows(int B, int C, int L, int k) { return hw_fused_tiles(B, C, L, k, nullptr); }
-extern "C" int ssv_highway_conv1d_fwd_fused(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
-                                            const float* g1, const float* b1, const float* g2, const float* b2, float* h, float* stats, float* y, long y_bs,
-                                            float* y_amax, int y_namax, void* sync, size_t sync_bytes,
-                                            int B, int C, int L, int k, int dilation, int causal, void* ws, size_t ws_bytes, ssv_stream_t stream) {
-  SSV_CHECK(x && w && g1 && b1 && g2 && b2 && y && sync, SSV_BAD_SHAPE, "highway_conv1d_fwd_fused: null argument");
-  SSV_CHECK(B > 0 && C > 0 && L > 0 && B <= 65535, SSV_BAD_SHAPE, "highway_conv1d_fwd_fused: bad shape B=%d C=%d L=%d", B, C, L);
-  const size_t need = ssv_highway_conv1d_fused_sync_bytes(B, C, L, k);
-  SSV_CHECK(need > 0, SSV_UNSUPPORTED, "highway_conv1d_fwd_fused: B=%d C=%d L=%d k=%d is not a fused shape (ssv_highway_conv1d_fused_sync_bytes)", B, C, L, k);
-  SSV_CHECK(sync_bytes >= need, SSV_BAD_SHAPE, "highway_conv1d_fwd_fused: sync area too small (%zu < %zu)", sync_bytes, need);
-  SSV_CHECK(!y_amax || y_namax >= ssv_highway_conv1d_fused_amax_rows(B, C, L, k), SSV_BAD_SHAPE, "highway_conv1d_fwd_fused: scale list too short");
-  SSV_CHECK(ws && ws_bytes >= ssv_conv1d_fwd_workspace(C, 2 * C, k), SSV_BAD_SHAPE, "highway_conv1d_fwd_fused: workspace too small");
-  SSV_CHECK(x_bs >= (long)C * L && y_bs >= (long)C * L, SSV_BAD_SHAPE, "highway_conv1d_fwd_fused: batch stride smaller than C*L");
-  SSV_CHECK((h != nullptr) == (stats != nullptr), SSV_BAD_SHAPE, "highway_conv1d_fwd_fused: h and stats are saved together (training) or not at all");
-  int shift[3];
-  SSV_TRY(conv_shifts(k, dilation, causal, shift));
-  const HwArgs hw = {g1, b1, g2, b2, y, y_bs, stats, y_amax, y_namax, (unsigned*)sync};
-  return conv_nn(x, x_bs, w, w_packed, (long)C * k, k, bias, nullptr, nullptr, 0, h, (long)2 * C * L, B, C, 2 * C, L, k, shift, true, ws, (hipStream_t)stream,
-                 packed_inv(w_packed, 2 * C, C, k, 0), x_amax, x_namax, 2 * split_bytes(2 * C, C, k), nullptr, nullptr, &hw);
 }
 
 // ---- 1x1 conv + LayerNorm (+ activation), whole backward ------------------------------------------------------------------

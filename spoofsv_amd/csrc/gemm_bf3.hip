@@ -370,8 +370,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   // one -- one barrier per chunk, and the split (VALU) runs under the MFMAs instead of between two barriers
   // (the epilogue re-uses the memory to turn the accumulator tiles into row-contiguous stores: 4 waves x 16 rows x (BN + 4))
   // (+ 4 * WM * BN (mean, M2) pairs behind the parked tiles when the caller wants the output's column statistics)
-  // (EPI == 2, the fused highwayConv: ALL 4 * WM blocks parked at once + their (mean, M2) pairs + the columns' final (mean, rstd) of both halves)
-  constexpr int IMG = 2 * X_SLOTS, EPI_U4 = EPI == 2 ? (4 * WM * 16 * (BN + 4) + 4 * WM * BN * 2 + 4 * BN + 8) / 4 : (4 * 16 * (BN + 4) + 4 * WM * BN * 2) / 4;
+  constexpr int IMG = 2 * X_SLOTS, EPI_U4 = (4 * 16 * (BN + 4) + 4 * WM * BN * 2) / 4;
   constexpr int LDS_U4 = 2 * IMG > EPI_U4 ? 2 * IMG : EPI_U4;
   __shared__ uint4 lds_all[LDS_U4];
   uint4 (*lds)[IMG] = reinterpret_cast<uint4 (*)[IMG]>(lds_all);
@@ -417,8 +416,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   long arow[WM];
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
-    // EPI == 2: waves 0, 1 own H1 row blocks 2 WM mt .. 2 WM mt + 2 WM - 1, waves 2, 3 the SAME blocks of H2 (GemmNNB: fused highwayConv)
-    const int mb = EPI == 2 ? (wave >> 1) * (p.M >> 5) + mt * (2 * WM) + (wave & 1) * WM + i : (m0 + wave * WM * 16 + i * 16) >> 4;
+    const int mb = (m0 + wave * WM * 16 + i * 16) >> 4;
     arow[i] = (long)min(mb, MB - 1) * nchunks_all * 512 + lane * 8;     // blocks past M re-read the last one: never stored
   }
   const long aplane = (long)MB * nchunks_all * 512;
@@ -692,195 +690,6 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
         Cb[(long)u * p.scm + gn] = go * tanhf(cn);
       }
     }
-    return;
-  }
-  if constexpr (EPI == 2) {
-    // ---- fused highwayConv epilogue (GemmNNB: hw_*) ---------------------------------------------------------------------------
-    constexpr int LDW = BN + 4, NBLK = 4 * WM, RH = 32 * WM;      // parked row pitch, 16-row blocks of the tile, rows of one half
-    float* stage = reinterpret_cast<float*>(lds_all);             // [NBLK * 16][LDW]: rows 0 .. RH - 1 = H1, RH .. 2 RH - 1 = H2
-    float* cst = stage + NBLK * 16 * LDW;                         // [NBLK][BN][2]: (mean, M2) of a block's 16 rows
-    float* fin = cst + NBLK * BN * 2;                             // [2][BN][2]: (mean, rstd) of a column, per half
-    float* amxs = fin + 4 * BN;                                   // [0..3] wave maxima, [4] the poll's verdict
-    const int Cc = p.M >> 1, ntiles = (int)gridDim.x / mtiles;
-    unsigned* hdr = p.hw_sync;
-    const size_t hdr_u32 = (size_t)(16 + gridDim.y * ntiles + 63) / 64 * 64;       // control words + one arrival counter per column tile, 256-byte multiple
-    unsigned long long* words = reinterpret_cast<unsigned long long*>(hdr + hdr_u32) + ((size_t)((size_t)b * ntiles + ntile) * mtiles) * (2 * BN * 2);
-    const unsigned epoch = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tag = epoch + 1u;
-    __syncthreads();                                              // every wave is done reading the last chunk's image
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      const int blk = wave * WM + i;
-      const int rbase = ((wave >> 1) * (p.M >> 5) + mt * (2 * WM) + (wave & 1) * WM + i) * 16;      // natural first row of the block
-      float* st_ = stage + blk * 16 * LDW;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float add = p.bias ? p.bias[rbase + kq * 4 + r] : 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) st_[(kq * 4 + r) * LDW + t * 16 + nq] = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add;
-      }
-      // (the block is private to the wave: its LDS operations complete in order)  column statistics of the block: two passes over 16 values
-#pragma unroll
-      for (int c0 = 0; c0 < BN; c0 += 64) {
-        const int c = c0 + lane;
-        if (c < BN) {
-          float v[16], sum = 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { v[r] = st_[r * LDW + c]; sum += v[r]; }
-          const float mean = sum * (1.f / 16.f);
-          float m2 = 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; m2 += d * d; }
-          cst[(blk * BN + c) * 2] = mean; cst[(blk * BN + c) * 2 + 1] = m2;
-        }
-      }
-    }
-    // h, row-contiguous (training: the backward reads it).  Issued AFTER the exchange: the polls of the exchange would otherwise queue behind
-    // these stores in each wave's memory pipeline
-    auto store_h = [&]() __attribute__((always_inline)) {
-      if (!p.C) return;
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const int blk = wave * WM + i;
-        const int rbase = ((wave >> 1) * (p.M >> 5) + mt * (2 * WM) + (wave & 1) * WM + i) * 16;
-        const float* st_ = stage + blk * 16 * LDW;
-#pragma unroll
-        for (int it = 0; it < NT; ++it) {
-          const int e = lane + 64 * it;
-          const int row = e / (BN / 4), c4 = e % (BN / 4);
-          const int gn = n0 + c4 * 4;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(st_ + row * LDW + c4 * 4);
-          if (gn < p.N) {
-            float* dst = Cb + (long)(rbase + row) * p.scm + gn;
-            if (gn + 3 < p.N) { f4u o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f4u*>(dst) = o; }
-            else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) if (gn + q < p.N) dst[q] = v[q];
-            }
-          }
-        }
-      }
-    };
-    __syncthreads();
-    // this row tile's (mean, M2) per half and column -> published; then ONE thread counts it in and waits for the column tile's other row tiles
-    // (a poll per thread and word -- 3,584 agent-scope loads per workgroup and round -- starved the very stores it was waiting for: 97 us a launch)
-    float mean_own = 0.f, m2_own = 0.f;
-    const int xhalf = tid / BN, xcol = tid % BN;
-    unsigned* arrive = hdr + 16 + ((size_t)b * ntiles + ntile);          // per column tile; grows by mtiles per launch, never reset
-    if (tid < 2 * BN) {
-      float mu[2 * WM], mean = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int q = 0; q < 2 * WM; ++q) { const int blk = xhalf * 2 * WM + q; mu[q] = cst[(blk * BN + xcol) * 2]; mean += mu[q]; m2 += cst[(blk * BN + xcol) * 2 + 1]; }
-      mean *= 1.f / (float)(2 * WM);
-#pragma unroll
-      for (int q = 0; q < 2 * WM; ++q) { const float d = mu[q] - mean; m2 += 16.f * d * d; }
-      unsigned long long* mine = words + ((size_t)mt * 2 + xhalf) * (BN * 2) + xcol * 2;
-      __hip_atomic_store(mine, ((unsigned long long)tag << 32) | __float_as_uint(mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(mine + 1, ((unsigned long long)tag << 32) | __float_as_uint(m2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      mean_own = mean; m2_own = m2;
-    }
-    __builtin_amdgcn_s_waitcnt(0);                                // this wave's words have been written (acknowledged) ...
-    __syncthreads();                                              // ... and so have the other waves'
-    store_h();                                                    // (h drains while the row tiles wait for each other)
-    bool bad = false;
-    if (tid == 0) {
-      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned target = (unsigned)mtiles * tag;
-      for (int tries = 0;; ++tries) {                             // bounded: peers that never run are a NaN in y and a flag, not a hung GPU
-        const unsigned c = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)(c - target) >= 0) break;
-        if (tries > (1 << 16)) { bad = true; break; }
-        __builtin_amdgcn_s_sleep(4);
-      }
-      amxs[4] = bad ? 1.f : 0.f;
-    }
-    __syncthreads();
-    bad = amxs[4] != 0.f;
-    if (tid < 2 * BN) {
-      const int half = xhalf, col = xcol;
-      float pm[8], pq[8];                                         // (at most 8 row tiles: the launcher checks; static indices: registers)
-      unsigned long long w0[8], w1[8];
-#pragma unroll
-      for (int pp = 0; pp < 8; ++pp) {
-        const unsigned long long* theirs = words + ((size_t)min(pp, mtiles - 1) * 2 + half) * (BN * 2) + col * 2;
-        w0[pp] = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        w1[pp] = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#pragma unroll
-      for (int pp = 0; pp < 8; ++pp) {
-        if (pp < mtiles && pp != mt) bad = bad || (unsigned)(w0[pp] >> 32) != tag || (unsigned)(w1[pp] >> 32) != tag;
-        pm[pp] = pp < mtiles ? __uint_as_float((unsigned)w0[pp]) : 0.f;
-        pq[pp] = pp < mtiles ? __uint_as_float((unsigned)w1[pp]) : 0.f;
-        if (pp == mt) { pm[pp] = mean_own; pq[pp] = m2_own; }
-      }
-      float gmean = 0.f, gm2 = 0.f;
-#pragma unroll
-      for (int pp = 0; pp < 8; ++pp) { gmean += pm[pp]; gm2 += pq[pp]; }
-      gmean /= (float)mtiles;
-#pragma unroll
-      for (int pp = 0; pp < 8; ++pp) if (pp < mtiles) { const float d = pm[pp] - gmean; gm2 += (float)RH * d * d; }
-      float rstd = rsqrtf(gm2 / (float)Cc + 1e-5f);
-      if (bad) { gmean = __uint_as_float(0x7fc00000u); rstd = gmean; __hip_atomic_store(hdr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      fin[(half * BN + col) * 2] = gmean; fin[(half * BN + col) * 2 + 1] = rstd;
-      const int gn = n0 + col;
-      if (mt == 0 && p.hw_stats && gn < p.N) { float* sb = p.hw_stats + (long)b * 4 * p.N + (long)(2 * half) * p.N + gn; sb[0] = gmean; sb[p.N] = rstd; }
-    }
-    __syncthreads();
-    // gate, in the row-contiguous domain: y(c, n) = s n2 + (1 - s) x,  s = sigmoid(n1),  n_i = (h_i - mu_i) r_i gamma_i + beta_i
-    float am = 0.f;
-    {
-      float* __restrict__ Yb = p.hw_y + (long)b * p.hw_ybs;
-      constexpr int V = BN / 4;
-      for (int e = tid; e < RH * V; e += 256) {
-        const int cl = e / V, c4 = e % V, c = mt * RH + cl, gn = n0 + 4 * c4;
-        if (gn >= p.N) continue;
-        const f32x4 h1 = *reinterpret_cast<const f32x4*>(stage + cl * LDW + 4 * c4);
-        const f32x4 h2 = *reinterpret_cast<const f32x4*>(stage + (RH + cl) * LDW + 4 * c4);
-        const float ga1 = p.hw_g1[c], be1 = p.hw_b1[c], ga2 = p.hw_g2[c], be2 = p.hw_b2[c];
-        const float* xr = Xb + (long)c * p.sxc + gn;
-        float* yr = Yb + (long)c * p.N + gn;
-        const bool full = gn + 3 < p.N;
-        float xv[4], y[4];
-        if (full) { const f4u q = *reinterpret_cast<const f4u*>(xr); xv[0] = q[0]; xv[1] = q[1]; xv[2] = q[2]; xv[3] = q[3]; }
-        else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) xv[j] = gn + j < p.N ? xr[j] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = 4 * c4 + j;
-          const float n1 = (h1[j] - fin[col * 2]) * fin[col * 2 + 1] * ga1 + be1;
-          const float n2 = (h2[j] - fin[(BN + col) * 2]) * fin[(BN + col) * 2 + 1] * ga2 + be2;
-          const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-n1));
-          y[j] = sg * n2 + (1.f - sg) * xv[j];
-        }
-        if (full) {
-          f4u o = {y[0], y[1], y[2], y[3]};
-          *reinterpret_cast<f4u*>(yr) = o;
-          am = fmaxf(fmaxf(am, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) if (gn + j < p.N) { yr[j] = y[j]; am = fmaxf(am, fabsf(y[j])); }
-        }
-      }
-    }
-    if (p.hw_yamax) {                                             // max |y| of this tile: entry ntile * mtiles + mt of the item's list
-      am = ssv_wg_max<4>(am, amxs);
-      if (tid == 0) {
-        float* al = p.hw_yamax + (long)b * p.hw_namax;
-        al[ntile * mtiles + mt] = am;
-        if (ntile == ntiles - 1 && mt == mtiles - 1) for (int e = ntiles * mtiles; e < p.hw_namax; ++e) al[e] = 0.f;
-      }
-    }
-    if (tid == 0) {                                               // the launch's last workgroup advances the epoch for the next one
-      const unsigned total = gridDim.x * gridDim.y;
-      const unsigned old = __hip_atomic_fetch_add(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == total - 1) {
-        __hip_atomic_store(hdr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(hdr, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    NN_STAMP_AT(3);
-    NN_RT(1);
     return;
   }
   if (p.scn == 1) {
@@ -1255,30 +1064,6 @@ static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
       return ssv_check_launch("gemm_nn_bf3_lstm");
     }
   }
-  if (g.epi == 2) {
-    // fused highwayConv: the four tiles the highway layers of the models run on (every other tile: instantiations nobody launches)
-    if constexpr ((KT == 3 && ((WM == 1 && NT == 7) || (WM == 2 && (NT == 6 || NT == 7)))) || (KT == 1 && WM == 2 && NT == 4)) {
-      SSV_CHECK(mtiles <= 8 && g.M == mtiles * 64 * WM && g.hw_sync && g.hw_y && !g.R && !g.bias_b && g.scn == 1 && g.sxn == 1, SSV_BAD_SHAPE, "gemm_nn_bf3: bad fused highway request");
-      const bool small = KT == 3 && span <= SSV_NN_HALO_SMALL;
-      if (ssv_shape_log_on()) {
-        char nm[96], note[96];
-        snprintf(nm, sizeof nm, "gemm_nn_bf3_kernel<%d, %d, %d, 2, %d, %d>", KT, WM, NT, g.f16, small ? SSV_NN_HALO_SMALL : 54);
-        snprintf(note, sizeof note, "B=%d M=%d N=%d K=%d k=%d +LN+gate", g.B, g.M, g.N, g.Kc, KT);
-        ssv_shape_log(nm, dim3(mtiles * ntiles, g.B), dim3(256), 2.0 * g.B * g.M * g.N * g.Kc * KT,
-                      4.0 * (2.0 * g.B * g.Kc * g.N + (double)g.B * g.M * g.N * (g.C ? 1.0 : 0.0) + (double)g.B * (g.M / 2) * g.N + (double)g.M * g.Kc * KT), note);
-      }
-      if constexpr (KT == 3) {
-        if (small) {
-          if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 2, 1, SSV_NN_HALO_SMALL>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
-          else hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 2, 0, SSV_NN_HALO_SMALL>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
-          return ssv_check_launch("gemm_nn_bf3 (fused highway)");
-        }
-      }
-      if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 2, 1>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
-      else hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 2, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
-      return ssv_check_launch("gemm_nn_bf3 (fused highway)");
-    } else return ssv_fail(SSV_UNSUPPORTED, "gemm_nn_bf3: no fused highway kernel on the %d x %d tile", 64 * WM, 16 * NT);
-  }
   if (ssv_shape_log_on()) {
     char nm[96], note[96];
     snprintf(nm, sizeof nm, "gemm_nn_bf3_kernel<%d, %d, %d, 0, %d, %d>", KT, WM, NT, g.f16, (KT == 3 && span <= SSV_NN_HALO_SMALL) ? SSV_NN_HALO_SMALL : 54);
@@ -1298,13 +1083,8 @@ static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   return ssv_check_launch("gemm_nn_bf3");
 }
 
-// tiles with a fused highwayConv epilogue (launch_nnb), and at most 8 row tiles of whole rows
-static bool nnb_hw_tile_ok(int KT, int a, int c, int M) {
-  const bool inst = KT == 3 ? ((a == 1 && c == 7) || (a == 2 && (c == 6 || c == 7))) : (a == 2 && c == 4);
-  return inst && M % (64 * a) == 0 && M / (64 * a) <= 8;
-}
 template <int KT>
-static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span, int* only_choose = nullptr) {
+static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   {
     // measured (round-1 tile sweep; in-step re-check: tools/sweep_force.sh): the wide workgroup wins for kernel-size-1 convolutions over long sequences
     // (SSRN's 513-channel layers: 150 -> 205 TFLOP/s); the k=3 layers are as fast or faster on the 4-wave kernel.
@@ -1328,7 +1108,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span, int* o
   // LSTM wavefront with two or more layers in one launch (the steady state of the GE2E embedder: 2 x 3072 x 880 x 1536): the
   // cost model below picks 64 x 112 tiles; measured over the 122 steps of config 5, 128 x 64 tiles are 6 % faster
   // (13.8 -> 13.0 ms; 128 x 96: 13.5, 128 x 112: 14.2, 64 x 96: 14.8) as long as they still give every CU two workgroups.
-  if (!forced && g.epi == 1 && g.lstm_D > 0 && g.B >= 2 && (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 64) * g.B >= 512) { wm = 2; nt = 4; forced = true; }
+  if (!forced && g.epi && g.lstm_D > 0 && g.B >= 2 && (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 64) * g.B >= 512) { wm = 2; nt = 4; forced = true; }
   if (!forced) {
     // tuning aid (tools/sweep_force.sh): SSV_NNB_FORCE="kt:M:N=a,c;kt:M:N=a,c;..." forces the tile of one problem shape
     // inside a whole training step, where a tile's effect on its neighbours shows (isolated timings miss it)
@@ -1338,7 +1118,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span, int* o
       const char* hit = strstr(e, key);
       int a = 0, c = 0;
       if (hit && (hit == e || hit[-1] == ';') && sscanf(hit + strlen(key), "%d,%d", &a, &c) == 2 && (a == 1 || a == 2))
-        for (int x : nts) if (x == c && (g.epi != 2 || nnb_hw_tile_ok(KT, a, c, g.M))) { wm = a; nt = c; forced = true; }
+        for (int x : nts) if (x == c) { wm = a; nt = c; forced = true; }
     }
   }
   if (!forced) {
@@ -1346,10 +1126,9 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span, int* o
     // k=1 products carry a third of the MFMAs per weight byte: 64-row tiles (twice the weight traffic per MAC) lose at every
     // conv shape measured (256 -> 256, L=650: 28 us on 64 x 112 tiles, 20 us on 128 x 64); only the single-"batch" LSTM
     // product, short of workgroups, still wants them
-    const int a_min = (KT == 1 && g.B > 1 && g.epi != 1 && g.M > 64) ? 2 : 1;
+    const int a_min = (KT == 1 && g.B > 1 && !g.epi && g.M > 64) ? 2 : 1;
     for (int a = a_min; a <= 2; ++a)
       for (int c : nts) {
-        if (g.epi == 2 && !nnb_hw_tile_ok(KT, a, c, g.M)) continue;
         const long tiles = (long)ssv_cdiv(g.M, 64 * a) * ssv_cdiv(g.N, 16 * c) * g.B;
         const double per_tile = (double)a * c + 0.9 * a + 0.25 * c + 1.0;
         // The most loaded CU runs n workgroups.  For kernel-size-1 products a K chunk carries a third of the MFMAs per
@@ -1364,7 +1143,6 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span, int* o
         if (cost < best) { best = cost; wm = a; nt = c; }
       }
   }
-  if (only_choose) { only_choose[0] = wm; only_choose[1] = nt; return (g.epi == 2 && !nnb_hw_tile_ok(KT, wm, nt, g.M)) ? SSV_UNSUPPORTED : 0; }
 #define SSV_CASE(A_, C_) if (wm == A_ && nt == C_) return launch_nnb<KT, A_, C_>(g, st, smin, span)
   SSV_CASE(2, 7); SSV_CASE(2, 6); SSV_CASE(2, 4); SSV_CASE(2, 2);
   SSV_CASE(1, 7); SSV_CASE(1, 6); SSV_CASE(1, 4); SSV_CASE(1, 2);
@@ -1377,8 +1155,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nn_bf3: kernel_size %d", g.KT);
   SSV_CHECK(g.B <= 65535, SSV_UNSUPPORTED, "gemm_nn_bf3: batch %d exceeds grid.y", g.B);
   SSV_CHECK(g.sxn >= 1 && g.scn >= 1 && (g.scn == 1 || (!g.R && !g.epi)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad column strides");
-  SSV_CHECK(g.epi != 1 || (g.KT == 1 && g.perm_h > 0 && g.M == 4 * g.perm_h && g.cstate && (g.B == 1 || g.lstm_D > 0)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad LSTM epilogue request");
-  SSV_CHECK(g.epi != 2 || (g.M % 64 == 0 && !g.perm_h && !g.colstats && g.hw_g1 && g.hw_b1 && g.hw_g2 && g.hw_b2), SSV_BAD_SHAPE, "gemm_nn_bf3: bad fused highway request");
+  SSV_CHECK(!g.epi || (g.KT == 1 && g.perm_h > 0 && g.M == 4 * g.perm_h && g.cstate && (g.B == 1 || g.lstm_D > 0)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad LSTM epilogue request");
   SSV_CHECK(g.lstm_D == 0 || (g.epi == 1 && g.lstm_out && g.lstm_D >= 1 && g.xsplit >= 0 && g.xsplit <= g.Kpad / 32 && g.Kc == g.Kpad && g.sxn == 1), SSV_BAD_SHAPE,
             "gemm_nn_bf3: bad LSTM wavefront request");
   int smin = g.shift[0], smax = g.shift[0];
@@ -1388,20 +1165,9 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   // the kernels address one batch item's input rows and the weight planes with 32-bit byte offsets (buffer loads)
   SSV_CHECK(((long)g.Kpad * g.sxc + (long)g.Lx * (g.sxn > 0 ? g.sxn : 1)) * 4 < (1L << 31) && (long)g.KT * ((g.M + 15) / 16) * (g.Kpad / 32) * 1024 < (1L << 31),
             SSV_UNSUPPORTED, "gemm_nn_bf3: a batch item's input or the weight planes span 2 GiB or more");
-  SSV_CHECK(!g.f16 || (g.a_inv && ((g.x_amax && g.x_namax > 0) || (g.epi == 1 && g.x_namax == 0))), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales");
+  SSV_CHECK(!g.f16 || (g.a_inv && ((g.x_amax && g.x_namax > 0) || (g.epi && g.x_namax == 0))), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales");
   SSV_CHECK(!g.colstats || (g.M % 64 == 0 && g.scn == 1 && !g.epi && !g.perm_h && !g.R), SSV_BAD_SHAPE, "gemm_nn_bf3: column statistics need M %% 64 == 0 and a plain epilogue");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
-}
-
-int ssv_nnb_hw_tiles(int B, int M, int N, int Kc, int KT, int* wm, int* nt) {
-  GemmNNB g;
-  memset(&g, 0, sizeof g);
-  g.B = B; g.M = M; g.N = N; g.Kc = Kc; g.KT = KT; g.epi = 2; g.sxn = g.scn = 1;
-  int pick[2] = {0, 0};
-  const int rc = KT == 3 ? pick_nnb<3>(g, nullptr, 0, 0, pick) : pick_nnb<1>(g, nullptr, 0, 0, pick);
-  if (rc != 0 || !pick[0]) return 0;
-  *wm = pick[0]; *nt = pick[1];
-  return (M / (64 * pick[0])) * ssv_cdiv(N, 16 * pick[1]);
 }
 
 // ---- NT (weight gradient) -------------------------------------------------------------------------------------------------

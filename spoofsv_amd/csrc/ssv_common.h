@@ -94,22 +94,8 @@ struct GemmNNB {
   // row of the fp32 weight; the kernel launches over M - 1 rows and the workgroups of row tile 0 add the row as plain fp32 dot products
   // from the values they stage anyway.  Null: not used.
   const float* xrow_w; long xrow_sk;
-  // Fused highwayConv forward (epi == 2; models/TTSModel.py:78-83 in ONE launch): M = 2C output rows, and a row tile holds 32 * WM rows of
-  // H1 AND the matching 32 * WM rows of H2 (the weight planes are indexed through that map, nothing is re-packed), so the gate is local to a
-  // workgroup and only the LayerNorm statistics cross workgroups: every row tile publishes, per column of its tile and per half, (mean, M2) of
-  // its rows as two 64-bit words (tag << 32 | value) with agent-scope stores and reads the words of the other row tiles of its column tile
-  // (bounded polls; see tools/probe/xchg_probe.hip for what that costs), merges them in a fixed order, normalises and gates its own rows from
-  // the tile parked in LDS.  X is the gate's residual input as well.  C (may be null: inference) receives h in the natural row order.
-  // hw_sync: caller-owned, zeroed ONCE, then only touched by these launches: [0] epoch, [1] finished workgroups, [2] error (a poll limit was
-  // hit: y is NaN), [16 ..] one arrival counter per column tile, then (256-byte aligned) the words.  A launch tags its words epoch + 1; its last
-  // workgroup to finish advances the epoch.
-  const float* hw_g1; const float* hw_b1; const float* hw_g2; const float* hw_b2;
-  float* hw_y; long hw_ybs; float* hw_stats; float* hw_yamax; int hw_namax;
-  unsigned* hw_sync;
 };
 int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
-// the row / column tile (wm, nt) the fused highwayConv launch of this problem runs on; returns row tiles * column tiles (per batch item)
-int ssv_nnb_hw_tiles(int B, int M, int N, int Kc, int KT, int* wm, int* nt);
 // 1x1 product (g: KT = 1, unit strides, no residual / LSTM epilogue, M <= 640) that finishes LayerNorm over its M rows and the activation in
 // the same launch: g.C receives the LayerNorm's input `pre`; y (B, M, N) dense, stats (B, 2, N) or null, y_amax: namax entries per item or null
 int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta, float* y, long ybs, float* stats, float* y_amax, int namax, int act,

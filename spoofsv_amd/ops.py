@@ -10,7 +10,6 @@ copies.  Each Function cites the reference code its forward replaces.
 """
 import contextlib
 import ctypes
-import os
 
 import torch
 
@@ -267,7 +266,7 @@ class HighwayConvFn(torch.autograd.Function):
     """highwayConv.forward, models/TTSModel.py:63-84 (conv -> 2x LayerNorm over channels -> gate)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, g1, b1, g2, b2, k, dilation, causal, x_amax=None, y_amax=None, sync=None):
+    def forward(ctx, x, w, bias, g1, b1, g2, b2, k, dilation, causal, x_amax=None, y_amax=None):
         x, xbs = _act3(x, "highwayConv input")
         B, C, L = x.shape
         w, bias, g1, b1, g2, b2 = map(_c, (w, bias, g1, b1, g2, b2))
@@ -275,21 +274,12 @@ class HighwayConvFn(torch.autograd.Function):
             raise RuntimeError("highwayConv: weight %s does not match input channels %d" % (tuple(w.shape), C))
         train = _needs_grad(ctx)
         y = torch.empty((B, C, L), dtype=_F32, device=x.device)
-        if sync is not None:
-            # ONE launch (ssv_highway_conv1d_fwd_fused): h and the statistics are written only when a backward will read them
-            h = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device) if train else None
-            stats = torch.empty((B, 4, L), dtype=_F32, device=x.device) if train else None
-            nb = _lib.query("ssv_conv1d_fwd_workspace", C, 2 * C, k)
-            ws = _ws(nb, x.device)
-            _lib.call("ssv_highway_conv1d_fwd_fused", _p(x), xbs, *_an(x_amax), _p(w), resident.lookup(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
-                      _p(h), _p(stats), _p(y), C * L, *_an(y_amax), _p(sync), sync.numel(), B, C, L, k, dilation, int(causal), _p(ws), nb, _stream())
-        else:
-            h = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
-            stats = torch.empty((B, 4, L), dtype=_F32, device=x.device) if train else None
-            nb = _lib.query("ssv_highway_conv1d_fwd_workspace", B, C, L, k)
-            ws = _ws(nb, x.device)
-            _lib.call("ssv_highway_conv1d_fwd", _p(x), xbs, *_an(x_amax), _p(w), resident.lookup(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
-                      _p(h), _p(stats), _p(y), C * L, _p(y_amax), B, C, L, k, dilation, int(causal), _p(ws), nb, _stream())
+        h = torch.empty((B, 2 * C, L), dtype=_F32, device=x.device)
+        stats = torch.empty((B, 4, L), dtype=_F32, device=x.device) if train else None
+        nb = _lib.query("ssv_highway_conv1d_fwd_workspace", B, C, L, k)
+        ws = _ws(nb, x.device)
+        _lib.call("ssv_highway_conv1d_fwd", _p(x), xbs, *_an(x_amax), _p(w), resident.lookup(w), _p(bias), _p(g1), _p(b1), _p(g2), _p(b2),
+                  _p(h), _p(stats), _p(y), C * L, _p(y_amax), B, C, L, k, dilation, int(causal), _p(ws), nb, _stream())
         if train:
             ctx.save_for_backward(x, w, g1, b1, g2, b2, h, stats)
             ctx.x_amax = x_amax
@@ -323,13 +313,13 @@ class HighwayConvFn(torch.autograd.Function):
             _lib.call("ssv_highway_conv1d_bwd_data", _p(dy), dybs, _p(x), xbs, _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
                       _p(h), _p(stats), _p(dx), C * L, _p(dh), _p(dh_amax), _p(part), B, C, L, k, dilation, causal, _p(ws), nb, _stream())
             _DEFER.add(dh, 2 * C * L, x, xbs, dw, part, pg, k, dilation, causal, 6 * C, rows, dh_amax, x_amax)
-            return (dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3]) + (None,) * 6
+            return (dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3]) + (None,) * 5
         nb = _lib.query("ssv_highway_conv1d_bwd_workspace", B, C, L, k)
         ws = _ws(nb, x.device)
         _lib.call("ssv_highway_conv1d_bwd", _p(dy), dybs, _p(x), xbs, *_an(ctx.x_amax), _p(w), resident.lookup(w), _p(g1), _p(b1), _p(g2), _p(b2),
                   _p(h), _p(stats), _p(dx), C * L, _p(dw), _p(pg), B, C, L, k, dilation, causal,
                   _p(ws), nb, _stream())
-        return (dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3]) + (None,) * 6
+        return (dx, dw, pg[4:6].reshape(2 * C), pg[0], pg[1], pg[2], pg[3]) + (None,) * 5
 
 
 # ------------------------------------------------------------------------------------------- conv
@@ -1139,37 +1129,11 @@ def _bf3_shape(x):
     return x.dim() == 3 and x.shape[0] * x.shape[2] >= 128
 
 
-HW_FUSED = os.environ.get("SSV_HW_FUSED", "1") != "0"      # (A/B switch: 0 = conv launch + streaming LayerNorm / gate launch, as before round 5)
-
-
-def _hw_sync(owner, B, C, L, k, device):
-    """The sync area of one highwayConv layer and shape for the fused forward (include/ssv_hip.h, ssv_highway_conv1d_fwd_fused): zeroed once,
-    kept on the owning module, never touched by anything else.  None: not a fused shape / arithmetic mode, or no owner to keep it."""
-    if owner is None or not HW_FUSED or _lib.precision() < 1:
-        return None
-    areas = owner.__dict__.setdefault("_ssv_sync", {})
-    key = (B, C, L, k, str(device))
-    a = areas.get(key, 0)
-    if isinstance(a, int):
-        nb = _lib.query("ssv_highway_conv1d_fused_sync_bytes", B, C, L, k)
-        if nb and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("highwayConv: run one eager iteration before capturing (the fused forward's sync area is allocated and zeroed then)")
-        a = areas[key] = torch.zeros(nb, dtype=torch.uint8, device=device) if nb else None
-    return a
-
-
-def highway_conv1d(x, w, bias, g1, b1, g2, b2, k, dilation, causal, owner=None):
-    """``owner``: the module the layer belongs to (keeps the fused forward's sync area); None: the two-launch form."""
-    B, C, L = x.shape
-    sync = _hw_sync(owner, B, C, L, k, x.device) if _bf3_shape(x) else None
+def highway_conv1d(x, w, bias, g1, b1, g2, b2, k, dilation, causal):
     if not (_f16() and _bf3_shape(x)):
-        return HighwayConvFn.apply(x, w, bias, g1, b1, g2, b2, k, dilation, causal, None, None, sync)
-    if sync is not None:
-        n = int(_lib.lib().ssv_highway_conv1d_fused_amax_rows(B, C, L, k))
-        ya = torch.empty((B, n), dtype=_F32, device=x.device)
-    else:
-        ya = _amax_out(B, L, x.device)
-    return _tag(HighwayConvFn.apply(x, w, bias, g1, b1, g2, b2, k, dilation, causal, amax_of(x), ya, sync), ya)
+        return HighwayConvFn.apply(x, w, bias, g1, b1, g2, b2, k, dilation, causal)
+    ya = _amax_out(x.shape[0], x.shape[2], x.device)
+    return _tag(HighwayConvFn.apply(x, w, bias, g1, b1, g2, b2, k, dilation, causal, amax_of(x), ya), ya)
 
 
 RELU_TAP = None      # diagnostics / tests: a list that receives (y > 0) of every fused-ReLU output, in call order

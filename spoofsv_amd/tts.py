@@ -46,7 +46,7 @@ class highwayConv(nn.Module):
 
     def forward(self, inputs):
         return ops.highway_conv1d(inputs, self.conv.weight, self.conv.bias, self.ln1.weight, self.ln1.bias,
-                                  self.ln2.weight, self.ln2.bias, self.kernel_size, self.dilation, self.causal, owner=self)
+                                  self.ln2.weight, self.ln2.bias, self.kernel_size, self.dilation, self.causal)
 
 
 class highwayDilationIncrement(nn.Module):

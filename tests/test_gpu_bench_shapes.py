@@ -221,12 +221,7 @@ def _highway_params(C, k, gen):
     return w, bias, g1, b1, g2, b2
 
 
-class _Owner:
-    """Stands in for the highwayConv module: keeps the fused forward's sync area (ops._hw_sync)."""
-
-
-@pytest.mark.parametrize("fused", [False, True], ids=["two_launches", "fused"])
-def test_all_zero_batch_item_through_the_operand_scale_path_on_a_real_layer_shape(fused):
+def test_all_zero_batch_item_through_the_operand_scale_path_on_a_real_layer_shape():
     """data/dataset.py:187-258 zero-pads every utterance to the batch maximum; a batch item (or, after the teacher-forcing shift, a
     whole input) can be all zeros.  Its operand scale comes from max |x| = 0 (csrc/ssv_common.h ssv_pow2_scale clamps the exponent):
     forward and every gradient of a real highway layer (C = 256, L = 325, k = 3, d = 3, causal) must equal float64's, for the zero
@@ -251,7 +246,7 @@ def test_all_zero_batch_item_through_the_operand_scale_path_on_a_real_layer_shap
             x = x0.to(DEV).requires_grad_(True)
             for q in p:
                 q.grad = None
-            y = ops.highway_conv1d(x, *p, k, d, bool(causal), owner=_Owner() if fused else None)
+            y = ops.highway_conv1d(x, *p, k, d, bool(causal))
             y.backward(dy)
             torch.cuda.synchronize()
             tol = 2e-4 if mode == "bf16x3" else 2e-5
@@ -270,9 +265,8 @@ def test_all_zero_batch_item_through_the_operand_scale_path_on_a_real_layer_shap
             spoofsv_amd.set_precision(prev)
 
 
-@pytest.mark.parametrize("fused", [False, True], ids=["two_launches", "fused"])
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), float("-inf")])
-def test_non_finite_element_propagates_through_the_operand_scale_path(bad, fused):
+def test_non_finite_element_propagates_through_the_operand_scale_path(bad):
     """One NaN / Inf in the input of a real highway layer: the reference's fp32 conv makes every output channel of the columns the
     element reaches non-finite, LayerNorm over channels keeps those columns non-finite, and so does the gate.  The scaled split-fp16
     path must not lose it (a scale computed from max |x| that ignores NaN, or an Inf that saturates to a finite fp16 value, would):
@@ -290,7 +284,7 @@ def test_non_finite_element_propagates_through_the_operand_scale_path(bad, fused
         prev = spoofsv_amd.set_precision(mode)
         try:
             with torch.no_grad():
-                y = ops.highway_conv1d(x0.to(DEV), *p, k, d, bool(causal), owner=_Owner() if fused else None)
+                y = ops.highway_conv1d(x0.to(DEV), *p, k, d, bool(causal))
             torch.cuda.synchronize()
             for t in touched:
                 assert not bool(torch.isfinite(y[2, :, t]).any()), (mode, bad, "column", t, "lost the non-finite value")
@@ -300,59 +294,5 @@ def test_non_finite_element_propagates_through_the_operand_scale_path(bad, fused
             rest = torch.ones(L, dtype=torch.bool)
             rest[touched] = False
             print("%s %s: %d of %d untouched columns of the same item stay finite" % (mode, bad, int(torch.isfinite(y[2][:, rest]).all(0).sum()), int(rest.sum())))
-        finally:
-            spoofsv_amd.set_precision(prev)
-
-
-HIGHWAY_SHAPES = [(32, 256, 325, 3, 27, 1), (32, 256, 325, 3, 1, 0), (32, 512, 186, 3, 9, 0), (32, 512, 186, 1, 1, 0), (32, 256, 650, 3, 3, 0),
-                  (32, 256, 1300, 3, 1, 0), (32, 512, 1300, 3, 1, 0), (3, 256, 100, 3, 3, 1), (2, 64, 200, 3, 1, 0), (5, 320, 77, 3, 9, 1)]
-
-
-@pytest.mark.parametrize("Bz,C,L,k,d,causal", HIGHWAY_SHAPES, ids=lambda v: str(v))
-def test_fused_highway_forward_exchanges_statistics_across_row_tiles_vs_float64(Bz, C, L, k, d, causal):
-    """models/TTSModel.py:63-84 in ONE launch (ssv_highway_conv1d_fwd_fused): the conv kernel's row tiles exchange their LayerNorm partial sums
-    through tagged words and gate their own accumulators.  Every highway shape of the timed step at B = 32 (8 row tiles x 3 / 2 / 6 / 12
-    column tiles; launches larger than the chip holds at once), ragged small shapes, both arithmetic modes that have the path; THREE calls on
-    the same sync area with different inputs (the tag of a call must not match the previous call's words), training (h and statistics saved:
-    the backward's gradients against float64) and inference; the error flag of the sync area must stay clear."""
-    import spoofsv_amd
-    from spoofsv_amd import _lib, ops
-    gen = torch.Generator().manual_seed(9 + C + L)
-    p = _highway_params(C, k, gen)
-    owner = _Owner()
-    for mode in ("f16x2", "bf16x3"):
-        prev = spoofsv_amd.set_precision(mode)
-        try:
-            assert _lib.query("ssv_highway_conv1d_fused_sync_bytes", Bz, C, L, k) > 0, "not a fused shape"
-            tol = 2e-4 if mode == "bf16x3" else 2e-5
-            for call in range(3):
-                x0 = torch.randn(Bz, C, L, generator=gen) * (1.0 + call)
-                dy = torch.randn(Bz, C, L, generator=gen).to(DEV)
-                x = x0.to(DEV).requires_grad_(call != 1)
-                for q in p:
-                    q.grad = None
-                if call == 1:
-                    with torch.no_grad():
-                        y = ops.highway_conv1d(x, *p, k, d, bool(causal), owner=owner)
-                else:
-                    y = ops.highway_conv1d(x, *p, k, d, bool(causal), owner=owner)
-                    y.backward(dy)
-                torch.cuda.synchronize()
-                area = list(owner._ssv_sync.values())[0]
-                assert int(area[:12].view(torch.int32)[2]) == 0, "a workgroup gave up waiting for its peers"
-                xr = x0.to(DEV).double().requires_grad_(True)
-                pr = [q.detach().double().requires_grad_(True) for q in p]
-                yr = _highway_ref64(xr, *pr, k, d, causal)
-                e = float((y.double() - yr).abs().max() / yr.abs().max())
-                assert e < tol, (mode, call, "y", e)
-                amax = y._ssv_amax[0] if hasattr(y, "_ssv_amax") else None
-                if amax is not None:                                    # the scale list bounds every item's max |y| (and is not far above it)
-                    got, want = amax.max(dim=1).values, y.detach().abs().amax(dim=(1, 2))
-                    assert bool((got >= want * (1 - 1e-6)).all()) and bool((got <= want * (1 + 1e-6)).all()), (mode, call, "scale list")
-                if call != 1:
-                    yr.backward(dy.double())
-                    assert float((x.grad.double() - xr.grad).norm() / xr.grad.norm()) < 10 * tol, (mode, call, "dx")
-                    for q, r, name in zip(p, pr, ("w", "bias", "g1", "b1", "g2", "b2")):
-                        assert float((q.grad.double() - r.grad).norm() / r.grad.norm()) < 10 * tol, (mode, call, name)
         finally:
             spoofsv_amd.set_precision(prev)
