@@ -25,7 +25,7 @@ python3 $R/tools/summarize_prof.py /tmp/p_adv > $O/adversarial.txt 2>> $O/summar
 head -30 $O/bench_f16x2.txt
 # the headline kernel alone, for roofline.traffic
 for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/p_h$c; (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p_h$c -- python3 $R/tools/pmc_headline.py > /dev/null 2> $O/headline_$c.err) || echo "headline $c rc=$?"; done
-python3 $R/tools/pmc_headline.py --json /tmp/p_hFETCH_SIZE /tmp/p_hWRITE_SIZE > $O/traffic_f16x2.json 2>> $O/summarize.err
+python3 $R/tools/pmc_headline.py --json /tmp/p_hFETCH_SIZE /tmp/p_hWRITE_SIZE profiles/round${ROUND}_bench_kernel_stats.txt > $O/traffic_f16x2.json 2>> $O/summarize.err
 # the headline kernel's counter rows themselves (one line per launch), so the figure can be recomputed from a committed file
 for c in FETCH_SIZE WRITE_SIZE; do f=$(ls /tmp/p_h$c/*/*counter_collection.csv /tmp/p_h$c/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && (head -1 "$f"; grep "gemm_nn_bf3_kernel<3, 1, 7" "$f") > $O/headline_$c.csv; done
 cat $O/traffic_f16x2.json
