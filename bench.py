@@ -459,7 +459,7 @@ def cpu_baseline():
         pass
     torch.set_num_threads(cores)
     out = {"host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
-    times, first = {}, {}
+    times, times8, first = {}, {}, {}
     for kind, b in (("text2mel", B_PER_GPU), ("ssrn", B_PER_GPU)):
         torch.manual_seed(1234)                    # the weights of Trainer(kind, ...): same seed, same construction order
         if kind == "text2mel":
@@ -492,11 +492,23 @@ def cpu_baseline():
         for _ in range(reps):
             one()
         times[kind] = (time.time() - t0) / reps / (b * T_MEL)     # seconds per mel frame
+        if cores > 8:
+            # SURVEY.md 8d's second arm: the same steps on 8 threads (the survey's own probe ran on 8 cores), 2 timed steps
+            torch.set_num_threads(8)
+            n_before = len(log)
+            t0 = time.time()
+            for _ in range(2):
+                one()
+            times8[kind] = (time.time() - t0) / 2 / (b * T_MEL)
+            del log[n_before:]
+            torch.set_num_threads(cores)
     fps = 1.0 / (times["text2mel"] + times["ssrn"])
     out.update({"value": round(fps, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": "1 warm-up + 4 timed train steps each of Text2Mel and SSRN at the workload's own batch (B=%d), N=186, T=325, fp32, torch CPU ops" % B_PER_GPU,
                 "text2mel_fps": round(1.0 / times["text2mel"], 1), "ssrn_fps": round(1.0 / times["ssrn"], 1),
                 "first_losses": {k: v[:2] for k, v in first.items()}})       # popped by main() after the parity check
+    if len(times8) == 2:
+        out["value_8_threads"] = round(1.0 / (times8["text2mel"] + times8["ssrn"]), 1)
     return out
 
 
