@@ -6,12 +6,12 @@ N = sys.argv[1] if len(sys.argv) > 1 else "5"
 R = 'gpurun_out/r%s/profiles' % N
 ms = json.loads(open(R + '/trace.json').read().strip().splitlines()[-1])['ms_per_step']
 d = json.loads(open('gpurun_out/r%s/bench_full.json' % N).read().strip().splitlines()[-1])
-hdr = ("# Round " + N + ", MI355X (gfx950), split-fp16 arithmetic (the default): `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ge2e --no-adversarial\n"
-       "# --no-fp32 --no-roofline` under rocprofv3 (tools/profile_round.sh): (1) --kernel-trace --stats, with the library's shape log (SSV_SHAPE_LOG) giving\n"
+hdr = ("# Round %s, MI355X (gfx950), split-fp16 arithmetic (the default): `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ge2e --no-adversarial\n"
+       "# --no-fp32 --no-roofline --no-stock` under rocprofv3 (tools/profile_round.sh): (1) --kernel-trace --stats, with the library's shape log (SSV_SHAPE_LOG) giving\n"
        "# the algorithmic FLOP / bytes of every launch shape -> \"achieved\" and \"frac\" of the roof per (kernel, grid); (2) --pmc FETCH_SIZE and (3) --pmc WRITE_SIZE\n"
        "# in separate passes; (4) one SQ pass with the MFMA-busy column.  Profiled runs hold a lower clock than un-profiled ones, and boxes differ by +-4 %% (%.1f ms per step here; the\n"
-       "# un-profiled line profiles/round" + N + "_bench_line.json, %.1f ms, was taken in a later call, possibly on another box): compare rows of this file with each other, not with bench.py's wall clock.\n"
-       "# Summary by tools/summarize_prof.py.\n" % (ms, d['ms_per_step']))
+       "# un-profiled line profiles/round%s_bench_line.json, %.1f ms, was taken in another call, possibly on another box): compare rows of this file with each other, not with bench.py's wall clock.\n"
+       "# Summary by tools/summarize_prof.py.\n" % (N, ms, N, d['ms_per_step']))
 open('profiles/round%s_bench_kernel_stats.txt' % N, 'w').write(hdr + open(R + '/bench_f16x2.txt').read())
 adv_h = ("# Round " + N + ", MI355X: the WGAN-GP cycle of train_ssrn --adversarial (1 G + 5 D iterations, B = 32, hipGraph replay), split-fp16 arithmetic:\n"
          "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_adversarial.py   (the last line gives the device-busy share of the replayed part)\n")
