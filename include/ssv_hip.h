@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 4 (2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
+int ssv_version(void);            /* ABI version, currently 5 (5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
                                     4 = compact partial rows: the nblk of a weight-gradient job is ssv_ln_bwd_partial_rows(...), not ssv_ln_partial_rows(B, L)) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -214,6 +214,10 @@ int ssv_text_embed_bwd(const int64_t* ids, const float* dy, float* dw, float* db
  * r: (B,d,T) with batch stride r_bs (pass the first half of the (B,2d,T) decoder input). */
 int ssv_attention_train_fwd(const float* k, const float* v, long kv_bs, const float* q, long q_bs,
                             float* a, float* r, long r_bs, int B, int d, int N, int T, ssv_stream_t stream);
+/* ABI 5: the decoder's input cat(R, Q) (models/TTSModel.py:270) in the same call -- rq (B, 2d, T): R in rows [0, d), a copy of Q in rows [d, 2d).
+ * For d % 64 == 0, d <= 256, N <= 192 scores, softmax and V A run in ONE launch (exact-fp32 MFMA, attn_fused.hip). */
+int ssv_attention_train_fwd_rq(const float* k, const float* v, long kv_bs, const float* q, long q_bs, float* a, float* rq, long rq_bs,
+                               int B, int d, int N, int T, ssv_stream_t stream);
 size_t ssv_attention_train_bwd_workspace(int B, int d, int N, int T);
 /* dr: grad of R; da_ext: extra dL/dA (guided-attention loss), may be NULL; dq_add: gradient reaching
  * Q through the concatenation, added into dq (may be NULL).  dk, dv have batch stride dkv_bs. */

@@ -93,7 +93,7 @@ extern "C" int ssv_set_precision(int mode) {
   return prev;
 }
 extern "C" int ssv_get_precision(void) { return ssv_precision(); }
-extern "C" int ssv_version(void) { return 4; }
+extern "C" int ssv_version(void) { return 5; }
 extern "C" const char* ssv_arch(void) { return "gfx950"; }
 extern "C" const char* ssv_last_error(void) { return g_err; }
 
@@ -731,10 +731,19 @@ extern "C" int ssv_attention_apply(const float* v, long kv_bs, const float* a, i
   g.M = d; g.N = T; g.Kc = N; g.B = B;
   return ssv_launch_gemm_nn(g, (hipStream_t)stream);
 }
+bool ssv_attn_fused_ok(int B, int d, int N, int T);        // attn_fused.hip: scores, softmax and V A (backward: dA, dS, dQ) in one launch
+int ssv_launch_attn_fwd_fused(const float* k, const float* v, long kv_bs, const float* q, long q_bs, float* a, float* rq, long rq_bs, int copy_q,
+                              int B, int d, int N, int T, hipStream_t st);
+int ssv_launch_attn_bwd_fused(const float* dr, long dr_bs, const float* da_ext, const float* dq_add, long dq_add_bs, const float* k, const float* v, long kv_bs,
+                              const float* a, float* ds, float* dq, long dq_bs, int B, int d, int N, int T, hipStream_t st);
+#ifndef SSV_ATTN_FUSED
+#define SSV_ATTN_FUSED 1     // (tuning builds: 0 = two GEMM launches, the softmax kernel and the row copy, as before round 5)
+#endif
 extern "C" int ssv_attention_train_fwd(const float* k, const float* v, long kv_bs, const float* q, long q_bs, float* a, float* r, long r_bs,
                                        int B, int d, int N, int T, ssv_stream_t stream) {
   SSV_CHECK(k && v && q && a && r && B > 0 && d > 0 && N > 0 && T > 0, SSV_BAD_SHAPE, "attention_train_fwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  if (SSV_ATTN_FUSED && ssv_attn_fused_ok(B, d, N, T)) return ssv_launch_attn_fwd_fused(k, v, kv_bs, q, q_bs, a, r, r_bs, 0, B, d, N, T, st);
   GemmNN g = nn_zero();                       // scores(b,n,t) = sum_c k(b,c,n) q(b,c,t) / sqrt(d)
   g.A = k; g.sab = kv_bs; g.sam = 1; g.sac = N; g.saj = 0;
   g.X = q; g.sxb = q_bs; g.sxc = T; g.Lx = T;
@@ -743,6 +752,14 @@ extern "C" int ssv_attention_train_fwd(const float* k, const float* v, long kv_b
   SSV_TRY(ssv_launch_gemm_nn(g, st));
   SSV_TRY(ssv_launch_softmax_cols(a, B, N, T, st));
   return ssv_attention_apply(v, kv_bs, a, T, r, r_bs, B, d, N, T, stream);
+}
+// The decoder's input cat(R, Q) (models/TTSModel.py:270) in the same call: rq (B, 2d, T) receives R in rows [0, d) and a copy of Q in rows [d, 2d).
+extern "C" int ssv_attention_train_fwd_rq(const float* k, const float* v, long kv_bs, const float* q, long q_bs, float* a, float* rq, long rq_bs,
+                                          int B, int d, int N, int T, ssv_stream_t stream) {
+  SSV_CHECK(k && v && q && a && rq && B > 0 && d > 0 && N > 0 && T > 0 && rq_bs >= (long)2 * d * T, SSV_BAD_SHAPE, "attention_train_fwd_rq: bad argument");
+  if (SSV_ATTN_FUSED && ssv_attn_fused_ok(B, d, N, T)) return ssv_launch_attn_fwd_fused(k, v, kv_bs, q, q_bs, a, rq, rq_bs, 1, B, d, N, T, (hipStream_t)stream);
+  SSV_TRY(ssv_attention_train_fwd(k, v, kv_bs, q, q_bs, a, rq, rq_bs, B, d, N, T, stream));
+  return ssv_copy_rows(q, q_bs, rq + (long)d * T, rq_bs, B, (long)d * T, stream);
 }
 extern "C" size_t ssv_attention_train_bwd_workspace(int B, int d, int N, int T) { (void)d; return align256((size_t)B * N * T * sizeof(float)) + 2 * AMAX_FB_BYTES; }
 // Per-batch-item products reduced over time (attention dV, dK): the split-bf16 weight-gradient kernel with one slab per batch
@@ -772,6 +789,27 @@ extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float*
   hipStream_t st = (hipStream_t)stream;
   float* dA = (float*)ws;
   float* fb = (float*)((char*)ws + align256((size_t)B * N * T * sizeof(float)));
+  if (SSV_ATTN_FUSED && ssv_attn_fused_ok(B, d, N, T)) {
+    // dA, dS (left in ws for dk) and dq in ONE launch; the two reductions over time stay on the weight-gradient kernel
+    SSV_TRY(ssv_launch_attn_bwd_fused(dr, dr_bs, da_ext, dq_add, dq_add_bs, k, v, kv_bs, a, dA, dq, dq_bs, B, d, N, T, st));
+    {  // dv(b,c,n) = sum_t dr(b,c,t) a(b,n,t)
+      GemmNT g = nt_zero();
+      g.A = dr; g.sab = dr_bs; g.sam = T; g.La = T;
+      g.X = a; g.sxb = (long)N * T; g.sxc = T; g.Lx = T;
+      g.C = dv; g.scz = dkv_bs; g.scm = N; g.scc = 1;
+      g.M = d; g.Nc = N; g.B = B; g.Z = B; g.bstep = B;
+      SSV_TRY(nt_per_batch(g, T, st, fb));
+    }
+    {  // dk(b,c,n) = sum_t q(b,c,t) ds(b,n,t)
+      GemmNT g = nt_zero();
+      g.A = q; g.sab = q_bs; g.sam = T; g.La = T;
+      g.X = dA; g.sxb = (long)N * T; g.sxc = T; g.Lx = T;
+      g.C = dk; g.scz = dkv_bs; g.scm = N; g.scc = 1;
+      g.M = d; g.Nc = N; g.B = B; g.Z = B; g.bstep = B;
+      SSV_TRY(nt_per_batch(g, T, st, fb));
+    }
+    return 0;
+  }
   {  // dA(b,n,t) = sum_c v(b,c,n) dr(b,c,t)
     GemmNN g = nn_zero();
     g.A = v; g.sab = kv_bs; g.sam = 1; g.sac = N;

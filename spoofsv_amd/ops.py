@@ -945,8 +945,7 @@ class AttentionTrainFn(torch.autograd.Function):
         rq = torch.empty((B, 2 * d, T), dtype=_F32, device=q.device)
         k_ptr = ctypes.c_void_p(kv.data_ptr())
         v_ptr = ctypes.c_void_p(kv.data_ptr() + 4 * d * N)
-        _lib.call("ssv_attention_train_fwd", k_ptr, v_ptr, kvbs, _p(q), qbs, _p(a), _p(rq), 2 * d * T, B, d, N, T, _stream())
-        _lib.call("ssv_copy_rows", _p(q), qbs, ctypes.c_void_p(rq.data_ptr() + 4 * d * T), 2 * d * T, B, d * T, _stream())
+        _lib.call("ssv_attention_train_fwd_rq", k_ptr, v_ptr, kvbs, _p(q), qbs, _p(a), _p(rq), 2 * d * T, B, d, N, T, _stream())
         if _needs_grad(ctx):
             ctx.save_for_backward(kv, q, a)
         return rq, a

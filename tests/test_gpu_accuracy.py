@@ -369,3 +369,28 @@ def test_layernorm_backward_sums_only_the_partial_rows_it_wrote(gate, B, C, L):
     for name in got:
         assert bool(torch.isfinite(got[name]).all()), (name, "a row nobody wrote was summed", rows)
         assert _rl2(got[name], want[name]) < 3e-6, (name, _rl2(got[name], want[name]))
+
+
+@pytest.mark.parametrize("B,d,N,T", [(32, 256, 186, 325), (3, 256, 43, 97), (2, 128, 192, 64), (2, 64, 17, 200), (1, 192, 100, 1)])
+def test_fused_attention_forward_and_backward_vs_float64(B, d, N, T):
+    """models/TTSModel.py:266-270 in one launch per direction (csrc/attn_fused.hip: scores, column softmax and V A from MFMA accumulators;
+    backward dA, dS and dQ likewise, dK / dV on the weight-gradient kernel): A, cat(R, Q) and the gradients of K|V and Q -- with an external
+    gradient on A, as the guided-attention loss supplies -- against float64 at the configured size (d = 256, N = 186, T = 325, B = 32),
+    ragged text / frame counts, fewer channels, a single frame."""
+    from spoofsv_amd import ops
+    gen = torch.Generator().manual_seed(21 + N)
+    kv = torch.randn(B, 2 * d, N, generator=gen)
+    q = torch.randn(B, d, T, generator=gen)
+    g_rq = torch.randn(B, 2 * d, T, generator=gen)
+    g_a = torch.randn(B, N, T, generator=gen) * 0.1
+    kvr, qr = kv.double().requires_grad_(True), q.double().requires_grad_(True)
+    a_ref = torch.softmax(torch.matmul(kvr[:, :d].transpose(1, 2), qr) / d ** 0.5, dim=1)
+    rq_ref = torch.cat((torch.matmul(kvr[:, d:], a_ref), qr), dim=1)
+    (rq_ref * g_rq.double()).sum().add((a_ref * g_a.double()).sum()).backward()
+    kvg, qg = kv.to(DEV).requires_grad_(True), q.to(DEV).requires_grad_(True)
+    rq, a = ops.attention_train(kvg, qg)
+    ((rq * g_rq.to(DEV)).sum() + (a * g_a.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    assert float((a.double().cpu() - a_ref).abs().max() / a_ref.abs().max()) < 2e-5
+    assert _rl2(rq, rq_ref.detach()) < 2e-6
+    assert _rl2(kvg.grad, kvr.grad) < 5e-6 and _rl2(qg.grad, qr.grad) < 5e-6, (_rl2(kvg.grad, kvr.grad), _rl2(qg.grad, qr.grad))
