@@ -109,6 +109,19 @@ __device__ __forceinline__ void attn_second_product(f32x4a (&rc)[DB][4], const f
   }
 }
 
+// rows 0 .. N - 1 of a tile parked as [n][AF_PITCH] -> dst(n, t0 ..): 16 bytes per lane along the row (rows of T floats are 4-byte aligned only)
+typedef float f4ua __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void store_tile_rows(float* __restrict__ dst, const float* tile, int N, int T, int t0) {
+  for (int e = threadIdx.x; e < N * (AF_BN / 4); e += 256) {
+    const int n = e / (AF_BN / 4), c4 = e % (AF_BN / 4), gt = t0 + 4 * c4;
+    if (gt >= T) continue;
+    const f32x4a v = *reinterpret_cast<const f32x4a*>(tile + n * AF_PITCH + 4 * c4);
+    float* o = dst + (long)n * T + gt;
+    if (gt + 3 < T) { f4ua w = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f4ua*>(o) = w; }
+    else for (int j = 0; j < 4; ++j) if (gt + j < T) o[j] = v[j];
+  }
+}
+
 // NB: score row blocks (16 text positions) per wave: ceil(ceil(N / 16) / 4); DB: output row blocks per wave of the d-row products (d / 64)
 template <int NB, int DB>
 __global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const float* __restrict__ K, const float* __restrict__ V, long kv_bs, const float* __restrict__ Q, long q_bs,
@@ -172,13 +185,12 @@ __global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const float* __rest
       const int n = (wave + 4 * i) * 16 + kq * 4 + r;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float p = acc[i][t][r] * sum[t];
-        sA[n * AF_PITCH + t * 16 + nq] = p;                              // (0 for n >= N)
-        const int gt = t0 + t * 16 + nq;
-        if (n < N && gt < T) Ab[(long)n * T + gt] = p;
+        sA[n * AF_PITCH + t * 16 + nq] = acc[i][t][r] * sum[t];         // (0 for n >= N)
       }
     }
-  // ---- R(c, t) = sum_n V(c, n) A(n, t)   (the second product's first barrier orders the tile's writes before its reads)
+  __syncthreads();
+  store_tile_rows(Ab, sA, N, T, t0);                                     // A, 256-byte row pieces per 16 lanes
+  // ---- R(c, t) = sum_n V(c, n) A(n, t)
   f32x4a rc[DB][4];
 #pragma unroll
   for (int i = 0; i < DB; ++i)
@@ -255,12 +267,11 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
       const int n = (wave + 4 * i) * 16 + kq * 4 + r;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float ds = av[i][t][r] * (acc[i][t][r] - dot[t]) * alpha;      // (0 where A was masked to 0)
-        sS[n * AF_PITCH + t * 16 + nq] = ds;
-        const int gt = t0 + t * 16 + nq;
-        if (n < N && gt < T) dSb[(long)n * T + gt] = ds;
+        sS[n * AF_PITCH + t * 16 + nq] = av[i][t][r] * (acc[i][t][r] - dot[t]) * alpha;      // (0 where A was masked to 0)
       }
     }
+  __syncthreads();
+  store_tile_rows(dSb, sS, N, T, t0);
   // ---- dQ(c, t) = sum_n K(c, n) dS(n, t) + dQ_add(c, t)
   f32x4a rc[DB][4];
 #pragma unroll

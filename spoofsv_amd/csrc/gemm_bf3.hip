@@ -809,6 +809,9 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
 #ifndef SSV_NNBW_XROW
 #define SSV_NNBW_XROW 1      // (tuning builds: 0 = M = 128 j + 1 on the 16-wave kernel with a fifth row tile, as before)
 #endif
+#ifndef SSV_NNBW_PARK
+#define SSV_NNBW_PARK 1      // (tuning builds: 0 = the output stored straight from the accumulator layout, 64-byte pieces of 16 rows per instruction)
+#endif
 template <int KT, int WM, int NT, int NWN, int F16, int XR = 0>
 __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm_nn_bf3w_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int T = 256 * NWN;
@@ -817,7 +820,10 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
   constexpr int WX = ((BN + HALO + 15) / 16) * 16;
   constexpr int A_SLOTS = KT * 4 * BM, X_SLOTS = 4 * WX;
   constexpr int NA = (A_SLOTS + T - 1) / T, NX = (X_SLOTS + T - 1) / T;
-  __shared__ uint4 lds[2 * A_SLOTS + 2 * X_SLOTS];
+  // (the epilogue re-uses the staging memory to park every wave's 16 x (16 NT) blocks for row-contiguous stores, as gemm_nn_bf3_kernel does)
+  constexpr int LDWP = 16 * NT + 4, PARK_U4 = SSV_NNBW_PARK ? (4 * NWN * 16 * LDWP) / 4 : 0;
+  constexpr int STAGE_U4 = 2 * A_SLOTS + 2 * X_SLOTS;
+  __shared__ uint4 lds[STAGE_U4 > PARK_U4 ? STAGE_U4 : PARK_U4];
   uint4* Ah = lds;
   uint4* Al = lds + A_SLOTS;
   uint4* Xh = lds + 2 * A_SLOTS;
@@ -988,6 +994,45 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
 
   float* __restrict__ Cb = p.C + (long)b * p.scb;
   const float* __restrict__ Rb = p.R ? p.R + (long)b * p.srb : nullptr;
+  if constexpr (SSV_NNBW_PARK) {
+    if (p.scn == 1) {
+      __syncthreads();                                            // every wave is done reading the last chunk's image
+      float* pk = reinterpret_cast<float*>(lds) + wave * 16 * LDWP;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int rbase = m0 + wm * WM * 16 + i * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gmc = min(rbase + kq * 4 + r, Mt - 1);
+          float add = 0.f;
+          if (p.bias) add += p.bias[gmc];
+          if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gmc];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) pk[(kq * 4 + r) * LDWP + t * 16 + nq] = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add;
+        }
+        // (the block is private to the wave: its LDS operations complete in order)
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+          const int e = lane + 64 * it;
+          const int row = e / (4 * NT), c4 = e % (4 * NT);
+          const int gm = rbase + row, gn = n0 + wn * NT * 16 + c4 * 4;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(pk + row * LDWP + c4 * 4);
+          if (gm < Mt && gn < p.N) {
+            float* dst = Cb + (long)gm * p.scm + gn;
+            if (gn + 3 < p.N) {
+              f4u o = {v[0], v[1], v[2], v[3]};
+              if (Rb) { const f4u rr = *reinterpret_cast<const f4u*>(Rb + (long)gm * p.srm + gn); o += rr; }
+              *reinterpret_cast<f4u*>(dst) = o;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) if (gn + j < p.N) dst[j] = v[j] + (Rb ? Rb[(long)gm * p.srm + gn + j] : 0.f);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!SSV_NNBW_PARK || p.scn != 1) {
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1006,6 +1051,7 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
         Cb[(long)gm * p.scm + gn] = v;
       }
     }
+  }
   if constexpr (XR) {
     if (xr_on) {                                            // (workgroup-uniform) row M - 1: the four k-groups' partial sums of a column, then bias and residual
 #pragma unroll
@@ -2041,6 +2087,9 @@ extern "C" int ssv_debug_pw_stamps(unsigned long long* out) { return (int)hipMem
 #ifndef SSV_PWLN_XROW
 #define SSV_PWLN_XROW 1      // (tuning builds: 0 = M = 513 on five row blocks per wave, as before)
 #endif
+#ifndef SSV_PWLN_PARK
+#define SSV_PWLN_PARK 1      // (tuning builds: 0 = `pre` and `y` stored straight from the accumulator layout, as in round 4)
+#endif
 struct PwLn {
   GemmNNB g;                      // A planes, X, C = pre (B, M, N), bias, bias_b, f16 scales
   const float* gamma; const float* beta;
@@ -2062,6 +2111,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   __shared__ float xw[XR ? 1056 : 1];
   __shared__ float xsum[XR ? 4 * BN : 1];
   __shared__ float xrow[XR ? 2 * BN : 1];                // the row's pre-activation per column, then its normalised value
+  // epilogue (round 5): every wave parks a 16-row block row-major and reads it back as 16-byte vectors along the rows, so a store instruction
+  // covers four whole 256-byte row pieces instead of 64-byte pieces of 16 rows (what gemm_nn_bf3_kernel's epilogue has done since round 2)
+  constexpr int LDWP = BN + 4;
+  __shared__ float park[SSV_PWLN_PARK ? 8 * 16 * LDWP : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int ntile = (int)(wg % gridDim.x), b = (int)(wg / gridDim.x);
@@ -2199,8 +2252,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   float csum[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) csum[t] = 0.f;
+  // the wave's parked block (rows rbase .. rbase + 15, private to the wave: its LDS operations complete in order) -> dst rows, 16 bytes per lane
+  float* pk = park + (SSV_PWLN_PARK ? wave * 16 * LDWP : 0);
+  auto store_block = [&](float* __restrict__ dst, long row_stride, int rbase) __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < WMB; ++i)
+    for (int it = 0; it < NT; ++it) {
+      const int e = lane + 64 * it;
+      const int row = e / (BN / 4), c4 = e % (BN / 4);
+      const int gm = rbase + row, gn = n0 + c4 * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pk + row * LDWP + c4 * 4);
+      if (gm < Mt && gn < p.N) {
+        float* o = dst + (long)gm * row_stride + gn;
+        if (gn + 3 < p.N) { f4u w = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f4u*>(o) = w; }
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (gn + j < p.N) o[j] = v[j];
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gm = (wave * WMB + i) * 16 + kq * 4 + r;
@@ -2214,10 +2286,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
         const float v = rv ? (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add : 0.f;
         acc[i][t][r] = v;
         csum[t] += v;
-        const int gn = n0 + t * 16 + nq;
-        if (rv && gn < p.N) Cb[(long)gm * p.scm + gn] = v;
+        if constexpr (SSV_PWLN_PARK) pk[(kq * 4 + r) * LDWP + t * 16 + nq] = v;
+        else { const int gn = n0 + t * 16 + nq; if (rv && gn < p.N) Cb[(long)gm * p.scm + gn] = v; }
       }
     }
+    if constexpr (SSV_PWLN_PARK) store_block(Cb, p.scm, (wave * WMB + i) * 16);
+  }
   const float invM = 1.f / (float)p.M;
   if constexpr (XR) {                                     // row M - 1: the four k-groups' partial sums of a column, bias; stored, and kept for the LayerNorm
     if (stager) xsum[tid] = xacc;                         // (slot tid = skg * BN + scol)
@@ -2280,21 +2354,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   }
   float am = 0.f;
 #pragma unroll
-  for (int i = 0; i < WMB; ++i)
+  for (int i = 0; i < WMB; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gm = (wave * WMB + i) * 16 + kq * 4 + r;
-      if (gm >= Mt) continue;
-      const float ga = q.gamma[gm], be = q.beta[gm];
+      const bool rv = gm < Mt;
+      const int gmc = min(gm, Mt - 1);
+      const float ga = q.gamma[gmc], be = q.beta[gmc];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int gn = n0 + t * 16 + nq;
         float n = (acc[i][t][r] - mean[t]) * rstd[t] * ga + be;
         if (q.act == 1) n = fmaxf(n, 0.f);
         else if (q.act == 2) n = 1.f / (1.f + __expf(-n));
-        if (gn < p.N) { Yb[(long)gm * p.N + gn] = n; am = fmaxf(am, fabsf(n)); }
+        if (rv && gn < p.N) am = fmaxf(am, fabsf(n));
+        if constexpr (SSV_PWLN_PARK) pk[(kq * 4 + r) * LDWP + t * 16 + nq] = n;
+        else if (rv && gn < p.N) Yb[(long)gm * p.N + gn] = n;
       }
     }
+    if constexpr (SSV_PWLN_PARK) store_block(Yb, p.N, (wave * WMB + i) * 16);
+  }
   if constexpr (XR) {
     if (tid < BN && n0 + tid < p.N) {                      // row M - 1 of y (colv is final: behind the second reduction's barrier)
       const int gm = p.M - 1;
