@@ -190,30 +190,40 @@ int ssv_launch_pack_wt(const float* w, float* wt, int Cout, int Cin, int KT, hip
 //   read 16 bytes at a time and served by the cache: 205 KB in all), four independent partial sums.
 //   (First form: 8 x 32 outputs per workgroup with w and x staged in LDS in chunks of 64 -- 32 workgroups, four load / barrier round trips
 //   each: 23.7 us per launch in-step against 21 us for the tiled GEMM it replaced.)
+// (round 5) EIGHT lanes per output: lane j takes the 16-byte pieces j, j + 8, .. of the weight row (128 contiguous bytes per group and trip) and the
+// eight partial sums meet through three lane exchanges.  With a thread per output the launch was 32 workgroups whose every thread walked its 800-byte
+// row alone, 50 dependent-issue trips: 29 us for 1.6 MFLOP.
 __global__ __launch_bounds__(256) void linear_len1_fwd_kernel(const float* __restrict__ x, long x_bs, const float* __restrict__ w, const float* __restrict__ bias,
                                                               const float* __restrict__ bias_b, long sbb, float* __restrict__ y, long y_bs, int B, int K, int M) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)B * M) return;
+  const long t = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+  const int j = threadIdx.x & 7;
+  if (t >= (long)B * M) return;                          // (a group of eight leaves or stays together)
   const int m = (int)(t % M), b = (int)(t / M);
   const float* __restrict__ wr = w + (long)m * K;
   const float* __restrict__ xr = x + (long)b * x_bs;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int k = 0;
+  int kdone = 0;
   if ((K & 3) == 0 && (((size_t)w | (size_t)x) & 15) == 0 && (x_bs & 3) == 0) {
-    for (; k + 3 < K; k += 4) {
+    for (int k = 4 * j; k + 3 < K; k += 32) {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k), xv = *reinterpret_cast<const f32x4*>(xr + k);
       a0 = __builtin_fmaf(wv[0], xv[0], a0); a1 = __builtin_fmaf(wv[1], xv[1], a1); a2 = __builtin_fmaf(wv[2], xv[2], a2); a3 = __builtin_fmaf(wv[3], xv[3], a3);
     }
+    kdone = K;
   }
-  for (; k < K; ++k) a0 = __builtin_fmaf(wr[k], xr[k], a0);
+  for (int k = kdone + j; k < K; k += 8) a0 = __builtin_fmaf(wr[k], xr[k], a0);
   float acc = (a0 + a1) + (a2 + a3);
-  if (bias) acc += bias[m];
-  if (bias_b) acc += bias_b[(long)b * sbb + m];
-  y[(long)b * y_bs + m] = acc;
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  if (j == 0) {
+    if (bias) acc += bias[m];
+    if (bias_b) acc += bias_b[(long)b * sbb + m];
+    y[(long)b * y_bs + m] = acc;
+  }
 }
 int ssv_launch_linear_len1_fwd(const float* x, long x_bs, const float* w, const float* bias, const float* bias_b, long sbb, float* y, long y_bs,
                                int B, int K, int M, hipStream_t st) {
-  hipLaunchKernelGGL(linear_len1_fwd_kernel, dim3(ssv_cdiv((long)B * M, 256)), dim3(256), 0, st, x, x_bs, w, bias, bias_b, sbb, y, y_bs, B, K, M);
+  hipLaunchKernelGGL(linear_len1_fwd_kernel, dim3(ssv_cdiv((long)B * M * 8, 256)), dim3(256), 0, st, x, x_bs, w, bias, bias_b, sbb, y, y_bs, B, K, M);
   return ssv_check_launch("linear_len1_fwd");
 }
 //   dw(m, c) = sum_b dy(b, m) x(b, c): a thread per entry, c fastest (x coalesced, dy one address per 64 lanes or two).
