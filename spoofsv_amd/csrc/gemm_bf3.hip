@@ -349,6 +349,10 @@ extern "C" int ssv_debug_nn_stamps(unsigned long long* out) { return (int)hipMem
 #define NN_STAMP_AT(slot) do {} while (0)
 #define NN_RT(which) do {} while (0)
 #endif
+#ifndef SSV_NN_XONE
+#define SSV_NN_XONE 1        // one-path input prefetch where it measured faster in-step (k = 1 tiles -2 %, 128 x 112 k = 3 tiles -2.5 %; the 64-row and
+                             // 96-column k = 3 tiles and every 54-column-halo tile were equal or up to 15 % SLOWER with it and keep the two-form prefetch)
+#endif
 #define SSV_NN_XBUF(KT, WM, NT) (!((KT) == 3 && (NT) == 6))   // input rows by buffer loads (ssv_buf) or through pointers: in-step, per tile -- the k = 1
                                                              // tiles are 5-12 % faster with buffer loads, the 96-column k = 3 tiles 4-6 % with pointers, the rest equal
 // waves per SIMD the register allocation must leave room for
@@ -471,8 +475,22 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
       }
     }
   };
+  // Convolutions (EPI == 0) prefetch on ONE path: a buffer whose range is the batch item's Kc rows, so the channels of a ragged last chunk past
+  // Kc read 0 (tools/probe/buf_oob.hip: voffset + soffset is checked against the range, per dword) and no "last, partial chunk" form is needed.
+  // Not for the branch: hipcc lays an if / else out as two tests in a row, its s_waitcnt bookkeeping then sees a path on which NEITHER form ran, and
+  // in front of every chunk's first MFMA it waited for all but the weight fragments' own loads -- i.e. for the input loads issued a few hundred
+  // cycles earlier, one exposed round trip per chunk (round 5; the steady / tail split below had removed only the "is there a chunk c + 2" tests).
+  const __amdgpu_buffer_rsrc_t rsXr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xb), 0,
+      (int)(((long)(p.Kc - 1) * Lrow + (long)(p.Lx - 1) * p.sxn + 1) * 4), 0x00020000);
   auto prefetchX = [&](int ch) {
-    if (!ragged || ch + 1 < nchunks) {
+    if constexpr (EPI == 0 && SSV_NN_XONE && (KT == 1 || (WM == 2 && NT == 7 && HW == 16))) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned so = (unsigned)((ch * 32 + i) * Lrow) * 4u;                // uniform row offset: scalar arithmetic
+#pragma unroll
+        for (int r = 0; r < NX; ++r) rx[r][i] = ssv_buf_f32(rsXr, voffb[r], so);
+      }
+    } else if (!ragged || ch + 1 < nchunks) {
       const bool seg2 = EPI == 1 && X2b && ch >= p.xsplit;                       // (LSTM: the h_{t-1} segment of K)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -2087,6 +2105,9 @@ extern "C" int ssv_debug_pw_stamps(unsigned long long* out) { return (int)hipMem
 #ifndef SSV_PWLN_XROW
 #define SSV_PWLN_XROW 1      // (tuning builds: 0 = M = 513 on five row blocks per wave, as before)
 #endif
+#ifndef SSV_PWLN_ROLL
+#define SSV_PWLN_ROLL 1      // (tuning builds: 0 = the one weight-fragment set of 4 row blocks per wave re-loaded at the end of the chunk)
+#endif
 #ifndef SSV_PWLN_PARK
 #define SSV_PWLN_PARK 1      // (tuning builds: 0 = `pre` and `y` stored straight from the accumulator layout, as in round 4)
 #endif
@@ -2146,7 +2167,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   }
   const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(p.Ahi), rsAl = ssv_buf(p.Alo), rsX = ssv_buf(Xb);
   auto loadA = [&](int set, int ch) {
-    const unsigned ub = (unsigned)ch * 1024u;
+    // (readfirstlane: hipcc kept this offset in a vector register in some instantiations and wrapped every load in a waterfall loop)
+    const unsigned ub = (unsigned)__builtin_amdgcn_readfirstlane(ch * 1024);
 #pragma unroll
     for (int i = 0; i < WMB; ++i) { Ah_[set][i] = ssv_buf_u4(rsAh, arowb[i], ub); Al_[set][i] = ssv_buf_u4(rsAl, arowb[i], ub); }
   };
@@ -2167,6 +2189,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) rx[i] = ssv_buf_f32(rsX, (unsigned)min(ch * 32 + 8 * skg + i, p.Kc - 1) * (unsigned)Lrow * 4u + colo, 0u);
     }
+  };
+  // the rolling loop's prefetch: ONE path (a buffer whose range is the batch item's Kc rows: channels past Kc read 0, tools/probe/buf_oob.hip),
+  // because with the two-path form above hipcc must assume at the loop head that neither path ran and waits for all weight fragments at once
+  const __amdgpu_buffer_rsrc_t rsXr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xb), 0, (int)(((long)(p.Kc - 1) * Lrow + p.Lx) * 4), 0x00020000);
+  auto prefetchXr = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rx[i] = ssv_buf_f32(rsXr, voffb, (unsigned)((ch * 32 + i) * Lrow) * 4u);
   };
   auto commitX = [&](int ch) {
     if (!stager) return;
@@ -2211,8 +2240,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   }
   if constexpr (XR) __syncthreads();                     // xw is staged
   commitX(0);
-  if (nchunks > 1) prefetchX(1);
-  if constexpr (NSET == 2) {
+  if constexpr (SSV_PWLN_ROLL) prefetchXr(min(1, nchunks - 1));
+  else if (nchunks > 1) prefetchX(1);
+  if constexpr (NSET == 2 && SSV_PWLN_ROLL) {
+    // two weight-fragment sets, every load unconditional (clamped chunk index, one-path prefetch: see the rolling loop below)
+    const int last = nchunks - 1;
+    loadA(1, min(1, last));
+    __syncthreads();
+    PW_STAMP(1);
+    for (int ch = 0; ch < nchunks; ch += 2) {
+      tap(0, ch);
+      if (ch + 1 < nchunks) commitX(ch + 1);
+      prefetchXr(min(ch + 2, last)); loadA(0, min(ch + 2, last));
+      __syncthreads();
+      if (ch + 1 < nchunks) tap(NSET - 1, ch + 1);
+      if (ch + 2 < nchunks) commitX(ch + 2);
+      prefetchXr(min(ch + 3, last)); loadA(NSET - 1, min(ch + 3, last));
+      __syncthreads();
+    }
+  } else if constexpr (NSET == 2) {
     if (nchunks > 1) loadA(1, 1);
     __syncthreads();
     PW_STAMP(1);
@@ -2227,6 +2273,39 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
         commitX(ch + 2);
         if (ch + 3 < nchunks) { prefetchX(ch + 3); loadA(NSET - 1, ch + 3); }
       }
+      __syncthreads();
+    }
+  } else if constexpr (SSV_PWLN_ROLL) {
+    // One register set, re-loaded ROW BLOCK BY ROW BLOCK (round 5): the loop runs row block outermost with all NT input fragments of the chunk
+    // in registers, so row block i's weight fragments are dead after its 3 NT MFMAs and chunk c + 1's are requested right there -- every
+    // fragment gets (WMB - 1) / WMB of a chunk of lead time.  (Before: the whole set was re-loaded after the chunk's last MFMA, i.e. the first
+    // MFMA of the next chunk waited for a full L2 round trip -- the 8 waves run in lock step, nothing else was there to cover it.)
+    // The re-load is unconditional (the last chunk re-reads itself): a load under a condition makes hipcc drain the whole queue.
+    __syncthreads();
+    PW_STAMP(1);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const uint4* Xh = lds[ch & 1];
+      const uint4* Xl = lds[ch & 1] + X_SLOTS;
+      uint4 bh[NT], bl[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { const int s_ = kq * BN + t * 16 + nq; bh[t] = Xh[s_]; bl[t] = Xl[s_]; }
+      const unsigned ubn = (unsigned)__builtin_amdgcn_readfirstlane(min(ch + 1, nchunks - 1) * 1024);
+#pragma unroll
+      for (int i = 0; i < WMB; ++i) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[i][t] = mma16<F16>(Al_[0][i], bh[t], acc[i][t]);
+          acc[i][t] = mma16<F16>(Ah_[0][i], bl[t], acc[i][t]);
+          acc[i][t] = mma16<F16>(Ah_[0][i], bh[t], acc[i][t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // the re-load stays behind this row block's MFMAs, and in front of the next block's
+        Ah_[0][i] = ssv_buf_u4(rsAh, arowb[i], ubn);
+        Al_[0][i] = ssv_buf_u4(rsAl, arowb[i], ubn);
+      }
+      // (the prefetch is unconditional too -- the last chunks re-read the last one -- so that every path into the loop head has the same loads in
+      //  flight and hipcc can wait for row block 0's fragments alone, vmcnt(14), instead of for the youngest count over all paths)
+      if (ch + 1 < nchunks) commitX(ch + 1);
+      prefetchXr(min(ch + 2, nchunks - 1));
       __syncthreads();
     }
   } else {
