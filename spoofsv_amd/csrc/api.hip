@@ -41,7 +41,7 @@ int ssv_precision() {
   }
   return g_precision;
 }
-static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_FORCE", "SSV_NNB_FORCE", "SSV_LN_GROUPS", "SSV_LN_PERSIST"};
+static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_FORCE", "SSV_NNB_FORCE", "SSV_LN_GROUPS", "SSV_LN_PERSIST", "SSV_LSTM_MERGE"};
 static char g_knob_val[SSV_T_COUNT][512];
 static const char* g_knob[SSV_T_COUNT];
 static int g_knobs_loaded = 0;
@@ -210,7 +210,7 @@ static GemmNNB nnb_zero() {
   g.shift[0] = g.shift[1] = g.shift[2] = 0;
   g.sxn = g.scn = 1;
   g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
-  g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0;
+  g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0; g.A0hi = g.A0lo = nullptr;
   g.gates_out = nullptr;
   g.f16 = 0; g.a_inv = nullptr; g.x_amax = nullptr; g.x_namax = 0; g.x_amax_bs = 0;
   g.colstats = nullptr;
@@ -1075,7 +1075,26 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   if (f16) { g.f16 = 1; g.a_inv = aux + 64; g.x_amax = nullptr; g.x_namax = 0; g.x_amax_bs = 0; }     // activations: |h| < 1, the fixed scale 2^14
   g.lstm_out = out; g.lstm_D = D; g.sbb = (long)8 * H; g.gates_out = keep_gates;
   g.X = out; g.C = out;                        // placeholders: the kernel derives X, X2 and C from (layer, frame)
-  for (int step = 0; step < T + layers - 1; ++step) {
+  // One launch per wavefront step (round 5): layer 0 (K = H: its own h_{t-1}; the input projection xp[t] through R) rides in the launch of the
+  // layers above it (K = 2 H) as entry 0.  Before, a step was two launches -- 336 workgroups with 24 chunks, then 672 with 48 -- each with a
+  // half-empty last round; together they are 1008 workgroups = two full rounds of 512.  SSV_LSTM_MERGE=0 keeps the two launches (tuning).
+  const char* mk = ssv_tuning(SSV_T_LSTM_MERGE);
+  const bool merge = !(mk && atoi(mk) == 0);
+  for (int step = 0; merge && layers >= 2 && step < T + layers - 1; ++step) {
+    g.lstm_s = step;
+    const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
+    const int lo1 = lo > 1 ? lo : 1;           // the first layer >= 1 of the launch: its planes are the launch's Ahi
+    g.Ahi = (unsigned short*)(base + s.comb + (size_t)(lo1 - 1) * s.comb_stride);
+    g.Alo = (unsigned short*)((char*)g.Ahi + split_bytes(4 * H, 2 * H, 1));
+    g.sab = (long)(s.comb_stride / sizeof(unsigned short));
+    g.Kpad = 2 * H; g.Kc = 2 * H;
+    g.xsplit = hch; g.lstm_lo = lo; g.B = hi - lo + 1;
+    g.bias = bias + (long)lo * 8 * H; g.bias_b = g.bias + 4 * H;
+    if (lo == 0) { g.A0hi = hh0_hi; g.A0lo = hh0_lo; g.R = xp + (long)step * 4 * H * Bn; g.srb = 0; }
+    else { g.A0hi = g.A0lo = nullptr; g.R = nullptr; }
+    SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+  }
+  for (int step = 0; !(merge && layers >= 2) && step < T + layers - 1; ++step) {
     g.lstm_s = step;
     if (step < T) {                            // layer 0: gates = W_hh h_{t-1} + xp[t] + b
       g.Ahi = hh0_hi; g.Alo = hh0_lo; g.Kpad = H; g.Kc = H; g.sab = 0;

@@ -388,18 +388,21 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   // LSTM wavefront (see GemmNNB): layer / frame of this grid.y entry, the second K segment, the chunks to run
   const float* __restrict__ X2b = nullptr;
   int lstm_layer = 0, lstm_t = 0;
+  bool lstm_l0 = false;                       // this entry is layer 0 riding in a wavefront launch (GemmNNB::A0hi)
   if constexpr (EPI == 1) {
     if (p.lstm_D > 0) {
       lstm_layer = p.lstm_lo + b;
       lstm_t = p.lstm_s - lstm_layer;
       const long HN = (long)p.perm_h * p.N;
+      lstm_l0 = p.A0hi != nullptr && lstm_layer == 0;
       Xb = p.lstm_out + ((long)max(lstm_layer - 1, 0) * p.lstm_D + lstm_t % p.lstm_D) * HN;
       X2b = p.lstm_out + ((long)lstm_layer * p.lstm_D + (lstm_t + p.lstm_D - 1) % p.lstm_D) * HN - (long)p.xsplit * 32 * (long)p.sxc;
+      if (lstm_l0) { Xb = X2b + (long)p.xsplit * 32 * (long)p.sxc; X2b = nullptr; }      // one segment: the layer's own h_{t-1}
     }
   }
-  // chunks to run: all of K, except that an LSTM entry at its first frame has no h_{t-1} segment
-  const int nchunks_all = p.Kpad / 32;
-  const int nchunks = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? p.xsplit : nchunks_all;
+  // chunks to run: all of K, except that an LSTM entry at its first frame has no h_{t-1} segment (layer 0 riding along: nothing but that segment)
+  const int nchunks_all = lstm_l0 ? p.xsplit : p.Kpad / 32;
+  const int nchunks = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? (lstm_l0 ? 0 : p.xsplit) : nchunks_all;
   const int W = BN + span;
   const int kq = lane >> 4, nq = lane & 15;
 
@@ -429,7 +432,9 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   unsigned arowb[WM];
 #pragma unroll
   for (int i = 0; i < WM; ++i) arowb[i] = (unsigned)(arow[i] * 2);
-  const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(p.Ahi + (long)b * p.sab), rsAl = ssv_buf(p.Alo + (long)b * p.sab);   // (see ssv_buf)
+  // (LSTM wavefront with layer 0 riding along: entry 0 reads the planes A0hi / A0lo, entry b >= 1 the planes of layer b at (b - 1) * sab)
+  const long aent = (EPI == 1 && p.A0hi) ? (long)(b > 0 ? b - 1 : 0) * p.sab : (long)b * p.sab;
+  const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(lstm_l0 ? p.A0hi : p.Ahi + aent), rsAl = ssv_buf(lstm_l0 ? p.A0lo : p.Alo + aent);   // (see ssv_buf)
   auto loadA = [&](int set, int j, int ch) {
     const unsigned ub = (unsigned)((j * aplane + (long)ch * 512) * 2);                                  // wave-uniform byte offset
     // (buffer loads everywhere: equal or 1-3 % faster than loads through pointers, measured in-step per tile)
@@ -660,6 +665,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_b
   float* __restrict__ Cb = p.C + (long)b * p.scb;
   const float* __restrict__ Rb = p.R ? p.R + (long)b * p.srb : nullptr;
   if constexpr (EPI == 1) {
+    if (p.A0hi && !lstm_l0) Rb = nullptr;         // the input projection in R belongs to layer 0 alone
     // Fused LSTM cell (torch gate order i, f, g, o).  Rows were packed gate-interleaved, so the four accumulator rows a
     // lane holds for a 16-row tile (rows kq*4 .. kq*4+3) are the four gates of ONE hidden unit at column nq.
     const int H = p.perm_h;
@@ -1172,6 +1178,20 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   // LSTM wavefront with two or more layers in one launch (the steady state of the GE2E embedder: 2 x 3072 x 880 x 1536): the
   // cost model below picks 64 x 112 tiles; measured over the 122 steps of config 5, 128 x 64 tiles are 6 % faster
   // (13.8 -> 13.0 ms; 128 x 96: 13.5, 128 x 112: 14.2, 64 x 96: 14.8) as long as they still give every CU two workgroups.
+  // (round 5, layer 0 riding along: three layers = 3 x 24 x 7 = 504 tiles of 128 x 128 are ONE round of two workgroups per CU, with half the weight
+  //  bytes per MFMA of the 64-column tile -- the launch is bound by L2 -> CU traffic, 69 GB/s per CU measured on 1008 tiles of 128 x 64)
+  if constexpr (KT == 1) {
+    if (!forced && g.epi && g.lstm_D > 0 && g.B >= 2) {
+      const long t128 = (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 128) * g.B;
+      const char* e = ssv_tuning(SSV_T_LSTM_MERGE);
+      if (t128 >= 448 && t128 <= 512 && !(e && atoi(e) == 2)) {
+        const int mtiles = ssv_cdiv(g.M, 128), ntiles = ssv_cdiv(g.N, 128);
+        if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<1, 2, 8, 1, 1>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+        else hipLaunchKernelGGL((gemm_nn_bf3_kernel<1, 2, 8, 1, 0>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+        return ssv_check_launch("gemm_nn_bf3_lstm");
+      }
+    }
+  }
   if (!forced && g.epi && g.lstm_D > 0 && g.B >= 2 && (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 64) * g.B >= 512) { wm = 2; nt = 4; forced = true; }
   if (!forced) {
     // tuning aid (tools/sweep_force.sh): SSV_NNB_FORCE="kt:M:N=a,c;kt:M:N=a,c;..." forces the tile of one problem shape

@@ -76,6 +76,10 @@ struct GemmNNB {
   // (skipped at t = 0).  All h live in lstm_out[layer][slot = frame % lstm_D][H][N]; the kernel derives X, X2 and C from
   // (layer, t), and offsets the weight planes by b*sab, the biases by b*sbb and cstate by layer*H*N.
   float* lstm_out; int lstm_s, lstm_lo, lstm_D, xsplit; long sab;
+  // Layer 0 in the same launch (round 5; A0hi != null, lstm_lo == 0): entry 0 is layer 0 at frame lstm_s -- its K axis is the layer's own
+  // h_{t-1} alone (xsplit chunks of the planes A0hi / A0lo; none at t = 0), its input projection comes in through R (no batch stride), and
+  // the entries b >= 1 are layers 1 .. with planes Ahi + (b - 1) * sab.  One launch per wavefront step instead of two.
+  const unsigned short* A0hi; const unsigned short* A0lo;
   // training (gates_out != null, lstm_D = number of frames): the activated gates i, f, g, o are saved as
   // gates_out[layer][frame][gate*H + u][N] (torch row order) and cstate is [layer][frame][H][N] (c_{t-1} read, c_t written)
   float* gates_out;
@@ -123,7 +127,7 @@ int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA, 2 = split
 // The three tuning knobs that remain (per-shape overrides for in-step sweeps: SSV_NNB_FORCE="kt:M:N=wm,nt;...", SSV_NT_FORCE="M:Nc:k=Z;...",
 // SSV_LN_GROUPS for tools/bench_ln.py): read from the environment ONCE at first use -- a launch must not cost getenv() scans -- and
 // again only when a tuning script calls ssv_reload_tuning() (exported, not part of include/ssv_hip.h).
-enum { SSV_T_NT_FORCE, SSV_T_NNB_FORCE, SSV_T_LN_GROUPS, SSV_T_LN_PERSIST, SSV_T_COUNT };
+enum { SSV_T_NT_FORCE, SSV_T_NNB_FORCE, SSV_T_LN_GROUPS, SSV_T_LN_PERSIST, SSV_T_LSTM_MERGE, SSV_T_COUNT };
 const char* ssv_tuning(int knob);          // value of the knob or nullptr
 int ssv_pack_job_blocks(const ssv_pack_job& j);           // workgroups one job of ssv_conv_pack_multi takes
 int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, float* amax_ws, hipStream_t st);   // amax_ws != null: split-fp16 planes
