@@ -41,7 +41,7 @@ int ssv_precision() {
   }
   return g_precision;
 }
-static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_FORCE", "SSV_NNB_FORCE", "SSV_LN_GROUPS", "SSV_LN_PERSIST", "SSV_LSTM_MERGE"};
+static const char* const g_knob_names[SSV_T_COUNT] = {"SSV_NT_FORCE", "SSV_NNB_FORCE", "SSV_LN_GROUPS", "SSV_LN_PERSIST", "SSV_LSTM_MERGE", "SSV_PWLN_BWD"};
 static char g_knob_val[SSV_T_COUNT][512];
 static const char* g_knob[SSV_T_COUNT];
 static int g_knobs_loaded = 0;
@@ -104,6 +104,7 @@ int ssv_launch_ln_gate_bwd(const float*, long, const float*, const float*, long,
 int ssv_ln_gate_bwd_nblk(int B, int L);
 int ssv_ln_gate_bwd_rows(int B, int C, int L, bool has_amax);      // partial rows the backward launch of this shape writes (norm.hip)
 int ssv_ln_act_bwd_rows(int B, int C, int L, bool has_amax);
+int ssv_ln_act_bwd_vec(int C, int L, bool has_amax);
 int ssv_launch_ln_gate_fwd_stream(const float* H, const float* X, long x_bs, const float* colstats, const float* g1, const float* b1, const float* g2, const float* b2,
                                   float* Y, long y_bs, float* stats, float* amax, int B, int C, int L, hipStream_t st);
 int ssv_launch_ln_bwd2(const float*, long, const float*, long, const float*, long, const float*, const float*, float*, long, float*, long, float*, float*, int, int, int, hipStream_t);
@@ -590,6 +591,30 @@ extern "C" int ssv_highway_conv1d_fwd(const float* x, long x_bs, const float* x_
 // ---- 1x1 conv + LayerNorm (+ activation), whole backward ------------------------------------------------------------------
 // y = act(LN(conv1x1(x) [+ s])) -- models/TTSModel.py:128-131, :173-180, :218-231, :343-361.  One entry for the backward so that
 // the LayerNorm partial rows and the weight-gradient slabs are summed by ONE launch (as in ssv_highway_conv1d_bwd).
+// LayerNorm / activation backward + the k = 1 data gradient of a link: ONE launch (round 5, pwln_bwd_kernel) when the transposed weight's planes
+// are resident and the shape fits, else ln_act_bwd*, then the data-gradient GEMM.  dpre (B, Cout, L) dense; part: ssv_ln_act_bwd_rows rows.
+static int pw_bwd_ln_and_data(const float* dy, long dy_bs, const float* w, const void* w_packed, const float* gamma, const float* beta, const float* pre,
+                              const float* stats, float* dx, long dx_bs, float* dpre, float* dpre_amax, float* part, int B, int Cin, int Cout, int L, int act,
+                              void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  const long pbs = (long)Cout * L;
+  if (dx && w_packed && use_bf3(B, L, Cout, Cin) && (!use_f16() || dpre_amax) && ssv_pwln_bwd_fused_ok(B, Cin, Cout, L)) {
+    const bool has_amax = dpre_amax != nullptr;
+    PwLnBw q;
+    q.dy = dy; q.dy_bs = dy_bs; q.pre = pre; q.stats = stats; q.gamma = gamma; q.beta = beta;
+    q.dpre = dpre; q.part = part; q.part_rows = ssv_ln_act_bwd_rows(1, Cout, L, has_amax); q.part_q = 4 / ssv_ln_act_bwd_vec(Cout, L, has_amax);
+    q.amax = dpre_amax; q.namax = ssv_amax_rows_(L);
+    q.Ahi = (const unsigned short*)((const char*)w_packed + 2 * split_bytes(Cout, Cin, 1));
+    q.Alo = (const unsigned short*)((const char*)q.Ahi + split_bytes(Cin, Cout, 1));
+    q.a_inv = packed_inv(w_packed, Cout, Cin, 1, 1);
+    q.dx = dx; q.dx_bs = dx_bs;
+    q.xrow_w = (Cin > 128 && Cin % 128 == 1) ? w + (Cin - 1) : nullptr; q.xrow_sk = Cin;       // w[o][Cin - 1], o < Cout
+    q.M = Cout; q.Cin = Cin; q.L = L; q.act = act;
+    return ssv_launch_pwln_bwd(q, B, use_f16() ? 1 : 0, (hipStream_t)stream);
+  }
+  SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, part, nullptr, B, Cout, L, act, (hipStream_t)stream, dpre_amax));
+  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, dpre_amax, ssv_amax_rows_(L), w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, ws, ws_bytes, stream));
+  return 0;
+}
 struct PwWs { size_t dpre, part, amax, wt, slabs, total; };
 static PwWs pw_ws(int B, int Cin, int Cout, int L) {
   PwWs s;
@@ -615,8 +640,8 @@ extern "C" int ssv_pointwise_conv_ln_act_bwd(const float* dy, long dy_bs, const 
   const long pbs = (long)Cout * L;
   float* da = use_f16() ? (float*)(base + s.amax) : nullptr;
   const int dn = ssv_amax_rows_(L);
-  SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, (float*)(base + s.part), nullptr, B, Cout, L, act, (hipStream_t)stream, da));
-  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, da, dn, w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, base + s.wt, s.slabs - s.wt, stream));
+  SSV_TRY(pw_bwd_ln_and_data(dy, dy_bs, w, w_packed, gamma, beta, pre, stats, dx, dx_bs, dpre, da, (float*)(base + s.part), B, Cin, Cout, L, act,
+                             base + s.wt, s.slabs - s.wt, stream));
   if (ds) SSV_TRY(ssv_rowsum(dpre, pbs, ds, B, Cout, L, stream));               // gradient of the broadcast (B, Cout, 1) term
   return conv1d_bwd_weight_impl(dpre, pbs, x, x_bs, dw, B, Cin, Cout, L, 1, 1, 0, base + s.slabs, s.total - s.slabs, stream,
                                 (const float*)(base + s.part), pgrads, 3 * Cout, ssv_ln_act_bwd_rows(B, Cout, L, da != nullptr), da, dn, x_amax, x_namax);
@@ -715,8 +740,7 @@ extern "C" int ssv_pointwise_conv_ln_act_bwd_data(const float* dy, long dy_bs, c
   SSV_CHECK(dy && w && gamma && beta && pre && stats && dpre && part, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd_data: null argument");
   SSV_CHECK(B > 0 && B <= 65535 && Cin > 0 && Cout > 0 && L > 0 && act >= 0 && act <= 2, SSV_BAD_SHAPE, "pointwise_conv_ln_act_bwd_data: bad shape");
   const long pbs = (long)Cout * L;
-  SSV_TRY(ssv_launch_ln_act_bwd(dy, dy_bs, pre, pbs, stats, gamma, beta, dpre, pbs, part, nullptr, B, Cout, L, act, (hipStream_t)stream, dpre_amax));
-  if (dx) SSV_TRY(ssv_conv1d_bwd_data(dpre, pbs, dpre_amax, ssv_amax_rows_(L), w, w_packed, nullptr, dx, dx_bs, B, Cin, Cout, L, 1, 1, 0, ws, ws_bytes, stream));
+  SSV_TRY(pw_bwd_ln_and_data(dy, dy_bs, w, w_packed, gamma, beta, pre, stats, dx, dx_bs, dpre, dpre_amax, part, B, Cin, Cout, L, act, ws, ws_bytes, stream));
   if (ds) SSV_TRY(ssv_rowsum(dpre, pbs, ds, B, Cout, L, stream));
   return 0;
 }

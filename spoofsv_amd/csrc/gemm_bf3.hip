@@ -2526,3 +2526,312 @@ int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta
 #undef SSV_PW
   return ssv_fail(SSV_UNSUPPORTED, "gemm_pwln: no instantiation for %d rows", g.M);
 }
+
+// ---- backward of a 1x1 conv + LayerNorm link in ONE launch (round 5): LayerNorm / activation backward, then dX = W^T dPre ------------------
+// models/TTSModel.py:128-131, :173-180, :218-231, :343-361 backward.  Until now two launches per link: ln_act_bwd* (dY, pre -> dPre, parameter
+// partials, scale list) and the k = 1 data-gradient GEMM re-reading dPre.  As in the forward (gemm_pwln_kernel) a workgroup owns ALL LN rows of a
+// 64-column tile, so the LayerNorm backward's two column sums are local.  Phase 1 (512 threads = 32 row groups x 16 column quads; a thread holds
+// 8 consecutive rows x 4 columns per unit): dPre from registers -> global (16-byte row pieces) AND, split with the TILE's own power-of-two scale,
+// into an LDS image of the GEMM's input operand for every K chunk at once ([chunk][k-group][column][8 halves]: 8 rows of a column = one
+// 16-byte slot).  Phase 2: the K loop runs with no staging and no barrier -- transposed weight fragments L2 -> registers (one set, re-loaded row
+// block by row block as in gemm_pwln_kernel), input fragments from the image.  Phase 3: the dX tile parked in the image's memory, row-contiguous
+// stores.  M = 128 j + 1 LN rows (513): the last row beside the row groups (threads 0 .. 15); Cin = 128 j + 1 output rows: the last one as fp32
+// dot products of its weights with the dPre values the threads hold.
+// Partial parameter-gradient rows [dgamma | dbeta | dbias] and the scale list keep the layout of the unfused kernels (ssv_ln_act_bwd_rows /
+// ssv_amax_rows): this tile's row at part_q * tile, the rows up to the next tile's zeroed; scale entry 4 * tile, the next three zeroed.
+#ifndef SSV_PWLN_BWD_FUSED
+#define SSV_PWLN_BWD_FUSED 1
+#endif
+template <int WMB, int NU, int F16>
+__global__ __launch_bounds__(512, 2) void pwln_bwd_kernel(const PwLnBw q) {
+  constexpr int BN = 64, NT = 4;
+  constexpr int NCH = NU == 1 ? 8 : 17;                 // K chunks (32 LN rows each) the image holds
+  constexpr int LDWP = BN + 4;
+  constexpr int IMG_U4 = NCH * 512, PARK_U4 = 8 * 16 * LDWP / 4;
+  __shared__ uint4 img[IMG_U4 > PARK_U4 ? IMG_U4 : PARK_U4];     // per chunk: hi [k-group][column] (256 slots), then lo (256 slots)
+  __shared__ float red[33 * 2 * BN];                    // column-sum partials of the 32 row groups (+ the extra LN row)
+  __shared__ float tot[2 * BN];
+  __shared__ float amx[8];
+  __shared__ float xw[NU == 2 ? 544 : 1];               // weights of the extra OUTPUT row, one per LN row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int ntile = (int)(wg % gridDim.x), b = (int)(wg / gridDim.x);
+  const int n0 = ntile * BN;
+  const int M = q.M, L = q.L, act = q.act;
+  const int nch = (M + 31) >> 5;
+  const bool xlr = (M & 7) == 1;                        // LN row M - 1 beside the row groups (M = 513)
+  const int Mg = xlr ? M - 1 : M;                       // rows in the row groups
+  const bool xo = NU == 2 && q.xrow_w != nullptr;       // output row Cin - 1 beside the MFMA row blocks
+  const int Mt = xo ? q.Cin - 1 : q.Cin;
+
+  // ---------------------------------------------------------------- phase 1: LayerNorm / activation backward
+  const int cq = tid & 15, rgt = tid >> 4;
+  const int t = n0 + 4 * cq;
+  bool cv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cv[j] = t + j < L;
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.dy + (long)b * q.dy_bs), 0, M * L * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rpr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.pre + (long)b * M * L), 0, M * L * 4, 0x00020000);
+  auto ld4 = [&](__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[4]) __attribute__((always_inline)) {
+    const f32x4 u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    v[0] = u[0]; v[1] = u[1]; v[2] = u[2]; v[3] = u[3];
+  };
+  float a[NU][8][4], xh[NU][8][4];                      // raw: dy, pre -> a = dn * gamma, xh; then a = dPre
+  float ea[4] = {0.f, 0.f, 0.f, 0.f}, exh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = min((rgt + 32 * u) * 8 + r, Mg - 1);
+      const unsigned o = ((unsigned)row * (unsigned)L + (unsigned)t) * 4u;
+      ld4(rdy, o, a[u][r]); ld4(rpr, o, xh[u][r]);
+    }
+  const bool exrow = xlr && tid < 16;
+  if (exrow) { const unsigned o = ((unsigned)(M - 1) * (unsigned)L + (unsigned)t) * 4u; ld4(rdy, o, ea); ld4(rpr, o, exh); }
+  if constexpr (NU == 2) {
+    if (xo) for (int k = tid; k < nch * 32; k += 512) xw[k] = k < M ? q.xrow_w[(long)k * q.xrow_sk] : 0.f;     // (visible after the first barrier)
+  }
+  float mu[4], rs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float* sb = q.stats + (long)b * 2 * L + min(t + j, L - 1); mu[j] = sb[0]; rs[j] = sb[L]; }
+  float* pblk = q.part + ((long)b * q.part_rows + (long)q.part_q * ntile) * 3 * M;
+  float sa[4] = {0.f, 0.f, 0.f, 0.f}, sah[4] = {0.f, 0.f, 0.f, 0.f};
+  // one row of 4 columns: dn and the row's (dgamma, dbeta) partials; a <- dn * gamma, xh <- normalised input
+  auto row_a = [&](float (&av)[4], float (&hv)[4], int row, bool rok) __attribute__((always_inline)) {
+    const int rc = min(row, M - 1);
+    const float gg0 = q.gamma[rc], bb = q.beta[rc];
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool v = rok && cv[j];
+      const float dy = v ? av[j] : 0.f, gg = v ? gg0 : 0.f;
+      const float h = v ? (hv[j] - mu[j]) * rs[j] : 0.f;
+      const float n = h * gg + bb;
+      float dn;
+      if (act == 1) dn = n > 0.f ? dy : 0.f;
+      else if (act == 2) { const float s = 1.f / (1.f + __expf(-n)); dn = dy * s * (1.f - s); }
+      else dn = dy;
+      q0 += dn * h; q1 += dn;
+      hv[j] = h; av[j] = dn * gg;
+      sa[j] += av[j]; sah[j] += av[j] * h;
+    }
+    q0 = ssv_row16_sum(q0); q1 = ssv_row16_sum(q1);
+    if (cq == 0 && rok) { pblk[rc] = q0; pblk[M + rc] = q1; }
+  };
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const int row = (rgt + 32 * u) * 8 + r; row_a(a[u][r], xh[u][r], row, row < Mg); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[(rgt * 2 + 0) * BN + 4 * cq + j] = sa[j]; red[(rgt * 2 + 1) * BN + 4 * cq + j] = sah[j]; }
+  if (xlr) {                                            // the extra LN row: threads 0 .. 15 (whose row groups are already summed above)
+    if (tid < 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sa[j] = sah[j] = 0.f;
+      row_a(ea, exh, M - 1, true);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { red[(32 * 2 + 0) * BN + 4 * cq + j] = sa[j]; red[(32 * 2 + 1) * BN + 4 * cq + j] = sah[j]; }
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * BN) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) sum += red[k * 2 * BN + tid];
+    if (xlr) sum += red[32 * 2 * BN + tid];
+    tot[tid] = sum;
+  }
+  __syncthreads();
+  const float invM = 1.f / (float)M;
+  float m[4], mh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { m[j] = tot[4 * cq + j] * invM; mh[j] = tot[BN + 4 * cq + j] * invM; }
+  float am = 0.f;
+  float xacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float* __restrict__ dPb = q.dpre + (long)b * M * L;
+  // a <- dPre = rstd (a - mean(a) - xh mean(a xh)); stored; the row's dbias partial; the extra output row's dot product
+  auto row_d = [&](float (&av)[4], float (&hv)[4], int row, bool rok) __attribute__((always_inline)) {
+    float q0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = (rok && cv[j]) ? rs[j] * (av[j] - m[j] - hv[j] * mh[j]) : 0.f;
+      av[j] = d;
+      am = fmaxf(am, fabsf(d));
+      q0 += d;
+    }
+    if (rok) {
+      float* o = dPb + (long)row * L + t;
+      if (cv[3]) { f4u w = {av[0], av[1], av[2], av[3]}; *reinterpret_cast<f4u*>(o) = w; }
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (cv[j]) o[j] = av[j];
+      }
+    }
+    if constexpr (NU == 2) {
+      if (xo) { const float wv = xw[min(row, NCH * 32 - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xacc[j] = __builtin_fmaf(wv, av[j], xacc[j]); }
+    }
+    q0 = ssv_row16_sum(q0);
+    if (cq == 0 && rok) pblk[2 * M + min(row, M - 1)] = q0;
+  };
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const int row = (rgt + 32 * u) * 8 + r; row_d(a[u][r], xh[u][r], row, row < Mg); }
+  if (exrow) row_d(ea, exh, M - 1, true);
+  // the tile's operand scale; its entry of the item's scale list; the partial rows between this tile's and the next one's
+  am = ssv_wg_max<8>(am, amx);
+  float xs = 1.f, xinv = 1.f;
+  if constexpr (F16) { float sc, inv; ssv_pow2_scale(am, sc, inv); xs = ssv_uniform(sc); xinv = ssv_uniform(inv); }
+  if (q.amax && tid < 4) { const int e = 4 * ntile + tid; if (e < q.namax) q.amax[(long)b * q.namax + e] = tid == 0 ? am : 0.f; }
+  {
+    const int r0 = q.part_q * ntile + 1, r1 = min(q.part_q * (ntile + 1), q.part_rows);
+    float* z = q.part + ((long)b * q.part_rows + r0) * 3 * M;
+    for (int e = tid; e < (r1 - r0) * 3 * M; e += 512) z[e] = 0.f;
+  }
+  // the image: 8 rows of one column -> one 16-byte slot of the hi plane and one of the lo plane
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int rb = (rgt + 32 * u) * 8, ch = rb >> 5, kg = (rb >> 3) & 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = a[u][r][j];
+      uint4 h, l;
+      split8s<F16>(v, xs, h, l);
+      const int sl = ch * 512 + kg * 64 + 4 * cq + j;
+      img[sl] = h; img[sl + 256] = l;
+    }
+  }
+  if (xlr) {                                            // chunk nch - 1 holds the extra row alone: k-group 0, element 0; the rest zero
+    const int base = (nch - 1) * 512;
+    if (tid < 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[8] = {ea[j], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        uint4 h, l;
+        split8s<F16>(v, xs, h, l);
+        img[base + 4 * cq + j] = h; img[base + 256 + 4 * cq + j] = l;
+      }
+    } else if (tid >= 64 && tid < 64 + 192) {           // k-groups 1 .. 3 of that chunk
+      const int sl = base + 64 + (tid - 64);
+      img[sl] = make_uint4(0, 0, 0, 0); img[sl + 256] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  if constexpr (NU == 2) {
+    if (xo) {                                           // the extra output row: sum of the row groups' partial dot products
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[rgt * BN + 4 * cq + j] = xacc[j];          // (the extra LN row's term is in threads 0 .. 15's xacc: row_d added it)
+    }
+  }
+  __syncthreads();
+  if constexpr (NU == 2) {
+    if (xo && tid < BN && n0 + tid < L) {
+      float sum = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) sum += red[k * BN + tid];
+      q.dx[(long)b * q.dx_bs + (long)(q.Cin - 1) * L + n0 + tid] = sum;
+    }
+  }
+
+  // ---------------------------------------------------------------- phase 2: dX tile = W^T dPre, K = the LN rows, straight from the image
+  const int kq = lane >> 4, nq = lane & 15;
+  f32x4 acc[WMB][NT];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[i][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 Ah_[WMB], Al_[WMB];
+  const int MB = (q.Cin + 15) >> 4;
+  unsigned arowb[WMB];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) arowb[i] = (unsigned)(((long)min(wave * WMB + i, MB - 1) * nch * 512 + lane * 8) * 2);
+  const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(q.Ahi), rsAl = ssv_buf(q.Alo);
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) { Ah_[i] = ssv_buf_u4(rsAh, arowb[i], 0u); Al_[i] = ssv_buf_u4(rsAl, arowb[i], 0u); }
+  for (int ch = 0; ch < nch; ++ch) {
+    const uint4* Xh = img + ch * 512;
+    const uint4* Xl = Xh + 256;
+    uint4 bh[NT], bl[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) { const int s_ = kq * BN + tt * 16 + nq; bh[tt] = Xh[s_]; bl[tt] = Xl[s_]; }
+    const unsigned ubn = (unsigned)__builtin_amdgcn_readfirstlane(min(ch + 1, nch - 1) * 1024);
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        acc[i][tt] = mma16<F16>(Al_[i], bh[tt], acc[i][tt]);
+        acc[i][tt] = mma16<F16>(Ah_[i], bl[tt], acc[i][tt]);
+        acc[i][tt] = mma16<F16>(Ah_[i], bh[tt], acc[i][tt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      Ah_[i] = ssv_buf_u4(rsAh, arowb[i], ubn);
+      Al_[i] = ssv_buf_u4(rsAl, arowb[i], ubn);
+    }
+  }
+  // ---------------------------------------------------------------- phase 3: dX rows, parked per wave, row-contiguous stores
+  __syncthreads();                                      // every wave is done with the image
+  const float us = F16 ? ssv_uniform(xinv * *q.a_inv) : 1.f;
+  float* pk = reinterpret_cast<float*>(img) + wave * 16 * LDWP;
+  float* __restrict__ Xo = q.dx + (long)b * q.dx_bs;
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) pk[(kq * 4 + r) * LDWP + tt * 16 + nq] = F16 ? acc[i][tt][r] * us : acc[i][tt][r];
+    const int rbase = (wave * WMB + i) * 16;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const int e = lane + 64 * it;
+      const int row = e / (BN / 4), c4 = e % (BN / 4);
+      const int gm = rbase + row, gn = n0 + c4 * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pk + row * LDWP + c4 * 4);
+      if (gm < Mt && gn < L) {
+        float* o = Xo + (long)gm * L + gn;
+        if (gn + 3 < L) { f4u w = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f4u*>(o) = w; }
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (gn + j < L) o[j] = v[j];
+        }
+      }
+    }
+  }
+}
+// true when the link's backward can take the one-launch kernel (split-fp16 / split-bf16 planes of the TRANSPOSED weight given; dense dPre)
+bool ssv_pwln_bwd_fused_ok(int B, int Cin, int Cout, int L) {
+  if (!SSV_PWLN_BWD_FUSED) return false;
+  // Measured in-step at B = 32 (round 5): links with up to 256 LN rows 24.3 us against 17.9 + 22.6 us in two launches; with 512 / 513 LN rows
+  // (one 155 KB workgroup per CU: its three phases cannot overlap with anything) 139 against 74 + 95 us for 513 -> 513 but 139 against 74 + 67 for
+  // 512 -> 513 and 123 against ~110 for 256 -> 512: no gain over the step.  Default: the small form only.  SSV_PWLN_BWD=0: never; =2: every shape.
+  int mode = 1;
+  if (const char* e = ssv_tuning(SSV_T_PWLN_BWD)) mode = atoi(e);
+  if (mode == 0 || (mode != 2 && Cout > 256)) return false;
+  const bool m_ok = (Cout % 8 == 0 && Cout >= 32 && Cout <= 512) || Cout == 513;
+  const bool c_ok = (Cin >= 32 && Cin <= 512) || (Cin == 513 && Cout > 256);
+  return m_ok && c_ok && B <= 65535 && L >= 16 && (long)Cout * L < (1L << 29) && (long)Cin * L < (1L << 29);
+}
+int ssv_launch_pwln_bwd(const PwLnBw& q, int B, int f16, hipStream_t st) {
+  SSV_CHECK(ssv_pwln_bwd_fused_ok(B, q.Cin, q.M, q.L), SSV_UNSUPPORTED, "pwln_bwd: shape %d -> %d not supported", q.Cin, q.M);
+  SSV_CHECK(q.dy && q.pre && q.stats && q.gamma && q.beta && q.dpre && q.part && q.Ahi && q.Alo && q.dx && (!f16 || q.a_inv), SSV_BAD_SHAPE, "pwln_bwd: null argument");
+  SSV_CHECK(q.Cin % 128 != 1 || q.Cin < 128 || q.xrow_w, SSV_BAD_SHAPE, "pwln_bwd: %d output rows need the extra row's weights", q.Cin);
+  const dim3 grid(ssv_cdiv(q.L, 64), B);
+  SSV_CHECK(q.part_q >= 1 && q.part_rows >= q.part_q * ((int)grid.x - 1) + 1 && (!q.amax || q.namax >= 4 * (int)grid.x - 3), SSV_BAD_SHAPE, "pwln_bwd: partial rows / scale list too short");
+  const int nu = q.M <= 256 ? 1 : 2;
+  const int wmb = q.Cin <= 128 ? 1 : (q.Cin <= 256 ? 2 : 4);
+  if (ssv_shape_log_on()) {
+    char nm[96], note[96];
+    snprintf(nm, sizeof nm, "pwln_bwd_kernel<%d, %d, %d>", wmb, nu, f16);
+    snprintf(note, sizeof note, "B=%d Cin=%d N=%d Cout=%d LN bwd + k=1 data gradient", B, q.Cin, q.L, q.M);
+    ssv_shape_log(nm, grid, dim3(512), 2.0 * B * q.Cin * q.L * q.M, 4.0 * ((double)B * q.M * q.L * 3 + (double)B * q.Cin * q.L + (double)q.M * q.Cin), note);
+  }
+#define SSV_PB(W_, U_) if (wmb == W_ && nu == U_) { \
+    if (f16) hipLaunchKernelGGL((pwln_bwd_kernel<W_, U_, 1>), grid, dim3(512), 0, st, q); \
+    else hipLaunchKernelGGL((pwln_bwd_kernel<W_, U_, 0>), grid, dim3(512), 0, st, q); \
+    return ssv_check_launch("pwln_bwd"); }
+  SSV_PB(1, 1) SSV_PB(2, 1) SSV_PB(4, 1) SSV_PB(1, 2) SSV_PB(2, 2) SSV_PB(4, 2)
+#undef SSV_PB
+  return ssv_fail(SSV_UNSUPPORTED, "pwln_bwd: no instantiation");
+}

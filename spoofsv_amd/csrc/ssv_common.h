@@ -105,6 +105,19 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta, float* y, long ybs, float* stats, float* y_amax, int namax, int act,
                          hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
+// backward of a 1x1 conv + LayerNorm link in one launch (gemm_bf3.hip, pwln_bwd_kernel): dy, pre (B, M, L) with M = Cout LN rows (pre dense),
+// stats (B, 2, L); dpre (B, M, L) dense, this tile's partial row [dgamma | dbeta | dbias] at part_q * tile of the item's part_rows rows, scale
+// list entry 4 * tile; Ahi / Alo: the TRANSPOSED weight's planes (rows = Cin, K = M); dx (B, Cin, L); xrow_w[o * xrow_sk]: the weights of
+// output row Cin - 1 when Cin = 128 j + 1
+struct PwLnBw {
+  const float* dy; long dy_bs; const float* pre; const float* stats; const float* gamma; const float* beta;
+  float* dpre; float* part; int part_rows; int part_q; float* amax; int namax;
+  const unsigned short* Ahi; const unsigned short* Alo; const float* a_inv;
+  float* dx; long dx_bs; const float* xrow_w; long xrow_sk;
+  int M, Cin, L, act;
+};
+bool ssv_pwln_bwd_fused_ok(int B, int Cin, int Cout, int L);
+int ssv_launch_pwln_bwd(const PwLnBw& q, int B, int f16, hipStream_t st);
 bool ssv_nt_bf3_xrow(int KT, int M, int Nc);    // this shape runs the extra-row kernel: its callers cut RANGE slabs (GemmNT::bstep = 0)
 bool ssv_nt_bf3_fits(const GemmNT& g);          // operands addressable with the kernel's 32-bit element offsets
 // nch_total / ch_off: this source fills K chunks [ch_off, ch_off + Kpad/32) of planes that have nch_total chunks per row block
@@ -127,7 +140,7 @@ int ssv_precision();      // 0 = exact fp32 MFMA, 1 = split-bf16 MFMA, 2 = split
 // The three tuning knobs that remain (per-shape overrides for in-step sweeps: SSV_NNB_FORCE="kt:M:N=wm,nt;...", SSV_NT_FORCE="M:Nc:k=Z;...",
 // SSV_LN_GROUPS for tools/bench_ln.py): read from the environment ONCE at first use -- a launch must not cost getenv() scans -- and
 // again only when a tuning script calls ssv_reload_tuning() (exported, not part of include/ssv_hip.h).
-enum { SSV_T_NT_FORCE, SSV_T_NNB_FORCE, SSV_T_LN_GROUPS, SSV_T_LN_PERSIST, SSV_T_LSTM_MERGE, SSV_T_COUNT };
+enum { SSV_T_NT_FORCE, SSV_T_NNB_FORCE, SSV_T_LN_GROUPS, SSV_T_LN_PERSIST, SSV_T_LSTM_MERGE, SSV_T_PWLN_BWD, SSV_T_COUNT };
 const char* ssv_tuning(int knob);          // value of the knob or nullptr
 int ssv_pack_job_blocks(const ssv_pack_job& j);           // workgroups one job of ssv_conv_pack_multi takes
 int ssv_launch_pack_multi(const ssv_pack_job* jobs_dev, int njobs, int nblocks, float* amax_ws, hipStream_t st);   // amax_ws != null: split-fp16 planes

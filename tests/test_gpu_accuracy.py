@@ -394,3 +394,57 @@ def test_fused_attention_forward_and_backward_vs_float64(B, d, N, T):
     assert float((a.double().cpu() - a_ref).abs().max() / a_ref.abs().max()) < 2e-5
     assert _rl2(rq, rq_ref.detach()) < 2e-6
     assert _rl2(kvg.grad, kvr.grad) < 5e-6 and _rl2(qg.grad, qr.grad) < 5e-6, (_rl2(kvg.grad, kvr.grad), _rl2(qg.grad, qr.grad))
+
+
+def _link_backward(B, Cin, Cout, L, act, mode, seed=5):
+    """Gradients of sum(gy * act(LN(conv1x1(x)))) on the HIP path with the link-backward form ``mode`` (SSV_PWLN_BWD: 0 two launches, 1 the
+    one-launch kernel for up to 256 LayerNorm rows, 2 for every shape), weights resident, deferred weight gradient -- the trainers' path."""
+    import os
+    from spoofsv_amd import _lib, ops, resident
+    os.environ["SSV_PWLN_BWD"] = str(mode)
+    _lib.lib().ssv_reload_tuning()
+    try:
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, Cin, L, generator=gen).to(DEV).requires_grad_(True)
+        w = (torch.randn(Cout, Cin, 1, generator=gen) / Cin ** 0.5).to(DEV).requires_grad_(True)
+        bias = torch.randn(Cout, generator=gen).to(DEV).requires_grad_(True)
+        gamma = (1 + 0.1 * torch.randn(Cout, generator=gen)).to(DEV).requires_grad_(True)
+        beta = (0.1 * torch.randn(Cout, generator=gen)).to(DEV).requires_grad_(True)
+        gy = torch.randn(B, Cout, L, generator=gen).to(DEV)
+        rw = resident.ResidentWeights([w])
+        rw.refresh(torch.cuda.current_stream().cuda_stream)
+        dfr = ops.DeferredWgrad()
+        dfr.begin_step()
+        y = ops.pointwise_conv_ln_act(x, w, bias, gamma, beta, None, act)
+        with dfr:
+            y.backward(gy)
+        dfr.flush()
+        torch.cuda.synchronize()
+        return (x, w, bias, gamma, beta, gy), [t.grad.double().cpu() for t in (x, w, bias, gamma, beta)]
+    finally:
+        os.environ.pop("SSV_PWLN_BWD", None)
+        _lib.lib().ssv_reload_tuning()
+        resident.invalidate()
+
+
+@pytest.mark.parametrize("B,Cin,Cout,L,act", [(2, 256, 256, 325, 1), (3, 128, 256, 70, 2), (2, 512, 256, 186, 0), (2, 96, 136, 333, 1),
+                                               (2, 256, 512, 650, 1), (2, 512, 513, 1300, 1), (2, 513, 513, 1299, 2)])
+def test_link_backward_in_one_launch_vs_float64_and_the_two_launch_form(B, Cin, Cout, L, act):
+    """models/TTSModel.py:128-131, :173-180, :218-231, :343-361 backward: LayerNorm / activation backward and the 1x1 data gradient in ONE launch
+    (pwln_bwd_kernel; round 5) -- every instantiation (row blocks per wave 1 / 2 / 4, one or two row-group units per thread, the 513th LayerNorm
+    row and the 513th output row beside the tiles, ragged last column group, a channel count that is not a multiple of 32) against a float64
+    autograd evaluation of the same expression, at the bar the two-launch form meets."""
+    ins, g2 = _link_backward(B, Cin, Cout, L, act, 2)
+    _, g0 = _link_backward(B, Cin, Cout, L, act, 0)
+    x, w, bias, gamma, beta, gy = [t.detach().double().cpu() for t in ins]
+    for t in (x, w, bias, gamma, beta):
+        t.requires_grad_(True)
+    pre = F.conv1d(x, w, bias)
+    n = F.layer_norm(pre.transpose(1, 2), (Cout,), gamma, beta, 1e-5).transpose(1, 2)
+    y = F.relu(n) if act == 1 else (torch.sigmoid(n) if act == 2 else n)
+    y.backward(gy)
+    for name, t, a2, a0 in zip(("dx", "dw", "dbias", "dgamma", "dbeta"), (x, w, bias, gamma, beta), g2, g0):
+        ref = t.grad
+        e2, e0 = float((a2 - ref).norm() / ref.norm()), float((a0 - ref).norm() / ref.norm())
+        assert e2 < 3e-6 and e0 < 3e-6, (name, e2, e0)
+        assert e2 < 2.0 * e0 + 2e-7, (name, e2, e0)
