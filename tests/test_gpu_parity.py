@@ -352,6 +352,30 @@ def test_ge2e_embedder_full_width_production_tiles_vs_oracle(precision):
     assert rel_err(eg, eo) < tol and rel_l2(eg, eo) < tol, (rel_err(eg, eo), rel_l2(eg, eo))
 
 
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_ge2e_embedder_wavefront_launch_forms_agree_with_the_oracle(mode):
+    """The LSTM wavefront's launch forms (SSV_LSTM_MERGE: 0 = two launches per step, layer 0 apart; 2 = one launch on 128 x 64 tiles; default =
+    one launch on 128 x 128 tiles when three layers make one round, which the full-width test above takes) at the real width, incl. the
+    first and last steps of the wavefront (fewer layers active) and an utterance count that is not a multiple of the tile."""
+    import os
+    from spoofsv_amd import _lib
+    from spoofsv_amd.ge2e import SpeechEmbedder
+    torch.manual_seed(1)
+    m = SpeechEmbedder()
+    x = torch.randn(700, 5, 40)
+    with torch.no_grad():
+        eo = GO.speech_embedder(x, m.state_dict())
+    os.environ["SSV_LSTM_MERGE"] = mode
+    _lib.lib().ssv_reload_tuning()
+    try:
+        eg = m.to(DEV).eval()(x.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("SSV_LSTM_MERGE", None)
+        _lib.lib().ssv_reload_tuning()
+    assert rel_err(eg, eo) < 2e-5 and rel_l2(eg, eo) < 2e-5, (mode, rel_err(eg, eo), rel_l2(eg, eo))
+
+
 def test_ge2e_loss_golden_and_known_answer():
     from spoofsv_amd.ge2e import GE2ELoss
     g = load("ge2e_loss.npz")
