@@ -355,16 +355,20 @@ extern "C" int ssv_debug_nn_stamps(unsigned long long* out) { return (int)hipMem
 #endif
 #define SSV_NN_XBUF(KT, WM, NT) (!((KT) == 3 && (NT) == 6))   // input rows by buffer loads (ssv_buf) or through pointers: in-step, per tile -- the k = 1
                                                              // tiles are 5-12 % faster with buffer loads, the 96-column k = 3 tiles 4-6 % with pointers, the rest equal
-// waves per SIMD the register allocation must leave room for
+
 #ifndef SSV_NN_HALO_SMALL
 #define SSV_NN_HALO_SMALL 16  // k = 3 layers whose taps span at most this many columns run the narrow-halo instantiation (tuning builds: -1 = never)
 #endif
-#define SSV_NNB_WAVES(KT, WM, NT, EPI) ((KT) == 1 && (WM) == 2 && (NT) == 4 && (EPI) == 0 ? 3 : 2)
+// waves per SIMD the register allocation must leave room for (the second __launch_bounds__ argument).  Round 5: the 128 x 112 k = 3 tile with the
+// 16-column halo at THREE (168 VGPRs, 6 spilled, three workgroups per CU instead of two): 177.6 -> 170.4 us in-step over its ten launches.
+// (The same for the 128 x 96 tile: 32 spilled, 63.2 -> 70.3 us; the 64 x 96 tile at four, 128 VGPRs: 47.6 -> 49.5 us.  Not kept.)
+#define SSV_NNB_WAVES(KT, WM, NT, EPI, HW) \
+  (((KT) == 1 && (WM) == 2 && (NT) == 4 && (EPI) == 0) || ((KT) == 3 && (WM) == 2 && (NT) == 7 && (EPI) == 0 && (HW) == 16) ? 3 : 2)
 // HW: the halo (columns beyond the tile that the taps reach) the instantiation stages for -- 54 (dilation 27, any form) or 16: most layers of the
 // models have dilation 1 or 3, and with the 54-column halo a third of the loads, splits and LDS stores of their chunks went into columns no tap reads
 // (112 + 54 -> 176 staged columns = 3 slots per thread; 112 + 16 -> 128 = 2).
 template <int KT, int WM, int NT, int EPI, int F16, int HW = 54>
-__global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI)) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
+__global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_nn_bf3_kernel(const GemmNNB p, const int mtiles, const int smin, const int span) {
   constexpr int BM = 64 * WM, BN = 16 * NT;
   constexpr int HALO = (KT == 1) ? 0 : HW;
   constexpr int WX = ((BN + HALO + 15) / 16) * 16;         // staged columns, plane = WX*16 B = multiple of 256 B
