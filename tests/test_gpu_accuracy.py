@@ -428,6 +428,7 @@ def _link_backward(B, Cin, Cout, L, act, mode, seed=5):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,L,act", [(2, 256, 256, 325, 1), (3, 128, 256, 70, 2), (2, 512, 256, 186, 0), (2, 96, 136, 333, 1),
+                                               (1, 32, 32, 129, 1), (8, 40, 256, 17, 2), (2, 256, 80, 64, 0), (5, 200, 248, 191, 1),
                                                (2, 256, 512, 650, 1), (2, 512, 513, 1300, 1), (2, 513, 513, 1299, 2)])
 def test_link_backward_in_one_launch_vs_float64_and_the_two_launch_form(B, Cin, Cout, L, act):
     """models/TTSModel.py:128-131, :173-180, :218-231, :343-361 backward: LayerNorm / activation backward and the 1x1 data gradient in ONE launch
