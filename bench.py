@@ -33,6 +33,8 @@ sys.path.insert(0, ROOT)
 B_PER_GPU, N_TEXT, T_MEL = 32, 186, 325
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparse figure)
+SUSTAINED_F16_MFMA_TFLOPS = 2100.0    # what a kernel of nothing but v_mfma_f32_16x16x32_f16 holds on this chip (tools/probe/mfma_rate.hip: 2,070-2,156 at 1-8 waves per SIMD)
+CPU_WARMUP, CPU_TIMED = 3, 10         # the CPU arm's protocol
 
 
 def parse():
@@ -415,6 +417,9 @@ def kernel_roofline(dev):
                    "algorithmic_tflops_if_three_products": round(flops / (3 * lus) / 1e6, 1)}
     return {"bound": "mfma", "kernel": name + ", dilated Conv1d fwd B=32 C=256->512 L=325",
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            # beside the nominal-peak fraction: against what the matrix pipes sustain under a pure-MFMA load (the split modes only)
+            **({"frac_of_sustained": round(ach / (SUSTAINED_F16_MFMA_TFLOPS / 3.0), 4), "sustained_peak": round(SUSTAINED_F16_MFMA_TFLOPS / 3.0, 1),
+                "sustained_note": "tools/probe/mfma_rate.hip: 2,070-2,156 TFLOP/s of fp16 MFMAs sustained (0.84 of nominal); / 3 products"} if split else {}),
             "peak_note": ("fp16 dense 2500 TFLOP/s / 3 (three fp16 MFMAs per fp32 product)" if mode == 2 else "bf16 dense 2500 TFLOP/s / 3") if split else "fp32-input MFMA dense",
             "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
             "hbm_alg_bytes_per_launch": bytes_alg, "hbm_frac_of_8TBs": round(bytes_alg / (ms * 1e-3) / 8e12, 4),
@@ -443,8 +448,8 @@ def pmc_traffic(mode):
 
 def cpu_baseline():
     """The CPU oracle (oracle/tts_oracle.py: the stock torch-CPU op sequence the reference itself runs),
-    Text2Mel and SSRN train steps on a bounded sample (1 warm-up + 4 timed steps each at the workload's batch, ~10-20 s),
-    all host threads torch gives us."""
+    Text2Mel and SSRN train steps at the workload's batch under BASELINE.md section 3's protocol (3 warm-up + 10 timed iterations of each
+    model, ~50 s on 16 cores), all host threads torch gives us; then the 8-thread arm on 2 timed iterations."""
     from oracle import tts_oracle as TO
     from spoofsv_amd import train
     from spoofsv_amd.tts import SSRN, melSyn
@@ -486,9 +491,10 @@ def cpu_baseline():
             sum(ls).backward()
             opt.step()
             log.append([float(v.detach()) for v in ls])
-        one()
+        for _ in range(CPU_WARMUP):
+            one()
         t0 = time.time()
-        reps = 4
+        reps = CPU_TIMED
         for _ in range(reps):
             one()
         times[kind] = (time.time() - t0) / reps / (b * T_MEL)     # seconds per mel frame
@@ -504,7 +510,8 @@ def cpu_baseline():
             torch.set_num_threads(cores)
     fps = 1.0 / (times["text2mel"] + times["ssrn"])
     out.update({"value": round(fps, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": "1 warm-up + 4 timed train steps each of Text2Mel and SSRN at the workload's own batch (B=%d), N=186, T=325, fp32, torch CPU ops" % B_PER_GPU,
+                "sample": "%d warm-up + %d timed train steps each of Text2Mel and SSRN (BASELINE.md section 3) at the workload's own batch (B=%d), N=186, T=325, fp32, torch CPU ops; "
+                          "value_8_threads: 2 timed steps" % (CPU_WARMUP, CPU_TIMED, B_PER_GPU),
                 "text2mel_fps": round(1.0 / times["text2mel"], 1), "ssrn_fps": round(1.0 / times["ssrn"], 1),
                 "first_losses": {k: v[:2] for k, v in first.items()}})       # popped by main() after the parity check
     if len(times8) == 2:

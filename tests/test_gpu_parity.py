@@ -594,6 +594,10 @@ def _bench_workload_oracle(kind, B):
         m = melSyn(34, True, 200, 128, 80, 256)
         batch = train.synthetic_text2mel_batch(B, 186, 325, seed=0)
         gaw = train.guided_attention_mat(186, 325)
+    elif kind == "universal":                               # the reference's `universal` pattern: melSyn(condition=False), no speaker code
+        m = melSyn(34, False, None, 128, 80, 256)
+        batch = train.synthetic_text2mel_batch(B, 186, 325, seed=0)[:2] + (None,)
+        gaw = train.guided_attention_mat(186, 325)
     else:
         m = SSRN(80, 513, 256)
         batch = train.synthetic_ssrn_batch(B, 325, seed=0)
@@ -620,12 +624,12 @@ def _oracle_pass(rec, dt, force=None):
     from spoofsv_amd import train
     m, batch, gaw, kind = rec["model"], rec["batch"], rec["gaw"], rec["kind"]
     sd = {k: v.detach().clone().cpu().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
-    cast = lambda t: t.to(dt) if t.is_floating_point() else t
+    cast = lambda t: t.to(dt) if (t is not None and t.is_floating_point()) else t
     ctx = TO.kink_sides(force=force) if force is not None else None
     if ctx is not None:
         ctx.__enter__()
     try:
-        if kind == "text2mel":
+        if kind in ("text2mel", "universal"):
             mel, text, spk = [cast(b) for b in batch]
             Y, A = TO.melsyn_train(train.shift_right(mel), text, spk, sd)
             losses = TO.text2mel_losses(Y, A, mel, gaw.to(dt))
@@ -704,6 +708,35 @@ def test_bench_workload_full_size_training_step_vs_oracle(kind, precision):
     sum(l).backward()
     torch.cuda.synchronize()
     _check_grads_on_hip_sides(o, m, sides, precision, "full-size %s" % kind, l1_sign)
+    m.cpu()
+    for p in m.parameters():
+        p.grad = None
+
+
+def test_unconditional_generator_full_size_training_step_vs_oracle(precision):
+    """melSyn(condition=False) -- the reference's `universal` pattern, models/TTSModel.py:185-195: audioEncoder without fc1 / fc2 and without
+    the speaker broadcast add -- at full width, depth and length (B = 4, N = 186, T = 325): forward, the reference's losses and backward on
+    the HIP path against the CPU ORACLE (not against another HIP path), same bars as the conditional step above."""
+    from spoofsv_amd import ops, train
+    o = _bench_workload_oracle("universal", 4)
+    m = o["model"].to(DEV).train()
+    assert not any(k.startswith("audio_encoder.fc") for k in m.state_dict())        # the unconditional encoder has no speaker projections
+    for p in m.parameters():
+        p.grad = None
+    out_tol = 2e-4 if precision == "bf16x3" else 2e-5
+    ops.RELU_TAP = []
+    mel, text = [b.to(DEV) for b in o["batch"][:2]]
+    Y, A = m(train.shift_right(mel), text, None)
+    l = train.text2mel_losses(Y, A, mel, o["gaw"].to(DEV))
+    assert rel_err(A, o["outs"]["A"]) < out_tol and rel_l2(A, o["outs"]["A"]) < out_tol, (rel_err(A, o["outs"]["A"]), rel_l2(A, o["outs"]["A"]))
+    assert rel_err(Y, o["outs"]["Y"]) < out_tol and rel_l2(Y, o["outs"]["Y"]) < out_tol, (rel_err(Y, o["outs"]["Y"]), rel_l2(Y, o["outs"]["Y"]))
+    sides, ops.RELU_TAP = [t.cpu() for t in ops.RELU_TAP] + [(Y.detach() > mel).cpu()], None
+    l1_sign = torch.sign(Y.detach() - mel).cpu()
+    for mine, ref in zip(l, o["losses"]):
+        assert abs(float(mine) - ref) < 1e-5 * max(1.0, abs(ref)), (float(mine), ref)
+    sum(l).backward()
+    torch.cuda.synchronize()
+    _check_grads_on_hip_sides(o, m, sides, precision, "unconditional generator", l1_sign)
     m.cpu()
     for p in m.parameters():
         p.grad = None

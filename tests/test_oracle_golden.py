@@ -66,6 +66,26 @@ def test_ssrn_small_and_full():
     assert worst < 2e-4, worst
 
 
+def test_ssrn_full_size_config1_oracle_vs_reference():
+    """BASELINE config 1 ("SSRN forward on 1 synthetic mel (80 x 200), CPU reference path only"): the oracle's full-size SSRN
+    (models/TTSModel.py:342-362) on the seeded input and the seeded initialisation of G4 against the reference's stored output
+    (strided 1/64 slice, sum).  The weights come from the host-side module's construction order + init_weights, which G9 pins
+    (tests/test_host_cpu.py); no HIP code runs."""
+    from spoofsv_amd.train import init_weights
+    from spoofsv_amd.tts import SSRN
+    g = load("ssrn_full.npz")
+    torch.manual_seed(int(g["w_seed"]))
+    m = SSRN(80, 513, 256)
+    m.apply(init_weights)
+    torch.manual_seed(int(g["x_seed"]))
+    x = torch.rand(1, 80, 200)
+    with torch.no_grad():
+        y = TO.ssrn(x, {k: v.detach() for k, v in m.state_dict().items()})
+    assert tuple(y.shape) == (1, 513, 800)
+    assert rel_err(y[0, ::8, ::8], t(g["y_slice"])) < TOL, rel_err(y[0, ::8, ::8], t(g["y_slice"]))
+    assert abs(float(y.double().sum()) - float(g["y_sum"])) < 1e-6 * float(g["y_abs"])
+
+
 def test_gaw_probes():
     g = load("gaw.npz")
     W = TO.guided_attention_mat(186, 325)
