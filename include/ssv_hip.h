@@ -40,7 +40,8 @@ const char* ssv_last_error(void); /* thread-local, valid until the next failing 
  *   2 = split-fp16 MFMA (default): each operand is scaled by a power of two (per tensor / per batch item, from its
  *       maximum magnitude) and split into fp16 hi+lo = 22 significand bits, three fp16 MFMAs per product (every
  *       fp16 x fp16 product is exact in fp32), fp32 accumulate, result rescaled; ~2^-22 per product = fp32-grade at
- *       the bf16/fp16 MFMA rate.  The LSTM products of the GE2E embedder stay on the split-bf16 arithmetic in this mode.
+ *       the bf16/fp16 MFMA rate.  The LSTM products of the GE2E embedder run in this arithmetic too (one power-of-two scale for all
+ *       weight matrices of a launch; the recurrent activations, |h| < 1, take the fixed scale 2^14).
  * Env SSV_PRECISION = fp32 | bf16x3 | f16x2 selects the mode at load.  Returns the previous mode.  Process-wide.
  *
  * Operand scales (mode 2).  A kernel that reads an fp32 tensor as an MFMA operand needs max |x| BEFORE it starts.  The
@@ -317,8 +318,11 @@ int ssv_proj_l2norm_bwd(const float* de, const float* e, const float* norms, con
                         float* dh, float* dw, float* dbias, int Bn, int H, int P, void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* Training (GE2E/train_speech_embedder.py:77-83): the same LSTM forward, keeping every frame of h, c and
  * the activated gates in `saved` (caller-owned, ssv_lstm_saved_bytes), and backpropagation through time from dh_last
- * (Bn,H) to the gradients of all weights and biases (arrays of `layers` DEVICE pointers, torch layouts).  Split-bf16 mode,
- * batch >= 8 and hidden % 32 == 0 only (SSV_UNSUPPORTED otherwise). */
+ * (Bn,H) to the gradients of all weights and biases (arrays of `layers` DEVICE pointers, torch layouts).  No shape or mode
+ * limits (nn.LSTM + autograd have none, GE2E/speech_embedder_net.py:19): in a split mode with hidden % 32 == 0 and
+ * batch >= 8 the (layer, frame) wavefront kernels run in that mode's arithmetic; every other case -- mode 0, any other
+ * hidden size, fewer than 8 utterances -- runs frame by frame on the exact-fp32 MFMA GEMMs.  One `saved` layout for both;
+ * forward and backward of one iteration must run in the same mode. */
 size_t ssv_lstm_saved_bytes(int Bn, int T, int F, int H, int layers);
 size_t ssv_lstm_train_fwd_workspace(int Bn, int T, int F, int H, int layers);
 int ssv_lstm_train_fwd(const float* x, const float* const* w_ih, const float* const* w_hh,

@@ -26,16 +26,21 @@ int ssv_check_launch(const char* what) {
   return -(int)e;
 }
 static int g_precision = -1;
+// SSV_PRECISION, strictly parsed: -> 0 | 1 | 2, or -1 when the variable names no mode (a typo must not silently select another arithmetic)
+static int precision_from_env() {
+  const char* e = getenv("SSV_PRECISION");
+  if (!e || !*e || !strcmp(e, "f16x2") || !strcmp(e, "2")) return 2;
+  if (!strcmp(e, "fp32") || !strcmp(e, "0")) return 0;
+  if (!strcmp(e, "bf16x3") || !strcmp(e, "1")) return 1;
+  return -1;
+}
 int ssv_precision() {
   if (g_precision < 0) {
-    const char* e = getenv("SSV_PRECISION");
-    if (!e || !*e || !strcmp(e, "f16x2") || !strcmp(e, "2")) g_precision = 2;
-    else if (!strcmp(e, "fp32") || !strcmp(e, "0")) g_precision = 0;
-    else if (!strcmp(e, "bf16x3") || !strcmp(e, "1")) g_precision = 1;
-    else {
-      // a typo must not silently select another arithmetic than the one asked for: no arithmetic at all.  (The Python loader
-      // checks the variable before the first call and raises there; a C host gets this message and an abort.)
-      fprintf(stderr, "libssv_hip: SSV_PRECISION=%s is not one of fp32|0, bf16x3|1, f16x2|2\n", e);
+    g_precision = precision_from_env();
+    if (g_precision < 0) {
+      // Reached only by a host that neither asked ssv_get_precision() (which reports the bad value as an error) nor chose a mode with
+      // ssv_set_precision() before its first compute call: no arithmetic at all rather than another one than was asked for.
+      fprintf(stderr, "libssv_hip: SSV_PRECISION=%s is not one of fp32|0, bf16x3|1, f16x2|2 (call ssv_set_precision to choose a mode)\n", getenv("SSV_PRECISION"));
       abort();
     }
   }
@@ -87,12 +92,19 @@ void ssv_shape_log(const char* kernel, dim3 grid, dim3 block, double flops, doub
   if (!g_shape_seen) g_shape_seen = new std::map<std::string, long>();
   ++(*g_shape_seen)[line];
 }
+// An unknown SSV_PRECISION value is an ERROR of these two entries (SSV_UNSUPPORTED + ssv_last_error), not the end of the process: a C host
+// that asks for the mode first, or sets one explicitly (which overrides the variable), never reaches the abort in ssv_precision().
 extern "C" int ssv_set_precision(int mode) {
-  const int prev = ssv_precision();
+  int prev = g_precision >= 0 ? g_precision : precision_from_env();
+  if (prev < 0) prev = ssv_fail(SSV_UNSUPPORTED, "SSV_PRECISION=%s is not one of fp32|0, bf16x3|1, f16x2|2; mode %d set explicitly", getenv("SSV_PRECISION"), mode);
   g_precision = mode <= 0 ? 0 : (mode == 1 ? 1 : 2);
   return prev;
 }
-extern "C" int ssv_get_precision(void) { return ssv_precision(); }
+extern "C" int ssv_get_precision(void) {
+  if (g_precision < 0 && precision_from_env() < 0)
+    return ssv_fail(SSV_UNSUPPORTED, "SSV_PRECISION=%s is not one of fp32|0, bf16x3|1, f16x2|2", getenv("SSV_PRECISION"));
+  return ssv_precision();
+}
 extern "C" int ssv_version(void) { return 5; }
 extern "C" const char* ssv_arch(void) { return "gfx950"; }
 extern "C" const char* ssv_last_error(void) { return g_err; }
@@ -117,6 +129,7 @@ int ssv_launch_softmax_cols(float*, int, int, int, hipStream_t);
 int ssv_launch_softmax_cols_bwd(const float*, float*, const float*, float, int, int, int, hipStream_t);
 int ssv_launch_lstm_in_transpose(const float*, float*, int, int, int, hipStream_t);
 int ssv_launch_lstm_cell(const float*, float*, float*, int, int, int, hipStream_t);
+int ssv_launch_lstm_cell_train(const float* pre, float* act, const float* cprev, float* c, float* h, int H, int Bn, hipStream_t st);
 int ssv_launch_transpose_out(const float*, float*, int, int, hipStream_t);
 int ssv_launch_l2norm_rows(const float*, float*, float*, int, int, hipStream_t);
 int ssv_launch_l2norm_bwd(const float*, const float*, const float*, float*, int, int, hipStream_t);
@@ -1271,15 +1284,46 @@ static LstmSaved lstm_saved(int Bn, int T, int F, int H, int layers) {
   return s;
 }
 extern "C" size_t ssv_lstm_saved_bytes(int Bn, int T, int F, int H, int layers) { return lstm_saved(Bn, T, F, H, layers).total; }
+// The wavefront kernels exist in the split modes, for hidden sizes that are multiples of 32 and at least 8 utterances.  Everything else -- the
+// exact-fp32 mode (ssv_set_precision(0)), any hidden size, any batch -- trains on the exact-fp32 MFMA GEMMs below: layer by layer and frame by
+// frame (nn.LSTM + autograd of the reference have no such limits: GE2E/speech_embedder_net.py:19, GE2E/train_speech_embedder.py:82-86).
+// Same saved-tensor layout, same cell backward kernel; only the products differ.
+static bool lstm_train_split_ok(int Bn, int H) { return ssv_precision() >= 1 && H % 32 == 0 && Bn >= 8; }
+static int lstm_train_fwd_f32(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                              float* h_last, int Bn, int T, int F, int H, int layers, char* base, hipStream_t st,
+                              float* xt, float* hs, float* cs, float* gates) {
+  const LstmWave s = lstm_wave_ws(Bn, T, F, H, layers);
+  float* xp = (float*)(base + s.xp);                               // [T][4H][Bn]: the layer's input projection of every frame, biases included
+  const long HN = (long)H * Bn;
+  SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));     // [T][F][Bn]
+  for (int l = 0; l < layers; ++l) {
+    const float* in = l == 0 ? xt : hs + (long)(l - 1) * T * HN;
+    const int Fin = l == 0 ? F : H;
+    SSV_TRY(lstm_gemm_f32(w_ih[l], in, (long)Fin * Bn, xp, 4 * HN, b_ih[l], b_hh[l], nullptr, 4 * H, Fin, Bn, T, st));
+    for (int t = 0; t < T; ++t) {
+      float* gt = gates + ((long)l * T + t) * 4 * HN;
+      const float* pre = xp + (long)t * 4 * HN;
+      if (t > 0) {                                                  // pre-activations = W_hh h_{t-1} + xp[t], into the saved slot (activated in place)
+        SSV_TRY(lstm_gemm_f32(w_hh[l], hs + ((long)l * T + t - 1) * HN, 0, gt, 0, nullptr, nullptr, pre, 4 * H, H, Bn, 1, st));
+        pre = gt;
+      }
+      SSV_TRY(ssv_launch_lstm_cell_train(pre, gt, t > 0 ? cs + ((long)l * T + t - 1) * HN : nullptr, cs + ((long)l * T + t) * HN,
+                                         hs + ((long)l * T + t) * HN, H, Bn, st));
+    }
+  }
+  return ssv_launch_transpose_out(hs + ((long)(layers - 1) * T + (T - 1)) * HN, h_last, H, Bn, st);
+}
 extern "C" size_t ssv_lstm_train_fwd_workspace(int Bn, int T, int F, int H, int layers) { return lstm_wave_ws(Bn, T, F, H, layers).total; }
 extern "C" int ssv_lstm_train_fwd(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                                   const float* const* b_hh, float* h_last, void* saved, int Bn, int T, int F, int H, int layers,
                                   void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w_ih && w_hh && b_ih && b_hh && h_last && saved && Bn > 0 && T > 0 && F > 0 && H > 0 && layers > 0, SSV_BAD_SHAPE, "lstm_train_fwd: bad argument");
-  SSV_CHECK(ssv_precision() >= 1 && H % 32 == 0 && Bn >= 8, SSV_UNSUPPORTED, "lstm_train_fwd: needs a split (bf16 / fp16) mode, batch >= 8 and hidden %% 32 == 0");
   SSV_CHECK(ws && ws_bytes >= ssv_lstm_train_fwd_workspace(Bn, T, F, H, layers), SSV_BAD_SHAPE, "lstm_train_fwd: workspace too small");
   const LstmSaved sv = lstm_saved(Bn, T, F, H, layers);
   char* sb = (char*)saved;
+  if (!lstm_train_split_ok(Bn, H))
+    return lstm_train_fwd_f32(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, (char*)ws, (hipStream_t)stream,
+                              (float*)(sb + sv.xt), (float*)(sb + sv.hs), (float*)(sb + sv.cs), (float*)(sb + sv.gates));
   return lstm_fwd_wave(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, (char*)ws, (hipStream_t)stream,
                        (float*)(sb + sv.xt), (float*)(sb + sv.hs), (float*)(sb + sv.cs), (float*)(sb + sv.gates));
 }
@@ -1306,7 +1350,8 @@ static LstmBwdWs lstm_bwd_ws(int Bn, int T, int F, int H, int layers) {
 }
 extern "C" size_t ssv_lstm_bwd_workspace(int Bn, int T, int F, int H, int layers) { return lstm_bwd_ws(Bn, T, F, H, layers).total; }
 // dW (M x Nc) = sum over `items` frames of A_item (M x Bn) X_item^T (Nc x Bn): the conv weight-gradient kernel with time = batch
-static int lstm_weight_grad(const float* A, long sab, const float* X, long sxb, float* dw, int M, int Nc, int Bn, int items, void* slabs, hipStream_t st) {
+static int lstm_weight_grad(const float* A, long sab, const float* X, long sxb, float* dw, int M, int Nc, int Bn, int items, void* slabs, hipStream_t st,
+                            bool f32 = false) {
   GemmNT g = nt_zero();
   const int Z = dw_splits(items, M, Nc, 1, Bn);
   const long n = (long)M * Nc;
@@ -1315,8 +1360,11 @@ static int lstm_weight_grad(const float* A, long sab, const float* X, long sxb, 
   if (Z == 1) { g.C = dw; g.scz = n; g.scm = Nc; g.scc = 1; g.scj = 0; }
   else { g.C = (float*)slabs; g.scz = n; g.scm = Nc; g.scc = 1; g.scj = 0; }
   g.M = M; g.Nc = Nc; g.KT = 1; g.B = items; g.Z = Z; g.bstep = Z;
-  SSV_CHECK(ssv_nt_bf3_fits(g), SSV_UNSUPPORTED, "lstm_bwd: sequence buffers exceed the weight-gradient kernel's 32-bit offsets");
-  SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
+  if (f32) SSV_TRY(ssv_launch_gemm_nt(g, st));
+  else {
+    SSV_CHECK(ssv_nt_bf3_fits(g), SSV_UNSUPPORTED, "lstm_bwd: sequence buffers exceed the weight-gradient kernel's 32-bit offsets");
+    SSV_TRY(ssv_launch_gemm_nt_bf3(g, st));
+  }
   if (Z > 1) SSV_TRY(ssv_launch_reduce_slabs((const float*)slabs, dw, n, Z, n, st));
   return 0;
 }
@@ -1324,7 +1372,7 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
                             float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh,
                             int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(dh_last && saved && w_ih && w_hh && dw_ih && dw_hh && db_ih && db_hh && Bn > 0 && T > 0 && F > 0 && H > 0 && layers > 0, SSV_BAD_SHAPE, "lstm_bwd: bad argument");
-  SSV_CHECK(ssv_precision() >= 1 && H % 32 == 0 && Bn >= 8, SSV_UNSUPPORTED, "lstm_bwd: needs a split (bf16 / fp16) mode, batch >= 8 and hidden %% 32 == 0");
+  const bool f32 = !lstm_train_split_ok(Bn, H);                    // the exact-fp32 products (see lstm_train_fwd_f32)
   const LstmBwdWs s = lstm_bwd_ws(Bn, T, F, H, layers);
   SSV_CHECK(ws && ws_bytes >= s.total, SSV_BAD_SHAPE, "lstm_bwd: workspace too small (%zu < %zu)", ws_bytes, s.total);
   hipStream_t st = (hipStream_t)stream;
@@ -1343,12 +1391,32 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
   float* rs = (float*)(base + s.rs);
   const long HN = (long)H * Bn;
   SSV_TRY(ssv_launch_transpose_out(dh_last, dhtop, Bn, H, st));               // (Bn, H) -> [H][Bn]
+  // the transposed product dX [H][Bn] = W^T dG with W (4H x H) row-major, on the exact-fp32 kernel: A(m = q, c = r) = W[r][q]
+  auto wt_gemm_f32 = [&](const float* W, const float* dg, float* out) -> int {
+    GemmNN q = nn_zero();
+    q.A = W; q.sam = 1; q.sac = H; q.saj = 1;
+    q.X = dg; q.sxc = Bn; q.Lx = Bn;
+    q.C = out; q.scm = Bn;
+    q.M = H; q.N = Bn; q.Kc = 4 * H; q.B = 1;
+    return ssv_launch_gemm_nn(q, st);
+  };
+  for (int step = T + layers - 2; f32 && step >= 0; --step) {
+    const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
+    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dx0, dxc, dhtop, dgates, dcarry, H, Bn, T, layers, step, lo, hi - lo + 1, st));
+    if (lo == 0 && step >= 1) SSV_TRY(wt_gemm_f32(w_hh[0], dgates + (long)step * 4 * HN, dx0 + (long)step * HN));
+    for (int l = lo > 1 ? lo : 1; l <= hi; ++l) {                            // [dh^{l-1}_t ; dh^l_{t-1}] = [W_ih | W_hh]^T dgates^l_t
+      const float* dg = dgates + ((long)l * T + (step - l)) * 4 * HN;
+      float* out = dxc + ((long)(l - 1) * T + (step - l)) * 2 * HN;
+      SSV_TRY(wt_gemm_f32(w_ih[l], dg, out));
+      SSV_TRY(wt_gemm_f32(w_hh[l], dg, out + HN));
+    }
+  }
   // transposed weights for the data-gradient products: rows = inputs of the layer, reduction over the 4H gate rows
   unsigned short* w0_hi = (unsigned short*)(base + s.wt0);
   unsigned short* w0_lo = (unsigned short*)(base + s.wt0 + split_bytes(H, 4 * H, 1));
-  SSV_TRY(ssv_launch_pack_split(w_hh[0], w0_hi, w0_lo, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));          // (m=q, k=r) = W_hh[r][q]
+  if (!f32) SSV_TRY(ssv_launch_pack_split(w_hh[0], w0_hi, w0_lo, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));          // (m=q, k=r) = W_hh[r][q]
   const size_t rows_h = (size_t)(H / 16) * (4 * H / 32) * 512;               // elements of the first H rows of a [2H x 4H] plane
-  for (int l = 1; l < layers; ++l) {
+  for (int l = 1; !f32 && l < layers; ++l) {
     unsigned short* hi = (unsigned short*)(base + s.wtc + (size_t)(l - 1) * s.wtc_stride);
     unsigned short* lo = (unsigned short*)((char*)hi + split_bytes(2 * H, 4 * H, 1));
     SSV_TRY(ssv_launch_pack_split(w_ih[l], hi, lo, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));
@@ -1356,7 +1424,7 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
   }
   GemmNNB g = nnb_zero();
   g.Kpad = 4 * H; g.Kc = 4 * H; g.sxc = Bn; g.Lx = Bn; g.scm = Bn; g.N = Bn;
-  for (int step = T + layers - 2; step >= 0; --step) {
+  for (int step = T + layers - 2; !f32 && step >= 0; --step) {
     const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
     SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dx0, dxc, dhtop, dgates, dcarry, H, Bn, T, layers, step, lo, hi - lo + 1, st));
     if (lo == 0 && step >= 1) {               // layer 0, frame t = step >= 1: dh_{t-1} = W_hh^T dgates_t (nothing to do for frame 0: x is data)
@@ -1382,8 +1450,8 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
     const float* dg = dgates + (long)l * T * 4 * HN;
     const int Fin = l == 0 ? F : H;
     const float* in = l == 0 ? xt : hs + (long)(l - 1) * T * HN;
-    SSV_TRY(lstm_weight_grad(dg, 4 * HN, in, (long)Fin * Bn, dw_ih[l], 4 * H, Fin, Bn, T, base + s.slabs, st));
-    if (T > 1) SSV_TRY(lstm_weight_grad(dg + 4 * HN, 4 * HN, hs + (long)l * T * HN, HN, dw_hh[l], 4 * H, H, Bn, T - 1, base + s.slabs, st));
+    SSV_TRY(lstm_weight_grad(dg, 4 * HN, in, (long)Fin * Bn, dw_ih[l], 4 * H, Fin, Bn, T, base + s.slabs, st, f32));
+    if (T > 1) SSV_TRY(lstm_weight_grad(dg + 4 * HN, 4 * HN, hs + (long)l * T * HN, HN, dw_hh[l], 4 * H, H, Bn, T - 1, base + s.slabs, st, f32));
     else SSV_TRY(ssv_launch_fill(dw_hh[l], 0.f, (long)4 * H * H, st));
     SSV_TRY(ssv_rowsum(dg, 4 * HN, rs, T, 4 * H, Bn, stream));              // rs[t][r] = sum_b dgates[l][t][r][b]
     SSV_TRY(ssv_launch_reduce_slabs(rs, db_ih[l], 4 * H, T, 4 * H, st));

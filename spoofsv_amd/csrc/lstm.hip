@@ -27,6 +27,24 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
   h[i] = go * tanhf(cn);
 }
 
+// training (exact-fp32 path): pre [4H][Bn] gate pre-activations in torch order -> act [4H][Bn] activated i, f, g, o (may alias pre); c_t and h_t
+// [H][Bn]; cprev null at t = 0
+__global__ __launch_bounds__(256) void lstm_cell_train_kernel(const float* pre, float* act, const float* __restrict__ cprev, float* __restrict__ c,
+                                                              float* __restrict__ h, int H, int Bn) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)H * Bn;
+  if (i >= n) return;
+  const float gi = sigm(pre[i]), gf = sigm(pre[n + i]), gg = tanhf(pre[2 * n + i]), go = sigm(pre[3 * n + i]);
+  const float cn = (cprev ? gf * cprev[i] : 0.f) + gi * gg;
+  act[i] = gi; act[n + i] = gf; act[2 * n + i] = gg; act[3 * n + i] = go;
+  c[i] = cn;
+  h[i] = go * tanhf(cn);
+}
+int ssv_launch_lstm_cell_train(const float* pre, float* act, const float* cprev, float* c, float* h, int H, int Bn, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_cell_train_kernel, dim3(ssv_cdiv((long)H * Bn, 256)), dim3(256), 0, st, pre, act, cprev, c, h, H, Bn);
+  return ssv_check_launch("lstm_cell_train");
+}
+
 // h_last [H][Bn] -> (Bn, H)
 __global__ __launch_bounds__(256) void transpose_out_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Bn) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index into dst (Bn, R)

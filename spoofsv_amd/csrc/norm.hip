@@ -1077,8 +1077,8 @@ int ssv_ln_act_bwd_vec(int C, int L, bool has_amax) {
   if (C > 256 && C <= 576 && L >= 64 && (long)C * L * 4 < (1L << 31) && (!has_amax || ssv_amax_rows_(L) >= ssv_cdiv(L, 16))) return 4;
   return 1;
 }
-// Workgroups per batch item of the PERSISTENT gate backward (ln_gate_bwd_pers_kernel), or 0 when the shape runs the tile kernels: 256 or 512
-// channels (8 channel steps per thread on 32 / 64 groups), B * wpi workgroups = the CUs (SSV_LN_PERSIST=<slots> overrides,
+// Workgroups per batch item of the PERSISTENT gate backward (ln_gate_bwd_pers_kernel), or 0 when the shape runs the tile kernels: 256
+// channels only (8 channel steps per thread on 32 groups; C = 512 keeps ln_gate_bwd_wide), B * wpi workgroups = the CUs (SSV_LN_PERSIST=<slots> overrides,
 // 0 switches the kernel off), every workgroup at least one 16-column sub-tile, one scale-list entry per workgroup.
 int ssv_launch_ln_gate_bwd_pers(const float* dY, long dy_bs, const float* H, const float* X, long x_bs, const float* stats, const float* g1, const float* b1,
                                 const float* g2, const float* b2, float* dH, float* dXres, long dx_bs, float* part, float* amax, int B, int C, int L, int wpi,

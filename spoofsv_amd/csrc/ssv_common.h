@@ -54,7 +54,7 @@ struct GemmNT {
 };
 int ssv_launch_gemm_nt(const GemmNT& g, hipStream_t st);
 
-// ---- split-bf16 variants (gemm_bf3.hip): same contracts, unit column strides, weights pre-split --------------
+// ---- split-MFMA variants (conv_nn.hip, wgrad_nt.hip, wgrad_nt3r.hip, pwln.hip; helpers in bf3_common.h): same contracts, unit column strides, weights pre-split --------------
 struct GemmNNB {
   const unsigned short* Ahi; const unsigned short* Alo; int Kpad;   // bf16 planes (hi, lo) in fragment order, see pack_split_kernel
   const float* X; long sxb, sxc; int Lx;
@@ -105,7 +105,8 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st);
 int ssv_launch_gemm_pwln(const GemmNNB& g, const float* gamma, const float* beta, float* y, long ybs, float* stats, float* y_amax, int namax, int act,
                          hipStream_t st);
 int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st);
-// backward of a 1x1 conv + LayerNorm link in one launch (gemm_bf3.hip, pwln_bwd_kernel): dy, pre (B, M, L) with M = Cout LN rows (pre dense),
+int ssv_launch_gemm_nt3r(const GemmNT& g, dim3 grid, int mtiles, int tchunks, int ring_ms, hipStream_t st);   // (wgrad_nt3r.hip; called by the line above)
+// backward of a 1x1 conv + LayerNorm link in one launch (pwln.hip, pwln_bwd_kernel): dy, pre (B, M, L) with M = Cout LN rows (pre dense),
 // stats (B, 2, L); dpre (B, M, L) dense, this tile's partial row [dgamma | dbeta | dbias] at part_q * tile of the item's part_rows rows, scale
 // list entry 4 * tile; Ahi / Alo: the TRANSPOSED weight's planes (rows = Cin, K = M); dx (B, Cin, L); xrow_w[o * xrow_sk]: the weights of
 // output row Cin - 1 when Cin = 128 j + 1

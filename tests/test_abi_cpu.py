@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()                      # raises if a declared symbol is missing
     assert L.ssv_version() == 5
     assert L.ssv_arch() == b"gfx950"
-    # the default arithmetic is split-fp16 (2) unless SSV_PRECISION names another mode (strictly parsed: a typo falls back to 2 with a warning)
+    # the default arithmetic is split-fp16 (2) unless SSV_PRECISION names another mode (strictly parsed: a typo is an error, see the test below)
     default = {"fp32": 0, "0": 0, "bf16x3": 1, "1": 1}.get(os.environ.get("SSV_PRECISION", ""), 2)
     prev = L.ssv_set_precision(0)
     assert prev == default and L.ssv_get_precision() == 0
@@ -39,6 +39,24 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIBPATH)
     for name in _lib.parse_header():
         assert hasattr(raw, name), name
+
+
+def test_unknown_precision_value_is_an_error_of_the_query_entries_not_an_abort():
+    """A C host (no Python loader in front) with SSV_PRECISION misspelt: ssv_get_precision() returns SSV_UNSUPPORTED with a message, and an
+    explicit ssv_set_precision(mode) overrides the variable -- the process lives.  (spoofsv_amd._lib raises on the same value before the first call.)"""
+    import subprocess, sys
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); L.ssv_last_error.restype = ctypes.c_char_p\n"
+            "r = L.ssv_get_precision(); msg = L.ssv_last_error()\n"
+            "assert r == -2 and b'fp33' in msg, (r, msg)\n"
+            "assert L.ssv_set_precision(0) == -2 and L.ssv_get_precision() == 0\n"
+            "assert L.ssv_set_precision(2) == 0 and L.ssv_get_precision() == 2\n"
+            "print('alive')")
+    env = dict(os.environ, SSV_PRECISION="fp33")
+    r = subprocess.run([sys.executable, "-c", code, _lib.LIBPATH], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "alive" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(_lib.HEADER)))
+    r = subprocess.run([sys.executable, "-c", "from spoofsv_amd import _lib; _lib.lib()"], env=dict(env, PYTHONPATH=root), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "SSV_PRECISION" in r.stderr, (r.returncode, r.stderr[-300:])        # the Python loader raises before the first call
 
 
 def test_no_torch_types_in_signatures():

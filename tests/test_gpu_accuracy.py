@@ -271,7 +271,7 @@ def test_batched_weight_gradient_with_mixed_dilations_and_the_shift_bound():
 @pytest.mark.parametrize("d,causal", [(7, False), (8, False), (8, True), (9, False), (9, True), (1, True)])
 def test_conv_forward_and_data_gradient_on_both_sides_of_the_narrow_halo_rule(d, causal):
     """The k = 3 forward / data-gradient kernels come in two instantiations: a 16-column halo for layers whose taps span at most 16
-    columns, 54 otherwise (csrc/gemm_bf3.hip, SSV_NN_HALO_SMALL).  Dilations 7 and 8 are the last ones on the narrow side (span 14 / 16),
+    columns, 54 otherwise (csrc/bf3_tuning.h, SSV_NN_HALO_SMALL).  Dilations 7 and 8 are the last ones on the narrow side (span 14 / 16),
     9 the first on the wide side: forward, data gradient and weight gradient against float64 at a row length that is a multiple of
     nothing, so that the last column tile is partly empty and its halo runs off the row (nn.Conv1d with the reference's padding,
     models/TTSModel.py:59-61)."""
@@ -298,7 +298,7 @@ def test_conv_forward_and_data_gradient_on_both_sides_of_the_narrow_halo_rule(d,
 def test_one_by_one_convolutions_with_128_j_plus_1_output_rows(B, Cin, Cout, L):
     """128 j + 1 output channels (SSRN's 513 frequency bins, models/TTSModel.py:353-361): the wide k = 1 forward / data-gradient kernel and
     the k = 1 weight-gradient kernel keep the LAST row out of their MFMA tiles and add it as fp32 dot products beside the staging
-    (csrc/gemm_bf3.hip: gemm_nn_bf3w_kernel<.., XR = 1> for long sequences, gemm_nt_bf3_kernel<.., XR = 1> with RANGE slabs -- a workgroup's
+    (csrc/conv_nn.hip, wgrad_nt.hip: gemm_nn_bf3w_kernel<.., XR = 1> for long sequences, gemm_nt_bf3_kernel<.., XR = 1> with RANGE slabs -- a workgroup's
     chunk range starts and ends inside batch items).  Forward, data gradient (whose output rows are the INPUT channels: 513 -> the extra
     row there too) and weight gradient against float64, at ragged lengths and channel counts (more slabs than chunks at L = 64, item
     boundaries inside every range), and the last row on its own (where a wrong row would hide in an L2 norm over 513 rows)."""

@@ -3,7 +3,7 @@ the Text2Mel + SSRN training step -- forward, data gradient, weight gradient (al
 equal-shaped layers) -- against float64 on the same operands, plus the two edge cases the reference's zero-padding collate and any
 diverging run can hand to the operand-scale path: an all-zero batch item and a non-finite element.
 
-Slab counts, tiles and the job-table Z all depend on B (csrc/api.hip dw_splits / nt_slabs, gemm_bf3.hip pick_nnb), so a test at
+Slab counts, tiles and the job-table Z all depend on B (csrc/api.hip dw_splits / nt_slabs, conv_nn.hip pick_nnb), so a test at
 B = 8 launches other configurations than the timed step; the rows below are the (B, Cin, Cout, L, k) of
 profiles/round4_shapes.tsv.  Reference semantics: nn.Conv1d in models/TTSModel.py:59,78 and autograd's two gradients behind
 train/ordinary.py:237,253; the collate that produces all-zero tails is data/dataset.py:187-258.  The float64 reference is a sum of

@@ -416,11 +416,11 @@ def test_ge2e_loss_backward_golden_and_full_size_vs_oracle():
 
 
 def _ge2e_train_mode(precision):
-    """The GE2E training kernels (LSTM forward keeping every frame, backpropagation through time) exist in the split modes; the exact-fp32
-    parametrisation of this module runs them in split-bf16, the other two in their own arithmetic (split-fp16: forward products fp32-grade)."""
+    """Every parametrisation of this module trains the embedder in its OWN arithmetic: the wavefront kernels in the split modes, and since
+    round 6 the exact-fp32 GEMMs in the "fp32" mode (before, that mode had no training kernels and these tests switched it to split-bf16)."""
     import spoofsv_amd
-    if precision == "fp32":
-        spoofsv_amd.set_precision("bf16x3")          # (the autouse fixture restores the mode after the test)
+    from spoofsv_amd import _lib
+    assert _lib.precision() == {"fp32": 0, "bf16x3": 1, "f16x2": 2}[precision]
 
 
 def test_ge2e_training_iteration_golden(precision):
@@ -574,6 +574,33 @@ def test_ge2e_backward_edge_shapes_vs_oracle(layers, T, precision):
     for k, p in m.named_parameters():
         ref = sd[k].grad
         assert (p.grad.cpu() - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-6, (k, float((p.grad.cpu() - ref).abs().max()), float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("hidden,proj,B,T,layers", [(40, 24, 5, 7, 3), (33, 16, 9, 4, 2), (96, 64, 3, 6, 3), (32, 16, 1, 3, 1)])
+def test_ge2e_training_has_no_shape_limits(hidden, proj, B, T, layers, precision):
+    """nn.LSTM + autograd (GE2E/speech_embedder_net.py:19, GE2E/train_speech_embedder.py:82-86) train at any hidden size and batch.  The
+    wavefront training kernels need hidden % 32 == 0 and at least 8 utterances; every other shape -- and the whole exact-fp32 mode -- runs the
+    same iteration on the exact-fp32 GEMMs (csrc/api.hip lstm_train_fwd_f32): embeddings and every parameter gradient against autograd over
+    the CPU oracle, in all three arithmetic modes."""
+    from spoofsv_amd.ge2e import SpeechEmbedder
+    torch.manual_seed(hidden + B)
+    m = SpeechEmbedder(nmels=40, hidden=hidden, num_layer=layers, proj=proj)
+    with torch.no_grad():
+        for n, p in m.LSTM_stack.named_parameters():
+            if "bias" in n:
+                p.uniform_(-0.2, 0.2)
+    x = torch.randn(B, T, 40)
+    de = torch.randn(B, proj)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    eo = GO.speech_embedder(x, sd, num_layers=layers)
+    eo.backward(de)
+    m = m.to(DEV).train()
+    eg = m(x.to(DEV))
+    eg.backward(de.to(DEV))
+    assert rel_err(eg, eo) < 1e-4, rel_err(eg, eo)
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        assert p.grad is not None and (p.grad.cpu() - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-6, (k, float((p.grad.cpu() - ref).abs().max()), float(ref.abs().max()))
 
 
 _BENCH_ORACLE = {}

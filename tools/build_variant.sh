@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../spoofsv_amd/csrc"
 mkdir -p build/ab/$name
-for f in api gemm_nn gemm_nt gemm_bf3 norm norm_pers attn attn_fused misc lstm vocoder synth critic; do
+for f in api gemm_nn gemm_nt pack conv_nn wgrad_nt wgrad_nt3r pwln norm norm_pers attn attn_fused misc lstm vocoder synth critic; do
   extra=""; [ $f = norm_pers ] && extra="-fno-slp-vectorize"
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $extra "$@" -c $f.hip -o build/ab/$name/$f.o &
 done

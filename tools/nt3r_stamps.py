@@ -18,9 +18,9 @@ for (C, L, k, d) in ((256, 325, 3, 3), (512, 186, 3, 3), (512, 1300, 3, 1), (256
         ops._conv_bwd_weight(dy, dy.stride(0), x, x.stride(0), w.shape, k, d, 1, None, dya, xa)
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
-    rc = _lib.lib().ssv_debug_nt_stamps(buf)
+    rc = _lib.lib().ssv_debug_nt3r_stamps(buf)
     wgb = (ctypes.c_ulonglong * (4096 * 4))()
-    ctypes.CDLL(_lib.LIBPATH).ssv_debug_nt_wg(wgb)
+    ctypes.CDLL(_lib.LIBPATH).ssv_debug_nt3r_wg(wgb)
     a = np.frombuffer(wgb, dtype=np.uint64).reshape(4096, 4).astype(np.int64)
     a = a[a[:, 1] > 0]
     t0 = a[:, 0].min()

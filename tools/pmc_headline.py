@@ -18,7 +18,7 @@ def entry(fetch_dir, write_dir, profile):
     w, _ = avg(write_dir, "WRITE_SIZE")
     corr = 2 * 512 * 256 * 3 * 2 / 1024.0 / 2          # hi + lo planes of the (512, 256, 3) weight = 1.5 MiB, fetched by 16-byte-per-lane loads: counted at half
     # everything the kernel's loads, scaling, tile and launch choice come from: a change in any of them withholds the figure
-    src = ["spoofsv_amd/csrc/gemm_bf3.hip", "spoofsv_amd/csrc/ssv_common.h", "spoofsv_amd/csrc/api.hip"]
+    src = ["spoofsv_amd/csrc/conv_nn.hip", "spoofsv_amd/csrc/bf3_common.h", "spoofsv_amd/csrc/bf3_tuning.h", "spoofsv_amd/csrc/ssv_common.h", "spoofsv_amd/csrc/api.hip"]
     h = hashlib.sha256()
     for s in src:
         h.update(open(os.path.join(ROOT, s), "rb").read())

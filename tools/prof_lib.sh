@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 [ -n "$lib" ] && export SSV_HIP_LIB=$R/$lib
 rm -rf /tmp/prof_$tag
-(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ge2e --no-adversarial --no-fp32 --no-roofline --precision $mode > $R/gpurun_out/r3/prof_$tag.json 2> $R/gpurun_out/r3/prof_$tag.err)
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ge2e --no-adversarial --no-fp32 --no-roofline --no-stock --precision $mode > $R/gpurun_out/r3/prof_$tag.json 2> $R/gpurun_out/r3/prof_$tag.err)
 python3 tools/summarize_prof.py /tmp/prof_$tag > gpurun_out/r3/prof_$tag.txt
 python3 tools/step_kernels.py /tmp/prof_$tag > gpurun_out/r3/steps_$tag.txt 2>&1
 tail -1 gpurun_out/r3/prof_$tag.txt | cut -c1-120
