@@ -57,3 +57,6 @@
 #ifndef SSV_PWLN_BWD_FUSED
 #define SSV_PWLN_BWD_FUSED 1
 #endif
+#ifndef SSV_PWLN_BK64
+#define SSV_PWLN_BK64 1      // (tuning builds: 0 = 32-channel chunks in gemm_pwln_kernel<4,4,..> with the staging by waves 0-3 after the chunk's MFMAs, as in round 5)
+#endif

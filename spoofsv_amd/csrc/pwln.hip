@@ -30,7 +30,13 @@ template <int WMB, int NT, int F16, int XR = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   const GemmNNB& p = q.g;
   constexpr int BN = 16 * NT;
-  constexpr int X_SLOTS = 4 * BN;                      // 16-byte slots of one 32-channel chunk: [k-group][column]
+  // K64 (round 6, the 4-row-block instantiations): a staged chunk is 64 channels -- two 32-channel sub-chunks of MFMAs per barrier, ALL 512 threads
+  // stage one slot each (with 32-channel chunks only waves 0-3 staged while waves 4-7 waited at the barrier), and the staging of chunk c + 1 runs
+  // in pieces behind the row blocks' MFMAs of chunk c (tools/probe/ldsdma_ring.hip, profiles/round6_ldsdma_ring_probe.txt: 1.12 -> 0.91 us per
+  // 32 channels in the probe's model of this loop; the weight stream itself is not the limit: 0.74 us with nothing else in the loop)
+  constexpr bool K64 = SSV_PWLN_BK64 && WMB == 4 && NT == 4;
+  constexpr int KG = K64 ? 8 : 4;                      // k-groups (8 channels each) of a staged chunk
+  constexpr int X_SLOTS = KG * BN;                     // 16-byte slots of one chunk: [k-group][column]
   static_assert(X_SLOTS <= 512, "one slot per thread");
   constexpr int IMG = 2 * X_SLOTS;
   __shared__ uint4 lds[2][IMG];
@@ -40,7 +46,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   // XR: row M - 1 (M = 128 j + 1: the 513-channel layers) is kept out of the MFMA row blocks -- a fifth row block per wave for ONE row otherwise
   // -- and comes from fp32 dot products of its weights (xw, staged once) with the raw values the staging threads hold before they split them
   __shared__ float xw[XR ? 1056 : 1];
-  __shared__ float xsum[XR ? 4 * BN : 1];
+  __shared__ float xsum[XR ? KG * BN : 1];
   __shared__ float xrow[XR ? 2 * BN : 1];                // the row's pre-activation per column, then its normalised value
   // epilogue (round 5): every wave parks a 16-row block row-major and reads it back as 16-byte vectors along the rows, so a store instruction
   // covers four whole 256-byte row pieces instead of 64-byte pieces of 16 rows (what gemm_nn_bf3_kernel's epilogue has done since round 2)
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
   for (int i = 0; i < WMB; ++i) arowb[i] = (unsigned)(((long)min(wave * WMB + i, MB - 1) * nchunks * 512 + lane * 8) * 2);
   float xacc = 0.f;
   if constexpr (XR) {
-    for (int k = tid; k < nchunks * 32; k += 512) xw[k] = k < p.Kc ? p.xrow_w[(long)k * p.xrow_sk] : 0.f;      // (visible after the first barrier)
+    for (int k = tid; k < (K64 ? ((nchunks + 1) >> 1) * 64 : nchunks * 32); k += 512) xw[k] = k < p.Kc ? p.xrow_w[(long)k * p.xrow_sk] : 0.f;      // (visible after the first barrier)
   }
   const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(p.Ahi), rsAl = ssv_buf(p.Alo), rsX = ssv_buf(Xb);
   auto loadA = [&](int set, int ch) {
@@ -142,16 +148,36 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
     }
   };
   loadA(0, 0);
-  prefetchX(0);
+  auto prefetch64 = [&](int c) {                         // (K64) chunk c = channels 64 c + 8 skg + i; rows past Kc read 0 through the ranged buffer
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rx[i] = ssv_buf_f32(rsXr, voffb, (unsigned)((c * 64 + i) * Lrow) * 4u);
+  };
+  if constexpr (K64) prefetch64(0);
+  else prefetchX(0);
   if constexpr (F16) {
     float sc, inv;
     ssv_pow2_scale(ssv_wave_list_max(p.x_amax + (long)b * p.x_amax_bs, p.x_namax), sc, inv);
     xs = ssv_uniform(sc); xinv = ssv_uniform(inv);
   }
   if constexpr (XR) __syncthreads();                     // xw is staged
-  commitX(0);
-  if constexpr (SSV_PWLN_ROLL) prefetchXr(min(1, nchunks - 1));
-  else if (nchunks > 1) prefetchX(1);
+  if constexpr (K64) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = cvs ? rx[i] : 0.f;
+    if constexpr (XR) {
+      const float* wq = xw + 8 * skg;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xacc = __builtin_fmaf(wq[i], v[i], xacc);
+    }
+    uint4 h, l;
+    split8s<F16>(v, xs, h, l);
+    lds[0][tid] = h; lds[0][X_SLOTS + tid] = l;
+    prefetch64(min(1, ((nchunks + 1) >> 1) - 1));
+  } else {
+    commitX(0);
+    if constexpr (SSV_PWLN_ROLL) prefetchXr(min(1, nchunks - 1));
+    else if (nchunks > 1) prefetchX(1);
+  }
   if constexpr (NSET == 2 && SSV_PWLN_ROLL) {
     // two weight-fragment sets, every load unconditional (clamped chunk index, one-path prefetch: see the rolling loop below)
     const int last = nchunks - 1;
@@ -185,6 +211,62 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
       }
       __syncthreads();
     }
+  } else if constexpr (K64) {
+    // 64-channel chunks: chunk c = the 32-channel weight chunks 2c and 2c + 1 (the last one may have only the first: Kpad / 32 odd).  Weight fragments
+    // as in the rolling form below (one set, row block i re-loaded right behind its MFMAs, now with the NEXT 32-channel chunk's).  Staging of chunk
+    // c + 1 from the raw values in rx, one piece behind each of the 8 row-block slots of chunk c: 4 x (mask, extra row's dot product, split one pair),
+    // the two LDS stores, 2 x 4 loads of chunk c + 2 -- all unconditional (past the end the last chunk is re-read and lands in the image nobody
+    // reads; its extra-row products are masked), so every path into the loop head has the same loads in flight.
+    const int nc64 = (nchunks + 1) >> 1, last32 = nchunks - 1;
+    unsigned ph[4], pl[4];
+    auto piece = [&](int c, int slot8) __attribute__((always_inline)) {
+      if (slot8 < 4) {
+        const bool live = cvs && c + 1 < nc64;
+        const float v0 = live ? rx[2 * slot8] : 0.f, v1 = live ? rx[2 * slot8 + 1] : 0.f;
+        if constexpr (XR) {
+          const float* wq = xw + (c + 1) * 64 + 8 * skg + 2 * slot8;
+          xacc = __builtin_fmaf(wq[0], v0, xacc); xacc = __builtin_fmaf(wq[1], v1, xacc);
+        }
+        split_pair<F16>(v0, v1, xs, ph[slot8], pl[slot8]);
+      } else if (slot8 == 4) lds[(c + 1) & 1][tid] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+      else if (slot8 == 5) lds[(c + 1) & 1][X_SLOTS + tid] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+      else {
+        const int cn = min(c + 2, nc64 - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rx[4 * (slot8 - 6) + j] = ssv_buf_f32(rsXr, voffb, (unsigned)((cn * 64 + 4 * (slot8 - 6) + j) * Lrow) * 4u);
+      }
+    };
+    auto sub = [&](int c, int sb, bool staging) __attribute__((always_inline)) {
+      const uint4* Xh = lds[c & 1];
+      const uint4* Xl = lds[c & 1] + X_SLOTS;
+      uint4 bh[NT], bl[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { const int s_ = (sb * 4 + kq) * BN + t * 16 + nq; bh[t] = Xh[s_]; bl[t] = Xl[s_]; }
+      const unsigned ubn = (unsigned)__builtin_amdgcn_readfirstlane(min(2 * c + sb + 1, last32) * 1024);
+#pragma unroll
+      for (int i = 0; i < WMB; ++i) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[i][t] = mma16<F16>(Al_[0][i], bh[t], acc[i][t]);
+          acc[i][t] = mma16<F16>(Ah_[0][i], bl[t], acc[i][t]);
+          acc[i][t] = mma16<F16>(Ah_[0][i], bh[t], acc[i][t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // re-load and staging piece stay behind this row block's MFMAs, in front of the next block's
+        Ah_[0][i] = ssv_buf_u4(rsAh, arowb[i], ubn);
+        Al_[0][i] = ssv_buf_u4(rsAl, arowb[i], ubn);
+        if (staging) piece(c, sb * WMB + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    __syncthreads();
+    PW_STAMP(1);
+    const int nfull = nchunks >> 1;                 // chunks with both halves
+    for (int c = 0; c < nfull; ++c) {
+      sub(c, 0, true);
+      sub(c, 1, true);
+      __syncthreads();
+    }
+    if (nchunks & 1) sub(nfull, 0, false);          // the odd last 32 channels (its image was staged by chunk nfull - 1's pieces, or by the prologue)
   } else if constexpr (SSV_PWLN_ROLL) {
     // One register set, re-loaded ROW BLOCK BY ROW BLOCK (round 5): the loop runs row block outermost with all NT input fragments of the chunk
     // in registers, so row block i's weight fragments are dead after its 3 NT MFMAs and chunk c + 1's are requested right there -- every
@@ -288,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pwln_kernel(const PwLn q) {
     if (tid < BN) {
       const int gm = p.M - 1, gn = n0 + tid;
       float v = (xsum[tid] + xsum[BN + tid]) + (xsum[2 * BN + tid] + xsum[3 * BN + tid]);
+      if constexpr (K64) v += (xsum[4 * BN + tid] + xsum[5 * BN + tid]) + (xsum[6 * BN + tid] + xsum[7 * BN + tid]);
       if (p.bias) v += p.bias[gm];
       if (p.bias_b) v += p.bias_b[(long)b * p.sbb + gm];
       if (gn >= p.N) v = 0.f;
