@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--check-replicas", action="store_true",
                     help="N > 1: after the timed steps (and the adversarial cycles) all-gather a checksum of every model's parameters and fail unless all ranks hold the same replica")
     ap.add_argument("--launch-check", action="store_true",
-                    help="rehearse ONLY the launch plumbing of --gpus N, without touching a GPU: N ranks, gloo rendezvous on 127.0.0.1, local-rank folding, "
+                    help="rehearse ONLY the launch plumbing of --gpus N, without any kernel launch or device memory (device COUNTING may initialise the HIP runtime): N ranks, gloo rendezvous on 127.0.0.1, local-rank folding, "
                          "one all-gather, ONE JSON line from rank 0, non-zero exit if any rank dies (runs on a GPU-less host)")
     ap.add_argument("--precision", choices=["f16x2", "bf16x3", "fp32"], default="f16x2",
                     help="conv GEMM arithmetic: split-fp16 MFMA with power-of-two operand scales (default, ~2^-22 per product = fp32-grade), "
@@ -712,7 +712,7 @@ def launch_check(args):
         raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    ndev = max(torch.cuda.device_count(), 1)           # (counting devices does not initialise HIP)
+    ndev = max(torch.cuda.device_count(), 1)           # (with amdsmi this only counts; without it torch falls back to hipGetDeviceCount, which runs hipInit -- harmless: no exec follows in the ranks)
     folded = local % ndev
     with _stdout_on_stderr():
         dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 5 (5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
+int ssv_version(void);            /* ABI version, currently 6 (6 = ssv_shift_right_amax, ssv_deinterleave2_amax, GE2E training without shape / mode limits; 5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
                                     4 = compact partial rows: the nblk of a weight-gradient job is ssv_ln_bwd_partial_rows(...), not ssv_ln_partial_rows(B, L)) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -55,6 +55,13 @@ int ssv_get_precision(void);
 int ssv_amax_rows(int L);         /* entries per batch item of the lists the LayerNorm / gate kernels write: 4 * ceil(L / 64) */
 /* amax[b * namax + i] = max |x| over the i-th of namax equal pieces of item b (n dense floats at x + b * x_bs). */
 int ssv_absmax(const float* x, long x_bs, int B, long n, float* amax, int namax, ssv_stream_t stream);
+/* Two layout changes of the trainers that also deliver the result's scale list (one launch instead of a copy kernel + ssv_absmax; amax may be
+ * NULL).  Teacher forcing, train/ordinary.py:226 = train/adversarial_wasserstein_gp.py:277 (`torch.cat((zeros, mel[:, :, :-1]), -1)`):
+ * y (B, C, T) dense, y(b, c, 0) = 0, y(b, c, t) = x(b, c, t - 1); x items x_bs apart. */
+int ssv_shift_right_amax(const float* x, long x_bs, float* y, int B, int C, int T, float* amax, int namax, ssv_stream_t stream);
+/* out[j][b][i] = x[b][2 i + j] for j = 0, 1, i < n: the two taps of a ConvTranspose1d(k = 2, s = 2) output gradient (models/TTSModel.py:309,314,
+ * backward), each then a dense (B, n) operand of a k = 1 weight gradient; amax: namax partial maxima of |x| per item. */
+int ssv_deinterleave2_amax(const float* x, long x_bs, float* out, int B, long n, float* amax, int namax, ssv_stream_t stream);
 
 /* ---- Conv1d (stride 1, kernel 1 or 3, dilated, "same" or causal zero padding) -------------------
  * Replaces nn.Conv1d as used at models/TTSModel.py:59,78 (highway), :115-117, :154-158, :203-214,

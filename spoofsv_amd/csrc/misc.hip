@@ -293,6 +293,64 @@ extern "C" int ssv_copy_rows(const float* src, long src_bs, float* dst, long dst
   return ssv_check_launch("copy_rows");
 }
 
+// ---- layout changes that also deliver the result's operand scale list (round 6: each replaced one torch copy kernel AND one ssv_absmax launch) ----
+// Teacher forcing (train/ordinary.py:226, train/adversarial_wasserstein_gp.py:277: torch.cat((zeros, mel[:, :, :-1]), -1)):
+// y(b, c, 0) = 0, y(b, c, t) = x(b, c, t - 1); amax[b * npb + i] = max |y| over the i-th of npb equal element ranges of item b (may be null).
+__global__ __launch_bounds__(256) void shift_right_amax_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ y, int T, long n,
+                                                               float* __restrict__ amax, int npb) {
+  __shared__ float sm[4];
+  const float* __restrict__ xb = x + (long)blockIdx.y * x_bs;
+  float* __restrict__ yb = y + (long)blockIdx.y * n;
+  const long piece = (n + npb - 1) / npb;
+  const long lo = (long)blockIdx.x * piece, hi = min(lo + piece, n);
+  float m = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = (i % T) ? xb[i - 1] : 0.f;
+    yb[i] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  m = ssv_wg_max<4>(m, sm);
+  if (amax && threadIdx.x == 0) amax[(long)blockIdx.y * npb + blockIdx.x] = m;
+}
+extern "C" int ssv_shift_right_amax(const float* x, long x_bs, float* y, int B, int C, int T, float* amax, int namax, ssv_stream_t stream) {
+  SSV_CHECK(x && y && B > 0 && B <= 65535 && C > 0 && T > 0 && namax > 0 && namax <= 65535, SSV_BAD_SHAPE, "shift_right_amax: bad argument");
+  hipLaunchKernelGGL(shift_right_amax_kernel, dim3(namax, B), dim3(256), 0, (hipStream_t)stream, x, x_bs, y, T, (long)C * T, amax, namax);
+  return ssv_check_launch("shift_right_amax");
+}
+// De-interleave: x (B items of 2 n floats, item stride x_bs) -> out[j][b][i] = x[b][2 i + j], j = 0, 1 (the two taps of the transposed
+// convolution's output gradient, models/TTSModel.py:309,314 backward); amax[b * npb + p] = max |x| over the p-th of npb equal PAIR ranges (may be null).
+__global__ __launch_bounds__(256) void deinterleave2_amax_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ out, long n, int B,
+                                                                 float* __restrict__ amax, int npb) {
+  __shared__ float sm[4];
+  const float* __restrict__ xb = x + (long)blockIdx.y * x_bs;
+  float* __restrict__ o0 = out + (long)blockIdx.y * n;
+  float* __restrict__ o1 = out + ((long)B + blockIdx.y) * n;
+  const long piece = (((n + npb - 1) / npb) + 1) & ~1L;            // pairs per workgroup, even: two pairs = one 16-byte load
+  const long lo = (long)blockIdx.x * piece, hi = min(lo + piece, n);
+  float m = 0.f;
+  const bool vec = ((((size_t)xb) & 15) == 0) && ((((size_t)o0) & 7) == 0) && ((((size_t)o1) & 7) == 0);
+  auto one = [&](long k) { const float a = xb[2 * k], c = xb[2 * k + 1]; o0[k] = a; o1[k] = c; m = fmaxf(m, fmaxf(fabsf(a), fabsf(c))); };
+  if (vec) {
+    long i = lo + 2L * threadIdx.x;                                 // (lo is even: 2 lo floats = a multiple of 16 bytes)
+    for (; i + 1 < hi; i += 512) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(xb + 2 * i);
+      *reinterpret_cast<float2*>(o0 + i) = make_float2(q[0], q[2]);
+      *reinterpret_cast<float2*>(o1 + i) = make_float2(q[1], q[3]);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(q[0]), fabsf(q[1])), fmaxf(fabsf(q[2]), fabsf(q[3]))));
+    }
+    if (i < hi) one(i);                                             // the odd last pair of the last range: exactly one thread arrives at i == hi - 1
+  } else {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) one(i);
+  }
+  m = ssv_wg_max<4>(m, sm);
+  if (amax && threadIdx.x == 0) amax[(long)blockIdx.y * npb + blockIdx.x] = m;
+}
+extern "C" int ssv_deinterleave2_amax(const float* x, long x_bs, float* out, int B, long n, float* amax, int namax, ssv_stream_t stream) {
+  SSV_CHECK(x && out && B > 0 && B <= 65535 && n > 0 && namax > 0 && namax <= 65535, SSV_BAD_SHAPE, "deinterleave2_amax: bad argument");
+  hipLaunchKernelGGL(deinterleave2_amax_kernel, dim3(namax, B), dim3(256), 0, (hipStream_t)stream, x, x_bs, out, n, B, amax, namax);
+  return ssv_check_launch("deinterleave2_amax");
+}
+
 // ---- text embedding ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int N, int E, int V) {

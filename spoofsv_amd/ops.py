@@ -100,6 +100,17 @@ def amax_of(x):
     return out               # NOT remembered on x: buffers that kernels update through raw pointers keep their version
 
 
+def shift_right(mel):
+    """Teacher-forcing input [0 | mel[:, :, :-1]] (train/ordinary.py:226) with its operand scale list as a by-product: ONE launch instead of
+    torch.cat's copy kernel plus an ``ssv_absmax`` launch at the audio encoder's first convolution.  No gradient (the input is data)."""
+    x, xbs = _act3(mel.detach(), "shift_right input")
+    B, C, T = x.shape
+    y = torch.empty((B, C, T), dtype=_F32, device=x.device)
+    amax = torch.empty((B, _AMAX_PIECES), dtype=_F32, device=x.device)
+    _lib.call("ssv_shift_right_amax", _p(x), xbs, _p(y), B, C, T, _p(amax), _AMAX_PIECES, _stream())
+    return _tag(y, amax)
+
+
 def _an(a):
     """(pointer, entries per item) of a scale list or (None, 0)."""
     return (None, 0) if a is None else (_p(a), a.shape[1])
@@ -152,6 +163,17 @@ class DeferredWgrad:
             self._side.synchronize()
         for slot in self.slots:
             slot[3] = False
+
+    def release_capture(self):
+        """The captured step that read this instance's frozen job tables has been dropped (its hipGraphs destroyed): the tables may be
+        rewritten by the next capture.  Call only when no replay of the old graphs can run any more (``TrainStep.release``)."""
+        if self._side is not None:
+            self._side.synchronize()
+        for slot in self.slots:
+            slot[3] = False
+            slot[5] = False
+        self.jobs = {}                 # (a capture that failed half way may have left its queue behind)
+        self.pending.clear()
 
     @staticmethod
     def accepts(B, Cin, Cout, L, k, nblk, params=()):
@@ -1056,11 +1078,19 @@ class DeconvK2S2Fn(torch.autograd.Function):
         # weight gradient of (dy' = x, x' = dy_j) and runs on the split-precision kernel; the entry is then told to skip dw.
         split = _lib.precision() >= 1 and B * L >= 256 and L >= 8 and dybs == Cout * 2 * L
         f16 = _f16()                      # the scale lists are read in the split-fp16 mode only
-        dy_am = amax_of(dy) if (split and f16) else None
+        dy_am = dyj = None
+        if split:
+            # the two taps de-interleaved, (2, B, Cout, L), by ONE kernel that also leaves dy's scale list (before: a torch copy kernel + ssv_absmax)
+            h = getattr(dy, "_ssv_amax", None)
+            have = h is not None and h[1] == dy._version and h[0].shape[0] == B and h[0].device == dy.device
+            dyj = torch.empty((2, B, Cout, L), dtype=_F32, device=x.device)
+            dy_am = h[0] if have else (torch.empty((B, 64), dtype=_F32, device=x.device) if f16 else None)
+            _lib.call("ssv_deinterleave2_amax", _p(dy), dybs, _p(dyj), B, Cout * L, None if (have or dy_am is None) else _p(dy_am), 64, _stream())
+            if not f16:
+                dy_am = None
         _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, *_an(dy_am), _p(x), xbs, _p(w), _p(dx), Cin * L, None if split else _p(dw), _p(db),
                   B, Cin, Cout, L, _p(ws), nb, _stream())
         if split:
-            dyj = dy.view(B, Cout, L, 2).permute(3, 0, 1, 2).contiguous()            # (2, B, Cout, L)
             x_am = amax_of(x) if f16 else None
             dwj = torch.empty((2, Cin, Cout), dtype=_F32, device=x.device)
             for j in range(2):

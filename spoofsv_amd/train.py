@@ -214,7 +214,9 @@ def synthetic_ssrn_batch(B, T=325, freq_bins=80, out_bins=513, seed=0, device=No
 
 def shift_right(mel_gt):
     """Teacher forcing input: [0 | mel[:, :, :-1]] (train/ordinary.py:226)."""
-    return torch.cat((torch.zeros_like(mel_gt[:, :, :1]), mel_gt[:, :, :-1]), dim=-1)
+    if mel_gt.is_cuda:          # one HIP launch that also leaves the result's operand scale list (ops.shift_right)
+        return ops.shift_right(mel_gt)
+    return torch.cat((torch.zeros_like(mel_gt[:, :, :1]), mel_gt[:, :, :-1]), dim=-1)          # host tensors (the tests' oracle inputs)
 
 
 # --------------------------------------------------------------------------------------------- DDP
@@ -650,9 +652,21 @@ class TrainStep:
         self.opt.step()
 
     def prepare(self):
+        """Warm up and capture (``graph=True``).  One-shot: a prepared step ignores further calls; to capture again -- other static
+        buffers, a graph invalidated by a freed pool -- call ``release()`` first."""
         self.stepper.prepare()
         if self.defer is not None:
             self.defer.finish_uploads()
+        return self
+
+    def release(self):
+        """Drop the captured hipGraphs (nothing may be replaying them) and free the batched weight gradients' frozen job tables for the
+        next ``prepare()``.  The step runs eagerly until then."""
+        torch.cuda.synchronize()
+        self.stepper.plan = None
+        self.stepper._graphs = []
+        if self.defer is not None:
+            self.defer.release_capture()
         return self
 
     def __call__(self, *batch):

@@ -449,3 +449,42 @@ def test_link_backward_in_one_launch_vs_float64_and_the_two_launch_form(B, Cin, 
         e2, e0 = float((a2 - ref).norm() / ref.norm()), float((a0 - ref).norm() / ref.norm())
         assert e2 < 3e-6 and e0 < 3e-6, (name, e2, e0)
         assert e2 < 2.0 * e0 + 2e-7, (name, e2, e0)
+
+
+@pytest.mark.parametrize("B,C,T", [(32, 80, 325), (3, 5, 7), (2, 1, 1), (1, 80, 1301)])
+def test_shift_right_kernel_matches_torch_cat_and_tags_its_scale_list(B, C, T):
+    """ops.shift_right (ssv_shift_right_amax) = torch.cat((zeros, mel[:, :, :-1]), -1) of train/ordinary.py:226, bit for bit, on dense and on
+    batch-strided inputs; the scale list it leaves has max |y| of every item as its maximum."""
+    from spoofsv_amd import ops, train
+    torch.manual_seed(B + T)
+    big = torch.randn(B, 2 * C, T, device="cuda")
+    for x in (big[:, :C].contiguous(), big[:, C:]):                        # dense, and items 2 C T apart
+        want = torch.cat((torch.zeros_like(x[:, :, :1]), x[:, :, :-1]), dim=-1)
+        got = train.shift_right(x)
+        assert torch.equal(got, want)
+        am = ops.amax_of(got)
+        assert am is got._ssv_amax[0] and torch.equal(am.max(dim=1).values, want.abs().amax(dim=(1, 2)))
+    cpu = train.shift_right(big[:, :C].cpu())                              # host tensors keep the torch expression
+    assert torch.equal(cpu, torch.cat((torch.zeros(B, C, 1), big[:, :C, :-1].cpu()), dim=-1))
+
+
+@pytest.mark.parametrize("B,n", [(32, 256 * 650), (3, 37), (2, 1), (5, 4096 + 3)])
+def test_deinterleave_kernel_matches_torch_and_delivers_the_scale_list(B, n):
+    """ssv_deinterleave2_amax: out[j][b][i] = x[b][2 i + j] and the partial maxima of |x| per item, against torch (dense and strided items,
+    odd pair counts, pieces that are not multiples of the vector width)."""
+    import ctypes
+    from spoofsv_amd import _lib
+    torch.manual_seed(n % 97)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    big = torch.randn(B, 2 * n + 6, device="cuda")
+    for x, bs in ((big[:, :2 * n].contiguous(), 2 * n), (big[:, 4:4 + 2 * n], 2 * n + 6), (big[:, 1:1 + 2 * n], 2 * n + 6)):      # the last: 4-byte aligned only
+        out = torch.full((2, B, n), float("nan"), device="cuda")
+        am = torch.full((B, 64), float("nan"), device="cuda")
+        _lib.call("ssv_deinterleave2_amax", P(x), bs, P(out), B, n, P(am), 64, st)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], x[:, 0::2]) and torch.equal(out[1], x[:, 1::2])
+        assert torch.equal(am.max(dim=1).values, x.abs().amax(dim=1))
+        _lib.call("ssv_deinterleave2_amax", P(x), bs, P(out), B, n, None, 64, st)           # without a list
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], x[:, 0::2])

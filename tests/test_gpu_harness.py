@@ -624,3 +624,55 @@ def test_integration_md_binding_snippet_runs_as_written():
     x = torch.randn(3, 32, 70, device="cuda:0")
     with torch.no_grad():
         assert torch.equal(doc(x), mine(x))
+
+
+@pytest.mark.gpu
+def test_captured_step_can_be_released_and_captured_again():
+    """TrainStep.prepare() is one-shot (a prepared step ignores further calls); release() drops the hipGraphs and frees the batched weight
+    gradients' frozen job tables (ops.DeferredWgrad.release_capture), after which the same step object captures and replays again with the
+    same results.  Without release(), forcing a second capture through the same DeferredWgrad is refused loudly."""
+    from spoofsv_amd import train
+    from spoofsv_amd.tts import SSRN
+    torch.manual_seed(3)
+    m = SSRN(80, 65, 32)
+    m.apply(train.init_weights)
+    m = m.to("cuda").train()
+    opt = train.FusedAdam(m.parameters(), 0.0, (0.5, 0.9), 1e-6, capturable=True)       # lr 0: every iteration sees the same weights
+    opt.refresh_resident_weights()
+    batch = train.synthetic_ssrn_batch(4, 40, out_bins=65, seed=0, device="cuda")
+    st = train.TrainStep("ssrn", m, opt, batch, None, None, graph=True, defer_wgrad=True).prepare()
+    first = [float(v) for v in st()]
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert st.prepare() is st and st.stepper.plan is not None                           # a second prepare() is a no-op
+    st.stepper.plan = None                                                              # forcing a re-capture without release(): refused
+    with pytest.raises(RuntimeError, match="frozen job tables"):
+        st.prepare()
+    torch.cuda.synchronize()
+    st.release().prepare()
+    again = [float(v) for v in st()]
+    torch.cuda.synchronize()
+    assert again == first
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, g1[k]), k
+
+
+@pytest.mark.gpu
+def test_input_grads_only_skips_the_critics_parameter_gradients():
+    """ops.input_grads_only(disc): inside the block the critic's twice-differentiable operators return no parameter gradients (the gradient
+    penalty's first pass and the generator iterations ask for the input gradient only) -- pinned here so that a future weight transform in
+    front of those operators (a contiguous copy, a cast: the match is by data_ptr) cannot silently bring the discarded GEMMs back."""
+    from spoofsv_amd import ops
+    from spoofsv_amd.critic import melDisc
+    torch.manual_seed(2)
+    d = melDisc(80, 32).to("cuda").eval()
+    x = torch.rand(3, 80, 40, device="cuda", requires_grad=True)
+    out = d(x)
+    with ops.input_grads_only(d):
+        out.sum().backward()
+    assert x.grad is not None and float(x.grad.abs().sum()) > 0
+    inside = {k: p.grad for k, p in d.named_parameters()}
+    assert all(g is None for g in inside.values()), [k for k, g in inside.items() if g is not None]
+    x2 = x.detach().clone().requires_grad_(True)
+    d(x2).sum().backward()                                                              # outside the block: every parameter gets its gradient
+    assert all(p.grad is not None for p in d.parameters())
+    assert torch.allclose(x2.grad, x.grad, rtol=1e-5, atol=1e-7)
