@@ -439,8 +439,11 @@ def pmc_traffic(mode):
     except Exception as e:
         return {"traffic": None, "traffic_source": "no PMC record (%s)" % type(e).__name__}
     h = hashlib.sha256()
-    for f in rec["sources"]:
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+    try:
+        for f in rec["sources"]:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+    except OSError as e:                       # a recorded source no longer exists (renamed / split): the record is stale by definition
+        return {"traffic": None, "traffic_source": "stale: %s (%s) since the PMC pass %s" % (os.path.basename(str(e.filename)), type(e).__name__, rec["profile"])}
     if h.hexdigest()[:16] != rec["sources_sha16"]:
         return {"traffic": None, "traffic_source": "stale: %s changed since the PMC pass %s" % (", ".join(rec["sources"]), rec["profile"])}
     return {"traffic": rec["traffic_bytes"], "traffic_corrected": rec.get("traffic_bytes_corrected"), "traffic_source": "%s (sources sha %s); %s" % (rec["profile"], rec["sources_sha16"], rec["note"])}

@@ -295,26 +295,27 @@ extern "C" int ssv_copy_rows(const float* src, long src_bs, float* dst, long dst
 
 // ---- layout changes that also deliver the result's operand scale list (round 6: each replaced one torch copy kernel AND one ssv_absmax launch) ----
 // Teacher forcing (train/ordinary.py:226, train/adversarial_wasserstein_gp.py:277: torch.cat((zeros, mel[:, :, :-1]), -1)):
-// y(b, c, 0) = 0, y(b, c, t) = x(b, c, t - 1); amax[b * npb + i] = max |y| over the i-th of npb equal element ranges of item b (may be null).
-__global__ __launch_bounds__(256) void shift_right_amax_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ y, int T, long n,
+// y(b, c, 0) = 0, y(b, c, t) = x(b, c, t - 1); amax[b * npb + i] = max |y| over the i-th of npb equal ROW ranges of item b (may be null; 0 for an empty range).
+__global__ __launch_bounds__(256) void shift_right_amax_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ y, int C, int T,
                                                                float* __restrict__ amax, int npb) {
   __shared__ float sm[4];
   const float* __restrict__ xb = x + (long)blockIdx.y * x_bs;
-  float* __restrict__ yb = y + (long)blockIdx.y * n;
-  const long piece = (n + npb - 1) / npb;
-  const long lo = (long)blockIdx.x * piece, hi = min(lo + piece, n);
+  float* __restrict__ yb = y + (long)blockIdx.y * C * T;
+  const int rows = (C + npb - 1) / npb;                             // a piece = a range of rows (any partition gives a valid list)
+  const int r0 = blockIdx.x * rows, r1 = min(r0 + rows, C);
   float m = 0.f;
-  for (long i = lo + threadIdx.x; i < hi; i += 256) {
-    const float v = (i % T) ? xb[i - 1] : 0.f;
-    yb[i] = v;
-    m = fmaxf(m, fabsf(v));
-  }
+  for (int r = r0; r < r1; ++r)
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float v = t ? xb[(long)r * T + t - 1] : 0.f;
+      yb[(long)r * T + t] = v;
+      m = fmaxf(m, fabsf(v));
+    }
   m = ssv_wg_max<4>(m, sm);
   if (amax && threadIdx.x == 0) amax[(long)blockIdx.y * npb + blockIdx.x] = m;
 }
 extern "C" int ssv_shift_right_amax(const float* x, long x_bs, float* y, int B, int C, int T, float* amax, int namax, ssv_stream_t stream) {
   SSV_CHECK(x && y && B > 0 && B <= 65535 && C > 0 && T > 0 && namax > 0 && namax <= 65535, SSV_BAD_SHAPE, "shift_right_amax: bad argument");
-  hipLaunchKernelGGL(shift_right_amax_kernel, dim3(namax, B), dim3(256), 0, (hipStream_t)stream, x, x_bs, y, T, (long)C * T, amax, namax);
+  hipLaunchKernelGGL(shift_right_amax_kernel, dim3(namax, B), dim3(256), 0, (hipStream_t)stream, x, x_bs, y, C, T, amax, namax);
   return ssv_check_launch("shift_right_amax");
 }
 // De-interleave: x (B items of 2 n floats, item stride x_bs) -> out[j][b][i] = x[b][2 i + j], j = 0, 1 (the two taps of the transposed

@@ -507,7 +507,8 @@ def adversarial_train(train_step, train_pattern, cfg, spec_dir=None, resume_chec
                                                 retain_graph=True, create_graph=True)[0]
                 loss_gp = torch.mean(cfg["LAMBDA"] * (torch.norm(grads, p=2, dim=(1, 2)) - 1) ** 2)
                 loss_gp.backward()
-                loss_D = torch.mean(disc(pred.detach()) - disc(gt.detach()))
+                disc_real = disc(gt.detach())                                         # the reference's call order: ground truth, then prediction (:313-314)
+                loss_D = torch.mean(disc(pred.detach()) - disc_real)
                 loss_D.backward()
                 opt_disc.step()
                 logs["loss_train_log_disc"].append(float(loss_D) + float(loss_gp))

@@ -106,8 +106,9 @@ def shift_right(mel):
     x, xbs = _act3(mel.detach(), "shift_right input")
     B, C, T = x.shape
     y = torch.empty((B, C, T), dtype=_F32, device=x.device)
-    amax = torch.empty((B, _AMAX_PIECES), dtype=_F32, device=x.device)
-    _lib.call("ssv_shift_right_amax", _p(x), xbs, _p(y), B, C, T, _p(amax), _AMAX_PIECES, _stream())
+    npb = min(C, 40)               # row ranges per item = workgroups per item (80 mel bins: two rows each; a launch of B * 40 small workgroups)
+    amax = torch.empty((B, npb), dtype=_F32, device=x.device)
+    _lib.call("ssv_shift_right_amax", _p(x), xbs, _p(y), B, C, T, _p(amax), npb, _stream())
     return _tag(y, amax)
 
 
