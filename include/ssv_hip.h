@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 6 (6 = ssv_shift_right_amax, ssv_deinterleave2_amax, GE2E training without shape / mode limits; 5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
+int ssv_version(void);            /* ABI version, currently 6 (6 = ssv_shift_right_amax, ssv_deinterleave2_amax, ssv_lstm_fwd_cached, GE2E training without shape / mode limits; 5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
                                     4 = compact partial rows: the nblk of a weight-gradient job is ssv_ln_bwd_partial_rows(...), not ssv_ln_partial_rows(B, L)) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -315,6 +315,12 @@ size_t ssv_lstm_fwd_workspace(int Bn, int T, int F, int H, int layers);
 int ssv_lstm_fwd(const float* x, const float* const* w_ih, const float* const* w_hh,
                  const float* const* b_ih, const float* const* b_hh, float* h_last,
                  int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream);
+/* The same forward for a caller that runs it again and again on FIXED weights (d-vector extraction, GE2E/dvector_create.py:100, batch after
+ * batch): weights_packed != 0 promises that `ws` is the buffer of an earlier call with the same shape, arithmetic mode and weight VALUES, not
+ * written by anyone since -- the call then skips the weights' scale scans and the split into fp16 / bf16 planes.  0 = ssv_lstm_fwd. */
+int ssv_lstm_fwd_cached(const float* x, const float* const* w_ih, const float* const* w_hh,
+                        const float* const* b_ih, const float* const* b_hh, float* h_last,
+                        int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, int weights_packed, ssv_stream_t stream);
 /* e = normalize(h W^T + b): h (Bn,H), w (P,H), e (Bn,P).  norms (Bn, may be NULL): |h W^T + b| per row, kept for the backward. */
 size_t ssv_proj_l2norm_fwd_workspace(int Bn, int P);
 int ssv_proj_l2norm_fwd(const float* h, const float* w, const float* bias, float* e, float* norms, int Bn, int H, int P,

@@ -1051,7 +1051,7 @@ extern "C" size_t ssv_lstm_fwd_workspace(int Bn, int T, int F, int H, int layers
 // Training (keep != null): every frame of h, c and the activated gates is kept in the caller's buffers (D = T instead of the 2-frame ring).
 static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                          const float* const* b_hh, float* h_last, int Bn, int T, int F, int H, int layers, char* base, hipStream_t st,
-                         float* keep_xt = nullptr, float* keep_hs = nullptr, float* keep_cs = nullptr, float* keep_gates = nullptr) {
+                         float* keep_xt = nullptr, float* keep_hs = nullptr, float* keep_cs = nullptr, float* keep_gates = nullptr, bool packed = false) {
   const LstmWave s = lstm_wave_ws(Bn, T, F, H, layers);
   const int D = keep_hs ? T : 2;
   float* xt = keep_xt ? keep_xt : (float*)(base + s.xt);
@@ -1061,7 +1061,10 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   float* bias = (float*)(base + s.bias);
   const long HN = (long)H * Bn;
   SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));    // [T][F][Bn]
-  for (int l = 0; l < layers; ++l) {                              // biases side by side: [layer][b_ih (4H) | b_hh (4H)]
+  // packed: the workspace still holds what a previous call of the same shape and arithmetic mode prepared from the SAME weight values -- bias
+  // rows, split weight planes, the weights' scale (ssv_lstm_fwd_cached: d-vector extraction runs batch after batch on fixed weights; the six
+  // absmax scans over 48 MB of weights and the six packs were ~0.35 ms of an 11.6 ms forward)
+  for (int l = 0; !packed && l < layers; ++l) {                   // biases side by side: [layer][b_ih (4H) | b_hh (4H)]
     SSV_HIP(hipMemcpyAsync(bias + (long)l * 8 * H, b_ih[l], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
     SSV_HIP(hipMemcpyAsync(bias + (long)l * 8 * H + 4 * H, b_hh[l], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
@@ -1076,21 +1079,25 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   float* aux = (float*)(base + s.aux);
   if (f16) {
     const int npb = 64 / (2 * layers);                            // partial maxima per weight matrix
-    SSV_HIP(hipMemsetAsync(aux, 0, LSTM_AUX_FLOATS * sizeof(float), st));
-    for (int l = 0; l < layers; ++l) {
-      SSV_TRY(ssv_launch_absmax(w_ih[l], 0, 1, (long)4 * H * (l == 0 ? F : H), aux + (2 * l) * npb, npb, st));
-      SSV_TRY(ssv_launch_absmax(w_hh[l], 0, 1, (long)4 * H * H, aux + (2 * l + 1) * npb, npb, st));
+    if (!packed) {
+      SSV_HIP(hipMemsetAsync(aux, 0, LSTM_AUX_FLOATS * sizeof(float), st));
+      for (int l = 0; l < layers; ++l) {
+        SSV_TRY(ssv_launch_absmax(w_ih[l], 0, 1, (long)4 * H * (l == 0 ? F : H), aux + (2 * l) * npb, npb, st));
+        SSV_TRY(ssv_launch_absmax(w_hh[l], 0, 1, (long)4 * H * H, aux + (2 * l + 1) * npb, npb, st));
+      }
     }
-    SSV_TRY(ssv_launch_absmax(xt, 0, 1, (long)T * F * Bn, aux + 128, 64, st));
+    SSV_TRY(ssv_launch_absmax(xt, 0, 1, (long)T * F * Bn, aux + 128, 64, st));       // (writes all 64 entries of the input's list)
   }
   auto pack = [&](const float* w, unsigned short* hi, unsigned short* lo, int K, int Kpad, int nch_total, int ch_off) -> int {
     if (f16) return ssv_launch_pack_split_f16_list(w, hi, lo, 4 * H, K, Kpad, 1, K, 1, 1, H, aux, 64, aux + 64, st, nch_total, ch_off);
     return ssv_launch_pack_split(w, hi, lo, 4 * H, K, Kpad, 1, K, 1, 1, H, st, nch_total, ch_off);
   };
-  SSV_TRY(pack(w_ih[0], ih0_hi, ih0_lo, F, pad32(F), 0, 0));
-  SSV_TRY(pack(w_hh[0], hh0_hi, hh0_lo, H, H, 0, 0));
+  if (!packed) {
+    SSV_TRY(pack(w_ih[0], ih0_hi, ih0_lo, F, pad32(F), 0, 0));
+    SSV_TRY(pack(w_hh[0], hh0_hi, hh0_lo, H, H, 0, 0));
+  }
   const int hch = H / 32;
-  for (int l = 1; l < layers; ++l) {
+  for (int l = 1; !packed && l < layers; ++l) {
     unsigned short* hi = (unsigned short*)(base + s.comb + (size_t)(l - 1) * s.comb_stride);
     unsigned short* lo = (unsigned short*)((char*)hi + split_bytes(4 * H, 2 * H, 1));
     SSV_TRY(pack(w_ih[l], hi, lo, H, H, 2 * hch, 0));
@@ -1156,9 +1163,20 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   return ssv_launch_transpose_out(out + ((long)(layers - 1) * D + (T - 1) % D) * H * Bn, h_last, H, Bn, st);
 }
 
+static int lstm_fwd_impl(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, float* h_last,
+                         int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream, bool packed);
 extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                             const float* const* b_hh, float* h_last, int Bn, int T, int F, int H, int layers,
                             void* ws, size_t ws_bytes, ssv_stream_t stream) {
+  return lstm_fwd_impl(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, ws, ws_bytes, stream, false);
+}
+extern "C" int ssv_lstm_fwd_cached(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                                   const float* const* b_hh, float* h_last, int Bn, int T, int F, int H, int layers,
+                                   void* ws, size_t ws_bytes, int weights_packed, ssv_stream_t stream) {
+  return lstm_fwd_impl(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, ws, ws_bytes, stream, weights_packed != 0);
+}
+static int lstm_fwd_impl(const float* x, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, float* h_last,
+                         int Bn, int T, int F, int H, int layers, void* ws, size_t ws_bytes, ssv_stream_t stream, bool packed) {
   SSV_CHECK(x && w_ih && w_hh && b_ih && b_hh && h_last && Bn > 0 && T > 0 && F > 0 && H > 0 && layers > 0, SSV_BAD_SHAPE, "lstm_fwd: bad argument");
   SSV_CHECK(T <= 65535, SSV_UNSUPPORTED, "lstm_fwd: T=%d exceeds grid.y", T);
   const LstmWs s = lstm_ws(Bn, T, F, H);
@@ -1167,7 +1185,8 @@ extern "C" int ssv_lstm_fwd(const float* x, const float* const* w_ih, const floa
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
   if (ssv_precision() >= 1 && lstm_wave_ok(Bn, H))
-    return lstm_fwd_wave(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, base, st);
+    return lstm_fwd_wave(x, w_ih, w_hh, b_ih, b_hh, h_last, Bn, T, F, H, layers, base, st, nullptr, nullptr, nullptr, nullptr, packed);
+  // (the layer-by-layer paths below re-pack per layer into ONE buffer: nothing to keep)
   float* xt = (float*)(base + s.xt);
   float* xp = (float*)(base + s.xp);
   float* seq[2] = {(float*)(base + s.seq0), (float*)(base + s.seq1)};

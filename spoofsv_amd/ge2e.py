@@ -27,6 +27,9 @@ def _ptr_array(tensors):
     return arr
 
 
+_FWD_CACHE = {}       # the last inference call's workspace and what it was prepared for (see _EmbedderFn.forward)
+
+
 class _EmbedderFn(torch.autograd.Function):
     """SpeechEmbedder.forward (speech_embedder_net.py:27-33) with its backward: LSTM stack -> last frame -> Linear -> x/|x|.
     Inputs: train flag (keep every frame for the backward), x, projection weight, projection bias, then per layer
@@ -48,9 +51,14 @@ class _EmbedderFn(torch.autograd.Function):
             ws = _ws(nb, x.device)
             _lib.call("ssv_lstm_train_fwd", _p(x), *args, _p(h_last), _p(saved), Bn, T, F, H, layers, _p(ws), nb, _stream())
         else:
+            # d-vector extraction runs batch after batch on fixed weights: the workspace (with the split weight planes and their scale) is kept
+            # between calls and re-used as long as shape, arithmetic mode, stream and every weight's (address, version) are the same
             nb = _lib.query("ssv_lstm_fwd_workspace", Bn, T, F, H, layers)
-            ws = _ws(nb, x.device)
-            _lib.call("ssv_lstm_fwd", _p(x), *args, _p(h_last), Bn, T, F, H, layers, _p(ws), nb, _stream())
+            key = (Bn, T, F, H, layers, _lib.precision(), x.device, _stream().value, tuple((t.data_ptr(), t._version) for t in lstm))
+            hit = _FWD_CACHE.get("key") == key
+            ws = _FWD_CACHE["ws"] if hit else _ws(nb, x.device)
+            _lib.call("ssv_lstm_fwd_cached", _p(x), *args, _p(h_last), Bn, T, F, H, layers, _p(ws), nb, 1 if hit else 0, _stream())
+            _FWD_CACHE["key"], _FWD_CACHE["ws"] = key, ws
         e = torch.empty((Bn, P), dtype=torch.float32, device=x.device)
         norms = torch.empty((Bn,), dtype=torch.float32, device=x.device) if train else None
         nb2 = _lib.query("ssv_proj_l2norm_fwd_workspace", Bn, P)

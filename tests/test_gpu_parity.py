@@ -376,6 +376,35 @@ def test_ge2e_embedder_wavefront_launch_forms_agree_with_the_oracle(mode):
     assert rel_err(eg, eo) < 2e-5 and rel_l2(eg, eo) < 2e-5, (mode, rel_err(eg, eo), rel_l2(eg, eo))
 
 
+def test_ge2e_embedder_reuses_packed_weights_until_a_weight_changes():
+    """d-vector extraction on fixed weights (GE2E/dvector_create.py:100): the second call of the same shape re-uses the split weight planes and
+    their scale in the kept workspace (ssv_lstm_fwd_cached) and returns the same bits; an in-place weight update is seen (version bump) and the
+    planes are rebuilt; a fresh module with the updated weights agrees."""
+    from spoofsv_amd import ge2e
+    from spoofsv_amd.ge2e import SpeechEmbedder
+    torch.manual_seed(6)
+    m = SpeechEmbedder(nmels=40, hidden=64, num_layer=3, proj=32).to(DEV).eval()
+    x = torch.randn(70, 9, 40, device=DEV)
+    ge2e._FWD_CACHE.clear()
+    e1 = m(x)
+    key1 = ge2e._FWD_CACHE["key"]
+    e2 = m(x)
+    assert ge2e._FWD_CACHE["key"] == key1 and torch.equal(e1, e2)            # a hit: same workspace, same result
+    e3 = m(2 * x)                                                            # other data, same weights: still a hit, new input scale
+    assert ge2e._FWD_CACHE["key"] == key1 and not torch.equal(e3, e1)
+    with torch.no_grad():
+        m.LSTM_stack.weight_hh_l1.mul_(1.25)
+    e4 = m(x)
+    assert ge2e._FWD_CACHE["key"] != key1 and not torch.equal(e4, e1)
+    fresh = SpeechEmbedder(nmels=40, hidden=64, num_layer=3, proj=32)
+    fresh.load_state_dict(m.state_dict())
+    ge2e._FWD_CACHE.clear()
+    assert torch.equal(fresh.to(DEV).eval()(x), e4)
+    with torch.no_grad():
+        eo = GO.speech_embedder(x.cpu(), {k: v.cpu() for k, v in m.state_dict().items()})
+    assert rel_err(e4, eo) < FWD_TOL, rel_err(e4, eo)
+
+
 def test_ge2e_loss_golden_and_known_answer():
     from spoofsv_amd.ge2e import GE2ELoss
     g = load("ge2e_loss.npz")
