@@ -60,3 +60,7 @@
 #ifndef SSV_PWLN_BK64
 #define SSV_PWLN_BK64 1      // (tuning builds: 0 = 32-channel chunks in gemm_pwln_kernel<4,4,..> with the staging by waves 0-3 after the chunk's MFMAs, as in round 5)
 #endif
+#ifndef SSV_NT3R_ABL
+#define SSV_NT3R_ABL 0       // (ablation builds only, results are garbage: bit 0 = the dH fragments of gemm_nt3r_kernel are not split, bit 1 = the input
+                             //  rows go into the ring unsplit -- bounds what the in-kernel splits cost under the ring, profiles/round6_nt3r_ablation.txt)
+#endif

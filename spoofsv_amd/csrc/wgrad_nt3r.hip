@@ -190,7 +190,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt3r_kernel(const GemmNT p, const
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (e >= 4 ? e + 12 : e) < nv ? v[e] : 0.f;      // (the second tuple holds steps 16 .. 19 of the lane's window)
         }
+#if SSV_NT3R_ABL & 1
+        (void)v;                                              // ablation build: the raw fp32 bits stand in for the hi / lo fragments (garbage values, same loads)
+#else
         split8p<F16>(v, as, AH[SET][i][s2], AL[SET][i][s2]);
+#endif
       }
   };
   auto loadX = [&](int b, int t0) __attribute__((always_inline)) {
@@ -218,8 +222,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt3r_kernel(const GemmNT p, const
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       unsigned h0, l0, h1, l1;
+#if SSV_NT3R_ABL & 2
+      h0 = __builtin_bit_cast(unsigned, v[0][i]); l0 = __builtin_bit_cast(unsigned, v[1][i]);      // ablation build: no split, same LDS stores
+      h1 = __builtin_bit_cast(unsigned, v[2][i]); l1 = __builtin_bit_cast(unsigned, v[3][i]);
+#else
       split_pair<F16>(v[0][i], v[1][i], xs, h0, l0);
       split_pair<F16>(v[2][i], v[3][i], xs, h1, l1);
+#endif
       ssv_lds_store2(a + i * ROWB, h0, h1);
       ssv_lds_store2(a + i * ROWB + PLANE, l0, l1);
       if (slot == 0 && tq < 8) {                             // rows 0 .. 31 again as rows 256 .. 287

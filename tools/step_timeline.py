@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""One replayed training step of a rocprofv3 kernel trace of bench.py in time order: start offset, duration, stream (queue), kernel, grid --
+to see which launches a small kernel sits between.   usage: step_timeline.py <trace dir>"""
+import csv, glob, re, sys
+d = sys.argv[1]
+hits = glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv")
+rows = list(csv.DictReader(open(hits[0])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_multi_kernel")]
+a, b = adam[-5], adam[-3]                               # Adam (model 2 of step n-2) .. Adam (model 2 of step n-1): one whole replayed step
+seg = rows[a + 1:b + 1]
+t0 = int(seg[0]["Start_Timestamp"])
+for r in seg:
+    k = re.sub(r"\(.*", "", re.sub(r"^void ", "", r["Kernel_Name"]))[:64]
+    print("%9.1f us  %7.1f us  q%-3s %-64s grid %sx%sx%s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+          r.get("Queue_Id", "?"), k, r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"), r.get("Grid_Size_Z", "?")))
