@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 6 (6 = ssv_shift_right_amax, ssv_deinterleave2_amax, ssv_lstm_fwd_cached, GE2E training without shape / mode limits; 5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
+int ssv_version(void);            /* ABI version, currently 7 (7 = ssv_spec_losses_fwd_bwd, ssv_deinterleave2_rows_amax; 6 = ssv_shift_right_amax, ssv_deinterleave2_amax, ssv_lstm_fwd_cached, GE2E training without shape / mode limits; 5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
                                     4 = compact partial rows: the nblk of a weight-gradient job is ssv_ln_bwd_partial_rows(...), not ssv_ln_partial_rows(B, L)) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -62,6 +62,11 @@ int ssv_shift_right_amax(const float* x, long x_bs, float* y, int B, int C, int 
 /* out[j][b][i] = x[b][2 i + j] for j = 0, 1, i < n: the two taps of a ConvTranspose1d(k = 2, s = 2) output gradient (models/TTSModel.py:309,314,
  * backward), each then a dense (B, n) operand of a k = 1 weight gradient; amax: namax partial maxima of |x| per item. */
 int ssv_deinterleave2_amax(const float* x, long x_bs, float* out, int B, long n, float* amax, int namax, ssv_stream_t stream);
+/* The same, row by row (ABI 7): out(b, 2 r + j, t) = x(b, r, 2 t + j), x (B, rows, 2 L) with items x_bs apart, out (B, 2 rows, L) dense.  A
+ * ConvTranspose1d(k = 2, s = 2) is the 1x1 convolution u = W2 x, W2 = w.view(Cin, 2 Cout), followed by y(b, o, 2 t + j) = u(b, 2 o + j, t): with its
+ * output gradient in this layout, dx is ONE ssv_conv1d_fwd of it with the weight w.view(Cin, 2 Cout, 1) and dw ONE ssv_conv1d_bwd_weight that lands in
+ * the weight's own (Cin, Cout, 2) layout (spoofsv_amd/ops.py, DeconvK2S2Fn.backward). */
+int ssv_deinterleave2_rows_amax(const float* x, long x_bs, float* out, int B, int rows, int L, float* amax, int namax, ssv_stream_t stream);
 
 /* ---- Conv1d (stride 1, kernel 1 or 3, dilated, "same" or causal zero padding) -------------------
  * Replaces nn.Conv1d as used at models/TTSModel.py:59,78 (highway), :115-117, :154-158, :203-214,
@@ -272,6 +277,11 @@ size_t ssv_spec_losses_workspace(long n);
 int ssv_spec_losses_fwd(const float* y, const float* gt, long n, float* out, void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* dy = gscale[0] * dl1/dy + gscale[1] * dbd/dy; gscale is a DEVICE pointer to 2 floats. */
 int ssv_spec_losses_bwd(const float* y, const float* gt, long n, const float* gscale, float* dy, ssv_stream_t stream);
+/* Both of the above in one pass over (y, gt) (ABI 7): `out` as ssv_spec_losses_fwd, `dy` as ssv_spec_losses_bwd for the gradient seed `gscale` (DEVICE pointer
+ * to 2 floats) that the caller will hand to the backward -- a trainer knows it before the forward runs (train/ordinary.py:237,253: loss.backward()
+ * seeds every term with 1).  The sums are taken in another order than ssv_spec_losses_fwd's (same value to fp32 rounding of a mean over n). */
+int ssv_spec_losses_fwd_bwd(const float* y, const float* gt, long n, const float* gscale, float* out, float* dy, void* ws, size_t ws_bytes,
+                            ssv_stream_t stream);
 /* Replaces train/ordinary.py:232-234: out[0] = sum(a * gaw[:N,:T]) / (B*N*T); gaw row stride gaw_T. */
 size_t ssv_guided_att_loss_workspace(int B, int N, int T);
 int ssv_guided_att_loss_fwd(const float* a, const float* gaw, int gaw_T, float* out, int B, int N, int T,

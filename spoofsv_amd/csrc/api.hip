@@ -105,7 +105,7 @@ extern "C" int ssv_get_precision(void) {
     return ssv_fail(SSV_UNSUPPORTED, "SSV_PRECISION=%s is not one of fp32|0, bf16x3|1, f16x2|2", getenv("SSV_PRECISION"));
   return ssv_precision();
 }
-extern "C" int ssv_version(void) { return 6; }
+extern "C" int ssv_version(void) { return 7; }
 extern "C" const char* ssv_arch(void) { return "gfx950"; }
 extern "C" const char* ssv_last_error(void) { return g_err; }
 

@@ -346,6 +346,37 @@ __global__ __launch_bounds__(256) void deinterleave2_amax_kernel(const float* __
   m = ssv_wg_max<4>(m, sm);
   if (amax && threadIdx.x == 0) amax[(long)blockIdx.y * npb + blockIdx.x] = m;
 }
+// The same split ROW by row (round 6): out(b, 2 r + j, t) = x(b, r, 2 t + j) -- the output gradient of a ConvTranspose1d(k = 2, s = 2) as the (B, 2 Cout, L)
+// output gradient of the 1x1 convolution it is (y(b, o, 2t + j) = u(b, 2o + j, t), u = W2 x, W2 = w.view(Cin, 2 Cout)): dx and dw are then ONE dense
+// k = 1 product each over 2 Cout channels instead of two per tap, and dw lands in the weight's own (Cin, Cout, 2) layout.
+__global__ __launch_bounds__(256) void deinterleave2_rows_amax_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ out, int rows, int L,
+                                                                      float* __restrict__ amax, int npb) {
+  __shared__ float sm[4];
+  const float* __restrict__ xb = x + (long)blockIdx.y * x_bs;
+  float* __restrict__ ob = out + (long)blockIdx.y * 2 * rows * L;
+  const long n = (long)rows * L;
+  const long piece = (n + npb - 1) / npb;
+  const long lo = (long)blockIdx.x * piece, hi = min(lo + piece, n);
+  const bool vec = (((size_t)xb) & 7) == 0;
+  float m = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const int r = (int)(i / L), t = (int)(i - (long)r * L);
+    float a, c;
+    if (vec) { const float2 v = *reinterpret_cast<const float2*>(xb + 2 * i); a = v.x; c = v.y; }
+    else { a = xb[2 * i]; c = xb[2 * i + 1]; }
+    ob[(long)(2 * r) * L + t] = a;
+    ob[(long)(2 * r + 1) * L + t] = c;
+    m = fmaxf(m, fmaxf(fabsf(a), fabsf(c)));
+  }
+  m = ssv_wg_max<4>(m, sm);
+  if (amax && threadIdx.x == 0) amax[(long)blockIdx.y * npb + blockIdx.x] = m;
+}
+extern "C" int ssv_deinterleave2_rows_amax(const float* x, long x_bs, float* out, int B, int rows, int L, float* amax, int namax, ssv_stream_t stream) {
+  SSV_CHECK(x && out && B > 0 && B <= 65535 && rows > 0 && L > 0 && namax > 0 && namax <= 65535 && (long)rows * L < (1L << 31), SSV_BAD_SHAPE,
+            "deinterleave2_rows_amax: bad argument");
+  hipLaunchKernelGGL(deinterleave2_rows_amax_kernel, dim3(namax, B), dim3(256), 0, (hipStream_t)stream, x, x_bs, out, rows, L, amax, namax);
+  return ssv_check_launch("deinterleave2_rows_amax");
+}
 extern "C" int ssv_deinterleave2_amax(const float* x, long x_bs, float* out, int B, long n, float* amax, int namax, ssv_stream_t stream) {
   SSV_CHECK(x && out && B > 0 && B <= 65535 && n > 0 && namax > 0 && namax <= 65535, SSV_BAD_SHAPE, "deinterleave2_amax: bad argument");
   hipLaunchKernelGGL(deinterleave2_amax_kernel, dim3(namax, B), dim3(256), 0, (hipStream_t)stream, x, x_bs, out, n, B, amax, namax);
@@ -466,6 +497,66 @@ extern "C" int ssv_spec_losses_fwd(const float* y, const float* gt, long n, floa
   const int nblk = (int)((n + 255) / 256 < LOSS_BLOCKS ? (n + 255) / 256 : LOSS_BLOCKS);
   hipLaunchKernelGGL(spec_loss_part_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, gt, n, (float*)ws);
   SSV_TRY(ssv_check_launch("spec_loss_part"));
+  hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, 2, 1.f / (float)n, out);
+  return ssv_check_launch("finish_sums");
+}
+// Forward and backward of the two spectrogram losses in ONE pass over (y, gt) (round 6): the partial sums of spec_loss_part_kernel and the dy of
+// spec_loss_bwd_kernel from the same 16-byte loads.  A training step knows the gradient of the loss vector before the forward runs (a constant seed),
+// and the two-kernel form read the 85 MB prediction and its target twice (67 + 46 us at (32, 513, 1300)); the forward kernel alone was bound by its two
+// logf per element, not by memory.  Same formulas and the same per-element arithmetic as the two kernels; the sums are taken in another order.
+__global__ __launch_bounds__(256) void spec_loss_fused_kernel(const float* __restrict__ y, const float* __restrict__ gt, long n, const float* __restrict__ gscale,
+                                                              float* __restrict__ dy, float* __restrict__ part) {
+  __shared__ float red[4];
+  const float inv = 1.f / (float)n, w1 = gscale[0] * inv, w2 = gscale[1] * inv;
+  float s1 = 0.f, s2 = 0.f;
+  auto one = [&](float a, float g, float& d) __attribute__((always_inline)) {
+    s1 += fabsf(g - a);
+    s2 += -g * logf(a + 1e-8f) - (1.f - g) * logf(1.f - a + 1e-8f);
+    const float df = a - g;
+    const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+    d = w1 * sgn + w2 * (-g / (a + 1e-8f) + (1.f - g) / (1.f - a + 1e-8f));
+  };
+  const long n4 = n >> 2;
+  const float4* __restrict__ y4 = reinterpret_cast<const float4*>(y);
+  const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gt);
+  float4* __restrict__ d4 = reinterpret_cast<float4*>(dy);
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {                 // two vectors of each operand in flight
+    const float4 a0 = y4[i], b0 = g4[i], a1 = y4[i + stride], b1 = g4[i + stride];
+    float4 d0, d1;
+    one(a0.x, b0.x, d0.x); one(a0.y, b0.y, d0.y); one(a0.z, b0.z, d0.z); one(a0.w, b0.w, d0.w);
+    one(a1.x, b1.x, d1.x); one(a1.y, b1.y, d1.y); one(a1.z, b1.z, d1.z); one(a1.w, b1.w, d1.w);
+    d4[i] = d0; d4[i + stride] = d1;
+  }
+  if (i < n4) {
+    const float4 a0 = y4[i], b0 = g4[i];
+    float4 d0;
+    one(a0.x, b0.x, d0.x); one(a0.y, b0.y, d0.y); one(a0.z, b0.z, d0.z); one(a0.w, b0.w, d0.w);
+    d4[i] = d0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {        // the last n % 4 elements
+    const long e = (n4 << 2) + threadIdx.x;
+    float d;
+    one(y[e], gt[e], d);
+    dy[e] = d;
+  }
+  s1 = block_sum256(s1, red);
+  s2 = block_sum256(s2, red);
+  if (threadIdx.x == 0) { part[blockIdx.x] = s1; part[gridDim.x + blockIdx.x] = s2; }
+}
+extern "C" int ssv_spec_losses_fwd_bwd(const float* y, const float* gt, long n, const float* gscale, float* out, float* dy, void* ws, size_t ws_bytes,
+                                       ssv_stream_t stream) {
+  SSV_CHECK(n > 0 && y && gt && gscale && out && dy, SSV_BAD_SHAPE, "spec_losses_fwd_bwd: bad argument (n=%ld)", n);
+  SSV_CHECK(ws && ws_bytes >= ssv_spec_losses_workspace(n), SSV_BAD_SHAPE, "spec_losses_fwd_bwd: workspace too small");
+  if ((((size_t)y | (size_t)gt | (size_t)dy) & 15) != 0) {      // 16-byte vectors need aligned tensors; otherwise the two passes
+    SSV_TRY(ssv_spec_losses_fwd(y, gt, n, out, ws, ws_bytes, stream));
+    return ssv_spec_losses_bwd(y, gt, n, gscale, dy, stream);
+  }
+  const long v = (n + 3) / 4;
+  const int nblk = (int)((v + 511) / 512 < LOSS_BLOCKS ? (v + 511) / 512 : LOSS_BLOCKS);
+  hipLaunchKernelGGL(spec_loss_fused_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, gt, n, gscale, dy, (float*)ws);
+  SSV_TRY(ssv_check_launch("spec_loss_fused"));
   hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, 2, 1.f / (float)n, out);
   return ssv_check_launch("finish_sums");
 }

@@ -1074,38 +1074,40 @@ class DeconvK2S2Fn(torch.autograd.Function):
         db = gradarena.grad_like(ctx.bias_ref)
         nb = _lib.query("ssv_deconv1d_k2s2_bwd_workspace", B, Cin, Cout)
         ws = _ws(nb, x.device)
-        # Weight gradient: dw[c, o, j] = sum_{b,t} x(b,c,t) dy(b,o,2t+j).  The entry's own product reads dy with stride 2, which only the
-        # exact-fp32 MFMA kernel takes (60 us per tap at C = 256, L = 650).  De-interleaved (one copy kernel), each tap is the k = 1 conv
-        # weight gradient of (dy' = x, x' = dy_j) and runs on the split-precision kernel; the entry is then told to skip dw.
+        # A ConvTranspose1d(k = 2, s = 2) is the 1x1 convolution u = W2 x, W2 = w.view(Cin, 2 Cout), followed by y(b, o, 2t + j) = u(b, 2o + j, t).  With
+        # dy de-interleaved row by row into du (B, 2 Cout, L) -- ONE kernel that also leaves the scale list -- the backward is that convolution's:
+        # dx = ONE forward 1x1 product of du with the weight w.view(Cin, 2 Cout, 1) (its planes are resident like any conv weight's), dw = ONE k = 1
+        # weight gradient over 2 Cout channels that lands in the weight's own (Cin, Cout, 2) layout, db = row sums of dy.  (Until round 6: two
+        # stride-2 data-gradient products behind a per-call weight scan + split, two weight gradients and a torch copy that permuted them.)
         split = _lib.precision() >= 1 and B * L >= 256 and L >= 8 and dybs == Cout * 2 * L
-        f16 = _f16()                      # the scale lists are read in the split-fp16 mode only
-        dy_am = dyj = None
         if split:
-            # the two taps de-interleaved, (2, B, Cout, L), by ONE kernel that also leaves dy's scale list (before: a torch copy kernel + ssv_absmax)
-            h = getattr(dy, "_ssv_amax", None)
-            have = h is not None and h[1] == dy._version and h[0].shape[0] == B and h[0].device == dy.device
-            dyj = torch.empty((2, B, Cout, L), dtype=_F32, device=x.device)
-            dy_am = h[0] if have else (torch.empty((B, 64), dtype=_F32, device=x.device) if f16 else None)
-            _lib.call("ssv_deinterleave2_amax", _p(dy), dybs, _p(dyj), B, Cout * L, None if (have or dy_am is None) else _p(dy_am), 64, _stream())
-            if not f16:
-                dy_am = None
-        _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, *_an(dy_am), _p(x), xbs, _p(w), _p(dx), Cin * L, None if split else _p(dw), _p(db),
-                  B, Cin, Cout, L, _p(ws), nb, _stream())
-        if split:
+            f16 = _f16()                  # the scale lists are read in the split-fp16 mode only
+            du = torch.empty((B, 2 * Cout, L), dtype=_F32, device=x.device)
+            du_am = torch.empty((B, 64), dtype=_F32, device=x.device) if f16 else None
+            _lib.call("ssv_deinterleave2_rows_amax", _p(dy), dybs, _p(du), B, Cout, L, _p(du_am), 64, _stream())
+            w2 = w.view(Cin, 2 * Cout, 1)
+            _conv_fwd(du, 2 * Cout * L, w2, None, None, dx, Cin * L, 1, 1, 0, du_am)
             x_am = amax_of(x) if f16 else None
-            dwj = torch.empty((2, Cin, Cout), dtype=_F32, device=x.device)
-            for j in range(2):
-                _conv_bwd_weight(x, xbs, dyj[j], Cout * L, (Cin, Cout, 1), 1, 1, 0, dwj[j].view(Cin, Cout, 1), x_am, dy_am)
-            dw.copy_(dwj.permute(1, 2, 0))
+            _conv_bwd_weight(x, xbs, du, 2 * Cout * L, (Cin, 2 * Cout, 1), 1, 1, 0, dw.view(Cin, 2 * Cout, 1), x_am, du_am)
+            rows = torch.empty((B, Cout), dtype=_F32, device=x.device)
+            _lib.call("ssv_rowsum", _p(dy), dybs, _p(rows), B, Cout, 2 * L, _stream())
+            _sum_over_batch(rows, B, Cout, out=db)
+            return dx, dw, db, None
+        _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, None, 0, _p(x), xbs, _p(w), _p(dx), Cin * L, _p(dw), _p(db),
+                  B, Cin, Cout, L, _p(ws), nb, _stream())
         return dx, dw, db, None
 
 
 # ------------------------------------------------------------------------------------------- losses
 class SpecLossFn(torch.autograd.Function):
-    """train/ordinary.py:230-231 / :249-250: returns a 2-vector (mean |gt - y|, binary divergence)."""
+    """train/ordinary.py:230-231 / :249-250: returns a 2-vector (mean |gt - y|, binary divergence).
+
+    ``seed``: the (2,) gradient vector the caller promises to seed this output's backward with (a training step knows it before the
+    forward runs: a constant).  Forward and backward then share ONE pass over (y, gt) (``ssv_spec_losses_fwd_bwd``) and the backward
+    hands out the stored dy -- provided it is really called with that tensor, unchanged; anything else takes the separate backward kernel."""
 
     @staticmethod
-    def forward(ctx, y, gt):
+    def forward(ctx, y, gt, seed=None):
         y, gt = _c(y), _c(gt)
         if y.shape != gt.shape:
             raise RuntimeError("spec loss: prediction %s vs target %s" % (tuple(y.shape), tuple(gt.shape)))
@@ -1113,17 +1115,29 @@ class SpecLossFn(torch.autograd.Function):
         out = torch.empty((2,), dtype=_F32, device=y.device)
         nb = _lib.query("ssv_spec_losses_workspace", n)
         ws = _ws(nb, y.device)
-        _lib.call("ssv_spec_losses_fwd", _p(y), _p(gt), n, _p(out), _p(ws), nb, _stream())
+        ctx.fused = None
+        if seed is not None and ctx.needs_input_grad[0]:
+            if seed.dtype != _F32 or seed.numel() != 2 or seed.device != y.device or not seed.is_contiguous():
+                raise RuntimeError("spec loss: the promised gradient seed must be a contiguous float32 2-vector on the prediction's device")
+            dy = torch.empty_like(y)
+            _lib.call("ssv_spec_losses_fwd_bwd", _p(y), _p(gt), n, _p(seed), _p(out), _p(dy), _p(ws), nb, _stream())
+            ctx.fused = (dy, seed.data_ptr(), seed._version)
+            ctx.seed_ref = seed
+        else:
+            _lib.call("ssv_spec_losses_fwd", _p(y), _p(gt), n, _p(out), _p(ws), nb, _stream())
         ctx.save_for_backward(y, gt)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         y, gt = ctx.saved_tensors
+        f = ctx.fused
+        if f is not None and gout.data_ptr() == f[1] and ctx.seed_ref._version == f[2] and gout.is_contiguous():
+            return f[0], None, None
         gout = _c(gout)
         dy = torch.empty_like(y)
         _lib.call("ssv_spec_losses_bwd", _p(y), _p(gt), y.numel(), _p(gout), _p(dy), _stream())
-        return dy, None
+        return dy, None, None
 
 
 class GuidedAttLossFn(torch.autograd.Function):
@@ -1205,11 +1219,11 @@ def spec_losses(y, gt):
     return out[0], out[1]
 
 
-def spec_losses_vec(y, gt):
+def spec_losses_vec(y, gt, seed=None):
     """(l1, binary divergence) as ONE 2-vector: a training step seeds its backward with a constant gradient vector for it instead of
     summing two selected scalars (each select's backward is a zeros + a scatter + an add of two 2-vectors: tiny launches in a row between
-    the end of the forward and the start of the backward)."""
-    return SpecLossFn.apply(y, gt)
+    the end of the forward and the start of the backward).  ``seed``: that vector, when the caller already has it (see SpecLossFn)."""
+    return SpecLossFn.apply(y, gt, seed)
 
 
 def guided_att_loss_vec(a, gaw):

@@ -47,7 +47,14 @@ def invalidate(params=None):
 
 
 def eligible(p):
-    return p.is_cuda and p.dtype == torch.float32 and p.dim() == 3 and p.shape[2] in (1, 3) and p.is_contiguous()
+    return p.is_cuda and p.dtype == torch.float32 and p.dim() == 3 and p.shape[2] in (1, 2, 3) and p.is_contiguous()
+
+
+def pack_shape(p):
+    """The (Cout, Cin, k) conv weight whose planes are kept for parameter ``p``: itself, or -- for the (Cin, Cout, 2) weight of a
+    ConvTranspose1d(k = 2, s = 2) -- the 1x1 weight ``p.view(Cin, 2 Cout, 1)`` that its data gradient is a forward convolution with
+    (ops.DeconvK2S2Fn.backward looks the planes up under that view: same address, same version counter)."""
+    return (p.shape[0], 2 * p.shape[1], 1) if p.shape[2] == 2 else tuple(p.shape)
 
 
 class ResidentWeights:
@@ -67,12 +74,12 @@ class ResidentWeights:
             _REG.pop(e.param.data_ptr(), None)
         n = len(self.params)
         dev = self.params[0].device
-        sizes = [int(_lib.query("ssv_conv_pack_bytes", p.shape[0], p.shape[1], p.shape[2])) for p in self.params]
+        sizes = [int(_lib.query("ssv_conv_pack_bytes", *pack_shape(p))) for p in self.params]
         self._planes = [torch.empty(s, dtype=torch.uint8, device=dev) for s in sizes]
         vp = ctypes.c_void_p
         w = (vp * n)(*[p.data_ptr() for p in self.params])
         pl = (vp * n)(*[t.data_ptr() for t in self._planes])
-        ci = lambda k: (ctypes.c_int * n)(*[p.shape[k] for p in self.params])
+        ci = lambda k: (ctypes.c_int * n)(*[pack_shape(p)[k] for p in self.params])
         jobs = (_lib.PackJob * (2 * n))()
         nblocks = _lib.lib().ssv_conv_pack_plan(n, w, pl, ci(0), ci(1), ci(2), jobs)
         if nblocks < 0:
@@ -86,7 +93,7 @@ class ResidentWeights:
         self._ws = torch.empty(max(self._ws_bytes, 256), dtype=torch.uint8, device=dev)      # the weights' partial maxima (split-fp16)
         for p, t in zip(self.params, self._planes):
             e = _Entry()
-            e.param, e.planes, e.version, e.shape, e.ptr = p, t, -1, tuple(p.shape), ctypes.c_void_p(t.data_ptr())
+            e.param, e.planes, e.version, e.shape, e.ptr = p, t, -1, pack_shape(p), ctypes.c_void_p(t.data_ptr())
             e.owner = self
             _REG[p.data_ptr()] = e
         self._key = key

@@ -616,19 +616,22 @@ class TrainStep:
         # The loss terms stay the vectors the loss kernels wrote -- (l1, bd) and (att) -- and the backward is seeded with CONSTANT gradient
         # vectors for them (made once, outside any capture): summing selected scalars put ~7 launches of a few microseconds each
         # (select backward: zeros + scatter, adds, the seed's fill) in a row between the forward's last kernel and the backward's first.
-        def seed(v):
-            key = (v.numel(), float(scale), v.device)
+        def seedvec(n, like):
+            key = (n, float(scale), like.device)
             g = self._seeds.get(key)
             if g is None:
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("TrainStep: run one eager iteration before capturing (the backward's seed vectors are made then)")
-                g = self._seeds[key] = torch.full((v.numel(),), float(scale), dtype=v.dtype, device=v.device)
-            return (v, g)
+                g = self._seeds[key] = torch.full((n,), float(scale), dtype=torch.float32, device=like.device)
+            return g
+
+        def seed(v):
+            return (v, seedvec(v.numel(), v))
         if self.kind == "text2mel":
             mel, text, spk = self.batch
             with _cuts_installed(self.model, self.cuts):
                 pred, att = self.model(shift_right(mel), text, spk)
-            lv, av = ops.spec_losses_vec(pred, mel), ops.guided_att_loss_vec(att, self.gaw)
+            lv, av = ops.spec_losses_vec(pred, mel, seedvec(2, pred)), ops.guided_att_loss_vec(att, self.gaw)
             lvd, avd = lv.detach(), av.detach()
             self.out, self.att = (lvd[0], lvd[1], avd[0]), att.detach()
             if "dec_in" in self.cuts.rec:
@@ -639,7 +642,7 @@ class TrainStep:
             mel, lin = self.batch
             with _cuts_installed(self.model, self.cuts):
                 pred = self.model(mel)
-            lv = ops.spec_losses_vec(pred, lin)
+            lv = ops.spec_losses_vec(pred, lin, seedvec(2, pred))          # (the seed is known: the loss's forward and backward share one pass)
             lvd = lv.detach()
             self.out = (lvd[0], lvd[1])
             segs = backward_segments(self.cuts, [seed(lv)], None, self.ddp, self.defer)

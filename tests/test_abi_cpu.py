@@ -28,7 +28,7 @@ def test_header_declares_expected_entry_points():
 
 def test_library_exports_every_declared_symbol():
     L = _lib.lib()                      # raises if a declared symbol is missing
-    assert L.ssv_version() == 6
+    assert L.ssv_version() == 7
     assert L.ssv_arch() == b"gfx950"
     # the default arithmetic is split-fp16 (2) unless SSV_PRECISION names another mode (strictly parsed: a typo is an error, see the test below)
     default = {"fp32": 0, "0": 0, "bf16x3": 1, "1": 1}.get(os.environ.get("SSV_PRECISION", ""), 2)

@@ -488,3 +488,58 @@ def test_deinterleave_kernel_matches_torch_and_delivers_the_scale_list(B, n):
         _lib.call("ssv_deinterleave2_amax", P(x), bs, P(out), B, n, None, 64, st)           # without a list
         torch.cuda.synchronize()
         assert torch.equal(out[0], x[:, 0::2])
+
+
+@pytest.mark.parametrize("shape", [(32, 513, 1300), (3, 7, 37), (2, 80, 325), (1, 1, 3)])
+def test_spectrogram_losses_forward_and_backward_in_one_pass_vs_float64_and_the_two_kernels(shape):
+    """ssv_spec_losses_fwd_bwd (round 6; train/ordinary.py:230-231, :249-250 and the dy of loss.backward(), :237,253): loss values and dy against
+    float64 and against the separate forward / backward kernels, at the SSRN loss's full size, on an element count that is no multiple of 4
+    (the kernel's 16-byte vectors have a tail), and with a backward that is NOT seeded with the promised tensor (must take the separate kernel)."""
+    from spoofsv_amd import ops
+    torch.manual_seed(5)
+    y = (torch.rand(shape) * 0.98 + 0.01)
+    gt = torch.rand(shape)
+    gt[..., 0] = y[..., 0]                                  # exact hits: the sign of (y - gt) is 0 there
+    seed = torch.tensor([0.7, 1.3], device=DEV)
+    yd, gd = y.double().requires_grad_(True), gt.double()
+    l1 = (gd - yd).abs().mean()
+    bd = (-gd * torch.log(yd + 1e-8) - (1.0 - gd) * torch.log(1.0 - yd + 1e-8)).mean()
+    (0.7 * l1 + 1.3 * bd).backward()
+    outs = {}
+    for form in ("fused", "separate", "other_seed"):
+        yg = y.to(DEV).requires_grad_(True)
+        lv = ops.spec_losses_vec(yg, gt.to(DEV), None if form == "separate" else seed)
+        lv.backward(seed.clone() if form == "other_seed" else seed)
+        torch.cuda.synchronize()
+        outs[form] = (lv.detach().double().cpu(), yg.grad.double().cpu())
+    for form, (lv, dy) in outs.items():
+        assert abs(float(lv[0]) - float(l1)) <= 2e-6 * float(l1), (form, float(lv[0]), float(l1))
+        assert abs(float(lv[1]) - float(bd)) <= 2e-6 * float(bd), (form, float(lv[1]), float(bd))
+        assert float((dy - yd.grad).abs().max() / yd.grad.abs().max()) <= 2e-6, form
+    # the same per-element formulas (hipcc contracts them differently in the two kernels: equal to rounding, not bit for bit)
+    assert float((outs["fused"][1] - outs["separate"][1]).abs().max()) <= 5e-7 * float(outs["separate"][1].abs().max())
+    assert torch.equal(outs["other_seed"][1], outs["separate"][1])       # not the promised seed tensor: the separate backward kernel ran
+
+
+@pytest.mark.parametrize("B,rows,L", [(32, 256, 650), (3, 5, 37), (2, 1, 1), (2, 7, 325)])
+def test_row_wise_deinterleave_kernel_matches_torch_and_delivers_the_scale_list(B, rows, L):
+    """ssv_deinterleave2_rows_amax: out(b, 2 r + j, t) = x(b, r, 2 t + j) and the partial maxima of |x| per item, against torch (dense and strided
+    items, odd row lengths, 4-byte aligned items)."""
+    import ctypes
+    from spoofsv_amd import _lib
+    torch.manual_seed(L)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    n = rows * 2 * L
+    big = torch.randn(B, n + 6, device="cuda")
+    for x, bs in ((big[:, :n].contiguous(), n), (big[:, 4:4 + n], n + 6), (big[:, 1:1 + n], n + 6)):
+        out = torch.full((B, 2 * rows, L), float("nan"), device="cuda")
+        am = torch.full((B, 64), float("nan"), device="cuda")
+        _lib.call("ssv_deinterleave2_rows_amax", P(x), bs, P(out), B, rows, L, P(am), 64, st)
+        torch.cuda.synchronize()
+        ref = x.reshape(B, rows, L, 2).permute(0, 1, 3, 2).reshape(B, 2 * rows, L)
+        assert torch.equal(out, ref)
+        assert torch.equal(am.max(dim=1).values, x.abs().amax(dim=1))
+        _lib.call("ssv_deinterleave2_rows_amax", P(x), bs, P(out), B, rows, L, None, 64, st)           # without a list
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)

@@ -506,8 +506,9 @@ def test_ge2e_backward_midsize_vs_oracle(precision):
 @pytest.mark.parametrize("B,C,L", [(32, 256, 325), (3, 64, 37), (2, 24, 9)])
 def test_deconv_k2s2_forward_backward_vs_float64_and_both_weight_gradient_routes(B, C, L, precision):
     """upsampling.deconv (models/TTSModel.py:309,314 = nn.ConvTranspose1d(C, C, 2, stride=2)) against torch's float64 conv_transpose1d
-    on the CPU: y, dx, dw, db.  In the split modes ops.py computes dw as two k = 1 conv weight gradients on de-interleaved dy and tells
-    ssv_deconv1d_k2s2_bwd to skip it (dw = NULL); the entry's own stride-2 product is checked beside it through the ABI."""
+    on the CPU: y, dx, dw, db.  In the split modes ops.py takes the backward of the 1x1 convolution the deconvolution is (dy de-interleaved
+    row by row: ONE data product with the weight viewed as (C, 2 C, 1) -- also from resident planes --, ONE weight gradient that lands in the
+    weight's layout); the entry ssv_deconv1d_k2s2_bwd, with and without dw, is checked beside it through the ABI."""
     from spoofsv_amd import ops, _lib
     torch.manual_seed(B + C + L)
     x0, w0, b0 = torch.randn(B, C, L), torch.randn(C, C, 2) * 0.05, torch.randn(C) * 0.1
@@ -521,6 +522,18 @@ def test_deconv_k2s2_forward_backward_vs_float64_and_both_weight_gradient_routes
     assert rel_l2(y, yr) < FWD_TOL
     for a, r, n in ((xg.grad, xr.grad, "dx"), (wg.grad, wr.grad, "dw"), (bg.grad, br.grad, "db")):
         assert rel_l2(a, r) < BWD_TOL, (n, rel_l2(a, r))
+    # the same backward with the weight's planes resident (what a training step runs): identical results
+    from spoofsv_amd import resident
+    rw = resident.ResidentWeights([wg])
+    rw.refresh(torch.cuda.current_stream().cuda_stream)
+    if precision != "fp32":
+        assert resident.lookup(wg.view(C, 2 * C, 1)) is not None
+    g1 = [t_.clone() for t_ in (xg.grad, wg.grad, bg.grad)]
+    xg.grad = wg.grad = bg.grad = None
+    ops.deconv1d_k2s2(xg, wg, bg).backward(g0.to(DEV))
+    for a, b_ in zip(g1, (xg.grad, wg.grad, bg.grad)):
+        assert torch.equal(a, b_)
+    resident.invalidate([wg])
     # the entry's own weight gradient (dw given) and its dx with dw = NULL
     dy = g0.to(DEV).contiguous()
     xd, wd = x0.to(DEV).contiguous(), w0.to(DEV).contiguous()

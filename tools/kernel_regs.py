@@ -6,7 +6,7 @@ txt = open(sys.argv[1]).read()
 for blk in txt.split("- .agpr_count:")[1:]:
     g = lambda k: (re.search(r"\.%s:\s+(\S+)" % k, blk) or [None, "?"])[1]
     name = g("name")
-    try: name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
+    try: name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
     except Exception: pass
     ag = re.match(r"\s*(\d+)", blk).group(1)
     print("%-48s vgpr %4s agpr %3s sgpr %3s lds %6s scratch %5s" % (name, g("vgpr_count"), ag, g("sgpr_count"), g("group_segment_fixed_size"), g("private_segment_fixed_size")))
