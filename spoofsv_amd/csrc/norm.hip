@@ -158,9 +158,6 @@ __global__ __launch_bounds__(16 * G) void ln_gate_fwd_kernel(
 // channels c0 + g, c0 + g + 16, ... as 16-byte accesses (256 contiguous bytes of a row per 16 lanes instead of 64 with the
 // 16-column tiles above), nothing is kept in registers across channels.
 typedef float f4ln __attribute__((ext_vector_type(4), aligned(4)));
-#ifndef SSV_LN_FWD_BATCH
-#define SSV_LN_FWD_BATCH 1     // (tuning builds: 0 = one channel per loop step in ln_gate_fwd_stream_kernel: load, compute, store)
-#endif
 __global__ __launch_bounds__(256) void ln_gate_fwd_stream_kernel(
     const float* __restrict__ H, const float* __restrict__ X, long x_bs, const float* __restrict__ cst,
     const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
@@ -206,41 +203,6 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_stream_kernel(
     float* __restrict__ Yb = Y + (long)b * y_bs + t;
     const bool full = t + 3 < L;
     const int cq4 = C >> 2, c0 = quarter * cq4;
-#if SSV_LN_FWD_BATCH
-    // Whole 16-byte columns: FOUR channels' loads in front of their four stores (round 6).  Loads and stores share the in-order vmcnt counter, so in the
-    // plain loop below (load, compute, store per channel) every channel's loads were waited for together with the store of the channel before it:
-    // C / 64 write round trips in a row per thread (tools/isa_store_waits.py).  Channels past the quarter's end are clamped and not stored.
-    if (full) {
-      const int cend = c0 + cq4;
-      for (int c = c0 + g; c < cend; c += 64) {
-        f4ln a[4], d[4], e[4];
-        float ga1[4], be1[4], ga2[4], be2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int cc = min(c + 16 * u, cend - 1);
-          const unsigned o = (unsigned)cc * (unsigned)L;
-          a[u] = *reinterpret_cast<const f4ln*>(H1 + o); d[u] = *reinterpret_cast<const f4ln*>(H2 + o); e[u] = *reinterpret_cast<const f4ln*>(Xb + o);
-          ga1[u] = g1[cc]; be1[u] = b1[cc]; ga2[u] = g2[cc]; be2[u] = b2[cc];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int cc = c + 16 * u;
-          float y[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float n1 = (a[u][j] - mu1[j]) * r1[j] * ga1[u] + be1[u];
-            const float n2 = (d[u][j] - mu2[j]) * r2[j] * ga2[u] + be2[u];
-            const float s = sigmoidf_(n1);
-            y[j] = s * n2 + (1.f - s) * e[u][j];
-          }
-          if (cc < cend) {
-            *reinterpret_cast<f4ln*>(Yb + (unsigned)cc * (unsigned)L) = (f4ln){y[0], y[1], y[2], y[3]};
-            am = fmaxf(fmaxf(am, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
-          }
-        }
-      }
-    } else
-#endif
 #pragma unroll 4
     for (int c = c0 + g; c < c0 + cq4; c += 16) {
       const unsigned o = (unsigned)c * (unsigned)L;
