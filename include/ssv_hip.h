@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 7 (7 = ssv_spec_losses_fwd_bwd, ssv_deinterleave2_rows_amax; 6 = ssv_shift_right_amax, ssv_deinterleave2_amax, ssv_lstm_fwd_cached, GE2E training without shape / mode limits; 5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
+int ssv_version(void);            /* ABI version, currently 7 (7 = ssv_spec_losses_fwd_bwd, ssv_deinterleave2_rows_amax, w_packed / y_amax of ssv_deconv1d_k2s2_fwd; 6 = ssv_shift_right_amax, ssv_deinterleave2_amax, ssv_lstm_fwd_cached, GE2E training without shape / mode limits; 5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
                                     4 = compact partial rows: the nblk of a weight-gradient job is ssv_ln_bwd_partial_rows(...), not ssv_ln_partial_rows(B, L)) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -259,9 +259,11 @@ int ssv_attention_apply(const float* v, long kv_bs, const float* a, int a_T, flo
 /* ---- ConvTranspose1d(kernel 2, stride 2) ----------------------------------------------------------
  * Replaces upsampling.deconv, models/TTSModel.py:309,314.  w: (Cin, Cout, 2) as nn.ConvTranspose1d.
  * y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t). */
-size_t ssv_deconv1d_k2s2_fwd_workspace(int Cin, int Cout);   /* pre-split weights of both taps */
-int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const float* bias, float* y, long y_bs,
-                          int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
+size_t ssv_deconv1d_k2s2_fwd_workspace(int Cin, int Cout);   /* pre-split weights (when no resident planes are given) */
+/* ABI 7: w_packed = the resident planes of the 1x1 weight w.view(Cin, 2 Cout, 1) (ssv_conv_pack_multi; NULL: split here) -- the forward is ONE product over
+ * 2 Cout rows whose epilogue interleaves the row pairs --, and y_amax (may be NULL) receives y's operand-scale list, y_namax entries per item. */
+int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
+                          float* y, long y_bs, float* y_amax, int y_namax, int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream);
 size_t ssv_deconv1d_k2s2_bwd_workspace(int B, int Cin, int Cout);
 /* dw may be NULL: the weight gradient is then left to the caller -- dw[:, :, j] is the k = 1 conv weight gradient of
  * (dy' = x, x' = dy[:, :, j::2]) and runs on the split-precision kernel through ssv_conv1d_bwd_weight once dy is de-interleaved,

@@ -223,6 +223,7 @@ static GemmNNB nnb_zero() {
   g.M = g.N = g.Kc = 0; g.KT = 1; g.B = 1;
   g.shift[0] = g.shift[1] = g.shift[2] = 0;
   g.sxn = g.scn = 1;
+  g.row_pair = 0; g.c_amax = nullptr; g.c_namax = 0;
   g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
   g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0; g.A0hi = g.A0lo = nullptr;
   g.gates_out = nullptr;
@@ -889,34 +890,52 @@ extern "C" int ssv_attention_train_bwd(const float* dr, long dr_bs, const float*
 // tap j is a k=1 product whose output (forward) or input (data gradient) columns have stride 2.
 static size_t deconv_pack_bytes(int rows, int K) { return 2 * split_bytes(rows, K, 2); }
 extern "C" size_t ssv_deconv1d_k2s2_fwd_workspace(int Cin, int Cout) { return deconv_pack_bytes(Cout, Cin) + conv_aux_bytes(); }
-extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const float* bias, float* y, long y_bs,
-                                     int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
+extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* x_amax, int x_namax, const float* w, const void* w_packed, const float* bias,
+                                     float* y, long y_bs, float* y_amax, int y_namax, int B, int Cin, int Cout, int L, void* ws, size_t ws_bytes, ssv_stream_t stream) {
   SSV_CHECK(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0, SSV_BAD_SHAPE, "deconv1d_k2s2_fwd: bad argument");
+  SSV_CHECK(!y_amax || y_namax > 0, SSV_BAD_SHAPE, "deconv1d_k2s2_fwd: scale list of %d entries", y_namax);
   hipStream_t st = (hipStream_t)stream;
   if (use_bf3(B, L, Cin, Cout)) {
+    // ONE product over 2 Cout rows (round 6): u = W2^T x with W2 = w.view(Cin, 2 Cout) -- row 2 o + j of u is tap j of output channel o -- whose
+    // epilogue interleaves row pairs into y(b, o, 2 t + j) (GemmNNB::row_pair).  The planes are the TRANSPOSED planes of the 1x1 weight
+    // w.view(Cin, 2 Cout, 1): resident ones when the caller keeps them (w_packed, ssv_conv_pack_multi), else split here.
+    // (Before: one stride-2 product per tap behind a per-call scan + split of the weight, and an ssv_absmax launch over y for the next layer.)
     SSV_CHECK(ws && ws_bytes >= ssv_deconv1d_k2s2_fwd_workspace(Cin, Cout), SSV_BAD_SHAPE, "deconv1d_k2s2_fwd: workspace too small");
-    const int Kpad = pad32(Cin);
-    const size_t tap = (size_t)((Cout + 15) / 16 * 16) * Kpad;                    // elements of one tap's plane
-    unsigned short* hi = (unsigned short*)ws;
-    unsigned short* lo = (unsigned short*)((char*)ws + split_bytes(Cout, Cin, 2));
+    const int M2 = 2 * Cout, Kpad = pad32(Cin);
     const bool f16 = use_f16();
     float* aux = (float*)((char*)ws + deconv_pack_bytes(Cout, Cin));
-    AmaxList xa = {nullptr, 0};
-    if (f16) {
-      SSV_TRY(ssv_launch_pack_split_f16(w, (long)Cin * Cout * 2, hi, lo, Cout, Cin, Kpad, 2, 2, (long)2 * Cout, 1, aux, st));
-      SSV_TRY(amax_of(x, x_bs, B, (long)Cin * L, x_amax, x_namax, aux + SSV_F16_AUX_FLOATS, &xa, st));
-    } else SSV_TRY(ssv_launch_pack_split(w, hi, lo, Cout, Cin, Kpad, 2, 2, (long)2 * Cout, 1, 0, st));   // (m=o, k=c, tap j) = w[c][o][j]
-    for (int j = 0; j < 2; ++j) {               // y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t)
-      GemmNNB g = nnb_zero();
-      if (f16) { g.f16 = 1; g.a_inv = aux + 64; g.x_amax = xa.p; g.x_namax = xa.n; g.x_amax_bs = xa.n; }
-      g.Ahi = hi + j * tap; g.Alo = lo + j * tap; g.Kpad = Kpad;
-      g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
-      g.C = y + j; g.scb = y_bs; g.scm = (long)2 * L; g.scn = 2;
-      g.bias = bias;
-      g.M = Cout; g.N = L; g.Kc = Cin; g.B = B;
-      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+    const unsigned short* hi; const unsigned short* lo; const float* a_inv = nullptr;
+    if (w_packed) {
+      hi = (const unsigned short*)((const char*)w_packed + 2 * split_bytes(Cin, M2, 1));       // behind the forward planes of the (Cin, 2 Cout, 1) weight
+      lo = (const unsigned short*)((const char*)hi + split_bytes(M2, Cin, 1));
+      if (f16) a_inv = packed_inv(w_packed, Cin, M2, 1, 1);
+    } else {
+      unsigned short* phi = (unsigned short*)ws;
+      unsigned short* plo = (unsigned short*)((char*)ws + split_bytes(M2, Cin, 1));
+      // (m = 2 o + j, k = c) = w[c][o][j] = w[c * 2 Cout + m]: row stride 1, column stride 2 Cout
+      if (f16) { SSV_TRY(ssv_launch_pack_split_f16(w, (long)Cin * M2, phi, plo, M2, Cin, Kpad, 1, 1, (long)M2, 1, aux, st)); a_inv = aux + 64; }
+      else SSV_TRY(ssv_launch_pack_split(w, phi, plo, M2, Cin, Kpad, 1, 1, (long)M2, 1, 0, st));
+      hi = phi; lo = plo;
     }
-    return 0;
+    GemmNNB g = nnb_zero();
+    if (f16) {
+      AmaxList xa = {nullptr, 0};
+      SSV_TRY(amax_of(x, x_bs, B, (long)Cin * L, x_amax, x_namax, aux + SSV_F16_AUX_FLOATS, &xa, st));
+      g.f16 = 1; g.a_inv = a_inv; g.x_amax = xa.p; g.x_namax = xa.n; g.x_amax_bs = xa.n;
+    }
+    g.Ahi = hi; g.Alo = lo; g.Kpad = Kpad;
+    g.X = x; g.sxb = x_bs; g.sxc = L; g.Lx = L;
+    g.C = y; g.scb = y_bs; g.scm = (long)2 * L; g.row_pair = 1;
+    g.bias = bias;
+    g.M = M2; g.N = L; g.Kc = Cin; g.B = B;
+    if (y_amax && f16) { g.c_amax = y_amax; g.c_namax = y_namax; }
+    const int rc = ssv_launch_gemm_nn_bf3(g, st);
+    if (rc == SSV_UNSUPPORTED && g.c_amax) {                   // more tiles per item than list entries: the product without the list, then a scan
+      g.c_amax = nullptr; g.c_namax = 0;
+      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
+      return ssv_launch_absmax(y, y_bs, B, (long)Cout * 2 * L, y_amax, y_namax, st);
+    }
+    return rc;
   }
   for (int j = 0; j < 2; ++j) {               // y(b,o,2t+j) = bias[o] + sum_c w[c,o,j] x(b,c,t)
     GemmNN g = nn_zero();
@@ -927,6 +946,7 @@ extern "C" int ssv_deconv1d_k2s2_fwd(const float* x, long x_bs, const float* x_a
     g.M = Cout; g.N = L; g.Kc = Cin; g.B = B;
     SSV_TRY(ssv_launch_gemm_nn(g, st));
   }
+  if (y_amax && use_f16()) return ssv_launch_absmax(y, y_bs, B, (long)Cout * 2 * L, y_amax, y_namax, st);
   return 0;
 }
 static int deconv_splits(int B, int Cin, int Cout) { return dw_splits(B, Cin, Cout, 1, SSV_NOMINAL_L); }     // (ssv_deconv1d_k2s2_bwd_workspace has no length)

@@ -382,6 +382,61 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
     }
     return;
   }
+  if constexpr (KT == 1 && EPI == 0) if (p.row_pair) {
+    // The transposed convolution's forward (ConvTranspose1d(k = 2, s = 2), GemmNNB::row_pair): rows 2 o and 2 o + 1 of the product are the even and
+    // the odd columns of output row o.  A wave parks its 16 x BN block as the other epilogues do and reads it back PAIRWISE: a 16-byte vector of
+    // output row o is two 8-byte pieces of the parked rows 2 o and 2 o + 1 -- 8 output rows of 2 BN contiguous floats per block, whole row pieces per
+    // store instruction (the two-launch form wrote every other float: each 128-byte line in two half-filled passes).
+    constexpr int LDW = BN + 4;
+    float* stage = reinterpret_cast<float*>(lds_all) + wave * 16 * LDW;
+    __shared__ float amx_rp[4];
+    __syncthreads();                                            // every wave is done reading the last chunk's image
+    float addv[WM][4];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gmc = min(m0 + wave * WM * 16 + i * 16 + kq * 4 + r, p.M - 1);
+        addv[i][r] = p.bias ? p.bias[gmc >> 1] : 0.f;
+      }
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int rbase = m0 + wave * WM * 16 + i * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) stage[(kq * 4 + r) * LDW + t * 16 + nq] = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + addv[i][r];
+#pragma unroll
+      for (int it = 0; it < NT; ++it) {
+        const int e = lane + 64 * it;                           // 16-byte vector index in the 8 x (2 BN) block of output rows
+        const int orow = e / (BN / 2), c2 = e % (BN / 2);       // the vector covers parked columns 2 c2, 2 c2 + 1 of rows 2 orow, 2 orow + 1
+        const float2 ev = *reinterpret_cast<const float2*>(stage + (2 * orow) * LDW + 2 * c2);
+        const float2 od = *reinterpret_cast<const float2*>(stage + (2 * orow + 1) * LDW + 2 * c2);
+        const int gm = rbase + 2 * orow, gn = n0 + 2 * c2;
+        if (gm < p.M && gn < p.N) {
+          float* dst = Cb + (long)(gm >> 1) * p.scm + 2 * gn;
+          if (gn + 1 < p.N) {
+            const f4u o = {ev.x, od.x, ev.y, od.y};
+            *reinterpret_cast<f4u*>(dst) = o;
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(ev.x), fabsf(od.x))), fmaxf(fabsf(ev.y), fabsf(od.y)));
+          } else {
+            dst[0] = ev.x; dst[1] = od.x;
+            am = fmaxf(am, fmaxf(fabsf(ev.x), fabsf(od.x)));
+          }
+        }
+      }
+    }
+    if (p.c_amax) {
+      am = ssv_wg_max<4>(am, amx_rp);
+      if (tid == 0) {
+        float* al = p.c_amax + (long)b * p.c_namax;
+        al[bxx] = am;
+        if (bxx == (int)gridDim.x - 1) for (int e = gridDim.x; e < p.c_namax; ++e) al[e] = 0.f;
+      }
+    }
+    return;
+  }
   if (p.scn == 1) {
     // Row-contiguous stores.  An MFMA accumulator holds 4 rows x 1 column per lane, so storing it directly writes 64-byte
     // pieces of 4 different rows per instruction (measured: the epilogue was 7.3 of 36.6 us at C = 256, L = 325).  The tile
@@ -820,6 +875,7 @@ static int launch_nnbw(const GemmNNB& g, hipStream_t st, int smin, int span) {
 template <int KT, int WM, int NT>
 static int launch_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   const int mtiles = ssv_cdiv(g.M, 64 * WM), ntiles = ssv_cdiv(g.N, 16 * NT);
+  SSV_CHECK(!g.c_amax || g.c_namax >= mtiles * ntiles, SSV_UNSUPPORTED, "gemm_nn_bf3: %d tiles per item, the output's scale list has %d entries", mtiles * ntiles, g.c_namax);
   if constexpr (KT == 1) {
     if (g.epi == 1) {
       if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<KT, WM, NT, 1, 1>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
@@ -855,7 +911,7 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
     // when M leaves a nearly empty last row tile (M = 513), where the 16-wave 128 x 448 tile loses less (round-1 sweep)
     // ... and only when the 128 x 192 tiling still gives every CU a workgroup: a single long utterance (the vocoder's DFT
     // at B = 1: 1026 x 1300 x 1024) is 27-56 wide tiles, a fifth of the chip; the cost model below then picks small tiles.
-    if (KT == 1 && !g.epi && !g.perm_h && !g.colstats && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256 &&
+    if (KT == 1 && !g.epi && !g.perm_h && !g.colstats && !g.row_pair && g.sxn == 1 && g.scn == 1 && g.N >= 1024 && g.M >= 256 && g.Kc >= 256 &&
         (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 192) * g.B >= 256)
     {
       // M = 128 j + 1 (SSRN's 513 channels): the last row beside the tiles of the 128 x 192 kernel (120.6 -> see DESIGN 4.6) instead of a fifth row tile
@@ -944,6 +1000,9 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
             SSV_UNSUPPORTED, "gemm_nn_bf3: a batch item's input or the weight planes span 2 GiB or more");
   SSV_CHECK(!g.f16 || (g.a_inv && ((g.x_amax && g.x_namax > 0) || (g.epi && g.x_namax == 0))), SSV_BAD_SHAPE, "gemm_nn_bf3: split-fp16 needs operand scales");
   SSV_CHECK(!g.colstats || (g.M % 64 == 0 && g.scn == 1 && !g.epi && !g.perm_h && !g.R), SSV_BAD_SHAPE, "gemm_nn_bf3: column statistics need M %% 64 == 0 and a plain epilogue");
+  SSV_CHECK(!g.row_pair || (g.KT == 1 && g.M % 2 == 0 && g.scn == 1 && !g.R && !g.epi && !g.perm_h && !g.colstats && !g.bias_b), SSV_BAD_SHAPE,
+            "gemm_nn_bf3: paired output rows need a plain k = 1 product over an even number of rows");
+  SSV_CHECK(g.row_pair || !g.c_amax, SSV_BAD_SHAPE, "gemm_nn_bf3: the output's scale list comes with paired output rows only");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
 }
 

@@ -65,6 +65,11 @@ struct GemmNNB {
   int M, N, Kc, KT, B;
   int shift[3];
   int sxn, scn;            // column strides of X and C (1 everywhere except the stride-2 deconvolution halves; R needs scn == 1)
+  // row_pair = 1 (round 6; the transposed convolution's forward in ONE product over 2 Cout rows): output row m, column n goes to
+  // C(b, m >> 1, 2 n + (m & 1)) -- scm is the stride of those M / 2 rows of 2 N floats -- and bias is indexed by m >> 1.  Plain k = 1 products only
+  // (M even, scn == 1, no R / LSTM / statistics).  c_amax != null: the launch also leaves the output's operand-scale list, c_namax entries per
+  // item at c_amax + b * c_namax: entry = the workgroup's tile (max |C| over it), the entries past the tiles zeroed by the item's last tile.
+  int row_pair; float* c_amax; int c_namax;
   // LSTM support.  perm_h = H > 0: output row m is gate (m % 4) of hidden unit (m / 4), i.e. row (m % 4) * H + m / 4 of
   // the torch layout -- the weights were packed in that order and the bias vectors are indexed through the same map.
   // epi = 1: fused cell epilogue -- the 4 accumulator rows of a lane are the (i, f, g, o) pre-activations of one unit;

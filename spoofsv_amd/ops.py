@@ -1046,7 +1046,7 @@ class DeconvK2S2Fn(torch.autograd.Function):
     """nn.ConvTranspose1d(C, C, kernel_size=2, stride=2), models/TTSModel.py:309,314."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, x_amax=None):
+    def forward(ctx, x, w, bias, x_amax=None, y_amax=None):
         x, xbs = _act3(x, "deconv input")
         B, Cin, L = x.shape
         w, bias = _c(w), _c(bias)
@@ -1056,7 +1056,10 @@ class DeconvK2S2Fn(torch.autograd.Function):
         y = torch.empty((B, Cout, 2 * L), dtype=_F32, device=x.device)
         nb = _lib.query("ssv_deconv1d_k2s2_fwd_workspace", Cin, Cout)
         ws = _ws(nb, x.device)
-        _lib.call("ssv_deconv1d_k2s2_fwd", _p(x), xbs, *_an(x_amax), _p(w), _p(bias), _p(y), Cout * 2 * L, B, Cin, Cout, L, _p(ws), nb, _stream())
+        # one product over 2 Cout rows on the planes of the 1x1 weight w.view(Cin, 2 Cout, 1) (resident when an optimizer keeps them), which also leaves
+        # y's operand-scale list (y_amax, (B, 64)) for the highway layer that follows (before: two stride-2 products, a per-call weight split, an ssv_absmax over y)
+        _lib.call("ssv_deconv1d_k2s2_fwd", _p(x), xbs, *_an(x_amax), _p(w), resident.lookup(w.view(Cin, 2 * Cout, 1)), _p(bias), _p(y), Cout * 2 * L,
+                  _p(y_amax), 64, B, Cin, Cout, L, _p(ws), nb, _stream())
         if _needs_grad(ctx):
             ctx.save_for_backward(x, w)
             ctx.bias_ref = bias
@@ -1092,10 +1095,10 @@ class DeconvK2S2Fn(torch.autograd.Function):
             rows = torch.empty((B, Cout), dtype=_F32, device=x.device)
             _lib.call("ssv_rowsum", _p(dy), dybs, _p(rows), B, Cout, 2 * L, _stream())
             _sum_over_batch(rows, B, Cout, out=db)
-            return dx, dw, db, None
+            return dx, dw, db, None, None
         _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, None, 0, _p(x), xbs, _p(w), _p(dx), Cin * L, _p(dw), _p(db),
                   B, Cin, Cout, L, _p(ws), nb, _stream())
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 # ------------------------------------------------------------------------------------------- losses
@@ -1211,7 +1214,8 @@ def attention_train(kv, q):
 def deconv1d_k2s2(x, w, bias):
     if not (_f16() and _bf3_shape(x)):
         return DeconvK2S2Fn.apply(x, w, bias)
-    return DeconvK2S2Fn.apply(x, w, bias, amax_of(x))
+    ya = torch.empty((x.shape[0], 64), dtype=_F32, device=x.device)
+    return _tag(DeconvK2S2Fn.apply(x, w, bias, amax_of(x), ya), ya)
 
 
 def spec_losses(y, gt):
