@@ -1063,6 +1063,7 @@ class DeconvK2S2Fn(torch.autograd.Function):
         if _needs_grad(ctx):
             ctx.save_for_backward(x, w)
             ctx.bias_ref = bias
+            ctx.x_amax = x_amax           # (a saved tensor comes back without its Python attributes: the list travels beside it)
         return y
 
     @staticmethod
@@ -1090,7 +1091,7 @@ class DeconvK2S2Fn(torch.autograd.Function):
             _lib.call("ssv_deinterleave2_rows_amax", _p(dy), dybs, _p(du), B, Cout, L, _p(du_am), 64, _stream())
             w2 = w.view(Cin, 2 * Cout, 1)
             _conv_fwd(du, 2 * Cout * L, w2, None, None, dx, Cin * L, 1, 1, 0, du_am)
-            x_am = amax_of(x) if f16 else None
+            x_am = (ctx.x_amax if ctx.x_amax is not None else amax_of(x)) if f16 else None
             _conv_bwd_weight(x, xbs, du, 2 * Cout * L, (Cin, 2 * Cout, 1), 1, 1, 0, dw.view(Cin, 2 * Cout, 1), x_am, du_am)
             rows = torch.empty((B, Cout), dtype=_F32, device=x.device)
             _lib.call("ssv_rowsum", _p(dy), dybs, _p(rows), B, Cout, 2 * L, _stream())
