@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ssv_stream_t; /* hipStream_t */
 
-int ssv_version(void);            /* ABI version, currently 7 (7 = ssv_spec_losses_fwd_bwd, ssv_deinterleave2_rows_amax, w_packed / y_amax of ssv_deconv1d_k2s2_fwd; 6 = ssv_shift_right_amax, ssv_deinterleave2_amax, ssv_lstm_fwd_cached, GE2E training without shape / mode limits; 5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
+int ssv_version(void);            /* ABI version, currently 7 (7 = ssv_spec_losses_fwd_bwd, ssv_deinterleave2_rows_amax, w_packed / y_amax of ssv_deconv1d_k2s2_fwd, ssv_bias_grad; 6 = ssv_shift_right_amax, ssv_deinterleave2_amax, ssv_lstm_fwd_cached, GE2E training without shape / mode limits; 5 = ssv_attention_train_fwd_rq; 2 = split-fp16 operand scales; 3 = max_shift of ssv_conv1d_bwd_weight_multi, ssv_pointwise_conv_ln_act_fwd;
                                     4 = compact partial rows: the nblk of a weight-gradient job is ssv_ln_bwd_partial_rows(...), not ssv_ln_partial_rows(B, L)) */
 const char* ssv_arch(void);       /* "gfx950" */
 const char* ssv_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -99,6 +99,8 @@ int ssv_conv1d_bwd_weight(const float* dy, long dy_bs, const float* dy_amax, int
                           void* ws, size_t ws_bytes, ssv_stream_t stream);
 /* out(b,c) = sum_t x(b,c,t): gradient of a (B,C,1) broadcast term / of a bias per batch item. */
 int ssv_rowsum(const float* x, long x_bs, float* out, int B, int C, int L, ssv_stream_t stream);
+/* out(c) = sum_{b,t} x(b,c,t): the bias gradient of a conv layer in one launch (ABI 7; ssv_rowsum + ssv_sum_slabs before), fixed summation order. */
+int ssv_bias_grad(const float* x, long x_bs, float* out, int B, int C, int L, ssv_stream_t stream);
 /* out[i] = sum_{z<Z} slabs[z*stride + i], i < n, summed in index order (bitwise reproducible). */
 int ssv_sum_slabs(const float* slabs, float* out, long n, int Z, long stride, ssv_stream_t stream);
 /* dst(b, 0:n) = src(b, 0:n) for B rows with independent row strides (the Q half of torch.cat((R, Q), 1),

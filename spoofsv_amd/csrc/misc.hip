@@ -279,6 +279,32 @@ extern "C" int ssv_rowsum(const float* x, long x_bs, float* out, int B, int C, i
   return ssv_check_launch("rowsum");
 }
 
+__device__ __forceinline__ float block_sum256(float v, float* red);        // (defined with the loss kernels below)
+// ---- out(c) = sum_{b,t} x(b,c,t): a conv layer's bias gradient in ONE launch (round 6; before: ssv_rowsum + ssv_sum_slabs) -------------------
+// One workgroup per channel; thread i adds the elements (b, t) with b * L + t = i, i + 256, ... in that order (four loads in flight), then the 256
+// partial sums are added in a fixed tree: bitwise reproducible, no atomics.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ out, int B, int C, int L) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const float* __restrict__ p = x + (long)c * L;
+  const long n = (long)B * L;
+  float s = 0.f;
+  long i = threadIdx.x;
+  auto at = [&](long k) { const int b = (int)(k / L); return p[(long)b * x_bs + (k - (long)b * L)]; };
+  for (; i + 768 < n; i += 1024) {
+    const float v0 = at(i), v1 = at(i + 256), v2 = at(i + 512), v3 = at(i + 768);
+    s += v0; s += v1; s += v2; s += v3;
+  }
+  for (; i < n; i += 256) s += at(i);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) out[c] = s;
+}
+extern "C" int ssv_bias_grad(const float* x, long x_bs, float* out, int B, int C, int L, ssv_stream_t stream) {
+  SSV_CHECK(x && out && B > 0 && C > 0 && L > 0, SSV_BAD_SHAPE, "bias_grad: bad shape B=%d C=%d L=%d", B, C, L);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, x_bs, out, B, C, L);
+  return ssv_check_launch("bias_grad");
+}
+
 extern "C" int ssv_sum_slabs(const float* slabs, float* out, long n, int Z, long stride, ssv_stream_t stream) {
   SSV_CHECK(slabs && out && n > 0 && Z > 0, SSV_BAD_SHAPE, "sum_slabs: bad argument n=%ld Z=%d", n, Z);
   return ssv_launch_reduce_slabs(slabs, out, n, Z, stride, (hipStream_t)stream);

@@ -484,9 +484,10 @@ class Conv1dFn(torch.autograd.Function):
         dw = _conv_bwd_weight(dy, dybs, x, xbs, tuple(w.shape), k, dilation, causal, out=gradarena.view(w), dy_amax=dy_amax, x_amax=ctx.x_amax)
         db = None
         if has_bias:
-            rows = torch.empty((B, Cout), dtype=_F32, device=x.device)
-            _lib.call("ssv_rowsum", _p(dy), dybs, _p(rows), B, Cout, L, _stream())
-            db = _sum_over_batch(rows, B, Cout, out=gradarena.view(ctx.bias_ref))
+            db = gradarena.view(ctx.bias_ref)
+            if db is None:
+                db = torch.empty((Cout,), dtype=_F32, device=x.device)
+            _lib.call("ssv_bias_grad", _p(dy), dybs, _p(db), B, Cout, L, _stream())
         return dx, dw, db, None, None, None, None
 
 
@@ -1093,9 +1094,7 @@ class DeconvK2S2Fn(torch.autograd.Function):
             _conv_fwd(du, 2 * Cout * L, w2, None, None, dx, Cin * L, 1, 1, 0, du_am)
             x_am = (ctx.x_amax if ctx.x_amax is not None else amax_of(x)) if f16 else None
             _conv_bwd_weight(x, xbs, du, 2 * Cout * L, (Cin, 2 * Cout, 1), 1, 1, 0, dw.view(Cin, 2 * Cout, 1), x_am, du_am)
-            rows = torch.empty((B, Cout), dtype=_F32, device=x.device)
-            _lib.call("ssv_rowsum", _p(dy), dybs, _p(rows), B, Cout, 2 * L, _stream())
-            _sum_over_batch(rows, B, Cout, out=db)
+            _lib.call("ssv_bias_grad", _p(dy), dybs, _p(db), B, Cout, 2 * L, _stream())
             return dx, dw, db, None, None
         _lib.call("ssv_deconv1d_k2s2_bwd", _p(dy), dybs, None, 0, _p(x), xbs, _p(w), _p(dx), Cin * L, _p(dw), _p(db),
                   B, Cin, Cout, L, _p(ws), nb, _stream())

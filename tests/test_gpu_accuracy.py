@@ -543,3 +543,22 @@ def test_row_wise_deinterleave_kernel_matches_torch_and_delivers_the_scale_list(
         _lib.call("ssv_deinterleave2_rows_amax", P(x), bs, P(out), B, rows, L, None, 64, st)           # without a list
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("B,C,L", [(32, 513, 1300), (32, 80, 325), (3, 5, 7), (2, 1, 1), (5, 33, 1030)])
+def test_bias_gradient_kernel_matches_float64_for_dense_and_strided_items(B, C, L):
+    """ssv_bias_grad: out(c) = sum over (b, t) of x(b, c, t) in one launch (the bias gradient of nn.Conv1d / nn.ConvTranspose1d under
+    loss.backward(), train/ordinary.py:237), items a stride apart, against float64."""
+    import ctypes
+    from spoofsv_amd import _lib
+    torch.manual_seed(C + L)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    big = torch.randn(B, C * L + 5, device="cuda")
+    for x, bs in ((big[:, :C * L].contiguous(), C * L), (big[:, 3:3 + C * L], C * L + 5)):
+        out = torch.full((C,), float("nan"), device="cuda")
+        _lib.call("ssv_bias_grad", P(x), bs, P(out), B, C, L, st)
+        torch.cuda.synchronize()
+        ref = x.double().reshape(B, C, L).sum(dim=(0, 2))
+        scale = x.double().reshape(B, C, L).abs().sum(dim=(0, 2))
+        assert float(((out.double() - ref).abs() / scale).max()) < 2e-7

@@ -503,7 +503,7 @@ def test_ge2e_backward_midsize_vs_oracle(precision):
         assert rel_err(p.grad, sd[k].grad) < 2e-3, (k, rel_err(p.grad, sd[k].grad))
 
 
-@pytest.mark.parametrize("B,C,L", [(32, 256, 325), (3, 64, 37), (2, 24, 9)])
+@pytest.mark.parametrize("B,C,L", [(32, 256, 325), (3, 64, 37), (2, 24, 9), (6, 72, 45), (5, 40, 200), (2, 256, 650)])      # (the last three: ragged row / column tiles of the one-product forward)
 def test_deconv_k2s2_forward_backward_vs_float64_and_both_weight_gradient_routes(B, C, L, precision):
     """upsampling.deconv (models/TTSModel.py:309,314 = nn.ConvTranspose1d(C, C, 2, stride=2)) against torch's float64 conv_transpose1d
     on the CPU: y, dx, dw, db.  In the split modes ops.py takes the backward of the 1x1 convolution the deconvolution is (dy de-interleaved
