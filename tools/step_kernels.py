@@ -13,6 +13,8 @@ for a, b in zip(adam[:-2:2], adam[2::2]):
     if len(seg) >= 200:
         steps.append(seg)
 steps = steps[len(steps) // 2:]            # the replayed ones
+med = sorted(len(sg) for sg in steps)[len(steps) // 2]
+steps = [sg for sg in steps if len(sg) == med]      # whole steps only (a pair of Adam launches can also straddle two phases of the benchmark)
 n = len(steps)
 cnt, tot, torch_k = collections.Counter(), collections.Counter(), collections.Counter()
 for seg in steps:
