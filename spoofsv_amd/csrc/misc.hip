@@ -281,7 +281,7 @@ extern "C" int ssv_rowsum(const float* x, long x_bs, float* out, int B, int C, i
 
 __device__ __forceinline__ float block_sum256(float v, float* red);        // (defined with the loss kernels below)
 // ---- out(c) = sum_{b,t} x(b,c,t): a conv layer's bias gradient in ONE launch (round 6; before: ssv_rowsum + ssv_sum_slabs) -------------------
-// One workgroup per channel; thread i adds the elements (b, t) with b * L + t = i, i + 256, ... in that order (four loads in flight), then the 256
+// One workgroup per channel; thread i adds the elements (b, t) with b * L + t = i, i + 256, ... in that order (eight loads in flight), then the 256
 // partial sums are added in a fixed tree: bitwise reproducible, no atomics.
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ out, int B, int C, int L) {
   __shared__ float red[4];
@@ -291,9 +291,12 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
   float s = 0.f;
   long i = threadIdx.x;
   auto at = [&](long k) { const int b = (int)(k / L); return p[(long)b * x_bs + (k - (long)b * L)]; };
-  for (; i + 768 < n; i += 1024) {
-    const float v0 = at(i), v1 = at(i + 256), v2 = at(i + 512), v3 = at(i + 768);
-    s += v0; s += v1; s += v2; s += v3;
+  for (; i + 1792 < n; i += 2048) {                          // eight loads in flight (a channel's B x L values are one workgroup's: 40-160 per thread)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = at(i + 256 * u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
   }
   for (; i < n; i += 256) s += at(i);
   s = block_sum256(s, red);
