@@ -17,7 +17,8 @@ def test_header_declares_expected_entry_points():
             "ssv_text_embed_fwd", "ssv_text_embed_bwd", "ssv_attention_train_fwd", "ssv_attention_train_bwd",
             "ssv_attention_step", "ssv_attention_apply", "ssv_deconv1d_k2s2_fwd", "ssv_deconv1d_k2s2_bwd",
             "ssv_spec_losses_fwd", "ssv_spec_losses_bwd", "ssv_guided_att_loss_fwd", "ssv_guided_att_loss_bwd",
-            "ssv_adam_multi", "ssv_lstm_fwd", "ssv_proj_l2norm_fwd", "ssv_ge2e_loss_fwd"]
+            "ssv_adam_multi", "ssv_lstm_fwd", "ssv_proj_l2norm_fwd", "ssv_ge2e_loss_fwd",
+            "ssv_spec_losses_fwd_bwd", "ssv_deinterleave2_rows_amax", "ssv_bias_grad"]          # ABI 7
     for name in must:
         assert name in protos, name
     # every prototype in the header text was parsed (count `ssv_xxx(` occurrences outside comments)
