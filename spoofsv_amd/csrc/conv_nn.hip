@@ -353,25 +353,43 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
         gsave = p.gates_out + ((long)lstm_layer * p.lstm_D + lstm_t) * 4 * HN;
       }
     }
+    // Every load of the cell -- the biases, c_{t-1}, layer 0's input projection -- in front of the first store (round 6).  c_t overwrites c_{t-1} in
+    // place at inference, so hipcc must keep each cell's load behind the previous cell's stores, and on gfx9 a load behind a store is waited for
+    // together with it (one in-order vmcnt): the WM x NT cells of a lane ran one memory round trip apart, 16 in a row on the 128 x 128 tile.
+    // A lane reads and writes only its own cells, so reading them all first is the same computation.
+    float addv[WM][4], cprev[WM][NT], rproj[WM][NT][4];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int row0 = m0 + wave * WM * 16 + i * 16 + kq * 4;       // = 4 * unit
+      const int u = row0 >> 2;
+      const bool uok = u < H;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) addv[i][r] = uok ? (bia ? bia[r * H + u] : 0.f) + (bib ? bib[r * H + u] : 0.f) : 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int gn = n0 + t * 16 + nq;
+        const bool ok = uok && gn < p.N;
+        cprev[i][t] = (ok && !first) ? cst[(long)u * p.N + gn] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rproj[i][t][r] = (ok && Rb) ? Rb[(long)(row0 + r) * p.srm + gn] : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int row0 = m0 + wave * WM * 16 + i * 16 + kq * 4;       // = 4 * unit
       const int u = row0 >> 2;
       if (u >= H) continue;
-      float add[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) add[r] = (bia ? bia[r * H + u] : 0.f) + (bib ? bib[r * H + u] : 0.f);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int gn = n0 + t * 16 + nq;
         if (gn >= p.N) continue;
         float gte[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gte[r] = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + add[r] + (Rb ? Rb[(long)(row0 + r) * p.srm + gn] : 0.f);
+        for (int r = 0; r < 4; ++r) gte[r] = (F16 ? acc[i][t][r] * us : acc[i][t][r]) + addv[i][r] + rproj[i][t][r];
         const float gi = 1.f / (1.f + expf(-gte[0])), gf = 1.f / (1.f + expf(-gte[1]));
         const float gg = tanhf(gte[2]), go = 1.f / (1.f + expf(-gte[3]));
         const long ci = (long)u * p.N + gn;
-        const float cn = (first ? 0.f : gf * cst[ci]) + gi * gg;
+        const float cn = (first ? 0.f : gf * cprev[i][t]) + gi * gg;
         cnew[ci] = cn;
         if (gsave) {
           const long HN = (long)H * p.N;
