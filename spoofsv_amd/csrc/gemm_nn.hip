@@ -158,22 +158,37 @@ __global__ __launch_bounds__(256, (WM == 1 ? 3 : 2)) void gemm_nn_kernel(const G
   // Epilogue.  C/D layout of the 16x16 tile: column = lane & 15, row = (lane >> 4) * 4 + r.
   float* __restrict__ Cb = p.C + (long)b * p.scb;
   const float* __restrict__ Rb = p.R ? p.R + (long)b * p.srb : nullptr;
+  // every load of the epilogue -- bias terms, the residual (the in-place data gradient: R = C) -- in front of the first store (round 6): a load behind a
+  // store is waited for together with it (one in-order vmcnt), and with the residual read inside the store loop the WM x 4 x NT elements of a lane
+  // ran one memory round trip apart (see gemm_nn_bf3_kernel's epilogue, conv_nn.hip)
+  float addv[WM][4], resv[WM][4][NT];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gm = m0 + wave * WM * 16 + i * 16 + kq * 4 + r;
+      const bool rok = gm < p.M;
+      float add = 0.f;
+      if (rok && p.bias) add += p.bias[gm];
+      if (rok && p.bias_b) add += p.bias_b[(long)b * p.sbb + gm];
+      addv[i][r] = add;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int gn = n0 + t * 16 + nq;
+        resv[i][r][t] = (Rb && rok && gn < p.N) ? Rb[(long)gm * p.srm + (long)gn * p.srn] : 0.f;
+      }
+    }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gm = m0 + wave * WM * 16 + i * 16 + kq * 4 + r;
       if (gm >= p.M) continue;
-      float add = 0.f;
-      if (p.bias) add += p.bias[gm];
-      if (p.bias_b) add += p.bias_b[(long)b * p.sbb + gm];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int gn = n0 + t * 16 + nq;
         if (gn >= p.N) continue;
-        float v = acc[i][t][r] * p.alpha + add;
-        if (Rb) v += Rb[(long)gm * p.srm + (long)gn * p.srn];
-        Cb[(long)gm * p.scm + (long)gn * p.scn] = v;
+        Cb[(long)gm * p.scm + (long)gn * p.scn] = acc[i][t][r] * p.alpha + addv[i][r] + resv[i][r][t];
       }
     }
   }
