@@ -64,3 +64,8 @@
 #define SSV_NT3R_ABL 0       // (ablation builds only, results are garbage: bit 0 = the dH fragments of gemm_nt3r_kernel are not split, bit 1 = the input
                              //  rows go into the ring unsplit -- bounds what the in-kernel splits cost under the ring, profiles/round6_nt3r_ablation.txt)
 #endif
+#ifndef SSV_LSTM_FAST_CELL
+#define SSV_LSTM_FAST_CELL 1  // the LSTM cell's sigmoids / tanh on v_exp_f32 + v_rcp_f32 (as the LayerNorm / gate kernels' sigmoid since round 5) instead of expf /
+                              // tanhf / IEEE division: config 5 10.51 -> 10.16 ms same box; the embeddings' distance from the float oracle 2.6e-7 -> 1.5e-6
+                              // (bar 2e-5; tanh(x) = 1 - 2 / (1 + e^2x) is absolute-accurate to ~1e-7, not relative, for |x| << 1).  0 = the libm forms.
+#endif
