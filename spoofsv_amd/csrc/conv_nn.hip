@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
   const long aent = (EPI == 1 && p.A0hi) ? (long)(b > 0 ? b - 1 : 0) * p.sab : (long)b * p.sab;
   const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(lstm_l0 ? p.A0hi : p.Ahi + aent), rsAl = ssv_buf(lstm_l0 ? p.A0lo : p.Alo + aent);   // (see ssv_buf)
   auto loadA = [&](int set, int j, int ch) {
-    const unsigned ub = (unsigned)((j * aplane + (long)ch * 512) * 2);                                  // wave-uniform byte offset
+    // wave-uniform byte offset, said so: in the LSTM instantiations hipcc kept it in a vector register and wrapped every weight load in a waterfall loop
+    // (readfirstlane + compare + branch per load, and its wait counts no longer counted: vmcnt(0) in front of each chunk pair's first MFMA; round 6)
+    const unsigned ub = (unsigned)__builtin_amdgcn_readfirstlane((int)((j * aplane + (long)ch * 512) * 2));
     // (buffer loads everywhere: equal or 1-3 % faster than loads through pointers, measured in-step per tile)
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
@@ -161,6 +163,18 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
 #pragma unroll
         for (int r = 0; r < NX; ++r) rx[r][i] = ssv_buf_f32(rsXr, voffb[r], so);
       }
+    } else if constexpr (EPI == 1) {
+      // LSTM products: ONE path too (round 6).  K is a whole number of chunks there (checked by the launcher), so no ragged form exists, and the two K
+      // segments differ only in the buffer descriptor -- a scalar select.  With the two forms below hipcc's wait counts for this loop collapsed to
+      // vmcnt(0) in front of every chunk pair's first MFMA, i.e. a wait for the input loads issued just before the barrier.
+      const bool seg2 = X2b && ch >= p.xsplit;                                   // (the h_{t-1} segment of K)
+      const __amdgpu_buffer_rsrc_t rs = seg2 ? rsX2 : rsX;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned so = (unsigned)((ch * 32 + i) * Lrow) * 4u;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) rx[r][i] = ssv_buf_f32(rs, voffb[r], so);
+      }
     } else if (!ragged || ch + 1 < nchunks) {
       const bool seg2 = EPI == 1 && X2b && ch >= p.xsplit;                       // (LSTM: the h_{t-1} segment of K)
 #pragma unroll
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
   auto commitX = [&](int ch) {
     uint4* Xh = lds[ch & 1];
     uint4* Xl = lds[ch & 1] + X_SLOTS;
-    const bool last_ragged = ragged && ch + 1 == nchunks;
+    const bool last_ragged = EPI == 0 && ragged && ch + 1 == nchunks;           // (the LSTM products have no ragged chunk)
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       const int e = tid + 256 * r;
@@ -698,8 +712,8 @@ __global__ __launch_bounds__(256 * NWN, (NWN == 2 && KT == 1) ? 4 : 1) void gemm
   auto prefetch = [&](int ch) {
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
-      rah[r] = ssv_buf_u4(rsAh, aoffb[r], (unsigned)ch * 1024u);
-      ral[r] = ssv_buf_u4(rsAl, aoffb[r], (unsigned)ch * 1024u);
+      rah[r] = ssv_buf_u4(rsAh, aoffb[r], (unsigned)__builtin_amdgcn_readfirstlane(ch * 1024));
+      ral[r] = ssv_buf_u4(rsAl, aoffb[r], (unsigned)__builtin_amdgcn_readfirstlane(ch * 1024));
     }
     if (!ragged || ch + 1 < nchunks) {
 #pragma unroll
@@ -1016,7 +1030,8 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(g.KT == 1 || g.KT == 3, SSV_UNSUPPORTED, "gemm_nn_bf3: kernel_size %d", g.KT);
   SSV_CHECK(g.B <= 65535, SSV_UNSUPPORTED, "gemm_nn_bf3: batch %d exceeds grid.y", g.B);
   SSV_CHECK(g.sxn >= 1 && g.scn >= 1 && (g.scn == 1 || (!g.R && !g.epi)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad column strides");
-  SSV_CHECK(!g.epi || (g.KT == 1 && g.perm_h > 0 && g.M == 4 * g.perm_h && g.cstate && (g.B == 1 || g.lstm_D > 0)), SSV_BAD_SHAPE, "gemm_nn_bf3: bad LSTM epilogue request");
+  SSV_CHECK(!g.epi || (g.KT == 1 && g.perm_h > 0 && g.M == 4 * g.perm_h && g.cstate && (g.B == 1 || g.lstm_D > 0) && g.Kc % 32 == 0), SSV_BAD_SHAPE,
+            "gemm_nn_bf3: bad LSTM epilogue request");
   SSV_CHECK(g.lstm_D == 0 || (g.epi == 1 && g.lstm_out && g.lstm_D >= 1 && g.xsplit >= 0 && g.xsplit <= g.Kpad / 32 && g.Kc == g.Kpad && g.sxn == 1), SSV_BAD_SHAPE,
             "gemm_nn_bf3: bad LSTM wavefront request");
   int smin = g.shift[0], smax = g.shift[0];
