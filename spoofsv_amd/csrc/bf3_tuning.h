@@ -69,3 +69,12 @@
                               // tanhf / IEEE division: config 5 10.51 -> 10.16 ms same box; the embeddings' distance from the float oracle 2.6e-7 -> 1.5e-6
                               // (bar 2e-5; tanh(x) = 1 - 2 / (1 + e^2x) is absolute-accurate to ~1e-7, not relative, for |x| << 1).  0 = the libm forms.
 #endif
+#ifndef SSV_NT_NOBREAK
+#define SSV_NT_NOBREAK 1     // gemm_nt_bf3_kernel multiplies the k-steps past a ragged row end too (the staged input is zero there) instead of branching out of the MFMA
+                             // sequence: the branch put an s_waitcnt vmcnt(0) in the middle of every step's MFMAs (hipcc's wait state is merged at the join).
+#endif
+#ifndef SSV_NT_SPLIT_FIRST
+#define SSV_NT_SPLIT_FIRST 1 // gemm_nt_bf3_kernel splits the next chunk's dH before it issues the loads of tile s + 2 (behind them the waits for dH came out as
+                             // vmcnt(5) .. vmcnt(0), i.e. for the loads just issued).  Both: the loop's waits are counted again (tools/isa_loop_waits.py, loop summary in
+                             // profiles/round6_nt_bf3_waits.txt); in-step 118.0 -> 116.8, 28.1 -> 27.7 us -- two workgroups per CU had been covering most of it.
+#endif

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
         if (g + NT_FD < G) frag(g + NT_FD, fb[(g + NT_FD) % (NT_FD + 1)]);
         __builtin_amdgcn_sched_barrier(0);                                   // or the scheduler sinks the reads back to their use
         const int s2 = g / NTC, q = g % NTC;
+#if !SSV_NT_NOBREAK
         if (s2 > 0 && q == 0 && ct0[0] + 32 * s2 >= p.La) break;           // ragged last chunk: the k-steps from here on lie past the row end (the input tile is zero there)
+#endif
         const uint4 bh = fb[g % (NT_FD + 1)][0];
         const uint4 bl = fb[g % (NT_FD + 1)][1];
 #pragma unroll
@@ -344,9 +346,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
         if (((PAR + j) & 1) == 0) commitX(P1{}, ct0[c1], j1); else commitX(P0{}, ct0[c1], j1);
       }
       NT_STAMP(2);
+#if SSV_NT_SPLIT_FIRST
+      // the next chunk's dH is split BEFORE the loads of tile s + 2 are issued (round 6): behind them, hipcc's waits for the dH registers came out as
+      // vmcnt(5) .. vmcnt(0) right after those loads, i.e. every step ended by waiting for the tile it had just requested
+      if (j == KT - 1 && more) splitA(NXT{});
+      NT_STAMP(3);
+      if (STEADY || s + 2 < steps) loadX(cb[c2], ct0[c2], j2);
+#else
       if (STEADY || s + 2 < steps) loadX(cb[c2], ct0[c2], j2);
       NT_STAMP(3);
       if (j == KT - 1 && more) splitA(NXT{});
+#endif
       NT_STAMP(4);
       __syncthreads();
       NT_STAMP(5);
