@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "ssv_common.h"
+#include "bf3_tuning.h"
 #include "../../include/ssv_hip.h"
 #define SSV_HIP(expr) do { hipError_t _he = (expr); if (_he != hipSuccess) { ssv_fail(0, "%s: %s", #expr, hipGetErrorString(_he)); return -(int)_he; } } while (0)
 
@@ -224,6 +225,7 @@ static GemmNNB nnb_zero() {
   g.shift[0] = g.shift[1] = g.shift[2] = 0;
   g.sxn = g.scn = 1;
   g.row_pair = 0; g.c_amax = nullptr; g.c_namax = 0;
+  g.hs_planes = nullptr; g.hs_plane_bytes = 0; g.hs_npad = 0;
   g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
   g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0; g.A0hi = g.A0lo = nullptr;
   g.gates_out = nullptr;
@@ -1039,7 +1041,7 @@ static int lstm_gemm_f32(const float* A, const float* X, long sxb, float* C, lon
   return ssv_launch_gemm_nn(g, st);
 }
 // Wavefront (split-bf16) layout: h of every layer lives in a 2-frame ring, weights of layer l >= 1 are [W_ih | W_hh] side by side.
-struct LstmWave { size_t xt, xp, out, c, bias, ih0, hh0, comb, comb_stride, aux, total; };
+struct LstmWave { size_t xt, xp, out, c, bias, ih0, hh0, comb, comb_stride, aux, hp, hp_plane, total; int npad; };
 // split-fp16 scales of the wavefront (floats at `aux`): [0, 64) partial maxima over ALL weight matrices (one scale for every layer: a
 // launch batches layers over grid.y and has one epilogue factor), [64] its inverse scale, [128, 192) partial maxima of the input frames
 // (layer 0's projection).  The recurrent activations need no list: |h| = |o tanh c| < 1, their scale is the constant 2^14 (x_namax = 0).
@@ -1056,7 +1058,11 @@ static LstmWave lstm_wave_ws(int Bn, int T, int F, int H, int layers) {
   s.comb = s.hh0 + 2 * split_bytes(4 * H, H, 1);
   s.comb_stride = 2 * split_bytes(4 * H, 2 * H, 1);
   s.aux = s.comb + (size_t)(layers > 1 ? layers - 1 : 0) * s.comb_stride;
-  s.total = s.aux + align256(LSTM_AUX_FLOATS * sizeof(float));
+  // pre-split recurrent activations (GemmNNB::hs_planes): hi and lo planes of [H / 8][npad][8 halves] per (layer, ring slot); npad = whole 128-column tiles
+  s.npad = (Bn + 127) / 128 * 128;
+  s.hp = s.aux + align256(LSTM_AUX_FLOATS * sizeof(float));
+  s.hp_plane = (H % 8 == 0) ? (size_t)(H / 8) * s.npad * 16 : 0;
+  s.total = s.hp + align256((size_t)layers * 2 * 2 * s.hp_plane);
   return s;
 }
 static bool lstm_wave_ok(int Bn, int H) { return Bn >= 64 && H >= 32 && H % 32 == 0; }
@@ -1144,6 +1150,14 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   // half-empty last round; together they are 1008 workgroups = two full rounds of 512.  SSV_LSTM_MERGE=0 keeps the two launches (tuning).
   const char* mk = ssv_tuning(SSV_T_LSTM_MERGE);
   const bool merge = !(mk && atoi(mk) == 0);
+  // Inference in the split-fp16 mode: the cells write h already split into the consumers' staging order (see GemmNNB::hs_planes): no split, no masks and a
+  // quarter of the load instructions in the products' input staging.  The planes' pad columns (and everything else) start as zeros.
+  const bool presplit = SSV_LSTM_PRESPLIT && f16 && merge && layers >= 2 && !keep_hs && D == 2 && H % 32 == 0 && s.hp_plane > 0 && s.hp_plane < ((size_t)1 << 31) &&
+                        !(mk && atoi(mk) == 2);
+  if (presplit) {
+    SSV_HIP(hipMemsetAsync(base + s.hp, 0, (size_t)layers * 2 * 2 * s.hp_plane, st));
+    g.hs_planes = (unsigned short*)(base + s.hp); g.hs_plane_bytes = (long)s.hp_plane; g.hs_npad = s.npad;
+  }
   for (int step = 0; merge && layers >= 2 && step < T + layers - 1; ++step) {
     g.lstm_s = step;
     const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;

@@ -78,3 +78,6 @@
                              // vmcnt(5) .. vmcnt(0), i.e. for the loads just issued).  Both: the loop's waits are counted again (tools/isa_loop_waits.py, loop summary in
                              // profiles/round6_nt_bf3_waits.txt); in-step 118.0 -> 116.8, 28.1 -> 27.7 us -- two workgroups per CU had been covering most of it.
 #endif
+#ifndef SSV_LSTM_PRESPLIT
+#define SSV_LSTM_PRESPLIT 1  // (tuning builds: 0 = the inference wavefront stages fp32 h and splits it in the consumer, as until round 6)
+#endif

@@ -66,6 +66,18 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
       if (lstm_l0) { Xb = X2b + (long)p.xsplit * 32 * (long)p.sxc; X2b = nullptr; }      // one segment: the layer's own h_{t-1}
     }
   }
+  // XS (HW = 3 marks the instantiation; GemmNNB::hs_planes): the same two K segments read from the pre-split planes of (layer - 1, slot t % 2) and
+  // (layer, slot (t - 1) % 2); the second is pre-offset by its first chunk so that one chunk formula serves both, as X2b above.
+  constexpr bool XS = EPI == 1 && KT == 1 && NT == 8 && HW == 3;
+  const char* Pb = nullptr;
+  const char* P2b = nullptr;
+  if constexpr (XS) {
+    const long pl = p.hs_plane_bytes, chunkb = (long)4 * p.hs_npad * 16;         // bytes of one chunk (4 k-groups) in a plane
+    const char* base = reinterpret_cast<const char*>(p.hs_planes);
+    Pb = base + ((long)max(lstm_layer - 1, 0) * 2 + (lstm_t & 1)) * 2 * pl;
+    P2b = base + ((long)lstm_layer * 2 + ((lstm_t + 1) & 1)) * 2 * pl - (long)p.xsplit * chunkb;
+    if (lstm_l0) { Pb = P2b + (long)p.xsplit * chunkb; P2b = nullptr; }
+  }
   // chunks to run: all of K, except that an LSTM entry at its first frame has no h_{t-1} segment (layer 0 riding along: nothing but that segment)
   const int nchunks_all = lstm_l0 ? p.xsplit : p.Kpad / 32;
   const int nchunks = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? (lstm_l0 ? 0 : p.xsplit) : nchunks_all;
@@ -120,6 +132,8 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
   // and the column mask is computed once; only a ragged last chunk (Kc % 32 != 0) needs per-channel clamps and masks.
   const int Lrow = (int)p.sxc;
   const __amdgpu_buffer_rsrc_t rsX = ssv_buf(Xb), rsX2 = ssv_buf(X2b ? X2b : Xb);        // (see ssv_buf)
+  const __amdgpu_buffer_rsrc_t rsP = ssv_buf(XS ? Pb : nullptr), rsP2 = ssv_buf(XS ? (P2b ? P2b : Pb) : nullptr);
+  uint4 rxs[XS ? NX : 1][2];                                                     // XS: the slot's hi and lo vectors as they lie in the planes
   unsigned voff[NX], voffb[NX];
   bool cvs[NX];
 #pragma unroll
@@ -163,6 +177,16 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
 #pragma unroll
         for (int r = 0; r < NX; ++r) rx[r][i] = ssv_buf_f32(rsXr, voffb[r], so);
       }
+    } else if constexpr (XS) {
+      const bool seg2 = P2b && ch >= p.xsplit;
+      const __amdgpu_buffer_rsrc_t rs = seg2 ? rsP2 : rsP;
+      const unsigned so = (unsigned)ch * (unsigned)(4 * p.hs_npad * 16);           // uniform: the chunk's four k-groups
+#pragma unroll
+      for (int r = 0; r < NX; ++r) {
+        const unsigned vo = (unsigned)(((tid + 256 * r) / WX) * p.hs_npad + n0 + (tid + 256 * r) % WX) * 16u;
+        rxs[r][0] = ssv_buf_u4(rs, vo, so);
+        rxs[r][1] = ssv_buf_u4(rs, vo, so + (unsigned)p.hs_plane_bytes);
+      }
     } else if constexpr (EPI == 1) {
       // LSTM products: ONE path too (round 6).  K is a whole number of chunks there (checked by the launcher), so no ragged form exists, and the two K
       // segments differ only in the buffer descriptor -- a scalar select.  With the two forms below hipcc's wait counts for this loop collapsed to
@@ -204,6 +228,11 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
     uint4* Xh = lds[ch & 1];
     uint4* Xl = lds[ch & 1] + X_SLOTS;
     const bool last_ragged = EPI == 0 && ragged && ch + 1 == nchunks;           // (the LSTM products have no ragged chunk)
+    if constexpr (XS) {                                                          // already split, already in slot order: straight into the image
+#pragma unroll
+      for (int r = 0; r < NX; ++r) { Xh[tid + 256 * r] = rxs[r][0]; Xl[tid + 256 * r] = rxs[r][1]; }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
       const int e = tid + 256 * r;
@@ -416,10 +445,21 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
           gsave[ci] = gi; gsave[HN + ci] = gf; gsave[2 * HN + ci] = gg; gsave[3 * HN + ci] = go;
         }
 #if SSV_LSTM_FAST_CELL
-        Cb[(long)u * p.scm + gn] = go * (1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * cn)));
+        const float hval = go * (1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * cn)));
 #else
-        Cb[(long)u * p.scm + gn] = go * tanhf(cn);
+        const float hval = go * tanhf(cn);
 #endif
+        Cb[(long)u * p.scm + gn] = hval;
+        if constexpr (XS) {
+          // the same h, split as its consumers would split it (scale 2^14: |h| < 1), into the planes of (layer, slot t % 2)
+          const float hs_ = hval * 16384.f;
+          const _Float16 hh = (_Float16)hs_;
+          const _Float16 hl = (_Float16)(hs_ - (float)hh);
+          _Float16* ph = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(p.hs_planes) + ((long)lstm_layer * 2 + (lstm_t & 1)) * 2 * p.hs_plane_bytes);
+          const long at = ((long)(u >> 3) * p.hs_npad + gn) * 8 + (u & 7);
+          ph[at] = hh;
+          ph[at + p.hs_plane_bytes / 2] = hl;
+        }
       }
     }
     return;
@@ -972,6 +1012,11 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   // (round 5, layer 0 riding along: three layers = 3 x 24 x 7 = 504 tiles of 128 x 128 are ONE round of two workgroups per CU, with half the weight
   //  bytes per MFMA of the 64-column tile -- the launch is bound by L2 -> CU traffic, 69 GB/s per CU measured on 1008 tiles of 128 x 64)
   if constexpr (KT == 1) {
+    if (g.hs_planes) {                      // pre-split recurrent activations: the 128 x 128 tile for every step of the wavefront (also its first and last, partly filled ones)
+      const int mtiles = ssv_cdiv(g.M, 128), ntiles = ssv_cdiv(g.N, 128);
+      hipLaunchKernelGGL((gemm_nn_bf3_kernel<1, 2, 8, 1, 1, 3>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
+      return ssv_check_launch("gemm_nn_bf3_lstm (pre-split h)");
+    }
     if (!forced && g.epi && g.lstm_D > 0 && g.B >= 2) {
       const long t128 = (long)ssv_cdiv(g.M, 128) * ssv_cdiv(g.N, 128) * g.B;
       const char* e = ssv_tuning(SSV_T_LSTM_MERGE);
@@ -1046,6 +1091,9 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(!g.row_pair || (g.KT == 1 && g.M % 2 == 0 && g.scn == 1 && !g.R && !g.epi && !g.perm_h && !g.colstats && !g.bias_b), SSV_BAD_SHAPE,
             "gemm_nn_bf3: paired output rows need a plain k = 1 product over an even number of rows");
   SSV_CHECK(g.row_pair || !g.c_amax, SSV_BAD_SHAPE, "gemm_nn_bf3: the output's scale list comes with paired output rows only");
+  SSV_CHECK(!g.hs_planes || (g.epi == 1 && g.lstm_D == 2 && g.f16 && !g.gates_out && g.x_namax == 0 && g.perm_h % 32 == 0 && g.hs_npad % 128 == 0 && g.hs_npad >= g.N &&
+                             g.hs_plane_bytes == (long)(g.perm_h / 8) * g.hs_npad * 16 && (long)(g.perm_h / 8) * g.hs_npad * 16 < (1L << 31)), SSV_BAD_SHAPE,
+            "gemm_nn_bf3: pre-split recurrent activations need the merged split-fp16 inference wavefront and whole column tiles of planes");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
 }
 

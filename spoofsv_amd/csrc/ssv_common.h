@@ -70,6 +70,11 @@ struct GemmNNB {
   // (M even, scn == 1, no R / LSTM / statistics).  c_amax != null: the launch also leaves the output's operand-scale list, c_namax entries per
   // item at c_amax + b * c_namax: entry = the workgroup's tile (max |C| over it), the entries past the tiles zeroed by the item's last tile.
   int row_pair; float* c_amax; int c_namax;
+  // LSTM wavefront at inference with PRE-SPLIT recurrent activations (round 6; hs_planes != null, split-fp16 mode, lstm_D == 2): |h| < 1, so its
+  // operand scale is the constant 2^14 and the cell epilogue can write h already split -- fp16 hi / lo planes in the consumer's own staging order,
+  // [k-group of 8 units][column][8 halves] over hs_npad columns (a multiple of the column tile; the pad columns stay zero) -- for (layer, ring slot) at
+  // hs_planes + ((layer * 2 + slot) * 2 + {0: hi, 1: lo}) * hs_plane_bytes.  The products then stage their input with 16-byte loads and no VALU split.
+  unsigned short* hs_planes; long hs_plane_bytes; int hs_npad;
   // LSTM support.  perm_h = H > 0: output row m is gate (m % 4) of hidden unit (m / 4), i.e. row (m % 4) * H + m / 4 of
   // the torch layout -- the weights were packed in that order and the bias vectors are indexed through the same map.
   // epi = 1: fused cell epilogue -- the 4 accumulator rows of a lane are the (i, f, g, o) pre-activations of one unit;
