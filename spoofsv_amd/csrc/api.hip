@@ -225,7 +225,7 @@ static GemmNNB nnb_zero() {
   g.shift[0] = g.shift[1] = g.shift[2] = 0;
   g.sxn = g.scn = 1;
   g.row_pair = 0; g.c_amax = nullptr; g.c_namax = 0;
-  g.hs_planes = nullptr; g.hs_plane_bytes = 0; g.hs_npad = 0;
+  g.hs_planes = nullptr; g.hs_plane_bytes = 0; g.hs_npad = 0; g.hs_keep_h = 1;
   g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
   g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0; g.A0hi = g.A0lo = nullptr;
   g.gates_out = nullptr;
@@ -1160,6 +1160,7 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   }
   for (int step = 0; merge && layers >= 2 && step < T + layers - 1; ++step) {
     g.lstm_s = step;
+    g.hs_keep_h = !presplit || step == T + layers - 2;            // (pre-split h: the fp32 copy is read by nobody but the caller, from the last step)
     const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
     const int lo1 = lo > 1 ? lo : 1;           // the first layer >= 1 of the launch: its planes are the launch's Ahi
     g.Ahi = (unsigned short*)(base + s.comb + (size_t)(lo1 - 1) * s.comb_stride);

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
 #else
         const float hval = go * tanhf(cn);
 #endif
-        Cb[(long)u * p.scm + gn] = hval;
+        if (!XS || p.hs_keep_h) Cb[(long)u * p.scm + gn] = hval;
         if constexpr (XS) {
           // the same h, split as its consumers would split it (scale 2^14: |h| < 1), into the planes of (layer, slot t % 2)
           const float hs_ = hval * 16384.f;

@@ -75,6 +75,7 @@ struct GemmNNB {
   // [k-group of 8 units][column][8 halves] over hs_npad columns (a multiple of the column tile; the pad columns stay zero) -- for (layer, ring slot) at
   // hs_planes + ((layer * 2 + slot) * 2 + {0: hi, 1: lo}) * hs_plane_bytes.  The products then stage their input with 16-byte loads and no VALU split.
   unsigned short* hs_planes; long hs_plane_bytes; int hs_npad;
+  int hs_keep_h;            // (with hs_planes) 1: this launch also stores the fp32 h -- only the wavefront's last step needs it, for the caller's h_last
   // LSTM support.  perm_h = H > 0: output row m is gate (m % 4) of hidden unit (m / 4), i.e. row (m % 4) * H + m / 4 of
   // the torch layout -- the weights were packed in that order and the bias vectors are indexed through the same map.
   // epi = 1: fused cell epilogue -- the 4 accumulator rows of a lane are the (i, f, g, o) pre-activations of one unit;
