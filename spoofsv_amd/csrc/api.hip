@@ -135,7 +135,7 @@ int ssv_launch_transpose_out(const float*, float*, int, int, hipStream_t);
 int ssv_launch_l2norm_rows(const float*, float*, float*, int, int, hipStream_t);
 int ssv_launch_l2norm_bwd(const float*, const float*, const float*, float*, int, int, hipStream_t);
 int ssv_launch_colsum(const float*, float*, int, int, hipStream_t);
-int ssv_launch_lstm_cell_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int ssv_launch_lstm_cell_bwd(const float*, const float*, const float*, long, int, const float*, float*, float*, int, int, int, int, int, int, int, hipStream_t);
 
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
@@ -226,6 +226,7 @@ static GemmNNB nnb_zero() {
   g.sxn = g.scn = 1;
   g.row_pair = 0; g.c_amax = nullptr; g.c_namax = 0;
   g.hs_planes = nullptr; g.hs_plane_bytes = 0; g.hs_npad = 0; g.hs_keep_h = 1;
+  g.ksplit = 1; g.scz = 0; g.skip_rows = 0;
   g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
   g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0; g.A0hi = g.A0lo = nullptr;
   g.gates_out = nullptr;
@@ -1382,22 +1383,24 @@ extern "C" int ssv_lstm_train_fwd(const float* x, const float* const* w_ih, cons
                        (float*)(sb + sv.xt), (float*)(sb + sv.hs), (float*)(sb + sv.cs), (float*)(sb + sv.gates));
 }
 
-struct LstmBwdWs { size_t dgates, dxc, dx0, dcarry, dhtop, rs, wt0, wtc, wtc_stride, slabs, total; };
+struct LstmBwdWs { size_t dgates, dxa, dxa_slab, dcarry, dhtop, rs, wta, wta_stride, slabs, total; };
 static size_t lstm_dw_slab_bytes(int Bn, int T, int H, int Fin) {
   return align256((size_t)dw_splits(T, 4 * H, Fin, 1, Bn) * 4 * H * Fin * sizeof(float));        // "batch" = frames, reduction length = utterances
 }
+// dxa: the data-gradient products of one reverse wavefront step, [K range z][step parity][layer][2H][Bn] -- layer l's product at frame t is
+// [dh^{l-1}_t ; dh^l_{t-1}] (layer 0: only the second half is used), written at step s = l + t under parity s & 1 and read by the cells of step s - 1:
+// two parities are the whole life of these values, so the buffer stays in the last-level cache instead of walking through T frames of HBM.
 static LstmBwdWs lstm_bwd_ws(int Bn, int T, int F, int H, int layers) {
   LstmBwdWs s;
   s.dgates = 0;
-  s.dxc = s.dgates + align256((size_t)layers * T * 4 * H * Bn * sizeof(float));
-  s.dx0 = s.dxc + align256((size_t)(layers > 1 ? layers - 1 : 0) * T * 2 * H * Bn * sizeof(float));
-  s.dcarry = s.dx0 + align256((size_t)T * H * Bn * sizeof(float));
+  s.dxa = s.dgates + align256((size_t)layers * T * 4 * H * Bn * sizeof(float));
+  s.dxa_slab = align256((size_t)2 * layers * 2 * H * Bn * sizeof(float));
+  s.dcarry = s.dxa + 2 * s.dxa_slab;
   s.dhtop = s.dcarry + align256((size_t)layers * H * Bn * sizeof(float));
   s.rs = s.dhtop + align256((size_t)H * Bn * sizeof(float));
-  s.wt0 = s.rs + align256((size_t)T * 4 * H * sizeof(float));
-  s.wtc = s.wt0 + 2 * split_bytes(H, 4 * H, 1);                    // W_hh[0]^T
-  s.wtc_stride = 2 * split_bytes(2 * H, 4 * H, 1);                 // [W_ih | W_hh]^T of a layer >= 1
-  s.slabs = s.wtc + (size_t)(layers > 1 ? layers - 1 : 0) * s.wtc_stride;
+  s.wta = s.rs + align256((size_t)T * 4 * H * sizeof(float));
+  s.wta_stride = 2 * split_bytes(2 * H, 4 * H, 1);                 // [W_ih | W_hh]^T of a layer (layer 0: the W_ih half stays zero)
+  s.slabs = s.wta + (size_t)layers * s.wta_stride;
   // every (items, M, Nc) lstm_weight_grad is called with: W_ih over T frames (Fin = F or H), W_hh over T - 1
   s.total = s.slabs + zmax(zmax(lstm_dw_slab_bytes(Bn, T, H, H), lstm_dw_slab_bytes(Bn, T > 1 ? T - 1 : 1, H, H)), lstm_dw_slab_bytes(Bn, T, H, F));
   return s;
@@ -1438,12 +1441,12 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
   const float* gates = (const float*)(sb + sv.gates);
   char* base = (char*)ws;
   float* dgates = (float*)(base + s.dgates);
-  float* dxc = (float*)(base + s.dxc);
-  float* dx0 = (float*)(base + s.dx0);
+  float* dxa = (float*)(base + s.dxa);
   float* dcarry = (float*)(base + s.dcarry);
   float* dhtop = (float*)(base + s.dhtop);
   float* rs = (float*)(base + s.rs);
   const long HN = (long)H * Bn;
+  const long zstride = (long)(s.dxa_slab / sizeof(float));
   SSV_TRY(ssv_launch_transpose_out(dh_last, dhtop, Bn, H, st));               // (Bn, H) -> [H][Bn]
   // the transposed product dX [H][Bn] = W^T dG with W (4H x H) row-major, on the exact-fp32 kernel: A(m = q, c = r) = W[r][q]
   auto wt_gemm_f32 = [&](const float* W, const float* dg, float* out) -> int {
@@ -1456,48 +1459,43 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
   };
   for (int step = T + layers - 2; f32 && step >= 0; --step) {
     const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
-    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dx0, dxc, dhtop, dgates, dcarry, H, Bn, T, layers, step, lo, hi - lo + 1, st));
-    if (lo == 0 && step >= 1) SSV_TRY(wt_gemm_f32(w_hh[0], dgates + (long)step * 4 * HN, dx0 + (long)step * HN));
+    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dxa, zstride, 1, dhtop, dgates, dcarry, H, Bn, T, layers, step, lo, hi - lo + 1, st));
+    float* outp = dxa + (long)(step & 1) * layers * 2 * HN;                   // this step's parity
+    if (lo == 0 && step >= 1) SSV_TRY(wt_gemm_f32(w_hh[0], dgates + (long)step * 4 * HN, outp + HN));
     for (int l = lo > 1 ? lo : 1; l <= hi; ++l) {                            // [dh^{l-1}_t ; dh^l_{t-1}] = [W_ih | W_hh]^T dgates^l_t
       const float* dg = dgates + ((long)l * T + (step - l)) * 4 * HN;
-      float* out = dxc + ((long)(l - 1) * T + (step - l)) * 2 * HN;
-      SSV_TRY(wt_gemm_f32(w_ih[l], dg, out));
-      SSV_TRY(wt_gemm_f32(w_hh[l], dg, out + HN));
+      SSV_TRY(wt_gemm_f32(w_ih[l], dg, outp + (long)l * 2 * HN));
+      SSV_TRY(wt_gemm_f32(w_hh[l], dg, outp + (long)l * 2 * HN + HN));
     }
   }
   // transposed weights for the data-gradient products: rows = inputs of the layer, reduction over the 4H gate rows
-  unsigned short* w0_hi = (unsigned short*)(base + s.wt0);
-  unsigned short* w0_lo = (unsigned short*)(base + s.wt0 + split_bytes(H, 4 * H, 1));
-  if (!f32) SSV_TRY(ssv_launch_pack_split(w_hh[0], w0_hi, w0_lo, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));          // (m=q, k=r) = W_hh[r][q]
   const size_t rows_h = (size_t)(H / 16) * (4 * H / 32) * 512;               // elements of the first H rows of a [2H x 4H] plane
-  for (int l = 1; !f32 && l < layers; ++l) {
-    unsigned short* hi = (unsigned short*)(base + s.wtc + (size_t)(l - 1) * s.wtc_stride);
+  for (int l = 0; !f32 && l < layers; ++l) {
+    unsigned short* hi = (unsigned short*)(base + s.wta + (size_t)l * s.wta_stride);
     unsigned short* lo = (unsigned short*)((char*)hi + split_bytes(2 * H, 4 * H, 1));
-    SSV_TRY(ssv_launch_pack_split(w_ih[l], hi, lo, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));
+    if (l == 0) {                                                            // no data gradient of the utterance itself: zero rows (mostly skipped, see skip_rows)
+      SSV_HIP(hipMemsetAsync(hi, 0, rows_h * sizeof(unsigned short), st));
+      SSV_HIP(hipMemsetAsync(lo, 0, rows_h * sizeof(unsigned short), st));
+    } else SSV_TRY(ssv_launch_pack_split(w_ih[l], hi, lo, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));               // (m=q, k=r) = W_ih[r][q]
     SSV_TRY(ssv_launch_pack_split(w_hh[l], hi + rows_h, lo + rows_h, H, 4 * H, 4 * H, 1, 1, H, 1, 0, st));
   }
+  // ONE product launch per reverse wavefront step: every active layer (layer 0 included) x two K ranges of 2H gate rows, on the forward wavefront's
+  // 128 x 128 tile -- 3 layers x 12 x 7 x 2 = 504 tiles less layer 0's 84 skipped ones for config 5 (before round 6's end: a 768-row and a 1536-row product
+  // on 128 x 32 tiles, 47 + 87 us per step)
   GemmNNB g = nnb_zero();
-  g.Kpad = 4 * H; g.Kc = 4 * H; g.sxc = Bn; g.Lx = Bn; g.scm = Bn; g.N = Bn;
+  g.Kpad = 4 * H; g.Kc = 2 * H; g.ksplit = 2; g.sxc = Bn; g.Lx = Bn; g.scm = Bn; g.N = Bn; g.M = 2 * H;
+  g.sab = (long)(s.wta_stride / sizeof(unsigned short)); g.sxb = (long)(T - 1) * 4 * HN; g.scb = 2 * HN; g.scz = zstride;
   for (int step = T + layers - 2; !f32 && step >= 0; --step) {
     const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
-    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dx0, dxc, dhtop, dgates, dcarry, H, Bn, T, layers, step, lo, hi - lo + 1, st));
-    if (lo == 0 && step >= 1) {               // layer 0, frame t = step >= 1: dh_{t-1} = W_hh^T dgates_t (nothing to do for frame 0: x is data)
-      g.Ahi = w0_hi; g.Alo = w0_lo; g.sab = 0;
-      g.X = dgates + (long)step * 4 * HN; g.sxb = 0;
-      g.C = dx0 + (long)step * HN; g.scb = 0;
-      g.M = H; g.B = 1;
-      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
-    }
-    const int l1 = lo > 1 ? lo : 1;
-    if (l1 <= hi) {                           // layers l1..hi at frames step - l: [dh^{l-1}_t ; dh^l_{t-1}] = [W_ih | W_hh]^T dgates^l_t
-      g.Ahi = (unsigned short*)(base + s.wtc + (size_t)(l1 - 1) * s.wtc_stride);
-      g.Alo = (unsigned short*)((char*)g.Ahi + split_bytes(2 * H, 4 * H, 1));
-      g.sab = (long)(s.wtc_stride / sizeof(unsigned short));
-      g.X = dgates + ((long)l1 * T + (step - l1)) * 4 * HN; g.sxb = (long)(T - 1) * 4 * HN;
-      g.C = dxc + ((long)(l1 - 1) * T + (step - l1)) * 2 * HN; g.scb = (long)(T - 1) * 2 * HN;
-      g.M = 2 * H; g.B = hi - l1 + 1;
-      SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
-    }
+    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dxa, zstride, 2, dhtop, dgates, dcarry, H, Bn, T, layers, step, lo, hi - lo + 1, st));
+    if (step == 0) break;                                                    // frame 0 of layer 0: its product would be the gradient of the initial state
+    g.Ahi = (unsigned short*)(base + s.wta + (size_t)lo * s.wta_stride);
+    g.Alo = (unsigned short*)((char*)g.Ahi + split_bytes(2 * H, 4 * H, 1));
+    g.X = dgates + ((long)lo * T + (step - lo)) * 4 * HN;
+    g.C = dxa + ((long)(step & 1) * layers + lo) * 2 * HN;
+    g.B = hi - lo + 1;
+    g.skip_rows = lo == 0 ? H : 0;
+    SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
   }
   // parameter gradients: one reduction over all frames per matrix
   for (int l = 0; l < layers; ++l) {

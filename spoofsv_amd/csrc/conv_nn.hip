@@ -47,10 +47,18 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned wg = ssv_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);   // see ssv_xcd_order
-  const int bxx = (int)(wg % gridDim.x), b = (int)(wg / gridDim.x);
+  const int bxx = (int)(wg % gridDim.x);
+  int b = (int)(wg / gridDim.x), kz = 0;
   const int mt = bxx % mtiles, ntile = bxx / mtiles;
   const int m0 = mt * BM, n0 = ntile * BN;
-  const float* __restrict__ Xb = p.X + (long)b * p.sxb;
+  if constexpr (EPI == 0 && KT == 1) {                 // split reduction (GemmNNB::ksplit): grid.y entry = (batch item, K range)
+    if (p.ksplit > 1) {
+      kz = b % p.ksplit;
+      b /= p.ksplit;
+      if (b == 0 && m0 + BM <= p.skip_rows) return;    // (whole workgroup, before any barrier)
+    }
+  }
+  const float* __restrict__ Xb = p.X + (long)b * p.sxb + (long)kz * p.Kc * p.sxc;
   // LSTM wavefront (see GemmNNB): layer / frame of this grid.y entry, the second K segment, the chunks to run
   const float* __restrict__ X2b = nullptr;
   int lstm_layer = 0, lstm_t = 0;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
   }
   // chunks to run: all of K, except that an LSTM entry at its first frame has no h_{t-1} segment (layer 0 riding along: nothing but that segment)
   const int nchunks_all = lstm_l0 ? p.xsplit : p.Kpad / 32;
-  const int nchunks = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? (lstm_l0 ? 0 : p.xsplit) : nchunks_all;
+  const int nchunks = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? (lstm_l0 ? 0 : p.xsplit) : (EPI == 0 && KT == 1 && p.ksplit > 1) ? p.Kc / 32 : nchunks_all;
   const int W = BN + span;
   const int kq = lane >> 4, nq = lane & 15;
 
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
 #pragma unroll
   for (int i = 0; i < WM; ++i) arowb[i] = (unsigned)(arow[i] * 2);
   // (LSTM wavefront with layer 0 riding along: entry 0 reads the planes A0hi / A0lo, entry b >= 1 the planes of layer b at (b - 1) * sab)
-  const long aent = (EPI == 1 && p.A0hi) ? (long)(b > 0 ? b - 1 : 0) * p.sab : (long)b * p.sab;
+  const long aent = (EPI == 1 && p.A0hi) ? (long)(b > 0 ? b - 1 : 0) * p.sab : (long)b * p.sab + (long)kz * (p.Kc / 32) * 512;
   const __amdgpu_buffer_rsrc_t rsAh = ssv_buf(lstm_l0 ? p.A0hi : p.Ahi + aent), rsAl = ssv_buf(lstm_l0 ? p.A0lo : p.Alo + aent);   // (see ssv_buf)
   auto loadA = [&](int set, int j, int ch) {
     // wave-uniform byte offset, said so: in the LSTM instantiations hipcc kept it in a vector register and wrapped every weight load in a waterfall loop
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
 
   NN_STAMP_AT(2);
   const float us = F16 ? ssv_uniform(xinv * ainv) : 1.f;
-  float* __restrict__ Cb = p.C + (long)b * p.scb;
+  float* __restrict__ Cb = p.C + (long)b * p.scb + (long)kz * p.scz;
   const float* __restrict__ Rb = p.R ? p.R + (long)b * p.srb : nullptr;
   if constexpr (EPI == 1) {
     if (p.A0hi && !lstm_l0) Rb = nullptr;         // the input projection in R belongs to layer 0 alone
@@ -1012,6 +1020,13 @@ static int pick_nnb(const GemmNNB& g, hipStream_t st, int smin, int span) {
   // (round 5, layer 0 riding along: three layers = 3 x 24 x 7 = 504 tiles of 128 x 128 are ONE round of two workgroups per CU, with half the weight
   //  bytes per MFMA of the 64-column tile -- the launch is bound by L2 -> CU traffic, 69 GB/s per CU measured on 1008 tiles of 128 x 64)
   if constexpr (KT == 1) {
+    if (g.ksplit > 1) {                     // split reduction (the LSTM backward's merged data-gradient product): the forward wavefront's 128 x 128 tile
+      const int mtiles = ssv_cdiv(g.M, 128), ntiles = ssv_cdiv(g.N, 128);
+      SSV_CHECK((long)g.B * g.ksplit <= 65535, SSV_UNSUPPORTED, "gemm_nn_bf3: batch %d x %d K ranges exceeds grid.y", g.B, g.ksplit);
+      if (g.f16) hipLaunchKernelGGL((gemm_nn_bf3_kernel<1, 2, 8, 0, 1>), dim3(mtiles * ntiles, g.B * g.ksplit), dim3(256), 0, st, g, mtiles, smin, span);
+      else hipLaunchKernelGGL((gemm_nn_bf3_kernel<1, 2, 8, 0, 0>), dim3(mtiles * ntiles, g.B * g.ksplit), dim3(256), 0, st, g, mtiles, smin, span);
+      return ssv_check_launch("gemm_nn_bf3 (split reduction)");
+    }
     if (g.hs_planes) {                      // pre-split recurrent activations: the 128 x 128 tile for every step of the wavefront (also its first and last, partly filled ones)
       const int mtiles = ssv_cdiv(g.M, 128), ntiles = ssv_cdiv(g.N, 128);
       hipLaunchKernelGGL((gemm_nn_bf3_kernel<1, 2, 8, 1, 1, 3>), dim3(mtiles * ntiles, g.B), dim3(256), 0, st, g, mtiles, smin, span);
@@ -1094,6 +1109,9 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(!g.hs_planes || (g.epi == 1 && g.lstm_D == 2 && g.f16 && !g.gates_out && g.x_namax == 0 && g.perm_h % 32 == 0 && g.hs_npad % 128 == 0 && g.hs_npad >= g.N &&
                              g.hs_plane_bytes == (long)(g.perm_h / 8) * g.hs_npad * 16 && (long)(g.perm_h / 8) * g.hs_npad * 16 < (1L << 31)), SSV_BAD_SHAPE,
             "gemm_nn_bf3: pre-split recurrent activations need the merged split-fp16 inference wavefront and whole column tiles of planes");
+  SSV_CHECK(g.ksplit == 1 || (g.ksplit > 1 && g.KT == 1 && !g.epi && !g.R && !g.bias && !g.bias_b && !g.colstats && !g.row_pair && !g.perm_h && g.sxn == 1 && g.scn == 1 &&
+                              g.Kc % 32 == 0 && g.Kpad == g.ksplit * g.Kc && g.skip_rows >= 0), SSV_BAD_SHAPE,
+            "gemm_nn_bf3: a split reduction needs a plain k = 1 product whose planes hold ksplit ranges of Kc (a multiple of 32) rows");
   return g.KT == 3 ? pick_nnb<3>(g, st, smin, span) : pick_nnb<1>(g, st, smin, span);
 }
 

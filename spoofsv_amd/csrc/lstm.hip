@@ -298,19 +298,23 @@ extern "C" int ssv_ge2e_loss_bwd(const float* emb, const float* w, const float* 
 
 // ---- LSTM backward: cell ----------------------------------------------------------------------------------
 // Layer l = lo + blockIdx.y at frame t = s - l (reverse wavefront step s).  dh_t collects the gradient from the layer above
-// (rows [0, H) of its data-gradient product at the same frame), from the layer's own next frame (rows [H, 2H) of its product
-// at t + 1; layer 0's product has only those H rows) and, for the top layer's last frame, from the projection.  Writes the
-// pre-activation gate gradients dgates[l][t] in torch row order (gate*H + u) and carries dc_{t-1} = dc_t * f_t in dcarry[l].
-__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cs, const float* __restrict__ dx0,
-                                                            const float* __restrict__ dxc, const float* __restrict__ dh_top, float* __restrict__ dgates,
+// (rows [0, H) of that layer's data-gradient product at the same frame), from the layer's own next frame (rows [H, 2H) of its own
+// product at t + 1) and, for the top layer's last frame, from the projection.  Both products ran at step s + 1 and lie under that step's
+// parity in dxa = [K range z][parity][layer][2H][Bn] (api.hip, lstm_bwd_ws); nz partial products are added here, in a fixed order.
+// Writes the pre-activation gate gradients dgates[l][t] in torch row order (gate*H + u) and carries dc_{t-1} = dc_t * f_t in dcarry[l].
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cs, const float* __restrict__ dxa,
+                                                            const long zstride, const int nz, const float* __restrict__ dh_top, float* __restrict__ dgates,
                                                             float* __restrict__ dcarry, int H, int Bn, int T, int layers, int s, int lo) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long HN = (long)H * Bn;
   if (i >= HN) return;
   const int l = lo + blockIdx.y, t = s - l;
+  const float* __restrict__ d = dxa + (long)((s + 1) & 1) * layers * 2 * HN;
   float dh = 0.f;
-  if (l + 1 < layers) dh += dxc[((long)l * T + t) * 2 * HN + i];                    // dxc is indexed by layer - 1
-  if (t + 1 < T) dh += (l == 0) ? dx0[(long)(t + 1) * HN + i] : dxc[((long)(l - 1) * T + t + 1) * 2 * HN + HN + i];
+  for (int z = 0; z < nz; ++z) {
+    if (l + 1 < layers) dh += d[z * zstride + (long)(l + 1) * 2 * HN + i];
+    if (t + 1 < T) dh += d[z * zstride + (long)l * 2 * HN + HN + i];
+  }
   if (l == layers - 1 && t == T - 1) dh += dh_top[i];
   const long gt = ((long)l * T + t) * 4 * HN;
   const float gi = gates[gt + i], gf = gates[gt + HN + i], gg = gates[gt + 2 * HN + i], go = gates[gt + 3 * HN + i];
@@ -324,9 +328,9 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
   dgates[gt + 2 * HN + i] = dc * gi * (1.f - gg * gg);
   dgates[gt + 3 * HN + i] = dh * tc * go * (1.f - go);
 }
-int ssv_launch_lstm_cell_bwd(const float* gates, const float* cs, const float* dx0, const float* dxc, const float* dh_top, float* dgates, float* dcarry,
+int ssv_launch_lstm_cell_bwd(const float* gates, const float* cs, const float* dxa, long zstride, int nz, const float* dh_top, float* dgates, float* dcarry,
                              int H, int Bn, int T, int layers, int s, int lo, int nl, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ssv_cdiv((long)H * Bn, 256), nl), dim3(256), 0, st, gates, cs, dx0, dxc, dh_top, dgates, dcarry, H, Bn, T,
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ssv_cdiv((long)H * Bn, 256), nl), dim3(256), 0, st, gates, cs, dxa, zstride, nz, dh_top, dgates, dcarry, H, Bn, T,
                      layers, s, lo);
   return ssv_check_launch("lstm_cell_bwd");
 }

@@ -76,6 +76,10 @@ struct GemmNNB {
   // hs_planes + ((layer * 2 + slot) * 2 + {0: hi, 1: lo}) * hs_plane_bytes.  The products then stage their input with 16-byte loads and no VALU split.
   unsigned short* hs_planes; long hs_plane_bytes; int hs_npad;
   int hs_keep_h;            // (with hs_planes) 1: this launch also stores the fp32 h -- only the wavefront's last step needs it, for the caller's h_last
+  // ksplit > 1 (round 6; plain k = 1 products whose K is long and whose output is small -- the LSTM backward's [W_ih | W_hh]^T dgates): grid.y = B * ksplit,
+  // entry (b, z) reduces over input rows [z Kc, (z + 1) Kc) against weight chunks [z Kc / 32, ...) of planes whose row length is Kpad = ksplit * Kc and
+  // writes its partial product at C + b scb + z scz (the consumer adds the slabs).  skip_rows: entry b = 0 has no use for its row tiles below this row.
+  int ksplit; long scz; int skip_rows;
   // LSTM support.  perm_h = H > 0: output row m is gate (m % 4) of hidden unit (m / 4), i.e. row (m % 4) * H + m / 4 of
   // the torch layout -- the weights were packed in that order and the bias vectors are indexed through the same map.
   // epi = 1: fused cell epilogue -- the 4 accumulator rows of a lane are the (i, f, g, o) pre-activations of one unit;
