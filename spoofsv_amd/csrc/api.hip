@@ -1153,7 +1153,7 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   const bool merge = !(mk && atoi(mk) == 0);
   // Inference in the split-fp16 mode: the cells write h already split into the consumers' staging order (see GemmNNB::hs_planes): no split, no masks and a
   // quarter of the load instructions in the products' input staging.  The planes' pad columns (and everything else) start as zeros.
-  const bool presplit = SSV_LSTM_PRESPLIT && f16 && merge && layers >= 2 && !keep_hs && D == 2 && H % 32 == 0 && s.hp_plane > 0 && s.hp_plane < ((size_t)1 << 31) &&
+  const bool presplit = SSV_LSTM_PRESPLIT && f16 && merge && layers >= 2 && (SSV_LSTM_PRESPLIT_TRAIN || (!keep_hs && D == 2)) && H % 32 == 0 && s.hp_plane > 0 && s.hp_plane < ((size_t)1 << 31) &&
                         !(mk && atoi(mk) == 2);
   if (presplit) {
     SSV_HIP(hipMemsetAsync(base + s.hp, 0, (size_t)layers * 2 * 2 * s.hp_plane, st));
@@ -1161,7 +1161,7 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   }
   for (int step = 0; merge && layers >= 2 && step < T + layers - 1; ++step) {
     g.lstm_s = step;
-    g.hs_keep_h = !presplit || step == T + layers - 2;            // (pre-split h: the fp32 copy is read by nobody but the caller, from the last step)
+    g.hs_keep_h = !presplit || keep_hs || step == T + layers - 2;   // (pre-split h at inference: the fp32 copy is read by nobody but the caller, from the last step)
     const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
     const int lo1 = lo > 1 ? lo : 1;           // the first layer >= 1 of the launch: its planes are the launch's Ahi
     g.Ahi = (unsigned short*)(base + s.comb + (size_t)(lo1 - 1) * s.comb_stride);

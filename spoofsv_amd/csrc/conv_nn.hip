@@ -1106,7 +1106,7 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(!g.row_pair || (g.KT == 1 && g.M % 2 == 0 && g.scn == 1 && !g.R && !g.epi && !g.perm_h && !g.colstats && !g.bias_b), SSV_BAD_SHAPE,
             "gemm_nn_bf3: paired output rows need a plain k = 1 product over an even number of rows");
   SSV_CHECK(g.row_pair || !g.c_amax, SSV_BAD_SHAPE, "gemm_nn_bf3: the output's scale list comes with paired output rows only");
-  SSV_CHECK(!g.hs_planes || (g.epi == 1 && g.lstm_D == 2 && g.f16 && !g.gates_out && g.x_namax == 0 && g.perm_h % 32 == 0 && g.hs_npad % 128 == 0 && g.hs_npad >= g.N &&
+  SSV_CHECK(!g.hs_planes || (g.epi == 1 && g.lstm_D >= 1 && g.f16 && g.x_namax == 0 && g.perm_h % 32 == 0 && g.hs_npad % 128 == 0 && g.hs_npad >= g.N &&
                              g.hs_plane_bytes == (long)(g.perm_h / 8) * g.hs_npad * 16 && (long)(g.perm_h / 8) * g.hs_npad * 16 < (1L << 31)), SSV_BAD_SHAPE,
             "gemm_nn_bf3: pre-split recurrent activations need the merged split-fp16 inference wavefront and whole column tiles of planes");
   SSV_CHECK(g.ksplit == 1 || (g.ksplit > 1 && g.KT == 1 && !g.epi && !g.R && !g.bias && !g.bias_b && !g.colstats && !g.row_pair && !g.perm_h && g.sxn == 1 && g.scn == 1 &&

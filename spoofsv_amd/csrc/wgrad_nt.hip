@@ -27,19 +27,21 @@ extern "C" int ssv_debug_nt_stamps(unsigned long long* out) { return (int)hipMem
 #define NT_WG(k, v) do {} while (0)
 #endif
 constexpr int NT_FD = 1;      // LDS fragment groups read ahead of the MFMAs (see the step loop)
-template <int KT, int WM, int NTC, int F16, int XR = 0>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
+// WV: waves per workgroup -- 4, or 8 (round 6): a 256-row tile whose waves share the staged input tile, one workgroup per CU
+template <int KT, int WM, int NTC, int F16, int XR = 0, int WV = 4>
+__global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 1) void gemm_nt_bf3_kernel(const GemmNT p, const int mtiles) {
+  constexpr int NTH = 64 * WV;
   constexpr int KB = 64, KG = KB / 8, KS = KB / 32;         // time steps per chunk, k-groups, MFMA k-steps
   constexpr int NCH = 16 * NTC;
   constexpr int X_SLOTS = KG * NCH;                         // 16-byte slots of one tap's tile (multiple of 256)
-  constexpr int NX = X_SLOTS / 256;
-  static_assert(X_SLOTS % 256 == 0, "tile slots must be a multiple of the workgroup size");
+  constexpr int NX = X_SLOTS / NTH;
+  static_assert(X_SLOTS % NTH == 0, "tile slots must be a multiple of the workgroup size");
   // [buffer][hi plane | lo plane], slot = kg*NCH + (channel ^ kg).  The staging threads take kg fastest (8 lanes = 256
   // contiguous bytes of one channel row in global memory), so without the XOR the 8 lanes of a ds_write_b128 group would
   // write slots 1 KB apart -- one bank set, an 8-way conflict that cost more than the step's MFMAs.  With it they land on
   // 8 distinct 16-byte bank groups, and the fragment reads (16 consecutive channels per quarter wave) stay conflict-free.
   __shared__ uint4 lds[2][2 * X_SLOTS];
-  __shared__ float amax_sm[8];
+  __shared__ float amax_sm[2 * WV];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   NT_WG(0, __builtin_amdgcn_s_memrealtime()); NT_WG(2, __builtin_readcyclecounter());
@@ -69,14 +71,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   auto scales = [&]() {
     if constexpr (F16) {
       float sa, sx, ia, ix;
-      ssv_pow2_scale(ssv_list_max<4>(a_amax, a_namax, amax_sm), sa, ia);       // long lists (B * tiles entries): shared among the waves
-      ssv_pow2_scale(ssv_list_max<4>(x_amax, x_namax, amax_sm + 4), sx, ix);
+      ssv_pow2_scale(ssv_list_max<WV>(a_amax, a_namax, amax_sm), sa, ia);      // long lists (B * tiles entries): shared among the waves
+      ssv_pow2_scale(ssv_list_max<WV>(x_amax, x_namax, amax_sm + WV), sx, ix);
       as = ssv_uniform(sa); xs = ssv_uniform(sx);
       us = ssv_uniform(ia * ix);
     }
   };
-  const int mt = bxx % mtiles, ct = bxx / mtiles;
-  const int m0 = mt * 64 * WM, c0 = ct * NCH;
+  // Tile order inside a slab.  Few tiles (every tile of the slab resident on its XCD at once): any order.  Many (the LSTM's 3072 x 768 outputs: 72-192
+  // tiles on 32-64 slots): the COLUMN tiles of a row tile next to each other -- they read the same dH rows, the larger operand (4H rows against H), at the
+  // same time, so it comes from HBM once per slab instead of once per round of column tiles (config 5's weight gradients 9.6 -> 8.5 ms).
+  const int ctiles_ = (int)gridDim.x / mtiles;
+  const bool ct_fast = gridDim.x > 64u;
+  const int mt = ct_fast ? bxx / ctiles_ : bxx % mtiles, ct = ct_fast ? bxx % ctiles_ : bxx / mtiles;
+  const int m0 = mt * 16 * WV * WM, c0 = ct * NCH;
   const int tchunks = (p.La + KB - 1) / KB;
   const int kq = lane >> 4, nq = lane & 15;
 
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
 
   float rx[NX][8];                     // raw loads in flight: the tile of step s + 2
   int mx[NX];                          // edge windows only: validity bits (low 8) | offset clamp distance << 8
-  static_assert(!XR || (KT == 1 && (256 % KG) == 0), "extra row: k = 1; a thread's slots share their k-group");
+  static_assert(!XR || (KT == 1 && WV == 4 && (256 % KG) == 0), "extra row: k = 1; a thread's slots share their k-group");
   const bool xr_on = XR && mt == 0;
   float xacc[XR ? NX : 1];
   uint4 xra[XR ? 2 : 1];               // dH(M - 1, t0 + 8 kg .. + 7) of the tile in flight (raw; what lies past the row meets masked input)
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
   const int xra_off = ((p.M - 1) * (int)p.sam + 8 * (tid % KG)) * 4;
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
-    const int f = tid + 256 * r;
+    const int f = tid + NTH * r;
     xrow[r] = min(c0 + f / KG, p.Nc - 1) * (int)p.sxc + 8 * (f % KG);
   }
   const bool rows_in_c = c0 + NCH <= p.Nc;
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     if (x_edge(t0, j)) {
 #pragma unroll
       for (int r = 0; r < NX; ++r) {
-        const int f = tid + 256 * r;
+        const int f = tid + NTH * r;
         mx[r] = edge_meta(dd[r], t0 + shj[j] + 8 * (f % KG), p.Lx, c0 + f / KG < p.Nc, t0 + 8 * (f % KG) + 8 - p.La);
       }
     }
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
     const bool edge = x_edge(t0, j);
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
-      const int f = tid + 256 * r;
+      const int f = tid + NTH * r;
       const int kg = f % KG, c = f / KG;
       uint4 h, l;
       if (!edge) split8p<F16>(rx[r], xs, h, l);
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(const GemmNT p, con
       for (int r = 0; r < NX; ++r) {
         float v = xacc[r];
         v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-        const int f = tid + 256 * r, gc = c0 + f / KG;
+        const int f = tid + NTH * r, gc = c0 + f / KG;
         if ((f % KG) == 0 && gc < p.Nc) Cz[(long)(p.M - 1) * p.scm + (long)gc * p.scc] = v;
       }
     }
@@ -431,6 +438,14 @@ void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
   // staged byte, so only large outputs (513 x 513) keep the 128 x 96 tile, smaller ones take 64 x 64 tiles with fewer slabs
   if (KT == 3) { *wm = 2; *ntc = 4; }
   else if (Nc <= 48) { *wm = 2; *ntc = 2; }
+  // (round 6) the LSTM's weight gradients (3072 x 768 over 120 frames x 880 utterances): 128 x 128.  The k = 1 kernel is bound by its dH path -- the
+  // fragments each wave loads for itself, 32 bytes per lane and 8 time steps: with 64-column tiles (twice the dH bytes per MFMA) the five launches of
+  // config 5 take +31 %, with 64-row tiles (twice the staged input per MFMA) +5 %, with 128 columns -14 % (11.2 -> 9.6 ms).  Not for the convolutions'
+  // shapes: their M = 513 outputs lose the extra-row form (115 -> 148 us in-step).
+  // ... and 256 x 128 on 8 waves (wm = 4 stands for 8 waves x 32 rows; one workgroup per CU) where the rows allow: the staged input tile serves twice the
+  // rows and half as many workgroups walk the rows of dH (8.5 -> 7.9 ms)
+  else if (M % 256 == 0 && Nc % 128 == 0 && (long)M * Nc >= (1L << 21)) { *wm = 4; *ntc = 8; }
+  else if (M % 128 == 0 && Nc % 128 == 0 && (long)M * Nc >= (1L << 21)) { *wm = 2; *ntc = 8; }
   else if ((long)M * Nc >= (1L << 18)) { *wm = 2; *ntc = 6; }
   else { *wm = 1; *ntc = 4; }
 }
@@ -438,8 +453,9 @@ void ssv_nt_bf3_tile(int KT, int M, int Nc, int* wm, int* ntc) {
 // (-Rpass-analysis=kernel-resource-usage: <3,2,4> 236, <3,2,2> 174, <3,1,4> 156, <3,1,2> 110, <1,2,6> 208, <1,2,4> 168, <1,2,2> 134,
 // <1,1,6> 148, <1,1,4> 120, <1,1,2> 94; the two LDS buffers of the largest tile (32 KB) allow 4)
 int ssv_nt_bf3_wg_per_cu(int KT, int wm, int ntc) {
+  if (wm == 4) return 1;                            // 8 waves, 64 KB of LDS, 2 waves per SIMD as the others
   if (KT == 3) return wm == 2 ? 2 : (ntc >= 4 ? 3 : 4);
-  if (wm == 2) return ntc >= 6 ? 2 : 3;
+  if (wm == 2) return ntc >= 6 ? 2 : 3;            // (<1,2,8>: 244 VGPRs, 64 KB of LDS)
   return ntc >= 6 ? 3 : (ntc >= 4 ? 4 : 5);
 }
 int ssv_nt_bf3_tiles(int KT, int M, int Nc) {
@@ -488,9 +504,10 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
     char nm[96], note[96];
     const int nj = g.jobs ? g.njobs : 1;
     if (ring_ms >= 0) snprintf(nm, sizeof nm, "gemm_nt3r_kernel<%d, %d>", wm, g.f16);
+    else if (wm == 4) snprintf(nm, sizeof nm, "gemm_nt_bf3_kernel<%d, 2, %d, %d, 0, 8>", g.KT, ntc, g.f16);
     else snprintf(nm, sizeof nm, xr ? "gemm_nt_bf3_kernel<%d, %d, %d, %d, 1>" : "gemm_nt_bf3_kernel<%d, %d, %d, %d>", g.KT, wm, ntc, g.f16);
     snprintf(note, sizeof note, "jobs=%d B=%d M=%d Nc=%d L=%d k=%d Z=%d", nj, g.B, g.M, g.Nc, g.La, g.KT, g.Z);
-    ssv_shape_log(nm, grid, dim3(256), 2.0 * nj * g.B * g.M * g.Nc * g.La * g.KT,
+    ssv_shape_log(nm, grid, dim3(wm == 4 ? 512 : 256), 2.0 * nj * g.B * g.M * g.Nc * g.La * g.KT,
                   4.0 * nj * ((double)g.B * g.M * g.La + (double)g.B * g.Nc * g.Lx + (double)g.Z * g.M * g.Nc * g.KT), note);
   }
   if (ring_ms >= 0) {
@@ -502,12 +519,17 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 6, 0, 1>), grid, dim3(256), 0, st, g, mtiles);
     return ssv_check_launch("gemm_nt_bf3 (extra row)");
   }
+  if (g.KT == 1 && wm == 4 && ntc == 8) {
+    if (g.f16) hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 8, 1, 0, 8>), grid, dim3(512), 0, st, g, mtiles);
+    else hipLaunchKernelGGL((gemm_nt_bf3_kernel<1, 2, 8, 0, 0, 8>), grid, dim3(512), 0, st, g, mtiles);
+    return ssv_check_launch("gemm_nt_bf3 (8 waves)");
+  }
 #define SSV_NT(K_, A_, C_) if (g.KT == K_ && wm == A_ && ntc == C_) { \
     if (g.f16) hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_, 1>), grid, dim3(256), 0, st, g, mtiles); \
     else hipLaunchKernelGGL((gemm_nt_bf3_kernel<K_, A_, C_, 0>), grid, dim3(256), 0, st, g, mtiles); \
     return ssv_check_launch("gemm_nt_bf3"); }
   SSV_NT(3, 2, 4) SSV_NT(3, 2, 2) SSV_NT(3, 1, 4) SSV_NT(3, 1, 2)
-  SSV_NT(1, 2, 6) SSV_NT(1, 2, 4) SSV_NT(1, 2, 2) SSV_NT(1, 1, 6) SSV_NT(1, 1, 4) SSV_NT(1, 1, 2)
+  SSV_NT(1, 2, 8) SSV_NT(1, 2, 6) SSV_NT(1, 2, 4) SSV_NT(1, 2, 2) SSV_NT(1, 1, 6) SSV_NT(1, 1, 4) SSV_NT(1, 1, 2)
 #undef SSV_NT
   return ssv_fail(SSV_UNSUPPORTED, "gemm_nt_bf3: no tile %d,%d for kernel size %d", wm, ntc, g.KT);
 }
