@@ -135,7 +135,7 @@ int ssv_launch_transpose_out(const float*, float*, int, int, hipStream_t);
 int ssv_launch_l2norm_rows(const float*, float*, float*, int, int, hipStream_t);
 int ssv_launch_l2norm_bwd(const float*, const float*, const float*, float*, int, int, hipStream_t);
 int ssv_launch_colsum(const float*, float*, int, int, hipStream_t);
-int ssv_launch_lstm_cell_bwd(const float*, const float*, const float*, long, int, const float*, float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int ssv_launch_lstm_cell_bwd(const float*, const float*, const float*, long, int, const float*, float*, float*, float*, int, int, int, int, int, int, int, hipStream_t);
 
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
@@ -1398,7 +1398,7 @@ static LstmBwdWs lstm_bwd_ws(int Bn, int T, int F, int H, int layers) {
   s.dcarry = s.dxa + 2 * s.dxa_slab;
   s.dhtop = s.dcarry + align256((size_t)layers * H * Bn * sizeof(float));
   s.rs = s.dhtop + align256((size_t)H * Bn * sizeof(float));
-  s.wta = s.rs + align256((size_t)T * 4 * H * sizeof(float));
+  s.wta = s.rs + align256((size_t)layers * T * 4 * H * sizeof(float));      // the bias gradients' per-frame terms, [layer][frame][4H] (lstm_cell_bwd_kernel)
   s.wta_stride = 2 * split_bytes(2 * H, 4 * H, 1);                 // [W_ih | W_hh]^T of a layer (layer 0: the W_ih half stays zero)
   s.slabs = s.wta + (size_t)layers * s.wta_stride;
   // every (items, M, Nc) lstm_weight_grad is called with: W_ih over T frames (Fin = F or H), W_hh over T - 1
@@ -1459,7 +1459,7 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
   };
   for (int step = T + layers - 2; f32 && step >= 0; --step) {
     const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
-    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dxa, zstride, 1, dhtop, dgates, dcarry, H, Bn, T, layers, step, lo, hi - lo + 1, st));
+    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dxa, zstride, 1, dhtop, dgates, dcarry, rs, H, Bn, T, layers, step, lo, hi - lo + 1, st));
     float* outp = dxa + (long)(step & 1) * layers * 2 * HN;                   // this step's parity
     if (lo == 0 && step >= 1) SSV_TRY(wt_gemm_f32(w_hh[0], dgates + (long)step * 4 * HN, outp + HN));
     for (int l = lo > 1 ? lo : 1; l <= hi; ++l) {                            // [dh^{l-1}_t ; dh^l_{t-1}] = [W_ih | W_hh]^T dgates^l_t
@@ -1487,7 +1487,7 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
   g.sab = (long)(s.wta_stride / sizeof(unsigned short)); g.sxb = (long)(T - 1) * 4 * HN; g.scb = 2 * HN; g.scz = zstride;
   for (int step = T + layers - 2; !f32 && step >= 0; --step) {
     const int lo = step - T + 1 > 0 ? step - T + 1 : 0, hi = step < layers - 1 ? step : layers - 1;
-    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dxa, zstride, 2, dhtop, dgates, dcarry, H, Bn, T, layers, step, lo, hi - lo + 1, st));
+    SSV_TRY(ssv_launch_lstm_cell_bwd(gates, cs, dxa, zstride, 2, dhtop, dgates, dcarry, rs, H, Bn, T, layers, step, lo, hi - lo + 1, st));
     if (step == 0) break;                                                    // frame 0 of layer 0: its product would be the gradient of the initial state
     g.Ahi = (unsigned short*)(base + s.wta + (size_t)lo * s.wta_stride);
     g.Alo = (unsigned short*)((char*)g.Ahi + split_bytes(2 * H, 4 * H, 1));
@@ -1505,8 +1505,7 @@ extern "C" int ssv_lstm_bwd(const float* dh_last, const void* saved, const float
     SSV_TRY(lstm_weight_grad(dg, 4 * HN, in, (long)Fin * Bn, dw_ih[l], 4 * H, Fin, Bn, T, base + s.slabs, st, f32));
     if (T > 1) SSV_TRY(lstm_weight_grad(dg + 4 * HN, 4 * HN, hs + (long)l * T * HN, HN, dw_hh[l], 4 * H, H, Bn, T - 1, base + s.slabs, st, f32));
     else SSV_TRY(ssv_launch_fill(dw_hh[l], 0.f, (long)4 * H * H, st));
-    SSV_TRY(ssv_rowsum(dg, 4 * HN, rs, T, 4 * H, Bn, stream));              // rs[t][r] = sum_b dgates[l][t][r][b]
-    SSV_TRY(ssv_launch_reduce_slabs(rs, db_ih[l], 4 * H, T, 4 * H, st));
+    SSV_TRY(ssv_launch_reduce_slabs(rs + (long)l * T * 4 * H, db_ih[l], 4 * H, T, 4 * H, st));      // sum over frames of sum_b dgates[l][t][r][b] (the cell kernel's row sums)
     SSV_HIP(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   return 0;

@@ -302,36 +302,68 @@ extern "C" int ssv_ge2e_loss_bwd(const float* emb, const float* w, const float* 
 // product at t + 1) and, for the top layer's last frame, from the projection.  Both products ran at step s + 1 and lie under that step's
 // parity in dxa = [K range z][parity][layer][2H][Bn] (api.hip, lstm_bwd_ws); nz partial products are added here, in a fixed order.
 // Writes the pre-activation gate gradients dgates[l][t] in torch row order (gate*H + u) and carries dc_{t-1} = dc_t * f_t in dcarry[l].
+// One workgroup per hidden unit u (a row of Bn utterances) and layer: besides the cells it leaves the row sums of the four gate gradients --
+// the bias gradient's terms of this frame, dbp[l][t][gate * H + u] -- in a fixed order (per thread over its columns, the 64 lanes of a wave by
+// ssv_wave_sum, the four waves in turn): the separate pass over all of dgates (ssv_rowsum: 3 x 0.22 ms for config 5) is gone.
+// V = 4: Bn % 4 == 0, a thread takes four neighbouring columns as 16-byte vectors (every row then starts 16-byte aligned); V = 1: any Bn.
+template <int V>
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cs, const float* __restrict__ dxa,
                                                             const long zstride, const int nz, const float* __restrict__ dh_top, float* __restrict__ dgates,
-                                                            float* __restrict__ dcarry, int H, int Bn, int T, int layers, int s, int lo) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+                                                            float* __restrict__ dcarry, float* __restrict__ dbp, int H, int Bn, int T, int layers, int s, int lo) {
+  typedef float vec __attribute__((ext_vector_type(V)));
+  __shared__ float red[4][4];
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long HN = (long)H * Bn;
-  if (i >= HN) return;
   const int l = lo + blockIdx.y, t = s - l;
   const float* __restrict__ d = dxa + (long)((s + 1) & 1) * layers * 2 * HN;
-  float dh = 0.f;
-  for (int z = 0; z < nz; ++z) {
-    if (l + 1 < layers) dh += d[z * zstride + (long)(l + 1) * 2 * HN + i];
-    if (t + 1 < T) dh += d[z * zstride + (long)l * 2 * HN + HN + i];
-  }
-  if (l == layers - 1 && t == T - 1) dh += dh_top[i];
   const long gt = ((long)l * T + t) * 4 * HN;
-  const float gi = gates[gt + i], gf = gates[gt + HN + i], gg = gates[gt + 2 * HN + i], go = gates[gt + 3 * HN + i];
-  const float c = cs[((long)l * T + t) * HN + i];
-  const float cprev = t > 0 ? cs[((long)l * T + t - 1) * HN + i] : 0.f;
-  const float tc = tanhf(c);
-  const float dc = dh * go * (1.f - tc * tc) + (t + 1 < T ? dcarry[(long)l * HN + i] : 0.f);
-  dcarry[(long)l * HN + i] = dc * gf;
-  dgates[gt + i] = dc * gg * gi * (1.f - gi);
-  dgates[gt + HN + i] = dc * cprev * gf * (1.f - gf);
-  dgates[gt + 2 * HN + i] = dc * gi * (1.f - gg * gg);
-  dgates[gt + 3 * HN + i] = dh * tc * go * (1.f - go);
+  const bool above = l + 1 < layers, nextf = t + 1 < T, top = l == layers - 1 && t == T - 1;
+  auto ld = [&](const float* q) -> vec { return *reinterpret_cast<const vec*>(q); };
+  auto st = [&](float* q, vec v) { *reinterpret_cast<vec*>(q) = v; };
+  vec sum[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sum[g] = (vec)0.f;
+  // every load of a pass in front of its first store (a load issued behind a store waits for it: one vmcnt)
+  for (int b = tid * V; b < Bn; b += 256 * V) {
+    const long i = (long)u * Bn + b;
+    vec dh = (vec)0.f;
+    for (int z = 0; z < nz; ++z) {
+      if (above) dh += ld(d + z * zstride + (long)(l + 1) * 2 * HN + i);
+      if (nextf) dh += ld(d + z * zstride + (long)l * 2 * HN + HN + i);
+    }
+    if (top) dh += ld(dh_top + i);
+    const vec gi = ld(gates + gt + i), gf = ld(gates + gt + HN + i), gg = ld(gates + gt + 2 * HN + i), go = ld(gates + gt + 3 * HN + i);
+    const vec c = ld(cs + ((long)l * T + t) * HN + i);
+    const vec cprev = t > 0 ? ld(cs + ((long)l * T + t - 1) * HN + i) : (vec)0.f;
+    const vec dcin = nextf ? ld(dcarry + (long)l * HN + i) : (vec)0.f;
+    vec tc;
+#pragma unroll
+    for (int k = 0; k < V; ++k) tc[k] = tanhf(c[k]);
+    const vec dc = dh * go * (1.f - tc * tc) + dcin;
+    const vec di = dc * gg * gi * (1.f - gi), df = dc * cprev * gf * (1.f - gf), dg = dc * gi * (1.f - gg * gg), d_o = dh * tc * go * (1.f - go);
+    st(dcarry + (long)l * HN + i, dc * gf);
+    st(dgates + gt + i, di);
+    st(dgates + gt + HN + i, df);
+    st(dgates + gt + 2 * HN + i, dg);
+    st(dgates + gt + 3 * HN + i, d_o);
+    sum[0] += di; sum[1] += df; sum[2] += dg; sum[3] += d_o;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v = sum[g][0];
+    if constexpr (V == 4) v = (sum[g][0] + sum[g][1]) + (sum[g][2] + sum[g][3]);
+    v = ssv_wave_sum(v);
+    if (lane == 0) red[wave][g] = v;
+  }
+  __syncthreads();
+  if (tid < 4) dbp[((long)l * T + t) * 4 * H + (long)tid * H + u] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 int ssv_launch_lstm_cell_bwd(const float* gates, const float* cs, const float* dxa, long zstride, int nz, const float* dh_top, float* dgates, float* dcarry,
-                             int H, int Bn, int T, int layers, int s, int lo, int nl, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ssv_cdiv((long)H * Bn, 256), nl), dim3(256), 0, st, gates, cs, dxa, zstride, nz, dh_top, dgates, dcarry, H, Bn, T,
-                     layers, s, lo);
+                             float* dbp, int H, int Bn, int T, int layers, int s, int lo, int nl, hipStream_t st) {
+  // (the vector form also wants 16-byte aligned bases: the workspace sections are 256-byte aligned, the saved tensors come from the caller)
+  const bool v4 = Bn % 4 == 0 && zstride % 4 == 0 && (((uintptr_t)gates | (uintptr_t)cs | (uintptr_t)dxa | (uintptr_t)dh_top | (uintptr_t)dgates | (uintptr_t)dcarry) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(lstm_cell_bwd_kernel<4>, dim3(H, nl), dim3(256), 0, st, gates, cs, dxa, zstride, nz, dh_top, dgates, dcarry, dbp, H, Bn, T, layers, s, lo);
+  else hipLaunchKernelGGL(lstm_cell_bwd_kernel<1>, dim3(H, nl), dim3(256), 0, st, gates, cs, dxa, zstride, nz, dh_top, dgates, dcarry, dbp, H, Bn, T, layers, s, lo);
   return ssv_check_launch("lstm_cell_bwd");
 }
 
@@ -347,19 +379,34 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
   const float inv = 1.f / norms[b];
   for (int p = lane; p < P; p += 64) dy[(long)b * P + p] = (de[(long)b * P + p] - e[(long)b * P + p] * s) * inv;
 }
-// out[p] = sum_b x[b][p]   (x (Bn, P) row-major), fixed order
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int P, int Bn) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
+// out[p] = sum_b x[b][p]   (x (Bn, P) row-major), fixed order: 64 columns per workgroup of 16 waves, wave w adds rows w, w + 16, ... (four loads in
+// flight), then the sixteen waves in turn (one thread per column walking all Bn rows took 0.2 ms of config 5's iteration)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int P, int Bn) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const int pc = p < P ? p : P - 1;
   float s = 0.f;
-  for (int b = 0; b < Bn; ++b) s += x[(long)b * P + p];
-  out[p] = s;
+  int b = wave;
+  for (; b + 48 < Bn; b += 64) {
+    const float v0 = x[(long)b * P + pc], v1 = x[(long)(b + 16) * P + pc], v2 = x[(long)(b + 32) * P + pc], v3 = x[(long)(b + 48) * P + pc];
+    s += v0; s += v1; s += v2; s += v3;
+  }
+  for (; b < Bn; b += 16) s += x[(long)b * P + pc];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && p < P) {
+    float r = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) r += red[w][lane];
+    out[p] = r;
+  }
 }
 int ssv_launch_l2norm_bwd(const float* de, const float* e, const float* norms, float* dy, int P, int Bn, hipStream_t st) {
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ssv_cdiv(Bn, 4)), dim3(256), 0, st, de, e, norms, dy, P, Bn);
   return ssv_check_launch("l2norm_bwd");
 }
 int ssv_launch_colsum(const float* x, float* out, int P, int Bn, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(ssv_cdiv(P, 256)), dim3(256), 0, st, x, out, P, Bn);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ssv_cdiv(P, 64)), dim3(1024), 0, st, x, out, P, Bn);
   return ssv_check_launch("colsum");
 }
