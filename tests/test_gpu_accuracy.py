@@ -319,6 +319,30 @@ def test_one_by_one_convolutions_with_128_j_plus_1_output_rows(B, Cin, Cout, L):
             assert e <= 2 * tol, (prec, name, e)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,L", [(5, 1024, 2048, 100), (3, 1152, 1920, 333), (7, 1024, 2304, 64)])
+def test_one_by_one_weight_gradient_on_the_large_output_tiles(B, Cin, Cout, L):
+    """k = 1 weight gradients whose output is 2^21 elements or more with whole 128-row / 128-column tiles -- the shape class of the GE2E embedder's LSTM
+    weight gradients (GE2E/speech_embedder_net.py:19: 3072 x 768 over 120 frames x 880 utterances), reached here through the convolution entry: the
+    256 x 128 tile on 8 waves (Cout % 256 == 0) and the 128 x 128 tile (Cout % 256 == 128), with the column tiles of a row tile adjacent
+    (csrc/wgrad_nt.hip, ssv_nt_bf3_tile and the tile order).  Ragged lengths, more tiles than one XCD holds, against float64."""
+    gen = torch.Generator().manual_seed(B * 1000 + Cin + Cout + L)
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(Cout, Cin, 1, generator=gen) * 0.05
+    dy = torch.randn(B, Cout, L, generator=gen)
+    ref = _reference(x, w, dy, 1, 1, False)
+    for prec, tol in (("f16x2", 2e-6), ("bf16x3", 3e-5)):
+        got = _hip(x, w, dy, 1, 1, False, prec)
+        e = _rl2(got[2], ref[2])
+        print("%-6s %4d -> %4d L %4d wgrad %.2e" % (prec, Cin, Cout, L, e))
+        assert e <= tol, (prec, e)
+        # every 128 x 128 block of the output on its own: a misplaced tile would hide in the norm over the whole matrix
+        d = (got[2].double().cpu() - ref[2]).squeeze(-1)
+        r = ref[2].squeeze(-1)
+        for i in range(0, Cout, 128):
+            for j in range(0, Cin, 128):
+                assert float(d[i:i + 128, j:j + 128].norm() / r[i:i + 128, j:j + 128].norm()) <= 3 * tol, (prec, i, j)
+
+
 @pytest.mark.parametrize("gate,B,C,L", [(0, 2, 513, 129), (0, 3, 320, 1030), (0, 2, 256, 100), (1, 2, 512, 70), (1, 2, 256, 1089), (1, 3, 192, 77)])
 def test_layernorm_backward_sums_only_the_partial_rows_it_wrote(gate, B, C, L):
     """The backward kernels leave one partial row of parameter-gradient sums per column tile in the caller's workspace -- compact, one
