@@ -129,6 +129,7 @@ int ssv_launch_ln_act_bwd(const float*, long, const float*, long, const float*, 
 int ssv_launch_softmax_cols(float*, int, int, int, hipStream_t);
 int ssv_launch_softmax_cols_bwd(const float*, float*, const float*, float, int, int, int, hipStream_t);
 int ssv_launch_lstm_in_transpose(const float*, float*, int, int, int, hipStream_t);
+int ssv_launch_lstm_x_planes(const float*, const float*, void*, long, int, int, int, int, int, hipStream_t);
 int ssv_launch_lstm_cell(const float*, float*, float*, int, int, int, hipStream_t);
 int ssv_launch_lstm_cell_train(const float* pre, float* act, const float* cprev, float* c, float* h, int H, int Bn, hipStream_t st);
 int ssv_launch_transpose_out(const float*, float*, int, int, hipStream_t);
@@ -227,6 +228,7 @@ static GemmNNB nnb_zero() {
   g.row_pair = 0; g.c_amax = nullptr; g.c_namax = 0;
   g.hs_planes = nullptr; g.hs_plane_bytes = 0; g.hs_npad = 0; g.hs_keep_h = 1;
   g.ksplit = 1; g.scz = 0; g.skip_rows = 0;
+  g.x0_planes = nullptr; g.x0_amax = nullptr; g.xsplit0 = 0;
   g.perm_h = g.epi = g.first = 0; g.cstate = nullptr;
   g.lstm_out = nullptr; g.lstm_s = g.lstm_lo = g.lstm_D = g.xsplit = 0; g.sab = 0; g.A0hi = g.A0lo = nullptr;
   g.gates_out = nullptr;
@@ -1042,7 +1044,7 @@ static int lstm_gemm_f32(const float* A, const float* X, long sxb, float* C, lon
   return ssv_launch_gemm_nn(g, st);
 }
 // Wavefront (split-bf16) layout: h of every layer lives in a 2-frame ring, weights of layer l >= 1 are [W_ih | W_hh] side by side.
-struct LstmWave { size_t xt, xp, out, c, bias, ih0, hh0, comb, comb_stride, aux, hp, hp_plane, total; int npad; };
+struct LstmWave { size_t xt, xp, out, c, bias, ih0, hh0, comb, comb_stride, aux, hp, hp_plane, l0c, x0p, total; int npad, xsplit0; };
 // split-fp16 scales of the wavefront (floats at `aux`): [0, 64) partial maxima over ALL weight matrices (one scale for every layer: a
 // launch batches layers over grid.y and has one epilogue factor), [64] its inverse scale, [128, 192) partial maxima of the input frames
 // (layer 0's projection).  The recurrent activations need no list: |h| = |o tanh c| < 1, their scale is the constant 2^14 (x_namax = 0).
@@ -1063,7 +1065,12 @@ static LstmWave lstm_wave_ws(int Bn, int T, int F, int H, int layers) {
   s.npad = (Bn + 127) / 128 * 128;
   s.hp = s.aux + align256(LSTM_AUX_FLOATS * sizeof(float));
   s.hp_plane = (H % 8 == 0) ? (size_t)(H / 8) * s.npad * 16 : 0;
-  s.total = s.hp + align256((size_t)layers * 2 * 2 * s.hp_plane);
+  // layer 0's input as the first K segment of its product (GemmNNB::x0_planes): the planes of [W_ih (F padded to whole chunk pairs) | W_hh] and the
+  // input frames pre-split, a (hi, lo) plane pair of the recurrent activations' size per frame (only its first 4 * xsplit0 k-groups are used)
+  s.xsplit0 = 2 * ((F + 63) / 64);
+  s.l0c = s.hp + align256((size_t)layers * 2 * 2 * s.hp_plane);
+  s.x0p = s.l0c + 2 * split_bytes(4 * H, 32 * s.xsplit0 + H, 1);
+  s.total = s.x0p + align256((size_t)T * 2 * s.hp_plane);
   return s;
 }
 static bool lstm_wave_ok(int Bn, int H) { return Bn >= 64 && H >= 32 && H % 32 == 0; }
@@ -1087,7 +1094,19 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   float* cbuf = keep_cs ? keep_cs : (float*)(base + s.c);
   float* bias = (float*)(base + s.bias);
   const long HN = (long)H * Bn;
-  SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));    // [T][F][Bn]
+  // Arithmetic of the products: split-fp16 in the default mode (the reference's nn.LSTM computes in fp32,
+  // GE2E/speech_embedder_net.py:19,28), split-bf16 when that mode is selected.
+  const bool f16 = use_f16() && 2 * layers <= 64;
+  // One launch per wavefront step (SSV_LSTM_MERGE=0 keeps the two launches: tuning), and in the split-fp16 mode the cells write h already split into the
+  // consumers' staging order (GemmNNB::hs_planes): no split, no masks and a quarter of the load instructions in the products' input staging.  The input
+  // frames are then pre-split the same way and layer 0's W_ih x_t is the first K segment of its product (GemmNNB::x0_planes): no projection of all frames
+  // (0.42 ms and 1.3 GB written, then read back by the cells, at config 5's shape).
+  const char* mk = ssv_tuning(SSV_T_LSTM_MERGE);
+  const bool merge = !(mk && atoi(mk) == 0);
+  const bool presplit = SSV_LSTM_PRESPLIT && f16 && merge && layers >= 2 && (SSV_LSTM_PRESPLIT_TRAIN || (!keep_hs && D == 2)) && H % 32 == 0 && s.hp_plane > 0 && s.hp_plane < ((size_t)1 << 31) &&
+                        !(mk && atoi(mk) == 2);
+  const bool x0fold = presplit && SSV_LSTM_X0FOLD && 4 * s.xsplit0 <= H / 8;
+  if (!x0fold || keep_xt) SSV_TRY(ssv_launch_lstm_in_transpose(x, xt, Bn, T, F, st));    // [T][F][Bn]  (training keeps it for W_ih[0]'s gradient)
   // packed: the workspace still holds what a previous call of the same shape and arithmetic mode prepared from the SAME weight values -- bias
   // rows, split weight planes, the weights' scale (ssv_lstm_fwd_cached: d-vector extraction runs batch after batch on fixed weights; the six
   // absmax scans over 48 MB of weights and the six packs were ~0.35 ms of an 11.6 ms forward)
@@ -1100,9 +1119,8 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   unsigned short* ih0_lo = (unsigned short*)(base + s.ih0 + split_bytes(4 * H, F, 1));
   unsigned short* hh0_hi = (unsigned short*)(base + s.hh0);
   unsigned short* hh0_lo = (unsigned short*)(base + s.hh0 + split_bytes(4 * H, H, 1));
-  // Arithmetic of the products: split-fp16 in the default mode (the reference's nn.LSTM computes in fp32,
-  // GE2E/speech_embedder_net.py:19,28), split-bf16 when that mode is selected.
-  const bool f16 = use_f16() && 2 * layers <= 64;
+  unsigned short* l0c_hi = (unsigned short*)(base + s.l0c);
+  unsigned short* l0c_lo = (unsigned short*)(base + s.l0c + split_bytes(4 * H, 32 * s.xsplit0 + H, 1));
   float* aux = (float*)(base + s.aux);
   if (f16) {
     const int npb = 64 / (2 * layers);                            // partial maxima per weight matrix
@@ -1113,17 +1131,21 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
         SSV_TRY(ssv_launch_absmax(w_hh[l], 0, 1, (long)4 * H * H, aux + (2 * l + 1) * npb, npb, st));
       }
     }
-    SSV_TRY(ssv_launch_absmax(xt, 0, 1, (long)T * F * Bn, aux + 128, 64, st));       // (writes all 64 entries of the input's list)
+    SSV_TRY(ssv_launch_absmax(x0fold ? x : xt, 0, 1, (long)T * F * Bn, aux + 128, 64, st));       // (writes all 64 entries of the input's list; the same values either way)
   }
   auto pack = [&](const float* w, unsigned short* hi, unsigned short* lo, int K, int Kpad, int nch_total, int ch_off) -> int {
     if (f16) return ssv_launch_pack_split_f16_list(w, hi, lo, 4 * H, K, Kpad, 1, K, 1, 1, H, aux, 64, aux + 64, st, nch_total, ch_off);
     return ssv_launch_pack_split(w, hi, lo, 4 * H, K, Kpad, 1, K, 1, 1, H, st, nch_total, ch_off);
   };
-  if (!packed) {
+  const int hch = H / 32;
+  if (!packed && !x0fold) {
     SSV_TRY(pack(w_ih[0], ih0_hi, ih0_lo, F, pad32(F), 0, 0));
     SSV_TRY(pack(w_hh[0], hh0_hi, hh0_lo, H, H, 0, 0));
   }
-  const int hch = H / 32;
+  if (!packed && x0fold) {                                       // [W_ih (zero-padded to xsplit0 chunks) | W_hh], one row of chunks per 16 output rows
+    SSV_TRY(pack(w_ih[0], l0c_hi, l0c_lo, F, 32 * s.xsplit0, s.xsplit0 + hch, 0));
+    SSV_TRY(pack(w_hh[0], l0c_hi, l0c_lo, H, H, s.xsplit0 + hch, s.xsplit0));
+  }
   for (int l = 1; !packed && l < layers; ++l) {
     unsigned short* hi = (unsigned short*)(base + s.comb + (size_t)(l - 1) * s.comb_stride);
     unsigned short* lo = (unsigned short*)((char*)hi + split_bytes(4 * H, 2 * H, 1));
@@ -1131,7 +1153,8 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
     SSV_TRY(pack(w_hh[l], hi, lo, H, H, 2 * hch, hch));
   }
   // layer 0's input projection for every frame at once (biases are left to the cell): xp[t] = W_ih x_t
-  {
+  if (x0fold) SSV_TRY(ssv_launch_lstm_x_planes(x, aux + 128, base + s.x0p, (long)s.hp_plane, Bn, T, F, 4 * s.xsplit0, s.npad, st));
+  else {
     GemmNNB g = nnb_zero();
     g.Ahi = ih0_hi; g.Alo = ih0_lo; g.Kpad = pad32(F); g.Kc = F;
     g.X = xt; g.sxb = (long)F * Bn; g.sxc = Bn; g.Lx = Bn;
@@ -1149,12 +1172,6 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
   // One launch per wavefront step (round 5): layer 0 (K = H: its own h_{t-1}; the input projection xp[t] through R) rides in the launch of the
   // layers above it (K = 2 H) as entry 0.  Before, a step was two launches -- 336 workgroups with 24 chunks, then 672 with 48 -- each with a
   // half-empty last round; together they are 1008 workgroups = two full rounds of 512.  SSV_LSTM_MERGE=0 keeps the two launches (tuning).
-  const char* mk = ssv_tuning(SSV_T_LSTM_MERGE);
-  const bool merge = !(mk && atoi(mk) == 0);
-  // Inference in the split-fp16 mode: the cells write h already split into the consumers' staging order (see GemmNNB::hs_planes): no split, no masks and a
-  // quarter of the load instructions in the products' input staging.  The planes' pad columns (and everything else) start as zeros.
-  const bool presplit = SSV_LSTM_PRESPLIT && f16 && merge && layers >= 2 && (SSV_LSTM_PRESPLIT_TRAIN || (!keep_hs && D == 2)) && H % 32 == 0 && s.hp_plane > 0 && s.hp_plane < ((size_t)1 << 31) &&
-                        !(mk && atoi(mk) == 2);
   if (presplit) {
     SSV_HIP(hipMemsetAsync(base + s.hp, 0, (size_t)layers * 2 * 2 * s.hp_plane, st));
     g.hs_planes = (unsigned short*)(base + s.hp); g.hs_plane_bytes = (long)s.hp_plane; g.hs_npad = s.npad;
@@ -1170,7 +1187,12 @@ static int lstm_fwd_wave(const float* x, const float* const* w_ih, const float* 
     g.Kpad = 2 * H; g.Kc = 2 * H;
     g.xsplit = hch; g.lstm_lo = lo; g.B = hi - lo + 1;
     g.bias = bias + (long)lo * 8 * H; g.bias_b = g.bias + 4 * H;
-    if (lo == 0) { g.A0hi = hh0_hi; g.A0lo = hh0_lo; g.R = xp + (long)step * 4 * H * Bn; g.srb = 0; }
+    g.x0_planes = nullptr;
+    if (lo == 0 && x0fold) {
+      g.A0hi = l0c_hi; g.A0lo = l0c_lo; g.R = nullptr;
+      g.x0_planes = (const unsigned short*)(base + s.x0p); g.x0_amax = aux + 128; g.xsplit0 = s.xsplit0;
+    }
+    else if (lo == 0) { g.A0hi = hh0_hi; g.A0lo = hh0_lo; g.R = xp + (long)step * 4 * H * Bn; g.srb = 0; }
     else { g.A0hi = g.A0lo = nullptr; g.R = nullptr; }
     SSV_TRY(ssv_launch_gemm_nn_bf3(g, st));
   }

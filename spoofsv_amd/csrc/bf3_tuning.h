@@ -81,6 +81,9 @@
 #ifndef SSV_LSTM_PRESPLIT
 #define SSV_LSTM_PRESPLIT 1  // (tuning builds: 0 = the inference wavefront stages fp32 h and splits it in the consumer, as until round 6)
 #endif
+#ifndef SSV_LSTM_X0FOLD
+#define SSV_LSTM_X0FOLD 1           // layer 0's input frames pre-split, W_ih x_t as the first K segment of layer 0's product; 0 (tuning builds): the projection of all frames
+#endif
 #ifndef SSV_LSTM_PRESPLIT_TRAIN
 #define SSV_LSTM_PRESPLIT_TRAIN 1   // the training forward (every frame's h, c and gates kept) on the pre-split planes too; 0 (tuning builds): inference only
 #endif

@@ -79,16 +79,25 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
   constexpr bool XS = EPI == 1 && KT == 1 && NT == 8 && HW == 3;
   const char* Pb = nullptr;
   const char* P2b = nullptr;
+  int xsp = p.xsplit;                           // first chunk of this entry's second K segment
+  bool x0fold = false;
   if constexpr (XS) {
     const long pl = p.hs_plane_bytes, chunkb = (long)4 * p.hs_npad * 16;         // bytes of one chunk (4 k-groups) in a plane
     const char* base = reinterpret_cast<const char*>(p.hs_planes);
     Pb = base + ((long)max(lstm_layer - 1, 0) * 2 + (lstm_t & 1)) * 2 * pl;
     P2b = base + ((long)lstm_layer * 2 + ((lstm_t + 1) & 1)) * 2 * pl - (long)p.xsplit * chunkb;
-    if (lstm_l0) { Pb = P2b + (long)p.xsplit * chunkb; P2b = nullptr; }
+    if (lstm_l0) {
+      Pb = P2b + (long)p.xsplit * chunkb; P2b = nullptr;
+      if (p.x0_planes) {                        // layer 0's input frame as the first K segment (GemmNNB::x0_planes), its own h_{t-1} as the second
+        x0fold = true; xsp = p.xsplit0;
+        P2b = Pb - (long)xsp * chunkb;
+        Pb = reinterpret_cast<const char*>(p.x0_planes) + (long)lstm_t * 2 * pl;
+      }
+    }
   }
   // chunks to run: all of K, except that an LSTM entry at its first frame has no h_{t-1} segment (layer 0 riding along: nothing but that segment)
-  const int nchunks_all = lstm_l0 ? p.xsplit : p.Kpad / 32;
-  const int nchunks = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? (lstm_l0 ? 0 : p.xsplit) : (EPI == 0 && KT == 1 && p.ksplit > 1) ? p.Kc / 32 : nchunks_all;
+  const int nchunks_all = lstm_l0 ? (x0fold ? xsp + p.perm_h / 32 : p.xsplit) : p.Kpad / 32;
+  const int nchunks = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? (lstm_l0 ? (x0fold ? xsp : 0) : p.xsplit) : (EPI == 0 && KT == 1 && p.ksplit > 1) ? p.Kc / 32 : nchunks_all;
   const int W = BN + span;
   const int kq = lane >> 4, nq = lane & 15;
 
@@ -157,11 +166,20 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
   // split-fp16: xs = 2^ex scales the input while it is split, us = 2^-(ea + ex) the accumulators in the epilogue.  The weights'
   // inverse scale is requested here (a scalar load) and first USED in the epilogue: nothing in the prologue waits for it.  The input's
   // scale is needed before the first split; x_namax == 0 (the LSTM products: |h| < 1 by construction) means the constant 2^14, no list.
-  float xs = 1.f, xinv = 1.f, ainv = 1.f;
+  float xs = 1.f, xinv = 1.f, ainv = 1.f, x0fac = 1.f;
   if constexpr (F16) ainv = *p.a_inv;
   auto scales = [&]() {
     if constexpr (F16) {
-      if (p.x_namax == 0) { xs = 16384.f; xinv = 1.f / 16384.f; }
+      if (p.x_namax == 0) {
+        xs = 16384.f; xinv = 1.f / 16384.f;
+        if constexpr (XS) {
+          if (x0fold) {                         // the input frames were split with their own scale 2^e: segment 1's sums, times 2^(14 - e), join segment 2's
+            float sc, inv;
+            ssv_pow2_scale(ssv_wave_list_max(p.x0_amax, 64), sc, inv);
+            x0fac = ssv_uniform(16384.f * inv);
+          }
+        }
+      }
       else {
         float sc, inv;
         ssv_pow2_scale(ssv_wave_list_max(p.x_amax + (long)b * p.x_amax_bs, p.x_namax), sc, inv);
@@ -186,7 +204,7 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
         for (int r = 0; r < NX; ++r) rx[r][i] = ssv_buf_f32(rsXr, voffb[r], so);
       }
     } else if constexpr (XS) {
-      const bool seg2 = P2b && ch >= p.xsplit;
+      const bool seg2 = P2b && ch >= xsp;
       const __amdgpu_buffer_rsrc_t rs = seg2 ? rsP2 : rsP;
       const unsigned so = (unsigned)ch * (unsigned)(4 * p.hs_npad * 16);           // uniform: the chunk's four k-groups
 #pragma unroll
@@ -337,10 +355,22 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
       NN_STAMP(5);
       return true;
     };
+    auto x0_rescale = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] *= x0fac;
+    };
     int ch = 0;
-    for (; ch + 3 < nchunks; ch += 2) pair(ST_{}, ch);
-    for (; ch < nchunks; ch += 2)
+    for (; ch + 3 < nchunks; ch += 2) {
+      if constexpr (XS) if (x0fold && ch == xsp) x0_rescale();       // (xsp is even: a pair never straddles the segments; VALU only on the branch)
+      pair(ST_{}, ch);
+    }
+    for (; ch < nchunks; ch += 2) {
+      if constexpr (XS) if (x0fold && ch == xsp) x0_rescale();
       if (!pair(TL_{}, ch)) break;
+    }
+    if constexpr (XS) if (x0fold && nchunks == xsp) x0_rescale();      // frame 0: no second segment
   } else {
 #pragma unroll
     for (int j = 0; j < KT; ++j) loadA(0, j, 0);
@@ -1109,6 +1139,8 @@ int ssv_launch_gemm_nn_bf3(const GemmNNB& g, hipStream_t st) {
   SSV_CHECK(!g.hs_planes || (g.epi == 1 && g.lstm_D >= 1 && g.f16 && g.x_namax == 0 && g.perm_h % 32 == 0 && g.hs_npad % 128 == 0 && g.hs_npad >= g.N &&
                              g.hs_plane_bytes == (long)(g.perm_h / 8) * g.hs_npad * 16 && (long)(g.perm_h / 8) * g.hs_npad * 16 < (1L << 31)), SSV_BAD_SHAPE,
             "gemm_nn_bf3: pre-split recurrent activations need the merged split-fp16 inference wavefront and whole column tiles of planes");
+  SSV_CHECK(!g.x0_planes || (g.hs_planes && g.A0hi && g.x0_amax && g.xsplit0 > 0 && g.xsplit0 % 2 == 0 && !g.R), SSV_BAD_SHAPE,
+            "gemm_nn_bf3: pre-split input frames need the pre-split wavefront with layer 0 riding along and an even number of input chunks");
   SSV_CHECK(g.ksplit == 1 || (g.ksplit > 1 && g.KT == 1 && !g.epi && !g.R && !g.bias && !g.bias_b && !g.colstats && !g.row_pair && !g.perm_h && g.sxn == 1 && g.scn == 1 &&
                               g.Kc % 32 == 0 && g.Kpad == g.ksplit * g.Kc && g.skip_rows >= 0), SSV_BAD_SHAPE,
             "gemm_nn_bf3: a split reduction needs a plain k = 1 product whose planes hold ksplit ranges of Kc (a multiple of 32) rows");

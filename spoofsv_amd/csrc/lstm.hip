@@ -14,6 +14,35 @@ __global__ __launch_bounds__(256) void lstm_in_transpose_kernel(const float* __r
   xt[i] = x[((long)b * T + t) * F + f];
 }
 
+// x (Bn, T, F) row-major  ->  the frames pre-split for layer 0's product (GemmNNB::x0_planes): frame t = a (hi, lo) pair of planes [k-group of 8 features][npad
+// columns][8 halves], `plane_bytes` apart, hi = fp16(x s), lo = fp16(x s - hi) with the power-of-two scale s of the whole input (amax: 64 partial maxima,
+// ssv_pow2_scale as every split-fp16 operand).  Features past F and columns past Bn are zeros.  One thread per 16-byte slot, columns fastest.
+__global__ __launch_bounds__(256) void lstm_x_planes_kernel(const float* __restrict__ x, const float* __restrict__ amax, char* __restrict__ planes,
+                                                            long plane_bytes, int Bn, int T, int F, int kgroups, int npad) {
+  float sc, inv;
+  ssv_pow2_scale(ssv_wave_list_max(amax, 64), sc, inv);
+  const int e = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+  if (e >= kgroups * npad) return;
+  const int kg = e / npad, col = e % npad;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = 8 * kg + i;
+    const float v = (col < Bn && f < F) ? x[((long)col * T + t) * F + f] * sc : 0.f;
+    const _Float16 h = (_Float16)v;
+    hi[i] = h;
+    lo[i] = (_Float16)(v - (float)h);
+  }
+  char* frame = planes + (long)t * 2 * plane_bytes;
+  *reinterpret_cast<h8*>(frame + (long)e * 16) = hi;
+  *reinterpret_cast<h8*>(frame + plane_bytes + (long)e * 16) = lo;
+}
+int ssv_launch_lstm_x_planes(const float* x, const float* amax, void* planes, long plane_bytes, int Bn, int T, int F, int kgroups, int npad, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_x_planes_kernel, dim3(ssv_cdiv((long)kgroups * npad, 256), T), dim3(256), 0, st, x, amax, (char*)planes, plane_bytes, Bn, T, F, kgroups, npad);
+  return ssv_check_launch("lstm_x_planes");
+}
+
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
 
 // g: [4H][Bn] gate pre-activations in torch order i, f, g, o; c: [H][Bn] updated in place; h: [H][Bn].

@@ -80,6 +80,12 @@ struct GemmNNB {
   // entry (b, z) reduces over input rows [z Kc, (z + 1) Kc) against weight chunks [z Kc / 32, ...) of planes whose row length is Kpad = ksplit * Kc and
   // writes its partial product at C + b scb + z scz (the consumer adds the slabs).  skip_rows: entry b = 0 has no use for its row tiles below this row.
   int ksplit; long scz; int skip_rows;
+  // x0_planes (with hs_planes, layer 0 riding along): layer 0's input frames pre-split as the recurrent activations are -- frame t at x0_planes + t * 2 *
+  // hs_plane_bytes, the first 4 * xsplit0 k-groups of the hi and of the lo plane, split with the frames' own power-of-two scale (x0_amax: 64 partial maxima) --
+  // so that W_ih x_t is the FIRST K segment (xsplit0 chunks, an even number) of layer 0's product instead of a projection of all frames written to memory
+  // and read back through R: A0hi / A0lo are then the planes of [W_ih | W_hh] (K = 32 xsplit0 + H).  The accumulators are rescaled by 2^14 / (the frames'
+  // scale) between the segments, exactly (powers of two): h's scale is the constant 2^14.
+  const unsigned short* x0_planes; const float* x0_amax; int xsplit0;
   // LSTM support.  perm_h = H > 0: output row m is gate (m % 4) of hidden unit (m / 4), i.e. row (m % 4) * H + m / 4 of
   // the torch layout -- the weights were packed in that order and the bias vectors are indexed through the same map.
   // epi = 1: fused cell epilogue -- the 4 accumulator rows of a lane are the (i, f, g, o) pre-activations of one unit;
