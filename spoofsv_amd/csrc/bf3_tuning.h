@@ -81,6 +81,9 @@
 #ifndef SSV_LSTM_PRESPLIT
 #define SSV_LSTM_PRESPLIT 1  // (tuning builds: 0 = the inference wavefront stages fp32 h and splits it in the consumer, as until round 6)
 #endif
+#ifndef SSV_LSTM_ABL
+#define SSV_LSTM_ABL 0               // ablation builds of the pre-split LSTM wavefront step (wrong results): 1 = no stores in the cell epilogue, 2 = two chunks per tile
+#endif
 #ifndef SSV_LSTM_X0FOLD
 #define SSV_LSTM_X0FOLD 1           // layer 0's input frames pre-split, W_ih x_t as the first K segment of layer 0's product; 0 (tuning builds): the projection of all frames
 #endif

@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
   }
   // chunks to run: all of K, except that an LSTM entry at its first frame has no h_{t-1} segment (layer 0 riding along: nothing but that segment)
   const int nchunks_all = lstm_l0 ? (x0fold ? xsp + p.perm_h / 32 : p.xsplit) : p.Kpad / 32;
-  const int nchunks = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? (lstm_l0 ? (x0fold ? xsp : 0) : p.xsplit) : (EPI == 0 && KT == 1 && p.ksplit > 1) ? p.Kc / 32 : nchunks_all;
+  const int nchunks_ = (EPI == 1 && p.lstm_D > 0 && lstm_t == 0) ? (lstm_l0 ? (x0fold ? xsp : 0) : p.xsplit) : (EPI == 0 && KT == 1 && p.ksplit > 1) ? p.Kc / 32 : nchunks_all;
+  // (tuning builds, -DSSV_LSTM_ABL: bit 0 = the pre-split wavefront's cells store nothing, bit 1 = its tiles run two chunks; profiles/round6_ge2e_cell_epilogue.txt (6))
+  const int nchunks = (SSV_LSTM_ABL & 2) && XS ? (nchunks_ < 2 ? nchunks_ : 2) : nchunks_;
   const int W = BN + span;
   const int kq = lane >> 4, nq = lane & 15;
 
@@ -477,7 +479,11 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
 #endif
         const long ci = (long)u * p.N + gn;
         const float cn = (first ? 0.f : gf * cprev[i][t]) + gi * gg;
+#if SSV_LSTM_ABL & 1
+        if (cn == 1234.5678f) cnew[ci] = cn;
+#else
         cnew[ci] = cn;
+#endif
         if (gsave) {
           const long HN = (long)H * p.N;
           gsave[ci] = gi; gsave[HN + ci] = gf; gsave[2 * HN + ci] = gg; gsave[3 * HN + ci] = go;
@@ -495,8 +501,12 @@ __global__ __launch_bounds__(256, SSV_NNB_WAVES(KT, WM, NT, EPI, HW)) void gemm_
           const _Float16 hl = (_Float16)(hs_ - (float)hh);
           _Float16* ph = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(p.hs_planes) + ((long)lstm_layer * 2 + (lstm_t & 1)) * 2 * p.hs_plane_bytes);
           const long at = ((long)(u >> 3) * p.hs_npad + gn) * 8 + (u & 7);
+#if SSV_LSTM_ABL & 1
+          if (hval == 1234.5678f) { ph[at] = hh; ph[at + p.hs_plane_bytes / 2] = hl; }
+#else
           ph[at] = hh;
           ph[at + p.hs_plane_bytes / 2] = hl;
+#endif
         }
       }
     }
