@@ -505,7 +505,7 @@ int ssv_launch_gemm_nt_bf3(const GemmNT& g, hipStream_t st) {
     const int nj = g.jobs ? g.njobs : 1;
     if (ring_ms >= 0) snprintf(nm, sizeof nm, "gemm_nt3r_kernel<%d, %d>", wm, g.f16);
     else if (wm == 4) snprintf(nm, sizeof nm, "gemm_nt_bf3_kernel<%d, 2, %d, %d, 0, 8>", g.KT, ntc, g.f16);
-    else snprintf(nm, sizeof nm, xr ? "gemm_nt_bf3_kernel<%d, %d, %d, %d, 1>" : "gemm_nt_bf3_kernel<%d, %d, %d, %d>", g.KT, wm, ntc, g.f16);
+    else snprintf(nm, sizeof nm, "gemm_nt_bf3_kernel<%d, %d, %d, %d, %d, 4>", g.KT, wm, ntc, g.f16, xr ? 1 : 0);       // (as rocprofv3 prints the instantiation)
     snprintf(note, sizeof note, "jobs=%d B=%d M=%d Nc=%d L=%d k=%d Z=%d", nj, g.B, g.M, g.Nc, g.La, g.KT, g.Z);
     ssv_shape_log(nm, grid, dim3(wm == 4 ? 512 : 256), 2.0 * nj * g.B * g.M * g.Nc * g.La * g.KT,
                   4.0 * nj * ((double)g.B * g.M * g.La + (double)g.B * g.Nc * g.Lx + (double)g.Z * g.M * g.Nc * g.KT), note);
