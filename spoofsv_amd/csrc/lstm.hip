@@ -122,38 +122,41 @@ __global__ __launch_bounds__(256) void ge2e_centroid_kernel(const float* __restr
   for (int m = 0; m < M; ++m) s += emb[((long)k * M + m) * D + d];
   csum[i] = s;
 }
-// One workgroup (one wave) per embedding (j, i): lane k handles centroids k, k+64, ...
+// One workgroup per embedding (j, i): wave w takes the centroids w, w + 4, ..., its lanes the D components (coalesced rows of csum; two wave sums per
+// centroid, no barrier in the loop).  (Until round 6's end one wave per embedding with lane = centroid, each lane walking a row of csum: 77 us at config 5.)
 //   cos_k = <e, c_k> / max(|e||c_k|, 1e-8) + 1e-6, c_k = csum_k / M, or (csum_j - e) / (M-1) for k == j
 //   per = -(S_j - log(sum_k exp(S_k) + 1e-6)), S = w cos + b
-__global__ __launch_bounds__(64) void ge2e_rows_kernel(const float* __restrict__ emb, const float* __restrict__ csum, const float* __restrict__ w,
-                                                        const float* __restrict__ bb, float* __restrict__ per, int N, int M, int D) {
-  const int ji = blockIdx.x, j = ji / M, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void ge2e_rows_kernel(const float* __restrict__ emb, const float* __restrict__ csum, const float* __restrict__ w,
+                                                         const float* __restrict__ bb, float* __restrict__ per, int N, int M, int D) {
+  __shared__ float s_exp[4], s_pos[4];
+  const int ji = blockIdx.x, j = ji / M, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* e = emb + (long)ji * D;
   float en = 0.f;
   for (int d = lane; d < D; d += 64) en += e[d] * e[d];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) en += __shfl_xor(en, o);
-  en = sqrtf(en);
+  en = sqrtf(ssv_wave_sum(en));
   const float ww = w[0], b0 = bb[0];
   float sexp = 0.f, spos = 0.f;
-  for (int k = lane; k < N; k += 64) {
+  for (int k = wave; k < N; k += 4) {
     const float* c = csum + (long)k * D;
+    const float inv = (k == j) ? 1.f / (float)(M - 1) : 1.f / (float)M;
     float dot = 0.f, cn = 0.f;
-    if (k == j) {
-      const float inv = 1.f / (float)(M - 1);
-      for (int d = 0; d < D; ++d) { const float cv = (c[d] - e[d]) * inv; dot += e[d] * cv; cn += cv * cv; }
-    } else {
-      const float inv = 1.f / (float)M;
-      for (int d = 0; d < D; ++d) { const float cv = c[d] * inv; dot += e[d] * cv; cn += cv * cv; }
+    for (int d = lane; d < D; d += 64) {
+      const float ev = e[d];
+      const float cv = ((k == j) ? c[d] - ev : c[d]) * inv;
+      dot += ev * cv; cn += cv * cv;
     }
+    dot = ssv_wave_sum(dot); cn = ssv_wave_sum(cn);
     const float cosv = dot / fmaxf(en * sqrtf(cn), 1e-8f) + 1e-6f;
     const float S = ww * cosv + b0;
     sexp += expf(S);
     if (k == j) spos = S;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { sexp += __shfl_xor(sexp, o); spos += __shfl_xor(spos, o); }
-  if (lane == 0) per[ji] = -(spos - logf(sexp + 1e-6f));
+  if (lane == 0) { s_exp[wave] = sexp; s_pos[wave] = spos; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float se = (s_exp[0] + s_exp[1]) + (s_exp[2] + s_exp[3]), sp = (s_pos[0] + s_pos[1]) + (s_pos[2] + s_pos[3]);
+    per[ji] = -(sp - logf(se + 1e-6f));
+  }
 }
 __global__ __launch_bounds__(256) void ge2e_total_kernel(const float* __restrict__ per, float* __restrict__ loss, int n) {
   __shared__ float red[4];
@@ -176,7 +179,7 @@ extern "C" int ssv_ge2e_loss_fwd(const float* emb, const float* w, const float* 
   float* perbuf = per ? per : csum + (size_t)N * D;
   hipLaunchKernelGGL(ge2e_centroid_kernel, dim3(ssv_cdiv((long)N * D, 256)), dim3(256), 0, st, emb, csum, N, M, D);
   SSV_TRY(ssv_check_launch("ge2e_centroid"));
-  hipLaunchKernelGGL(ge2e_rows_kernel, dim3(N * M), dim3(64), 0, st, emb, csum, w, b, perbuf, N, M, D);
+  hipLaunchKernelGGL(ge2e_rows_kernel, dim3(N * M), dim3(256), 0, st, emb, csum, w, b, perbuf, N, M, D);
   SSV_TRY(ssv_check_launch("ge2e_rows"));
   hipLaunchKernelGGL(ge2e_total_kernel, dim3(1), dim3(256), 0, st, perbuf, loss, N * M);
   return ssv_check_launch("ge2e_total");
@@ -212,16 +215,16 @@ __global__ __launch_bounds__(256) void ge2e_bwd_rows_kernel(const float* __restr
   float t = 0.f;
   for (int d = tid; d < D; d += 256) t += e[d] * e[d];
   const float en = sqrtf(block_sum_256(t, red4));
-  for (int k = 0; k < N; ++k) {
+  for (int k = tid >> 6; k < N; k += 4) {                     // a wave per centroid, lanes over D: two wave sums, no barrier (352 barriers before)
     const float* c = csum + (long)k * D;
     float dot = 0.f, cn = 0.f;
-    for (int d = tid; d < D; d += 256) {
+    for (int d = tid & 63; d < D; d += 64) {
       const float v = (k == j) ? (c[d] - e[d]) * invM1 : c[d] * invM;
       dot += e[d] * v; cn += v * v;
     }
-    dot = block_sum_256(dot, red4);
-    cn = block_sum_256(cn, red4);
-    if (tid == 0) {
+    dot = ssv_wave_sum(dot);
+    cn = ssv_wave_sum(cn);
+    if ((tid & 63) == 0) {
       const float vn = sqrtf(cn), c0 = dot / fmaxf(en * vn, 1e-8f);
       sC[k] = c0; sV[k] = vn; sS[k] = w * (c0 + 1e-6f) + b;
     }
@@ -253,25 +256,42 @@ __global__ __launch_bounds__(256) void ge2e_bwd_rows_kernel(const float* __restr
     dloo[(long)ji * D + d] = sH[j] * (e[d] / denj - sC[j] * vj / fmaxf(sV[j] * sV[j], 1e-16f)) * invM1;
   }
 }
-// one workgroup per speaker k: gradient that reaches the centroid c_k from the rows of the OTHER speakers
-__global__ __launch_bounds__(256) void ge2e_bwd_centroid_kernel(const float* __restrict__ emb, const float* __restrict__ csum, const float* __restrict__ Hc,
-                                                                const float* __restrict__ C0, const float* __restrict__ En, float* __restrict__ dcent,
-                                                                int N, int M, int D) {
-  __shared__ float red4[4];
-  const int k = blockIdx.x, tid = threadIdx.x;
+// one workgroup per speaker k: gradient that reaches the centroid c_k from the rows of the OTHER speakers.  16 waves: thread = (component d, one of four
+// interleaved row ranges), four rows in flight per thread, the four ranges added in turn (one thread per component walking all N M rows one load
+// at a time took 0.32 ms at config 5).
+__global__ __launch_bounds__(1024) void ge2e_bwd_centroid_kernel(const float* __restrict__ emb, const float* __restrict__ csum, const float* __restrict__ Hc,
+                                                                 const float* __restrict__ C0, const float* __restrict__ En, float* __restrict__ dcent,
+                                                                 int N, int M, int D) {
+  __shared__ float part[4][256];
+  const int k = blockIdx.x, tid = threadIdx.x, dl = tid & 255, g = tid >> 8, lane = tid & 63;
   const float invM = 1.f / (float)M;
   float t = 0.f;
-  for (int d = tid; d < D; d += 256) { const float v = csum[(long)k * D + d] * invM; t += v * v; }
-  const float vk = sqrtf(block_sum_256(t, red4));
-  for (int d = tid; d < D; d += 256) {
-    const float v = csum[(long)k * D + d] * invM;
+  for (int d = lane; d < D; d += 64) { const float v = csum[(long)k * D + d] * invM; t += v * v; }
+  const float vk = sqrtf(ssv_wave_sum(t));                                   // (every wave on its own)
+  const float vk2 = fmaxf(vk * vk, 1e-16f);
+  const int NM = N * M;
+  for (int d0 = 0; d0 < D; d0 += 256) {
+    const int d = d0 + dl;
+    const bool dok = d < D;
+    const float v = dok ? csum[(long)k * D + d] * invM : 0.f;
     float acc = 0.f;
-    for (int ji = 0; ji < N * M; ++ji) {
-      if (ji / M == k) continue;
-      const float h = Hc[(long)ji * N + k];
-      acc += h * (emb[(long)ji * D + d] / fmaxf(En[ji] * vk, 1e-8f) - C0[(long)ji * N + k] * v / fmaxf(vk * vk, 1e-16f));
+    auto term = [&](int ji, float h, float ev, float c0, float en) -> float { return (ji / M == k) ? 0.f : h * (ev / fmaxf(en * vk, 1e-8f) - c0 * v / vk2); };
+    int ji = g;
+    for (; ji + 12 < NM; ji += 16) {
+      float h[4], ev[4], c0[4], en[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = ji + 4 * q;
+        h[q] = Hc[(long)r * N + k]; c0[q] = C0[(long)r * N + k]; en[q] = En[r]; ev[q] = dok ? emb[(long)r * D + d] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc += term(ji + 4 * q, h[q], ev[q], c0[q], en[q]);
     }
-    dcent[(long)k * D + d] = acc * invM;
+    for (; ji < NM; ji += 4) acc += term(ji, Hc[(long)ji * N + k], dok ? emb[(long)ji * D + d] : 0.f, C0[(long)ji * N + k], En[ji]);
+    __syncthreads();
+    part[g][dl] = acc;
+    __syncthreads();
+    if (g == 0 && dok) dcent[(long)k * D + d] = (((part[0][dl] + part[1][dl]) + part[2][dl]) + part[3][dl]) * invM;
   }
 }
 __global__ __launch_bounds__(256) void ge2e_bwd_finish_kernel(const float* __restrict__ direct, const float* __restrict__ dcent, const float* __restrict__ dloo,
@@ -316,7 +336,7 @@ extern "C" int ssv_ge2e_loss_bwd(const float* emb, const float* w, const float* 
   SSV_TRY(ssv_check_launch("ge2e_centroid"));
   hipLaunchKernelGGL(ge2e_bwd_rows_kernel, dim3(N * M), dim3(256), 0, st, emb, (const float*)csum, w, b, dloss, Hc, C0, Vn, En, direct, dloo, part, N, M, D);
   SSV_TRY(ssv_check_launch("ge2e_bwd_rows"));
-  hipLaunchKernelGGL(ge2e_bwd_centroid_kernel, dim3(N), dim3(256), 0, st, emb, (const float*)csum, (const float*)Hc, (const float*)C0, (const float*)En, dcent, N, M, D);
+  hipLaunchKernelGGL(ge2e_bwd_centroid_kernel, dim3(N), dim3(1024), 0, st, emb, (const float*)csum, (const float*)Hc, (const float*)C0, (const float*)En, dcent, N, M, D);
   SSV_TRY(ssv_check_launch("ge2e_bwd_centroid"));
   hipLaunchKernelGGL(ge2e_bwd_finish_kernel, dim3(N * M), dim3(256), 0, st, (const float*)direct, (const float*)dcent, (const float*)dloo, demb, N, M, D);
   SSV_TRY(ssv_check_launch("ge2e_bwd_finish"));

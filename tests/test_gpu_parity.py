@@ -376,6 +376,22 @@ def test_ge2e_embedder_wavefront_launch_forms_agree_with_the_oracle(mode):
     assert rel_err(eg, eo) < 2e-5 and rel_l2(eg, eo) < 2e-5, (mode, rel_err(eg, eo), rel_l2(eg, eo))
 
 
+@pytest.mark.parametrize("nmels,hidden,scale", [(20, 256, 1.0), (64, 256, 50.0), (80, 256, 1e-3), (130, 256, 1.0), (80, 64, 1.0)])
+def test_ge2e_embedder_input_widths_and_magnitudes_vs_oracle(nmels, hidden, scale):
+    """Layer 0's input projection rides in its product as the first K segment (csrc/conv_nn.hip, GemmNNB::x0_planes; GE2E/speech_embedder_net.py:19,28): the
+    frames are pre-split with their own power-of-two scale and the accumulators rescaled between the segments.  Input widths that pad to two, four and six
+    chunks (20 and 64, 80, 130 mel bands), inputs far from unit magnitude, and a hidden size too small for the folded form (the projection of all frames
+    then runs as before), against the CPU oracle."""
+    from spoofsv_amd.ge2e import SpeechEmbedder
+    torch.manual_seed(nmels + hidden)
+    m = SpeechEmbedder(nmels=nmels, hidden=hidden, num_layer=3, proj=48)
+    x = torch.randn(70, 6, nmels) * scale
+    with torch.no_grad():
+        eo = GO.speech_embedder(x, m.state_dict())
+    eg = m.to(DEV).eval()(x.to(DEV))
+    assert rel_err(eg, eo) < FWD_TOL and rel_l2(eg, eo) < FWD_TOL, (nmels, hidden, scale, rel_err(eg, eo), rel_l2(eg, eo))
+
+
 def test_ge2e_embedder_reuses_packed_weights_until_a_weight_changes():
     """d-vector extraction on fixed weights (GE2E/dvector_create.py:100): the second call of the same shape re-uses the split weight planes and
     their scale in the kept workspace (ssv_lstm_fwd_cached) and returns the same bits; an in-place weight update is seen (version bump) and the
